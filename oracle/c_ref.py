@@ -1,0 +1,148 @@
+"""ctypes wrapper around the plain-C oracle (oracle/raster_ref.c).
+
+TEST INFRASTRUCTURE ONLY (see the header of raster_ref.c): imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libraster_ref.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "raster_ref.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.ref_create.restype = C.c_void_p
+        L.ref_destroy.argtypes = [C.c_void_p]
+        L.ref_num_rendered.restype = C.c_int64
+        L.ref_num_rendered.argtypes = [C.c_void_p]
+        for name, rt in (("ref_ranges", C.c_int), ("ref_list", C.c_int), ("ref_final_T", C.c_float),
+                         ("ref_n_contrib", C.c_int), ("ref_geom_xy", C.c_float),
+                         ("ref_geom_conic_op", C.c_float), ("ref_geom_depth", C.c_float)):
+            f = getattr(L, name)
+            f.restype = C.POINTER(rt)
+            f.argtypes = [C.c_void_p]
+        L.ref_forward.restype = C.c_int
+        L.ref_backward.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _f(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t=C.c_float):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+class CRef:
+    """One forward (+ optional backward) of the C oracle on numpy arrays.
+
+    Matrices are passed exactly as the settings tuple holds them
+    (/root/reference/utils/recon_helpers.py:8-13): viewmatrix = w2c^T,
+    projmatrix = (P w2c)^T, flattened row-major (== column-major of w2c)."""
+
+    def __init__(self):
+        self.L = lib()
+        self.ctx = C.c_void_p(self.L.ref_create())
+
+    def __del__(self):
+        try:
+            self.L.ref_destroy(self.ctx)
+        except Exception:
+            pass
+
+    def forward(self, means3D, colors, opacities, scales, rotations, view, proj, tanfovx, tanfovy,
+                W, H, bg, scale_modifier=1.0, cov3D_precomp=None):
+        self.a = dict(means3D=_f(means3D), colors=_f(colors), opac=_f(np.reshape(opacities, -1)),
+                      scales=_f(scales), rot=_f(rotations), view=_f(np.reshape(view, -1)),
+                      proj=_f(np.reshape(proj, -1)), bg=_f(bg), cov=_f(cov3D_precomp))
+        a = self.a
+        P, Cc = a['means3D'].shape[0], a['colors'].shape[1]
+        self.P, self.C, self.W, self.H = P, Cc, W, H
+        self.tan = (float(tanfovx), float(tanfovy))
+        self.mod = float(scale_modifier)
+        color = np.zeros((Cc, H, W), np.float32)
+        depth = np.zeros((1, H, W), np.float32)
+        radii = np.zeros(P, np.int32)
+        rc = self.L.ref_forward(self.ctx, P, Cc, W, H, _p(a['bg']), _p(a['means3D']), _p(a['colors']),
+                                _p(a['opac']), _p(a['scales']), C.c_float(self.mod), _p(a['rot']), _p(a['cov']),
+                                _p(a['view']), _p(a['proj']), C.c_float(self.tan[0]), C.c_float(self.tan[1]),
+                                _p(color), _p(depth), _p(radii, C.c_int))
+        if rc != 0:
+            raise RuntimeError(f"ref_forward failed: {rc}")
+        return color, radii, depth
+
+    # saved state accessors -------------------------------------------------
+    def num_rendered(self):
+        return int(self.L.ref_num_rendered(self.ctx))
+
+    def _arr(self, fn, n, dt):
+        ptr = getattr(self.L, fn)(self.ctx)
+        return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True)
+
+    def final_T(self):
+        return self._arr("ref_final_T", self.W * self.H, np.float32).reshape(self.H, self.W)
+
+    def n_contrib(self):
+        return self._arr("ref_n_contrib", self.W * self.H, np.int32).reshape(self.H, self.W)
+
+    def ranges(self):
+        tiles = ((self.W + 15) // 16) * ((self.H + 15) // 16)
+        return self._arr("ref_ranges", tiles + 1, np.int32)
+
+    def point_list(self):
+        n = self.num_rendered()
+        return self._arr("ref_list", n, np.int32) if n else np.zeros(0, np.int32)
+
+    def geom(self):
+        return dict(xy=self._arr("ref_geom_xy", 2 * self.P, np.float32).reshape(-1, 2),
+                    conic_op=self._arr("ref_geom_conic_op", 4 * self.P, np.float32).reshape(-1, 4),
+                    depth=self._arr("ref_geom_depth", self.P, np.float32))
+
+    def backward(self, dL_dcolor):
+        a = self.a
+        P, Cc = self.P, self.C
+        g = _f(dL_dcolor)
+        out = dict(means3D=np.zeros((P, 3), np.float32), means2D=np.zeros((P, 3), np.float32),
+                   colors=np.zeros((P, Cc), np.float32), opacities=np.zeros((P, 1), np.float32),
+                   cov3D=np.zeros((P, 6), np.float32))
+        use_sr = a['cov'] is None
+        if use_sr:
+            out['scales'] = np.zeros((P, 3), np.float32)
+            out['rotations'] = np.zeros((P, 4), np.float32)
+        rc = self.L.ref_backward(self.ctx, _p(a['bg']), _p(a['means3D']), _p(a['colors']),
+                                 _p(a['scales']) if use_sr else None, C.c_float(self.mod),
+                                 _p(a['rot']) if use_sr else None,
+                                 _p(a['view']), _p(a['proj']), C.c_float(self.tan[0]), C.c_float(self.tan[1]),
+                                 _p(g), _p(out['means3D']), _p(out['means2D']), _p(out['colors']),
+                                 _p(out['opacities']), _p(out.get('scales')), _p(out.get('rotations')),
+                                 _p(out['cov3D']))
+        if rc != 0:
+            raise RuntimeError(f"ref_backward failed: {rc}")
+        return out
+
+
+def mark_visible(means3D, view):
+    m = _f(means3D)
+    out = np.zeros(m.shape[0], np.uint8)
+    lib().ref_mark_visible(m.shape[0], _p(m), _p(_f(np.reshape(view, -1))), out.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return out.astype(bool)

@@ -1,0 +1,382 @@
+/*
+ * CPU oracle #2 for the Gaussian-splat rasterizer: plain C, float32 arithmetic,
+ * forward AND hand-written backward.
+ *
+ * TEST INFRASTRUCTURE ONLY -- only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load the library built from this file.
+ *
+ * PARITY UNPINNED: the arithmetic of this path lives in the un-vendored
+ * dependency JonathonLuiten/diff-gaussian-rasterization-w-depth @ cb65e4b8
+ * (/root/reference/requirements.txt:15); the reference carries no golden
+ * vectors.  This file restates the published algorithm
+ *  step by step; it is cross-checked against the
+ * autograd oracle oracle/raster_ref.py in tests/test_oracle.py.
+ *
+ * Reference call sites this restates the callee of:
+ *   forward  .. /root/reference/scripts/splatam.py:249,253,384
+ *   backward .. /root/reference/scripts/splatam.py:702,854 (loss.backward())
+ *   settings .. /root/reference/utils/recon_helpers.py:14-26 (matrix layout :8-13)
+ *
+ * Build: see oracle/Makefile  ->  oracle/_build/libraster_ref.so
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define TILE 16
+#define MAXC 8
+
+typedef struct {
+    int P, C, W, H, gx, gy;
+    /* per-Gaussian geometry (Appendix A, preprocess outputs) */
+    float *depth, *xy, *conic_op, *cov3d, *cov2d;
+    int *radii, *rect;          /* rect: minx,miny,maxx,maxy (tiles) */
+    /* binning */
+    int64_t R;
+    int *range;                 /* [tiles+1] */
+    int *list;                  /* [R] Gaussian ids, per tile sorted by (depth bits, id) */
+    /* per-pixel */
+    float *final_T;
+    int *n_contrib;
+} ref_ctx;
+
+ref_ctx *ref_create(void) { return (ref_ctx *)calloc(1, sizeof(ref_ctx)); }
+
+static void ctx_release(ref_ctx *c) {
+    free(c->depth); free(c->xy); free(c->conic_op); free(c->cov3d); free(c->cov2d);
+    free(c->radii); free(c->rect); free(c->range); free(c->list);
+    free(c->final_T); free(c->n_contrib);
+    memset(c, 0, sizeof(*c));
+}
+void ref_destroy(ref_ctx *c) { if (c) { ctx_release(c); free(c); } }
+int64_t ref_num_rendered(const ref_ctx *c) { return c->R; }
+const int *ref_ranges(const ref_ctx *c) { return c->range; }
+const int *ref_list(const ref_ctx *c) { return c->list; }
+const float *ref_final_T(const ref_ctx *c) { return c->final_T; }
+const int *ref_n_contrib(const ref_ctx *c) { return c->n_contrib; }
+const float *ref_geom_xy(const ref_ctx *c) { return c->xy; }
+const float *ref_geom_conic_op(const ref_ctx *c) { return c->conic_op; }
+const float *ref_geom_depth(const ref_ctx *c) { return c->depth; }
+
+/* 4x4 given as 16 floats, element (row r, col c) at m[c*4+r] (Appendix A conventions). */
+static inline float m4(const float *m, int r, int c) { return m[c * 4 + r]; }
+
+static void quat_rot(const float *q, float R[3][3]) {
+    /* same polynomial as /root/reference/utils/slam_external.py:33-41, no renormalisation */
+    float r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
+    R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+    R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+static void cov3d_of(const float *scale, float mod, const float *q, float *out6) {
+    float R[3][3], M[3][3];
+    quat_rot(q, R);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[i][j] = R[i][j] * (mod * scale[j]);
+    float S[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        float a = 0.f; for (int k = 0; k < 3; k++) a += M[i][k] * M[j][k]; S[i][j] = a;
+    }
+    out6[0] = S[0][0]; out6[1] = S[0][1]; out6[2] = S[0][2]; out6[3] = S[1][1]; out6[4] = S[1][2]; out6[5] = S[2][2];
+}
+
+typedef struct { uint32_t key; int id; } kv_t;
+static int kv_cmp(const void *a, const void *b) {
+    const kv_t *x = (const kv_t *)a, *y = (const kv_t *)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return (x->id > y->id) - (x->id < y->id);
+}
+
+/* Forward.  cov3D_precomp may be NULL.  Returns 0. */
+int ref_forward(ref_ctx *c, int P, int C, int W, int H,
+                const float *bg, const float *means3D, const float *colors, const float *opac,
+                const float *scales, float mod, const float *rot, const float *cov3D_precomp,
+                const float *view, const float *proj, float tanfovx, float tanfovy,
+                float *out_color, float *out_depth, int *out_radii)
+{
+    if (C > MAXC) return 1;
+    ctx_release(c);
+    int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, tiles = gx * gy;
+    c->P = P; c->C = C; c->W = W; c->H = H; c->gx = gx; c->gy = gy;
+    c->depth = (float *)calloc(P, 4); c->xy = (float *)calloc(P, 8); c->conic_op = (float *)calloc(P, 16);
+    c->cov3d = (float *)calloc(P, 24); c->cov2d = (float *)calloc(P, 12);
+    c->radii = (int *)calloc(P, 4); c->rect = (int *)calloc(P, 16);
+    c->range = (int *)calloc(tiles + 1, 4);
+    c->final_T = (float *)malloc((size_t)W * H * 4); c->n_contrib = (int *)calloc((size_t)W * H, 4);
+    const float fx = W / (2.f * tanfovx), fy = H / (2.f * tanfovy);
+    int *count = (int *)calloc(tiles, 4);
+
+    /* ---- preprocess (Appendix A steps 1-9) ---- */
+    for (int i = 0; i < P; i++) {
+        const float *p = means3D + 3 * i;
+        float tv[3];
+        for (int r = 0; r < 3; r++) tv[r] = m4(view, r, 0) * p[0] + m4(view, r, 1) * p[1] + m4(view, r, 2) * p[2] + m4(view, r, 3);
+        out_radii[i] = 0;
+        if (tv[2] <= 0.2f) continue;
+        float hom[4];
+        for (int r = 0; r < 4; r++) hom[r] = m4(proj, r, 0) * p[0] + m4(proj, r, 1) * p[1] + m4(proj, r, 2) * p[2] + m4(proj, r, 3);
+        float pw = 1.f / (hom[3] + 0.0000001f);
+        float ndcx = hom[0] * pw, ndcy = hom[1] * pw;
+        float *S6 = c->cov3d + 6 * i;
+        if (cov3D_precomp) memcpy(S6, cov3D_precomp + 6 * i, 24);
+        else cov3d_of(scales + 3 * i, mod, rot + 4 * i, S6);
+        /* EWA */
+        float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+        float txtz = tv[0] / tv[2], tytz = tv[1] / tv[2];
+        float tx = fminf(limx, fmaxf(-limx, txtz)) * tv[2];
+        float ty = fminf(limy, fmaxf(-limy, tytz)) * tv[2];
+        float tz = tv[2];
+        float J[2][3] = {{fx / tz, 0.f, -(fx * tx) / (tz * tz)}, {0.f, fy / tz, -(fy * ty) / (tz * tz)}};
+        float T[2][3];
+        for (int r = 0; r < 2; r++) for (int k = 0; k < 3; k++)
+            T[r][k] = J[r][0] * m4(view, 0, k) + J[r][1] * m4(view, 1, k) + J[r][2] * m4(view, 2, k);
+        float Sg[3][3] = {{S6[0], S6[1], S6[2]}, {S6[1], S6[3], S6[4]}, {S6[2], S6[4], S6[5]}};
+        float TS[2][3];
+        for (int r = 0; r < 2; r++) for (int k = 0; k < 3; k++) TS[r][k] = T[r][0] * Sg[0][k] + T[r][1] * Sg[1][k] + T[r][2] * Sg[2][k];
+        float a = TS[0][0] * T[0][0] + TS[0][1] * T[0][1] + TS[0][2] * T[0][2] + 0.3f;
+        float b = TS[0][0] * T[1][0] + TS[0][1] * T[1][1] + TS[0][2] * T[1][2];
+        float cc = TS[1][0] * T[1][0] + TS[1][1] * T[1][1] + TS[1][2] * T[1][2] + 0.3f;
+        float det = a * cc - b * b;
+        if (det == 0.f) continue;
+        float di = 1.f / det;
+        float mid = 0.5f * (a + cc);
+        float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+        float lam = fmaxf(mid + disc, mid - disc);
+        float radius = ceilf(3.f * sqrtf(lam));
+        float px = ((ndcx + 1.f) * W - 1.f) * 0.5f, py = ((ndcy + 1.f) * H - 1.f) * 0.5f;
+        int x0 = (int)((px - radius) / TILE), y0 = (int)((py - radius) / TILE);
+        int x1 = (int)((px + radius + TILE - 1) / TILE), y1 = (int)((py + radius + TILE - 1) / TILE);
+        x0 = x0 < 0 ? 0 : (x0 > gx ? gx : x0); x1 = x1 < 0 ? 0 : (x1 > gx ? gx : x1);
+        y0 = y0 < 0 ? 0 : (y0 > gy ? gy : y0); y1 = y1 < 0 ? 0 : (y1 > gy ? gy : y1);
+        if ((x1 - x0) * (y1 - y0) == 0) continue;
+        c->depth[i] = tv[2]; c->radii[i] = out_radii[i] = (int)radius;
+        c->xy[2 * i] = px; c->xy[2 * i + 1] = py;
+        c->conic_op[4 * i] = cc * di; c->conic_op[4 * i + 1] = -b * di; c->conic_op[4 * i + 2] = a * di; c->conic_op[4 * i + 3] = opac[i];
+        c->cov2d[3 * i] = a; c->cov2d[3 * i + 1] = b; c->cov2d[3 * i + 2] = cc;
+        int *rc = c->rect + 4 * i; rc[0] = x0; rc[1] = y0; rc[2] = x1; rc[3] = y1;
+        for (int y = y0; y < y1; y++) for (int x = x0; x < x1; x++) count[y * gx + x]++;
+    }
+    /* ---- binning: per tile, ascending (float bits of depth, id) ---- */
+    for (int t = 0; t < tiles; t++) c->range[t + 1] = c->range[t] + count[t];
+    c->R = c->range[tiles];
+    c->list = (int *)malloc((size_t)(c->R ? c->R : 1) * 4);
+    kv_t *kv = (kv_t *)malloc((size_t)(c->R ? c->R : 1) * sizeof(kv_t));
+    memset(count, 0, (size_t)tiles * 4);
+    for (int i = 0; i < P; i++) {
+        if (c->radii[i] <= 0) continue;
+        const int *rc = c->rect + 4 * i;
+        uint32_t key; memcpy(&key, &c->depth[i], 4);
+        for (int y = rc[1]; y < rc[3]; y++) for (int x = rc[0]; x < rc[2]; x++) {
+            int t = y * gx + x; kv_t *e = kv + c->range[t] + count[t]++;
+            e->key = key; e->id = i;
+        }
+    }
+    #pragma omp parallel for schedule(dynamic, 8)
+    for (int t = 0; t < tiles; t++) {
+        int n = c->range[t + 1] - c->range[t];
+        if (n > 1) qsort(kv + c->range[t], n, sizeof(kv_t), kv_cmp);
+        for (int k = 0; k < n; k++) c->list[c->range[t] + k] = kv[c->range[t] + k].id;
+    }
+    free(kv); free(count);
+
+    /* ---- composite (Appendix A "Forward composite (K6)") ---- */
+    #pragma omp parallel for schedule(dynamic, 4)
+    for (int t = 0; t < tiles; t++) {
+        int tx = t % gx, ty = t / gx, s = c->range[t], e = c->range[t + 1];
+        for (int ly = 0; ly < TILE; ly++) for (int lx = 0; lx < TILE; lx++) {
+            int px = tx * TILE + lx, py = ty * TILE + ly;
+            if (px >= W || py >= H) continue;
+            float T = 1.f, D = 0.f, Cc[MAXC] = {0};
+            int contributor = 0, last = 0;
+            for (int k = s; k < e; k++) {
+                int id = c->list[k]; contributor++;
+                float dx = c->xy[2 * id] - (float)px, dy = c->xy[2 * id + 1] - (float)py;
+                const float *co = c->conic_op + 4 * id;
+                float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                if (power > 0.f) continue;
+                float alpha = fminf(0.99f, co[3] * expf(power));
+                if (alpha < 1.f / 255.f) continue;
+                float test_T = T * (1.f - alpha);
+                if (test_T < 0.0001f) break;
+                for (int ch = 0; ch < C; ch++) Cc[ch] += colors[(size_t)id * C + ch] * alpha * T;
+                D += c->depth[id] * alpha * T;
+                T = test_T; last = contributor;
+            }
+            size_t pix = (size_t)py * W + px;
+            c->final_T[pix] = T; c->n_contrib[pix] = last;
+            for (int ch = 0; ch < C; ch++) out_color[(size_t)ch * W * H + pix] = Cc[ch] + T * bg[ch];
+            out_depth[pix] = D;
+        }
+    }
+    return 0;
+}
+
+/* Backward.  dL_dpix: [C,H,W].  Outputs (all overwritten):
+ * dmeans3D[P,3] dmeans2D[P,3] dcolors[P,C] dopac[P] dscales[P,3] drot[P,4] dcov3D[P,6]
+ * (dscales/drot are skipped when scales==NULL, i.e. cov3D_precomp was used). */
+int ref_backward(const ref_ctx *c, const float *bg, const float *means3D, const float *colors,
+                 const float *scales, float mod, const float *rot,
+                 const float *view, const float *proj, float tanfovx, float tanfovy,
+                 const float *dL_dpix,
+                 float *dmeans3D, float *dmeans2D, float *dcolors, float *dopac,
+                 float *dscales, float *drot, float *dcov3D)
+{
+    const int P = c->P, C = c->C, W = c->W, H = c->H, gx = c->gx, tiles = c->gx * c->gy;
+    /* double accumulators keep the OpenMP result order-independent to float precision */
+    double *acc = (double *)calloc((size_t)P * (6 + C), sizeof(double));
+    const int NA = 6 + C; /* 0,1 mean2D(ndc)  2,3,4 conic (true derivative)  5 opacity  6.. colour */
+
+    #pragma omp parallel for schedule(dynamic, 4)
+    for (int t = 0; t < tiles; t++) {
+        int tx = t % gx, ty = t / gx, s = c->range[t];
+        for (int ly = 0; ly < TILE; ly++) for (int lx = 0; lx < TILE; lx++) {
+            int px = tx * TILE + lx, py = ty * TILE + ly;
+            if (px >= W || py >= H) continue;
+            size_t pix = (size_t)py * W + px;
+            const float T_final = c->final_T[pix];
+            float T = T_final;
+            int last = c->n_contrib[pix];
+            float dpix[MAXC], accum[MAXC] = {0}, last_col[MAXC] = {0}, last_alpha = 0.f, bgdot = 0.f;
+            for (int ch = 0; ch < C; ch++) { dpix[ch] = dL_dpix[(size_t)ch * W * H + pix]; bgdot += bg[ch] * dpix[ch]; }
+            for (int k = s + last - 1; k >= s; k--) {
+                int id = c->list[k];
+                float dx = c->xy[2 * id] - (float)px, dy = c->xy[2 * id + 1] - (float)py;
+                const float *co = c->conic_op + 4 * id;
+                float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                if (power > 0.f) continue;
+                float G = expf(power);
+                float alpha = fminf(0.99f, co[3] * G);
+                if (alpha < 1.f / 255.f) continue;
+                T = T / (1.f - alpha);
+                float w = alpha * T, dL_dalpha = 0.f;
+                double *a = acc + (size_t)id * NA;
+                for (int ch = 0; ch < C; ch++) {
+                    float col = colors[(size_t)id * C + ch];
+                    accum[ch] = last_alpha * last_col[ch] + (1.f - last_alpha) * accum[ch];
+                    last_col[ch] = col;
+                    dL_dalpha += (col - accum[ch]) * dpix[ch];
+                    #pragma omp atomic
+                    a[6 + ch] += (double)(w * dpix[ch]);
+                }
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final / (1.f - alpha)) * bgdot;
+                float dL_dG = co[3] * dL_dalpha;
+                float gdx = G * dx, gdy = G * dy;
+                float dG_ddx = -gdx * co[0] - gdy * co[1], dG_ddy = -gdy * co[2] - gdx * co[1];
+                #pragma omp atomic
+                a[0] += (double)(dL_dG * dG_ddx * 0.5f * W);
+                #pragma omp atomic
+                a[1] += (double)(dL_dG * dG_ddy * 0.5f * H);
+                #pragma omp atomic
+                a[2] += (double)(-0.5f * gdx * dx * dL_dG);
+                #pragma omp atomic
+                a[3] += (double)(-gdx * dy * dL_dG);
+                #pragma omp atomic
+                a[4] += (double)(-0.5f * gdy * dy * dL_dG);
+                #pragma omp atomic
+                a[5] += (double)(G * dL_dalpha);
+            }
+        }
+    }
+
+    /* ---- per-Gaussian backward (Appendix A "Backward preprocess (K8+K9)") ---- */
+    const float fx = W / (2.f * tanfovx), fy = H / (2.f * tanfovy);
+    for (int i = 0; i < P; i++) {
+        float *gm = dmeans3D + 3 * i; gm[0] = gm[1] = gm[2] = 0.f;
+        dmeans2D[3 * i] = dmeans2D[3 * i + 1] = dmeans2D[3 * i + 2] = 0.f;
+        for (int ch = 0; ch < C; ch++) dcolors[(size_t)i * C + ch] = 0.f;
+        dopac[i] = 0.f;
+        if (dscales) { for (int k = 0; k < 3; k++) dscales[3 * i + k] = 0.f; for (int k = 0; k < 4; k++) drot[4 * i + k] = 0.f; }
+        if (dcov3D) for (int k = 0; k < 6; k++) dcov3D[6 * i + k] = 0.f;
+        if (c->radii[i] <= 0) continue;
+        const double *a = acc + (size_t)i * NA;
+        float g2x = (float)a[0], g2y = (float)a[1], gcx = (float)a[2], gcy = (float)a[3], gcz = (float)a[4];
+        dmeans2D[3 * i] = g2x; dmeans2D[3 * i + 1] = g2y;
+        dopac[i] = (float)a[5];
+        for (int ch = 0; ch < C; ch++) dcolors[(size_t)i * C + ch] = (float)a[6 + ch];
+
+        const float *p = means3D + 3 * i;
+        float tv[3];
+        for (int r = 0; r < 3; r++) tv[r] = m4(view, r, 0) * p[0] + m4(view, r, 1) * p[1] + m4(view, r, 2) * p[2] + m4(view, r, 3);
+        float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+        float txtz = tv[0] / tv[2], tytz = tv[1] / tv[2];
+        float tx = fminf(limx, fmaxf(-limx, txtz)) * tv[2], ty = fminf(limy, fmaxf(-limy, tytz)) * tv[2], tz = tv[2];
+        float xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f, ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+        float J[2][3] = {{fx / tz, 0.f, -(fx * tx) / (tz * tz)}, {0.f, fy / tz, -(fy * ty) / (tz * tz)}};
+        float T[2][3];
+        for (int r = 0; r < 2; r++) for (int k = 0; k < 3; k++)
+            T[r][k] = J[r][0] * m4(view, 0, k) + J[r][1] * m4(view, 1, k) + J[r][2] * m4(view, 2, k);
+        const float *S6 = c->cov3d + 6 * i;
+        float Sg[3][3] = {{S6[0], S6[1], S6[2]}, {S6[1], S6[3], S6[4]}, {S6[2], S6[4], S6[5]}};
+        float ca = c->cov2d[3 * i], cb = c->cov2d[3 * i + 1], cc = c->cov2d[3 * i + 2];
+        float det = ca * cc - cb * cb;
+        float d2 = 1.f / (det * det + 0.0000001f);
+        float dLa = d2 * (-cc * cc * gcx + cb * cc * gcy - cb * cb * gcz);
+        float dLc = d2 * (-cb * cb * gcx + ca * cb * gcy - ca * ca * gcz);
+        float dLb = d2 * (2.f * cb * cc * gcx - (det + 2.f * cb * cb) * gcy + 2.f * ca * cb * gcz);
+        /* symmetric gradient of the 2x2 covariance */
+        float G2[2][2] = {{dLa, 0.5f * dLb}, {0.5f * dLb, dLc}};
+        /* dL/dSigma = T^T G2 T */
+        float GT[2][3];
+        for (int r = 0; r < 2; r++) for (int k = 0; k < 3; k++) GT[r][k] = G2[r][0] * T[0][k] + G2[r][1] * T[1][k];
+        float dS[3][3];
+        for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) dS[r][k] = T[0][r] * GT[0][k] + T[1][r] * GT[1][k];
+        float g6[6] = {dS[0][0], 2.f * dS[0][1], 2.f * dS[0][2], dS[1][1], 2.f * dS[1][2], dS[2][2]};
+        if (dcov3D) memcpy(dcov3D + 6 * i, g6, 24);
+        /* dL/dT = 2 G2 T Sigma */
+        float TS[2][3], dT[2][3];
+        for (int r = 0; r < 2; r++) for (int k = 0; k < 3; k++) TS[r][k] = T[r][0] * Sg[0][k] + T[r][1] * Sg[1][k] + T[r][2] * Sg[2][k];
+        for (int r = 0; r < 2; r++) for (int k = 0; k < 3; k++) dT[r][k] = 2.f * (G2[r][0] * TS[0][k] + G2[r][1] * TS[1][k]);
+        /* dL/dJ = dT W3^T */
+        float dJ[2][3];
+        for (int r = 0; r < 2; r++) for (int k = 0; k < 3; k++)
+            dJ[r][k] = dT[r][0] * m4(view, k, 0) + dT[r][1] * m4(view, k, 1) + dT[r][2] * m4(view, k, 2);
+        float iz = 1.f / tz, iz2 = iz * iz, iz3 = iz2 * iz;
+        float dtx = xmul * -fx * iz2 * dJ[0][2];
+        float dty = ymul * -fy * iz2 * dJ[1][2];
+        float dtz = -fx * iz2 * dJ[0][0] - fy * iz2 * dJ[1][1] + 2.f * fx * tx * iz3 * dJ[0][2] + 2.f * fy * ty * iz3 * dJ[1][2];
+        for (int k = 0; k < 3; k++) gm[k] = m4(view, 0, k) * dtx + m4(view, 1, k) * dty + m4(view, 2, k) * dtz;
+        /* projection: NDC gradient -> centre */
+        float hom[4];
+        for (int r = 0; r < 4; r++) hom[r] = m4(proj, r, 0) * p[0] + m4(proj, r, 1) * p[1] + m4(proj, r, 2) * p[2] + m4(proj, r, 3);
+        float pw = 1.f / (hom[3] + 0.0000001f);
+        for (int k = 0; k < 3; k++) {
+            float dndcx = m4(proj, 0, k) * pw - hom[0] * pw * pw * m4(proj, 3, k);
+            float dndcy = m4(proj, 1, k) * pw - hom[1] * pw * pw * m4(proj, 3, k);
+            gm[k] += dndcx * g2x + dndcy * g2y;
+        }
+        /* Sigma = M M^T, M = R diag(mod*s)  ->  scale and quaternion */
+        if (dscales && scales) {
+            float R[3][3], Gs[3][3] = {{g6[0], 0.5f * g6[1], 0.5f * g6[2]}, {0.5f * g6[1], g6[3], 0.5f * g6[4]}, {0.5f * g6[2], 0.5f * g6[4], g6[5]}};
+            const float *q = rot + 4 * i; quat_rot(q, R);
+            float sv[3] = {mod * scales[3 * i], mod * scales[3 * i + 1], mod * scales[3 * i + 2]};
+            float dM[3][3], A[3][3];
+            for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) {
+                float v = 0.f; for (int m = 0; m < 3; m++) v += Gs[r][m] * R[m][k] * sv[k];
+                dM[r][k] = 2.f * v;
+            }
+            for (int k = 0; k < 3; k++) {
+                dscales[3 * i + k] = mod * (dM[0][k] * R[0][k] + dM[1][k] * R[1][k] + dM[2][k] * R[2][k]);
+                for (int r = 0; r < 3; r++) A[r][k] = dM[r][k] * sv[k];
+            }
+            float r_ = q[0], x = q[1], y = q[2], z = q[3];
+            drot[4 * i + 0] = 2.f * (-z * A[0][1] + y * A[0][2] + z * A[1][0] - x * A[1][2] - y * A[2][0] + x * A[2][1]);
+            drot[4 * i + 1] = 2.f * (y * A[0][1] + z * A[0][2] + y * A[1][0] - 2.f * x * A[1][1] - r_ * A[1][2] + z * A[2][0] + r_ * A[2][1] - 2.f * x * A[2][2]);
+            drot[4 * i + 2] = 2.f * (-2.f * y * A[0][0] + x * A[0][1] + r_ * A[0][2] + x * A[1][0] + z * A[1][2] - r_ * A[2][0] + z * A[2][1] - 2.f * y * A[2][2]);
+            drot[4 * i + 3] = 2.f * (-2.f * z * A[0][0] - r_ * A[0][1] + x * A[0][2] + r_ * A[1][0] - 2.f * z * A[1][1] + y * A[1][2] + x * A[2][0] + y * A[2][1]);
+        }
+    }
+    free(acc);
+    return 0;
+}
+
+/* markVisible of the boundary */
+void ref_mark_visible(int P, const float *means3D, const float *view, unsigned char *present) {
+    for (int i = 0; i < P; i++) {
+        const float *p = means3D + 3 * i;
+        float z = m4(view, 2, 0) * p[0] + m4(view, 2, 1) * p[1] + m4(view, 2, 2) * p[2] + m4(view, 2, 3);
+        present[i] = z > 0.2f;
+    }
+}
