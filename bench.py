@@ -1,0 +1,323 @@
+#!/usr/bin/env python3
+"""Benchmark of the SplaTAM hot path on MI355X.
+
+A *step* is one optimisation iteration of the reference's per-frame loops
+(/root/reference/scripts/splatam.py:690-711 tracking, :828-869 mapping):
+``get_loss`` (two rasterizer forwards) -> ``backward`` (two rasterizer backwards)
+-> Adam step, at BASELINE.json config B: 300 000 Gaussians, 1200x680, Replica
+intrinsics, synthetic data.  Steps follow the reference's 40:60 tracking:mapping
+mix (2 tracking + 3 mapping per 5 steps).  With N > 1 ranks every rank runs the
+same schedule on its own frame / keyframe view (weak scaling); mapping steps
+exchange Gaussian gradients with one RCCL all-reduce, tracking steps are replicas.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    # name: (N, W, H, fx, fy, cx, cy)
+    "A": (10_000, 320, 240, 300.0, 300.0, 159.5, 119.5),
+    "B": (300_000, 1200, 680, 600.0, 600.0, 599.5, 339.5),       # /root/reference/configs/data/replica.yaml:3-8
+    "D": (150_000, 640, 480, 517.3, 516.5, 318.6, 255.3),        # /root/reference/configs/data/TUM/freiburg1_desk.yaml:3-8
+    "E": (1_000_000, 1752, 1168, 1200.0, 1200.0, 875.5, 583.5),  # /root/reference/datasets/gradslam_datasets/scannetpp.py:28-29
+}
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_scene(name, dev, n_views, seed=0):
+    from splatam_amd import slam
+    N, W, H, fx, fy, cx, cy = WORKLOADS[name]
+    num_frames = 2 + n_views
+    params, variables = slam.synthetic_params(N, W, H, fx, fy, cx, cy, num_frames=num_frames, seed=seed, device=dev)
+    k = [[fx, 0, cx], [0, fy, cy], [0, 0, 1]]
+    first_w2c = torch.eye(4, device=dev)
+    cam = slam.setup_camera(W, H, k, first_w2c.cpu().numpy(), device=dev)
+    g = torch.Generator().manual_seed(seed + 7)
+    frames = {}
+    # frame 1 is the frame being tracked; frames 2.. are keyframe views on a small arc
+    for t in range(1, num_frames):
+        rot = 0.5 if t == 1 else 0.3 * (t - 1)
+        tr = 0.01 if t == 1 else 0.02 * (t - 1)
+        im, depth = slam.synthetic_frame(params, cam, first_w2c, t, rot_deg=rot, trans_m=tr)
+        if t > 1:   # keyframes: the pose is known (set it), add sensor noise so that mapping has a gradient
+            import math
+            with torch.no_grad():
+                ang = math.radians(rot)
+                params['cam_unnorm_rots'][..., t] = torch.tensor([[math.cos(ang / 2), 0.0, math.sin(ang / 2), 0.0]], device=dev)
+                params['cam_trans'][..., t] = torch.tensor([[tr, -tr / 2, tr / 2]], device=dev)
+            im = (im + 0.05 * torch.randn(im.shape, generator=g).to(dev)).clamp(0, 1)
+            depth = depth * (1 + 0.01 * torch.randn(depth.shape, generator=g).to(dev))
+        frames[t] = {'cam': cam, 'im': im, 'depth': depth, 'id': t, 'w2c': first_w2c}
+    return params, variables, frames, (N, W, H)
+
+
+def run_steps(params, variables, frames, bucket, rank, world, nsteps, opt_track, opt_map, track_state, start=0):
+    from splatam_amd import slam
+    n_views = len(frames) - 1
+    for i in range(start, start + nsteps):
+        if i % 5 < 2:
+            slam.tracking_iteration(params, frames[1], variables, 1, opt_track, track_state)
+        else:
+            view = 2 + (rank + i * world) % n_views
+            data = frames[view]
+            loss, variables, _ = slam.get_loss(params, data, variables, view, slam.REPLICA_MAPPING['loss_weights'],
+                                               False, 0.5, True, False, mapping=True)
+            loss.backward()
+            if world > 1:
+                bucket.all_reduce_mean(params)
+            with torch.no_grad():
+                opt_map.step()
+                opt_map.zero_grad(set_to_none=True)
+    return variables
+
+
+def phase_rate(fn, n, dev):
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize(dev)
+    return n / (time.perf_counter() - t0)
+
+
+def kernel_roofline(params, frames, shape, dev):
+    """Live HIP-event timing of the two composite kernels on the stream they are
+    launched on (splat_time_kernel), priced against the algorithmic bytes of
+    SURVEY.md 8(d): K6 = R*44 + HW*24, K7 = R*40 + HW*20 + N*44."""
+    import ctypes as C
+    from splatam_amd import _capi, slam
+    from splatam_amd import rasterizer as rz
+    N, W, H = shape
+    with torch.no_grad():
+        tg = slam.transform_to_frame(params, 1, False, False)
+        rv = slam.transformed_params2rendervar(params, tg)
+    empty = torch.empty(0, device=dev)
+    args = (frames[1]['cam'], rv['means3D'].contiguous(), rv['colors_precomp'].detach().contiguous(),
+            rv['opacities'].detach().reshape(-1).contiguous(), rv['scales'].detach().contiguous(),
+            rv['rotations'].detach().contiguous(), empty, empty)
+    mode = rz.get_sync_mode()
+    rz.set_sync_mode("exact")
+    color, radii, depth, pk = rz.rasterize_forward(*args)
+    rz.set_sync_mode(mode)
+    R = pk.num_rendered
+    gcol = torch.randn_like(color)
+    f32 = torch.float32
+    bufs = dict(accum=torch.empty(N, _capi.SPLAT_GRAD_STRIDE, dtype=f32, device=dev), m3=torch.empty(N, 3, device=dev),
+                m2=torch.empty(N, 3, device=dev), col=torch.empty(N, 3, device=dev), op=torch.empty(N, device=dev),
+                sc=torch.empty(N, 3, device=dev), ro=torch.empty(N, 4, device=dev))
+    gr = _capi.SplatGrads()
+    gr.dL_dcolor, gr.accum = gcol.data_ptr(), bufs['accum'].data_ptr()
+    gr.dL_dmeans3D, gr.dL_dmeans2D, gr.dL_dcolors = bufs['m3'].data_ptr(), bufs['m2'].data_ptr(), bufs['col'].data_ptr()
+    gr.dL_dopacities, gr.dL_dscales, gr.dL_drotations = bufs['op'].data_ptr(), bufs['sc'].data_ptr(), bufs['ro'].data_ptr()
+    L = _capi.lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    out = {}
+    for fn, name in ((0, "render_forward"), (1, "render_backward")):
+        ms = C.c_float(0)
+        for iters in (3, 20):     # warm-up, then measure
+            _capi.check(L.splat_time_kernel(fn, iters, C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), C.byref(gr),
+                                            color.data_ptr(), depth.data_ptr(), stream, C.byref(ms)), "splat_time_kernel")
+        out[name] = ms.value
+    HW = W * H
+    bytes_fwd = R * 44 + HW * 24
+    bytes_bwd = R * 40 + HW * 20 + N * 44
+    gbs_f = bytes_fwd / (out["render_forward"] * 1e-3) / 1e9
+    gbs_b = bytes_bwd / (out["render_backward"] * 1e-3) / 1e9
+    dominant = "render_backward" if out["render_backward"] >= out["render_forward"] else "render_forward"
+    ach = gbs_b if dominant == "render_backward" else gbs_f
+    roof = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+            "traffic": None, "kernel": dominant, "kernel_ms": round(out[dominant], 4),
+            "algorithmic_bytes": bytes_bwd if dominant == "render_backward" else bytes_fwd,
+            "other": {"render_forward_ms": round(out["render_forward"], 4), "render_forward_GBps": round(gbs_f, 2),
+                      "render_backward_ms": round(out["render_backward"], 4), "render_backward_GBps": round(gbs_b, 2),
+                      "num_rendered": R, "pairs_per_launch": None}}
+    return roof, pk
+
+
+def render_mpix(params, frames, shape, dev, reps=10):
+    """Forward + backward of ONE 3-channel rasterizer call through the autograd surface."""
+    from splatam_amd import slam
+    from splatam_amd.rasterizer import GaussianRasterizer as Renderer
+    N, W, H = shape
+    with torch.no_grad():
+        tg = slam.transform_to_frame(params, 1, False, False)
+        rv = {k: v.detach() for k, v in slam.transformed_params2rendervar(params, tg).items()}
+    inp = {k: v.clone().requires_grad_(True) for k, v in rv.items()}
+    gout = torch.randn(3, H, W, device=dev)
+
+    def once():
+        im, _, _ = Renderer(raster_settings=frames[1]['cam'])(**inp)
+        im.backward(gout)
+        for v in inp.values():
+            v.grad = None
+    once()
+    rate = phase_rate(once, reps, dev)
+    return W * H * rate / 1e6, 1e3 / rate
+
+
+def cpu_baseline(name, params, frames, budget_s=25.0):
+    """The reference's CPU plumbing (same host-side code on CPU tensors) around the
+    C oracle rasterizer (oracle/raster_ref.c, 'port'), one tracking iteration of the
+    same workload, timed on this box's host cores."""
+    from oracle import c_ref
+    from splatam_amd import slam
+    import numpy as np
+
+    class _CpuRaster(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, means3D, means2D, colors, opac, scales, rots, cam):
+            cr = c_ref.CRef()
+            col, radii, dep = cr.forward(means3D.detach().numpy(), colors.detach().numpy(), opac.detach().numpy(),
+                                         scales.detach().numpy(), rots.detach().numpy(), cam.viewmatrix.numpy(),
+                                         cam.projmatrix.numpy(), cam.tanfovx, cam.tanfovy, cam.image_width,
+                                         cam.image_height, cam.bg.numpy())
+            ctx.cr = cr
+            return torch.from_numpy(col), torch.from_numpy(radii), torch.from_numpy(dep)
+
+        @staticmethod
+        def backward(ctx, gcol, _r, _d):
+            g = ctx.cr.backward(gcol.contiguous().numpy())
+            t = torch.from_numpy
+            return t(g['means3D']), t(g['means2D']), t(g['colors']), t(g['opacities']), t(g['scales']), t(g['rotations']), None
+
+    class _CpuRenderer:
+        def __init__(self, raster_settings):
+            self.s = raster_settings
+
+        def __call__(self, means3D, means2D, opacities, colors_precomp, scales, rotations):
+            return _CpuRaster.apply(means3D, means2D, colors_precomp, opacities, scales, rotations, self.s)
+
+    cpu_params = {k: torch.nn.Parameter(v.detach().cpu().clone()) for k, v in params.items()}
+    f = frames[1]
+    cam = f['cam']
+    cam_cpu = type(cam)(*[(x.cpu() if torch.is_tensor(x) else x) for x in cam])
+    data = {'cam': cam_cpu, 'im': f['im'].cpu(), 'depth': f['depth'].cpu(), 'id': 1, 'w2c': torch.eye(4)}
+    n = cpu_params['means3D'].shape[0]
+    variables = {'max_2D_radius': torch.zeros(n)}
+    opt = slam.initialize_optimizer(cpu_params, slam.REPLICA_TRACKING['lrs'], tracking=True)
+    saved = slam.Renderer
+    slam.Renderer = _CpuRenderer
+    try:
+        def one():
+            cfg = slam.REPLICA_TRACKING
+            loss, _, _ = slam.get_loss(cpu_params, data, variables, 1, cfg['loss_weights'], cfg['use_sil_for_loss'],
+                                       cfg['sil_thres'], cfg['use_l1'], cfg['ignore_outlier_depth_loss'], tracking=True)
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        one()                                   # warm-up
+        times = []
+        t_all = time.perf_counter()
+        while len(times) < 5 and (time.perf_counter() - t_all) < budget_s:
+            t0 = time.perf_counter()
+            one()
+            times.append(time.perf_counter() - t0)
+    finally:
+        slam.Renderer = saved
+    med = float(np.median(times))
+    return {"value": round(1.0 / med, 4), "unit": "iters/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{len(times)} tracking iterations (2 fwd + 2 bwd rasterizations + host glue + Adam) of workload {name} "
+                      f"at full size; C oracle (OpenMP, {os.cpu_count()} threads) + PyTorch-CPU glue; median {med:.3f} s/iter"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="B", choices=sorted(WORKLOADS))
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--sync-mode", default="exact", choices=["exact", "lazy"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from splatam_amd import dist as sdist
+    from splatam_amd import rasterizer as rz
+    from splatam_amd import slam
+    rank, world, local_rank = sdist.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP rasterizer has no CPU path)")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    rz.set_sync_mode(args.sync_mode)
+
+    params, variables, frames, shape = build_scene(args.workload, dev, args.views)
+    bucket = sdist.GradBucket(params) if world > 1 else None
+    opt_track = slam.initialize_optimizer(params, slam.REPLICA_TRACKING['lrs'], tracking=True)
+    opt_map = slam.initialize_optimizer(params, slam.REPLICA_MAPPING['lrs'], tracking=False)
+    tstate = slam.TrackingState(params, 1)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    variables = run_steps(params, variables, frames, bucket, rank, world, args.warmup, opt_track, opt_map, tstate, 0)
+    barrier()
+    t0 = time.perf_counter()
+    variables = run_steps(params, variables, frames, bucket, rank, world, args.steps, opt_track, opt_map, tstate, args.warmup)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-phase rates (rank-local, informational)
+    n_phase = max(5, min(20, args.steps))
+    track_rate = phase_rate(lambda: slam.tracking_iteration(params, frames[1], variables, 1, opt_track, tstate), n_phase, dev)
+
+    def map_once():
+        loss, _, _ = slam.get_loss(params, frames[2], variables, 2, slam.REPLICA_MAPPING['loss_weights'], False, 0.5, True, False, mapping=True)
+        loss.backward()
+        with torch.no_grad():
+            opt_map.step()
+            opt_map.zero_grad(set_to_none=True)
+    map_rate = phase_rate(map_once, n_phase, dev)
+
+    result = None
+    if rank == 0:
+        N, W, H = shape
+        mpix, ms_call = render_mpix(params, frames, shape, dev)
+        result = {
+            "metric": "track+map iters/sec @300k Gaussians (render+backward Mpix/s alongside)",
+            "value": round(args.steps * world / elapsed, 3), "unit": "iters/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {N} Gaussians, {W}x{H}, SplaTAM tracking+mapping loop (2:3 mix), isotropic map",
+                       "gaussians": N, "width": W, "height": H, "views": args.views, "sync_mode": args.sync_mode,
+                       "parallelism": "1 process/GPU; mapping views sharded, one gradient all-reduce; tracking replicas"},
+            "tracking_iters_per_s": round(track_rate, 3), "mapping_iters_per_s": round(map_rate, 3),
+            "render_fwd_bwd_mpix_per_s": round(mpix, 2), "render_fwd_bwd_ms": round(ms_call, 4),
+            "host_cores": os.cpu_count(),
+        }
+        if not args.no_roofline:
+            roof, _ = kernel_roofline(params, frames, shape, dev)
+            result["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.workload, params, frames)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,171 @@
+/*
+ * splat_hip.h -- C ABI of libsplat_hip.so, the MI355X (gfx950) Gaussian-splat
+ * rasterizer (forward + backward).
+ *
+ * This is the drop-in boundary for the one hot path of SplaTAM: the un-vendored
+ * extension `diff_gaussian_rasterization._C` (pinned at
+ * /root/reference/requirements.txt:15, imported at
+ * /root/reference/scripts/splatam.py:37 and /root/reference/utils/recon_helpers.py:2).
+ * Each entry point below names the reference-side call it replaces.  Every
+ * pointer is a raw DEVICE pointer owned by the caller (PyTorch's caching
+ * allocator in the Python binding); the library never allocates, never frees,
+ * never synchronises the device and launches everything on the stream it is
+ * handed.  All functions return 0 on success and a SPLAT_E_* code otherwise
+ * (nothing is thrown across the ABI); splat_error_string() maps codes to text.
+ *
+ * Conventions (/root/reference/utils/recon_helpers.py:8-13):
+ *   - viewmatrix / projmatrix: 16 floats, element (row r, col c) at m[c*4+r],
+ *     i.e. the bytes of the settings tensor `w2c^T` / `(P w2c)^T` as stored.
+ *   - quaternions (r,x,y,z), not renormalised; opacities already in (0,1);
+ *     scales already exponentiated (/root/reference/utils/slam_helpers.py:131-138).
+ *   - images are planar [C][H][W] float32.
+ */
+#ifndef SPLAT_HIP_H
+#define SPLAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPLAT_ABI_VERSION 1
+#define SPLAT_TILE 16            /* tile edge in pixels (one wave64 = one 16x16 tile, 4 px per lane) */
+#define SPLAT_MAX_CHANNELS 8     /* colour channels per call: 3 for the reference API, up to 8 for fused passes */
+#define SPLAT_GRAD_STRIDE 16     /* floats per Gaussian in the backward accumulator (one 64-byte line) */
+
+enum {
+    SPLAT_OK = 0,
+    SPLAT_E_INVALID = 1,         /* bad argument (null pointer, channel count, negative size) */
+    SPLAT_E_LAUNCH = 2,          /* hipGetLastError() != hipSuccess after a launch */
+    SPLAT_E_UNSUPPORTED = 3      /* feature not built into this library */
+};
+
+/* Mirrors the reference settings tuple field by field
+ * (/root/reference/utils/recon_helpers.py:14-26); tensors become device pointers. */
+typedef struct SplatCamera {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    const float *bg;             /* [channels] */
+    float scale_modifier;
+    const float *viewmatrix;     /* [16] */
+    const float *projmatrix;     /* [16] */
+    int32_t sh_degree;
+    const float *campos;         /* [3] (only read when shs != NULL) */
+    int32_t prefiltered;
+} SplatCamera;
+
+/* The per-Gaussian inputs of GaussianRasterizer.__call__
+ * (/root/reference/scripts/splatam.py:249; kwargs built at
+ * /root/reference/utils/slam_helpers.py:131-138). */
+typedef struct SplatGaussians {
+    int32_t P;                   /* number of Gaussians */
+    int32_t channels;            /* colour channels C (3 through the reference API) */
+    const float *means3D;        /* [P][3] */
+    const float *opacities;      /* [P] */
+    const float *colors_precomp; /* [P][C] or NULL when shs is given */
+    const float *scales;         /* [P][3] or NULL when cov3D_precomp is given */
+    const float *rotations;      /* [P][4] or NULL when cov3D_precomp is given */
+    const float *cov3D_precomp;  /* [P][6] or NULL */
+    const float *shs;            /* [P][sh_coeffs][3] or NULL */
+    int32_t sh_coeffs;           /* M */
+} SplatGaussians;
+
+/* State that lives from forward to backward (the reference keeps the same
+ * information in its geomBuffer / binningBuffer / imgBuffer byte tensors). */
+typedef struct SplatState {
+    /* per-Gaussian geometry, written by splat_preprocess_forward */
+    float *depth;                /* [P]     view-space z */
+    float *xy;                   /* [P][2]  pixel centre */
+    float *conic_opacity;        /* [P][4]  inverse 2D covariance (xx, xy, yy) + opacity */
+    uint32_t *rect;              /* [P][2]  tile rect packed (minx | miny<<16, maxx | maxy<<16); max exclusive */
+    int32_t *radii;              /* [P]     3-sigma radius in pixels, 0 = culled (an OUTPUT of the reference API) */
+    float *rgb;                  /* [P][3]  colours evaluated from SH (NULL unless shs is used) */
+    uint8_t *clamped;            /* [P][3]  SH clamp flags (NULL unless shs is used) */
+    /* per-tile */
+    uint32_t *tile_count;        /* [T]     instances per tile */
+    uint32_t *tile_base;         /* [T+1]   exclusive prefix sum of tile_count */
+    uint32_t *tile_cursor;       /* [T]     scatter cursors */
+    /* per-instance ((Gaussian, tile) pairs) */
+    uint64_t *keys;              /* [capacity] (float bits of depth << 32) | Gaussian id, bucketed by tile */
+    uint32_t *point_list;        /* [capacity] Gaussian ids, each tile's slice sorted by key */
+    int64_t capacity;
+    /* per-pixel */
+    float *final_T;              /* [H][W] */
+    int32_t *n_contrib;          /* [H][W] 1-based list position of the last contributor */
+    /* status words: [0] num_rendered  [1] overflow flag (num_rendered > capacity)
+     *               [2] longest tile list  [3] reserved */
+    int32_t *status;             /* [4] */
+} SplatState;
+
+const char *splat_error_string(int code);
+int splat_abi_version(void);
+
+/* Bytes of scratch each SplatState array needs; lets a host binding size its
+ * buffers the way the reference's resize-callback does. */
+size_t splat_num_tiles(int32_t width, int32_t height);
+
+/* K1 + tile scan.  Replaces the first half of `_C.rasterize_gaussians`
+ * (preprocess, prefix sum).  Writes depth/xy/conic_opacity/rect/radii,
+ * tile_count/tile_base/tile_cursor and status[0..2].  The host may read
+ * status[0] (num_rendered) to size keys/point_list, as the reference does. */
+int splat_preprocess_forward(const SplatCamera *cam, const SplatGaussians *g, SplatState *st, void *stream);
+
+/* Scatter (Gaussian, tile) instances into per-tile buckets and sort every
+ * bucket by (depth bits, id).  Replaces duplicateWithKeys + the global radix
+ * sort + identifyTileRanges of the reference.  A no-op that leaves status[1]
+ * set when num_rendered > st->capacity. */
+int splat_bin_forward(const SplatCamera *cam, const SplatGaussians *g, SplatState *st, void *stream);
+
+/* Tile-wise alpha compositing.  out_color [C][H][W], out_depth [H][W].
+ * `colors` is [P][C]: colors_precomp, or st->rgb when SH were evaluated. */
+int splat_render_forward(const SplatCamera *cam, const SplatGaussians *g, SplatState *st,
+                         float *out_color, float *out_depth, void *stream);
+
+/* All three of the above back to back (capacity must already be sufficient). */
+int splat_forward(const SplatCamera *cam, const SplatGaussians *g, SplatState *st,
+                  float *out_color, float *out_depth, void *stream);
+
+/* Gradient outputs of `_C.rasterize_gaussians_backward`
+ * (autograd backward reached from /root/reference/scripts/splatam.py:702,854). */
+typedef struct SplatGrads {
+    const float *dL_dcolor;      /* [C][H][W] incoming gradient of out_color */
+    float *accum;                /* [P][SPLAT_GRAD_STRIDE] scratch, zeroed by the library */
+    float *dL_dmeans3D;          /* [P][3] */
+    float *dL_dmeans2D;          /* [P][3] NDC-space gradient of the projected centre, z = 0 */
+    float *dL_dcolors;           /* [P][C] (NULL when shs are used) */
+    float *dL_dopacities;        /* [P] */
+    float *dL_dscales;           /* [P][3] or NULL */
+    float *dL_drotations;        /* [P][4] or NULL */
+    float *dL_dcov3D;            /* [P][6] or NULL */
+    float *dL_dshs;              /* [P][M][3] or NULL */
+} SplatGrads;
+
+/* Per-pixel back-to-front replay; accumulates per-Gaussian partial sums into gr->accum. */
+int splat_render_backward(const SplatCamera *cam, const SplatGaussians *g, const SplatState *st,
+                          SplatGrads *gr, void *stream);
+
+/* Per-Gaussian chain rule from gr->accum to every dL_d* output. */
+int splat_preprocess_backward(const SplatCamera *cam, const SplatGaussians *g, const SplatState *st,
+                              SplatGrads *gr, void *stream);
+
+/* Both of the above back to back. */
+int splat_backward(const SplatCamera *cam, const SplatGaussians *g, const SplatState *st,
+                   SplatGrads *gr, void *stream);
+
+/* `_C.mark_visible` of the reference extension: present[i] = (view-space z > 0.2). */
+int splat_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, uint8_t *present, void *stream);
+
+/* Kernel-only timing helper for bench.py: runs `fn` (0 = render forward,
+ * 1 = render backward) `iters` times on `stream` between two hipEvents created
+ * on that same stream and returns the mean milliseconds per launch in *ms. */
+int splat_time_kernel(int fn, int iters, const SplatCamera *cam, const SplatGaussians *g, SplatState *st,
+                      SplatGrads *gr, float *out_color, float *out_depth, void *stream, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPLAT_HIP_H */

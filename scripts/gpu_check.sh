@@ -1,0 +1,22 @@
+#!/bin/bash
+# One gpurun call: GPU self-tests, parity tests, smoke, bench; logs land in gpurun_out/.
+# usage: scripts/gpu_check.sh [quick|full|prof]
+mode=${1:-quick}
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+python -c "import torch; print(torch.cuda.get_device_name(0))" > gpurun_out/device.log 2>&1
+nproc >> gpurun_out/device.log
+for f in test_gpu_primitives test_gpu_parity; do
+  timeout 600 python -m pytest tests/$f.py -m gpu -q --timeout 300 -p no:cacheprovider 2>&1 | tail -60 > gpurun_out/$f.log
+done
+timeout 300 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1
+if [ "$mode" != "quick" ]; then
+  timeout 900 python bench.py --steps 30 --warmup 10 > gpurun_out/bench.log 2>&1
+fi
+if [ "$mode" = "prof" ]; then
+  cd /tmp
+  timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r1 -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1
+  cd $GRAFT_REPO_ROOT
+  find gpurun_out/prof -name "*stats*" | head -20 > gpurun_out/prof_files.log
+fi
+tail -5 gpurun_out/*.log

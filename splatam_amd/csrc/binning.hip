@@ -1,0 +1,135 @@
+// binning.hip -- builds the per-tile, depth-ordered Gaussian lists.
+//
+// The reference does this with one global 64-bit radix sort over all
+// (tile | depth) keys (5-6 passes over R instances in HBM).  Here every
+// instance is scattered ONCE into its tile's bucket (bucket offsets come from
+// the tile scan), and each bucket is then sorted on its own inside LDS by one
+// workgroup: one read + one write of the instance stream in HBM in total.
+// Keys are (float bits of depth << 32) | Gaussian id -- unique, so the order
+// is exactly "ascending depth, ties by ascending index" (the order a stable
+// sort of index-ordered emission produces), independent of scatter order.
+#include "splat_device.h"
+
+namespace splat {
+
+constexpr int kBlock = 256;
+constexpr int kSortLds = 4096;                 // keys sorted in LDS per tile (32 KiB); longer lists spill to HBM
+
+// K3: one lane per Gaussian, one bucket slot per touched tile.
+__global__ __launch_bounds__(kBlock) void scatter_kernel(SplatGaussians g, SplatState st, int gx) {
+    if ((long long)st.status[0] > st.capacity) return;      // lists would not fit: host re-sizes and retries
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= g.P) return;
+    if (st.radii[i] <= 0) return;
+    const uint2 r = reinterpret_cast<const uint2 *>(st.rect)[i];
+    const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff, y1 = r.y >> 16;
+    const uint64_t key = ((uint64_t)__float_as_uint(st.depth[i]) << 32) | (uint32_t)i;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            const unsigned slot = atomicAdd(&st.tile_cursor[y * gx + x], 1u);
+            st.keys[slot] = key;
+        }
+}
+
+// Bitonic network with ascending-only compare-exchanges ("flip" form), so that
+// virtual +inf padding above n never has to be stored: an exchange whose upper
+// index is >= n is skipped.
+template <typename KeyPtr>
+__device__ __forceinline__ void bitonic_sort(KeyPtr keys, const int n, const int tid, const int nthreads) {
+    int N2 = 2;
+    while (N2 < n) N2 <<= 1;
+    const int half_n = N2 >> 1;
+    for (int k = 2; k <= N2; k <<= 1) {
+        const int hk = k >> 1;
+        for (int i = tid; i < half_n; i += nthreads) {
+            const int blk = i / hk, off = i - blk * hk;
+            const int a = blk * k + off, b = blk * k + k - 1 - off;
+            if (b < n) {
+                const uint64_t ka = keys[a], kb = keys[b];
+                if (ka > kb) { keys[a] = kb; keys[b] = ka; }
+            }
+        }
+        __syncthreads();
+        for (int j = hk >> 1; j >= 1; j >>= 1) {
+            for (int i = tid; i < half_n; i += nthreads) {
+                const int blk = i / j, off = i - blk * j;
+                const int a = blk * 2 * j + off, b = a + j;
+                if (b < n) {
+                    const uint64_t ka = keys[a], kb = keys[b];
+                    if (ka > kb) { keys[a] = kb; keys[b] = ka; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// K4(+K5): one workgroup per tile.  tile_base already holds the ranges.
+__global__ __launch_bounds__(kBlock) void tile_sort_kernel(SplatState st) {
+    __shared__ uint64_t s_keys[kSortLds];
+    if ((long long)st.status[0] > st.capacity) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) st.status[1] = 1;
+        return;
+    }
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    const unsigned lo = st.tile_base[tile], hi = st.tile_base[tile + 1];
+    const int n = (int)(hi - lo);
+    if (n == 0) return;
+    uint64_t *gk = st.keys + lo;
+    if (n <= kSortLds) {
+        for (int i = tid; i < n; i += kBlock) s_keys[i] = gk[i];
+        __syncthreads();
+        if (n > 1) bitonic_sort(s_keys, n, tid, kBlock);
+        for (int i = tid; i < n; i += kBlock) st.point_list[lo + i] = (uint32_t)s_keys[i];
+    } else {
+        // spilled tile list: same network run in place on the HBM bucket (L2-resident)
+        bitonic_sort(gk, n, tid, kBlock);
+        for (int i = tid; i < n; i += kBlock) st.point_list[lo + i] = (uint32_t)gk[i];
+    }
+}
+
+hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s) {
+    const int gx = (cam.image_width + kTile - 1) / kTile;
+    const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
+    if (g.P > 0) hipLaunchKernelGGL(scatter_kernel, dim3((g.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, g, st, gx);
+    if (T > 0) hipLaunchKernelGGL(tile_sort_kernel, dim3(T), dim3(kBlock), 0, s, st);
+    return hipGetLastError();
+}
+
+// ---- self tests (driven from tests/test_gpu_primitives.py) ------------------
+// which = 0: wave_reduce4_packed on 4*64 floats per wave -> 64 floats per wave
+// which = 1: bitonic_sort of n uint64 keys in LDS (n <= kSortLds), one workgroup
+// which = 2: bitonic_sort of n uint64 keys in global memory, one workgroup
+__global__ __launch_bounds__(64) void selftest_reduce_kernel(const float *in, float *out) {
+    const int l = threadIdx.x, w = blockIdx.x;
+    const float *p = in + (size_t)w * 256;
+    out[(size_t)w * 64 + l] = wave_reduce4_packed(p[l], p[64 + l], p[128 + l], p[192 + l]);
+}
+__global__ __launch_bounds__(kBlock) void selftest_sort_lds_kernel(const uint64_t *in, uint64_t *out, int n) {
+    __shared__ uint64_t s_keys[kSortLds];
+    for (int i = threadIdx.x; i < n; i += kBlock) s_keys[i] = in[i];
+    __syncthreads();
+    if (n > 1) bitonic_sort(s_keys, n, threadIdx.x, kBlock);
+    for (int i = threadIdx.x; i < n; i += kBlock) out[i] = s_keys[i];
+}
+__global__ __launch_bounds__(kBlock) void selftest_sort_global_kernel(uint64_t *keys, int n) {
+    if (n > 1) bitonic_sort(keys, n, threadIdx.x, kBlock);
+}
+
+hipError_t launch_selftest(int which, const void *in, void *out, int n, hipStream_t s) {
+    if (which == 0) {
+        hipLaunchKernelGGL(selftest_reduce_kernel, dim3(n), dim3(64), 0, s, (const float *)in, (float *)out);
+    } else if (which == 1) {
+        if (n > kSortLds) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(selftest_sort_lds_kernel, dim3(1), dim3(kBlock), 0, s, (const uint64_t *)in, (uint64_t *)out, n);
+    } else if (which == 2) {
+        hipError_t e = hipMemcpyAsync(out, in, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(selftest_sort_global_kernel, dim3(1), dim3(kBlock), 0, s, (uint64_t *)out, n);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace splat

@@ -1,0 +1,217 @@
+// preprocess.hip -- per-Gaussian kernels: forward projection (K1, fused with the
+// per-tile instance count), the single-workgroup tile scan (K2), the adjoint
+// chain rule (K8+K9 fused) and mark_visible (K10).  One lane per Gaussian; the
+// [P][3]/[P][4] inputs are read straight from the caller's tensors (a wave
+// touches one contiguous 768 B / 1 KiB span per attribute).
+#include "splat_device.h"
+
+namespace splat {
+
+constexpr int kBlock = 256;
+
+// K1: Appendix A steps 1-9 + one atomicAdd per touched tile.
+__global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(SplatCamera cam, SplatGaussians g, SplatState st) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= g.P) return;
+    CamConst c;
+    load_cam(c, cam);
+    const float p[3] = {g.means3D[3 * i], g.means3D[3 * i + 1], g.means3D[3 * i + 2]};
+    float S6[6];
+    if (g.cov3D_precomp) {
+        for (int k = 0; k < 6; ++k) S6[k] = g.cov3D_precomp[6 * i + k];
+    } else {
+        const float s[3] = {g.scales[3 * i], g.scales[3 * i + 1], g.scales[3 * i + 2]};
+        const float q[4] = {g.rotations[4 * i], g.rotations[4 * i + 1], g.rotations[4 * i + 2], g.rotations[4 * i + 3]};
+        cov3d_from_scale_rot(s, c.scale_modifier, q, S6);
+    }
+    Projected o;
+    const bool vis = project_gaussian(c, p, S6, o);
+    st.depth[i] = o.depth;
+    reinterpret_cast<float2 *>(st.xy)[i] = make_float2(o.px, o.py);
+    reinterpret_cast<float4 *>(st.conic_opacity)[i] = make_float4(o.conic[0], o.conic[1], o.conic[2], g.opacities[i]);
+    reinterpret_cast<uint2 *>(st.rect)[i] = make_uint2((unsigned)o.x0 | ((unsigned)o.y0 << 16), (unsigned)o.x1 | ((unsigned)o.y1 << 16));
+    st.radii[i] = o.radius;
+    if (g.shs) {
+        // colour from spherical harmonics, clamped at 0 (flags kept for the adjoint)
+        float d[3] = {p[0] - cam.campos[0], p[1] - cam.campos[1], p[2] - cam.campos[2]};
+        const float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        d[0] *= inv; d[1] *= inv; d[2] *= inv;
+        float basis[16];
+        sh_basis(cam.sh_degree, d, basis, nullptr);
+        const int nb = (cam.sh_degree + 1) * (cam.sh_degree + 1);
+        const float *sh = g.shs + (size_t)i * g.sh_coeffs * 3;
+        for (int ch = 0; ch < 3; ++ch) {
+            float v = 0.f;
+            for (int k = 0; k < nb; ++k) v += basis[k] * sh[3 * k + ch];
+            v += 0.5f;
+            st.clamped[3 * i + ch] = v < 0.f;
+            st.rgb[3 * i + ch] = fmaxf(v, 0.f);
+        }
+    }
+    if (vis) {
+        for (int y = o.y0; y < o.y1; ++y)
+            for (int x = o.x0; x < o.x1; ++x) atomicAdd(&st.tile_count[y * c.gx + x], 1u);
+    }
+}
+
+// K2: exclusive prefix sum of tile_count (T <= a few 10^4) by one 1024-thread
+// workgroup: serial chunk per thread, wave64 shuffle scan, LDS across waves.
+__global__ __launch_bounds__(1024) void tile_scan_kernel(SplatState st, int T) {
+    __shared__ unsigned wave_tot[16];
+    __shared__ unsigned wave_max[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (T + 1023) / 1024;
+    const int lo = tid * per, hi = min(T, lo + per);
+    unsigned sum = 0, mx = 0;
+    for (int t = lo; t < hi; ++t) { const unsigned v = st.tile_count[t]; sum += v; mx = max(mx, v); }
+    unsigned incl = sum;
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = (unsigned)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    mx = wave_max_u32(mx);
+    if (lane == 63) wave_tot[wave] = incl;
+    if (lane == 0) wave_max[wave] = mx;
+    __syncthreads();
+    unsigned wave_off = 0, total = 0, gmax = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) wave_off += wave_tot[w];
+        total += wave_tot[w];
+        gmax = max(gmax, wave_max[w]);
+    }
+    unsigned run = wave_off + incl - sum;
+    for (int t = lo; t < hi; ++t) {
+        st.tile_base[t] = run;
+        st.tile_cursor[t] = run;
+        run += st.tile_count[t];
+    }
+    if (tid == 0) {
+        st.tile_base[T] = total;
+        st.status[0] = (int)total;
+        st.status[1] = (long long)total > st.capacity ? 1 : 0;
+        st.status[2] = (int)gmax;
+        st.status[3] = 0;
+    }
+}
+
+// K8+K9 fused: from the per-Gaussian partial sums of the backward composite
+// (accum[i] = {S1..S6, colour sums}) to every dL/d(input).
+__global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(SplatCamera cam, SplatGaussians g, SplatState st,
+                                                                    SplatGrads gr) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= g.P) return;
+    const int C = g.channels;
+    const bool vis = st.radii[i] > 0;
+    float acc[SPLAT_GRAD_STRIDE];
+    {
+        const float4 *a4 = reinterpret_cast<const float4 *>(gr.accum + (size_t)i * SPLAT_GRAD_STRIDE);
+        for (int k = 0; k < SPLAT_GRAD_STRIDE / 4; ++k) {
+            const float4 v = a4[k];
+            acc[4 * k] = v.x; acc[4 * k + 1] = v.y; acc[4 * k + 2] = v.z; acc[4 * k + 3] = v.w;
+        }
+    }
+    float dmean[3] = {0.f, 0.f, 0.f}, dS6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float g_ndc[2] = {0.f, 0.f};
+    if (vis) {
+        CamConst c;
+        load_cam(c, cam);
+        const float p[3] = {g.means3D[3 * i], g.means3D[3 * i + 1], g.means3D[3 * i + 2]};
+        float S6[6];
+        if (g.cov3D_precomp) {
+            for (int k = 0; k < 6; ++k) S6[k] = g.cov3D_precomp[6 * i + k];
+        } else {
+            const float s[3] = {g.scales[3 * i], g.scales[3 * i + 1], g.scales[3 * i + 2]};
+            const float q[4] = {g.rotations[4 * i], g.rotations[4 * i + 1], g.rotations[4 * i + 2], g.rotations[4 * i + 3]};
+            cov3d_from_scale_rot(s, c.scale_modifier, q, S6);
+        }
+        const float4 co = reinterpret_cast<const float4 *>(st.conic_opacity)[i];
+        // S1 = sum q*G*dx, S2 = sum q*G*dy, S3 = sum q*G*dx*dx, S4 = sum q*G*dx*dy, S5 = sum q*G*dy*dy
+        g_ndc[0] = -(co.x * acc[0] + co.y * acc[1]) * 0.5f * c.W;
+        g_ndc[1] = -(co.z * acc[1] + co.y * acc[0]) * 0.5f * c.H;
+        const float g_conic[3] = {-0.5f * acc[2], -acc[3], -0.5f * acc[4]};
+        project_gaussian_backward(c, p, S6, g_ndc, g_conic, dmean, dS6);
+        if (gr.dL_dscales && g.scales) {
+            const float s[3] = {g.scales[3 * i], g.scales[3 * i + 1], g.scales[3 * i + 2]};
+            const float q[4] = {g.rotations[4 * i], g.rotations[4 * i + 1], g.rotations[4 * i + 2], g.rotations[4 * i + 3]};
+            float ds[3], dq[4];
+            cov3d_backward(s, c.scale_modifier, q, dS6, ds, dq);
+            for (int k = 0; k < 3; ++k) gr.dL_dscales[3 * i + k] = ds[k];
+            for (int k = 0; k < 4; ++k) gr.dL_drotations[4 * i + k] = dq[k];
+        }
+        if (g.shs && gr.dL_dshs) {
+            // adjoint of the SH colour: coefficients, and the centre through the view direction
+            float d[3] = {p[0] - cam.campos[0], p[1] - cam.campos[1], p[2] - cam.campos[2]};
+            const float n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            const float inv = 1.0f / sqrtf(n2);
+            const float u[3] = {d[0] * inv, d[1] * inv, d[2] * inv};
+            float basis[16], db[3][16];
+            sh_basis(cam.sh_degree, u, basis, db);
+            const int nb = (cam.sh_degree + 1) * (cam.sh_degree + 1);
+            const float *sh = g.shs + (size_t)i * g.sh_coeffs * 3;
+            float *dsh = gr.dL_dshs + (size_t)i * g.sh_coeffs * 3;
+            float ddir[3] = {0.f, 0.f, 0.f};
+            for (int ch = 0; ch < 3; ++ch) {
+                const float gc = st.clamped[3 * i + ch] ? 0.f : acc[6 + ch];
+                for (int k = 0; k < nb; ++k) {
+                    dsh[3 * k + ch] = basis[k] * gc;
+                    const float w = sh[3 * k + ch] * gc;
+                    ddir[0] += db[0][k] * w; ddir[1] += db[1][k] * w; ddir[2] += db[2][k] * w;
+                }
+                for (int k = nb; k < g.sh_coeffs; ++k) dsh[3 * k + ch] = 0.f;
+            }
+            // d(unit dir)/d(p) = (I - u u^T) / |d|
+            const float dot = u[0] * ddir[0] + u[1] * ddir[1] + u[2] * ddir[2];
+            for (int k = 0; k < 3; ++k) dmean[k] += (ddir[k] - u[k] * dot) * inv;
+        }
+    } else {
+        if (gr.dL_dscales) {
+            for (int k = 0; k < 3; ++k) gr.dL_dscales[3 * i + k] = 0.f;
+            for (int k = 0; k < 4; ++k) gr.dL_drotations[4 * i + k] = 0.f;
+        }
+        if (g.shs && gr.dL_dshs) {
+            float *dsh = gr.dL_dshs + (size_t)i * g.sh_coeffs * 3;
+            for (int k = 0; k < g.sh_coeffs * 3; ++k) dsh[k] = 0.f;
+        }
+    }
+    for (int k = 0; k < 3; ++k) gr.dL_dmeans3D[3 * i + k] = dmean[k];
+    gr.dL_dmeans2D[3 * i] = g_ndc[0];
+    gr.dL_dmeans2D[3 * i + 1] = g_ndc[1];
+    gr.dL_dmeans2D[3 * i + 2] = 0.f;
+    gr.dL_dopacities[i] = vis ? acc[5] : 0.f;
+    if (gr.dL_dcolors)
+        for (int ch = 0; ch < C; ++ch) gr.dL_dcolors[(size_t)i * C + ch] = vis ? acc[6 + ch] : 0.f;
+    if (gr.dL_dcov3D)
+        for (int k = 0; k < 6; ++k) gr.dL_dcov3D[6 * i + k] = dS6[k];
+}
+
+__global__ __launch_bounds__(kBlock) void mark_visible_kernel(int P, const float *means3D, const float *view, uint8_t *present) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P) return;
+    const float z = mat(view, 2, 0) * means3D[3 * i] + mat(view, 2, 1) * means3D[3 * i + 1] +
+                    mat(view, 2, 2) * means3D[3 * i + 2] + mat(view, 2, 3);
+    present[i] = z > kNearZ;
+}
+
+hipError_t launch_preprocess_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s) {
+    const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
+    hipError_t e = hipMemsetAsync(st.tile_count, 0, sizeof(uint32_t) * (size_t)T, s);
+    if (e != hipSuccess) return e;
+    if (g.P > 0)
+        hipLaunchKernelGGL(preprocess_forward_kernel, dim3((g.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, cam, g, st);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, st, T);
+    return hipGetLastError();
+}
+
+hipError_t launch_preprocess_backward(const SplatCamera &cam, const SplatGaussians &g, const SplatState &st,
+                                      SplatGrads &gr, hipStream_t s) {
+    if (g.P > 0)
+        hipLaunchKernelGGL(preprocess_backward_kernel, dim3((g.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, cam, g, st, gr);
+    return hipGetLastError();
+}
+
+hipError_t launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s) {
+    if (P > 0) hipLaunchKernelGGL(mark_visible_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, P, means3D, view, present);
+    return hipGetLastError();
+}
+
+}  // namespace splat

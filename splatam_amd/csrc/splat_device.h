@@ -1,0 +1,98 @@
+// splat_device.h -- device-side helpers shared by the gfx950 kernels: camera
+// constant loading, wave64 cross-lane primitives (DPP row reductions,
+// v_permlane{16,32}_swap packed reductions), and the launch-side declarations.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/splat_hip.h"
+#include "splat_math.h"
+
+namespace splat {
+
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------------------
+// launchers (one per .hip file); every one returns hipGetLastError()
+// ---------------------------------------------------------------------------
+hipError_t launch_preprocess_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s);
+hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s);
+hipError_t launch_render_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st,
+                                 float *out_color, float *out_depth, hipStream_t s);
+hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &g, const SplatState &st,
+                                  SplatGrads &gr, hipStream_t s);
+hipError_t launch_preprocess_backward(const SplatCamera &cam, const SplatGaussians &g, const SplatState &st,
+                                      SplatGrads &gr, hipStream_t s);
+hipError_t launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
+hipError_t launch_selftest(int which, const void *in, void *out, int n, hipStream_t s);
+
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ void load_cam(CamConst &c, const SplatCamera &cam) {
+    // uniform addresses -> scalar loads into SGPRs
+    init_cam(c, cam.viewmatrix, cam.projmatrix, cam.image_width, cam.image_height, cam.tanfovx, cam.tanfovy,
+             cam.scale_modifier);
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// ---- DPP helpers -----------------------------------------------------------
+// dpp_ctrl encodings: quad_perm = 0x00..0xFF, row_half_mirror = 0x141, row_mirror = 0x140
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return __builtin_amdgcn_update_dpp(0u, v, CTRL, 0xf, 0xf, false);
+}
+
+// After this every lane of a 16-lane row holds the sum over its row (4 v_add_f32_dpp).
+__device__ __forceinline__ float row16_allreduce_add(float v) {
+    v += dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);   // row_half_mirror
+    v += dpp_f32<0x140>(v);   // row_mirror
+    return v;
+}
+
+// Packed wave64 reduction of four values: returns u such that every lane of
+// row r (lanes 16r..16r+15) holds the wave-wide sum of value row_value(r),
+// row_value = {0, 2, 1, 3}.  3 permlane swaps + 3 adds + 4 DPP adds for four
+// values instead of 4 x 7 for four separate butterflies.
+__device__ __forceinline__ float wave_reduce4_packed(float v0, float v1, float v2, float v3) {
+#if defined(SPLAT_SAFE_REDUCE)
+    // reference formulation on ds_bpermute butterflies (used by the self-test)
+    float v[4] = {v0, v1, v2, v3};
+    for (int i = 0; i < 4; ++i)
+        for (int m = 32; m >= 1; m >>= 1) v[i] += __shfl_xor(v[i], m, 64);
+    const int row = lane_id() >> 4;
+    return row == 0 ? v[0] : (row == 1 ? v[2] : (row == 2 ? v[1] : v[3]));
+#else
+    // lanes 0-31 <- partial sums of v0, lanes 32-63 <- partial sums of v1
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+    const float s01 = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v2), __float_as_uint(v3), false, false);
+    const float s23 = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    // rows: s01 = [v0 v0 v1 v1], s23 = [v2 v2 v3 v3]  ->  [v0 v2 v1 v3]
+    auto c = __builtin_amdgcn_permlane16_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
+    const float u = __uint_as_float(c[0]) + __uint_as_float(c[1]);
+    return row16_allreduce_add(u);
+#endif
+}
+// value index held by row r after wave_reduce4_packed: {0, 2, 1, 3}
+__device__ __forceinline__ int row_value(int row) { return ((row & 1) << 1) | (row >> 1); }
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)v, m, 64);
+        v = v > o ? v : o;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+#endif  // __HIPCC__
+
+}  // namespace splat

@@ -1,0 +1,77 @@
+"""View-sharded mapping across the GPUs of one node.
+
+The reference is single-GPU.  Mapping optimises the SAME replicated Gaussian map
+against independent keyframe views, so the views shard across ranks with one
+exchange step per iteration: a sum all-reduce of the Gaussian gradients
+(12 floats per isotropic Gaussian, one flat bucket), followed by the identical
+Adam step on every rank.  One process per GPU; backend "nccl" is RCCL over xGMI
+on ROCm, "gloo" is used by the CPU tests.  Tracking has no exchange step
+(replicas only).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Iterable, Optional
+
+import torch
+import torch.distributed as dist
+
+GAUSSIAN_KEYS = ('means3D', 'rgb_colors', 'unnorm_rotations', 'logit_opacities', 'log_scales')
+
+
+def init_from_env(backend: Optional[str] = None):
+    """Initialise torch.distributed from torchrun's environment; returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+class GradBucket:
+    """One flat buffer holding the gradients of the replicated Gaussian parameters,
+    so that the exchange is a single large collective (xGMI rings are per-link
+    bound: fewer, larger messages)."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], keys: Iterable[str] = GAUSSIAN_KEYS):
+        self.keys = [k for k in keys if k in params]
+        self.sizes = [params[k].numel() for k in self.keys]
+        dev, dt = params[self.keys[0]].device, params[self.keys[0]].dtype
+        self.flat = torch.zeros(sum(self.sizes), device=dev, dtype=dt)
+        self.views = []
+        o = 0
+        for k, n in zip(self.keys, self.sizes):
+            self.views.append(self.flat[o:o + n].view_as(params[k]))
+            o += n
+
+    def all_reduce_mean(self, params: Dict[str, torch.Tensor], group=None) -> None:
+        """grad <- mean over ranks of grad, for every replicated Gaussian parameter."""
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return
+        world = dist.get_world_size(group)
+        with torch.no_grad():
+            for k, v in zip(self.keys, self.views):
+                g = params[k].grad
+                if g is None:
+                    v.zero_()
+                else:
+                    v.copy_(g)
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.div_(world)
+            for k, v in zip(self.keys, self.views):
+                if params[k].grad is None:
+                    params[k].grad = v.clone()
+                else:
+                    params[k].grad.copy_(v)
+
+
+def shard_views(num_views: int, rank: int, world: int):
+    """Indices of the keyframe views rank ``rank`` renders (round-robin)."""
+    return list(range(rank, num_views, world))

@@ -1,0 +1,368 @@
+"""Host-side mirror of the reference's rasterizer package.
+
+Same surface as ``diff_gaussian_rasterization`` (the un-vendored dependency
+imported at /root/reference/scripts/splatam.py:37 and
+/root/reference/utils/recon_helpers.py:2):
+
+* ``GaussianRasterizationSettings`` -- the 11-field NamedTuple built at
+  /root/reference/utils/recon_helpers.py:14-26;
+* ``GaussianRasterizer(raster_settings=...)(means3D=, means2D=, opacities=,
+  colors_precomp=|shs=, scales=+rotations=|cov3D_precomp=)`` ->
+  ``(color[C,H,W], radii[P] int32, depth[1,H,W])``
+  (/root/reference/scripts/splatam.py:249,253,384);
+* gradients for means3D, means2D, shs/colors_precomp, opacities, scales,
+  rotations, cov3D_precomp through ``torch.autograd``.
+
+Everything is computed by libsplat_hip.so (include/splat_hip.h) on the current
+torch HIP stream.  PyTorch only owns the device memory.  There is no fallback:
+CPU tensors or a missing library raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _capi
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+
+
+# ---------------------------------------------------------------------------
+# Instance-capacity policy.
+#   "exact": after the per-Gaussian pass the host reads num_rendered (one 16-byte
+#            D2H copy + stream sync, exactly what the reference extension does to
+#            size its sort buffers) and allocates the lists to fit.
+#   "lazy" : no host sync.  Lists are sized from the high-water mark of earlier
+#            calls (x1.5); status words are checked when they are next needed
+#            and an overflow re-runs the binning with a larger capacity.
+# ---------------------------------------------------------------------------
+_SYNC_MODE = "exact"
+_capacity_hint: dict = {}
+
+
+def set_sync_mode(mode: str) -> None:
+    global _SYNC_MODE
+    if mode not in ("exact", "lazy"):
+        raise ValueError(mode)
+    _SYNC_MODE = mode
+
+
+def get_sync_mode() -> str:
+    return _SYNC_MODE
+
+
+_contig_cache: dict = {}
+
+
+def _cached_contiguous(t: torch.Tensor) -> torch.Tensor:
+    """Settings tensors (viewmatrix is a transposed, non-contiguous view:
+    /root/reference/utils/recon_helpers.py:8) are re-used across thousands of
+    calls; make them contiguous float32 once."""
+    if t.is_contiguous() and t.dtype == torch.float32:
+        return t
+    key = (t.data_ptr(), t._version, tuple(t.stride()), t.dtype)
+    hit = _contig_cache.get(key)
+    if hit is not None and hit[0] is t:
+        return hit[1]
+    c = t.to(torch.float32).contiguous()
+    if len(_contig_cache) > 64:
+        _contig_cache.clear()
+    _contig_cache[key] = (t, c)
+    return c
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None or t.numel() == 0 else t.data_ptr()
+
+
+def _check_input(name: str, t: torch.Tensor, device) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); the HIP rasterizer has no CPU path")
+    if t.device != device:
+        raise RuntimeError(f"{name} is on {t.device}, expected {device}")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32 (got {t.dtype})")
+    return t.contiguous()
+
+
+class _Pack:
+    """The ctypes structs of one call plus the tensors that keep their memory alive."""
+
+    def __init__(self):
+        self.keep = []
+        self.cam = _capi.SplatCamera()
+        self.g = _capi.SplatGaussians()
+        self.st = _capi.SplatState()
+
+
+def _build_pack(settings, means3D, colors, opacities, scales, rotations, cov3D, shs) -> _Pack:
+    dev = means3D.device
+    pk = _Pack()
+    P = means3D.shape[0]
+    bg = _cached_contiguous(settings.bg)
+    view = _cached_contiguous(settings.viewmatrix)
+    proj = _cached_contiguous(settings.projmatrix)
+    campos = _cached_contiguous(settings.campos)
+    for name, t in (("bg", bg), ("viewmatrix", view), ("projmatrix", proj), ("campos", campos)):
+        if not t.is_cuda or t.device != dev:
+            raise RuntimeError(f"raster_settings.{name} must be on {dev} (got {t.device})")
+    use_sh = shs.numel() > 0
+    channels = 3 if use_sh else colors.shape[1]
+    if not (1 <= channels <= _capi.SPLAT_MAX_CHANNELS):
+        raise RuntimeError(f"colors_precomp must have 1..{_capi.SPLAT_MAX_CHANNELS} channels, got {channels}")
+    if bg.numel() < channels:
+        raise RuntimeError(f"raster_settings.bg has {bg.numel()} entries for {channels} channels")
+    cam = pk.cam
+    cam.image_height, cam.image_width = int(settings.image_height), int(settings.image_width)
+    cam.tanfovx, cam.tanfovy = float(settings.tanfovx), float(settings.tanfovy)
+    cam.bg, cam.scale_modifier = bg.data_ptr(), float(settings.scale_modifier)
+    cam.viewmatrix, cam.projmatrix = view.data_ptr(), proj.data_ptr()
+    cam.sh_degree, cam.campos, cam.prefiltered = int(settings.sh_degree), campos.data_ptr(), int(bool(settings.prefiltered))
+    g = pk.g
+    g.P, g.channels = P, channels
+    g.means3D, g.opacities = _ptr(means3D), _ptr(opacities)
+    g.colors_precomp = None if use_sh else _ptr(colors)
+    g.scales, g.rotations, g.cov3D_precomp = _ptr(scales), _ptr(rotations), _ptr(cov3D)
+    g.shs = _ptr(shs) if use_sh else None
+    g.sh_coeffs = shs.shape[1] if use_sh else 0
+    pk.keep += [bg, view, proj, campos, means3D, colors, opacities, scales, rotations, cov3D, shs]
+    return pk
+
+
+def _alloc_state(pk: _Pack, dev, P: int, H: int, W: int, use_sh: bool):
+    """Per-call scratch (the reference's geomBuffer / imgBuffer): one int32 slab
+    for the per-Gaussian + per-tile words, torch's caching allocator makes this a
+    host-side pointer bump."""
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    f32, i32 = torch.float32, torch.int32
+    geom = torch.empty(P * 9 + 3 * T + 1 + 4 + 8, dtype=i32, device=dev)   # depth1 xy2 conic4 rect2 | tiles | status
+    o = 0
+
+    def take(n, align=4):
+        nonlocal o
+        o = (o + align - 1) // align * align
+        v = geom[o:o + n]
+        o += n
+        return v
+    conic = take(4 * P)
+    xy = take(2 * P, 2)
+    rect = take(2 * P, 2)
+    depth = take(P, 1)
+    tile_count, tile_base, tile_cursor = take(T, 1), take(T + 1, 1), take(T, 1)
+    status = take(4, 1)
+    radii = torch.empty(P, dtype=i32, device=dev)
+    final_T = torch.empty(H, W, dtype=f32, device=dev)
+    n_contrib = torch.empty(H, W, dtype=i32, device=dev)
+    st = pk.st
+    st.depth, st.xy, st.conic_opacity, st.rect = depth.data_ptr(), xy.data_ptr(), conic.data_ptr(), rect.data_ptr()
+    st.radii = radii.data_ptr()
+    st.tile_count, st.tile_base, st.tile_cursor = tile_count.data_ptr(), tile_base.data_ptr(), tile_cursor.data_ptr()
+    st.status = status.data_ptr()
+    st.final_T, st.n_contrib = final_T.data_ptr(), n_contrib.data_ptr()
+    rgb = clamped = None
+    if use_sh:
+        rgb = torch.empty(P, 3, dtype=f32, device=dev)
+        clamped = torch.empty(P, 3, dtype=torch.uint8, device=dev)
+        st.rgb, st.clamped = rgb.data_ptr(), clamped.data_ptr()
+    pk.tensors = dict(geom=geom, radii=radii, final_T=final_T, n_contrib=n_contrib, status=status,
+                      tile_base=tile_base, rgb=rgb, clamped=clamped)
+    pk.num_tiles = T
+    return radii, status
+
+
+def _alloc_lists(pk: _Pack, dev, capacity: int):
+    capacity = max(int(capacity), 1)
+    keys = torch.empty(capacity, dtype=torch.int64, device=dev)
+    plist = torch.empty(capacity, dtype=torch.int32, device=dev)
+    pk.st.keys, pk.st.point_list, pk.st.capacity = keys.data_ptr(), plist.data_ptr(), capacity
+    pk.tensors.update(keys=keys, point_list=plist)
+
+
+def _stream(dev) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def rasterize_forward(settings, means3D, colors, opacities, scales, rotations, cov3D, shs):
+    """One forward through the C ABI.  Returns (color, radii, depth, pack)."""
+    L = _capi.lib()
+    dev = means3D.device
+    H, W = int(settings.image_height), int(settings.image_width)
+    P = means3D.shape[0]
+    pk = _build_pack(settings, means3D, colors, opacities, scales, rotations, cov3D, shs)
+    use_sh = shs.numel() > 0
+    radii, status = _alloc_state(pk, dev, P, H, W, use_sh)
+    Cn = pk.g.channels
+    out_color = torch.empty(Cn, H, W, dtype=torch.float32, device=dev)
+    out_depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+    stream = _stream(dev)
+    with torch.cuda.device(dev):
+        _capi.check(L.splat_preprocess_forward(C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), stream), "splat_preprocess_forward")
+        hint_key = (dev.index, P, H, W)
+        if _SYNC_MODE == "exact":
+            num_rendered = int(status[0].item())          # the reference's one D2H read per forward
+            _alloc_lists(pk, dev, num_rendered)
+            pk.num_rendered = num_rendered
+        else:
+            cap = _capacity_hint.get(hint_key)
+            if cap is None:                               # first call for this shape: learn the size
+                cap = int(int(status[0].item()) * 1.5) + 1024
+                _capacity_hint[hint_key] = cap
+            _alloc_lists(pk, dev, cap)
+            pk.num_rendered = None
+        _capi.check(L.splat_bin_forward(C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), stream), "splat_bin_forward")
+        _capi.check(L.splat_render_forward(C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), out_color.data_ptr(),
+                                           out_depth.data_ptr(), stream), "splat_render_forward")
+        if _SYNC_MODE == "lazy":
+            pk.pending_status = _async_status(status, dev)
+            pk.hint_key = hint_key
+    return out_color, radii, out_depth, pk
+
+
+def _async_status(status, dev):
+    host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+    host.copy_(status, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    return host, ev
+
+
+def resolve_lazy(pk) -> None:
+    """Lazy mode: confirm that the instance lists fitted.  Called before the
+    backward pass touches them; raises if the forward that was handed out was
+    rendered from truncated lists (the caller must re-run it)."""
+    pend = getattr(pk, "pending_status", None)
+    if pend is None:
+        return
+    host, ev = pend
+    ev.synchronize()
+    pk.pending_status = None
+    n = int(host[0])
+    pk.num_rendered = n
+    _capacity_hint[pk.hint_key] = max(_capacity_hint.get(pk.hint_key, 0), int(n * 1.5) + 1024)
+    if int(host[1]) != 0 or n > pk.st.capacity:
+        raise RuntimeError(
+            f"lazy sync mode: {n} (Gaussian, tile) instances did not fit the {pk.st.capacity}-entry lists; "
+            "the capacity hint has been raised -- re-run the forward (or use set_sync_mode('exact'))")
+
+
+def rasterize_backward(pk: _Pack, grad_color, need_scale_rot: bool, need_cov3D: bool, use_sh: bool, sh_shape):
+    L = _capi.lib()
+    P, Cn = pk.g.P, pk.g.channels
+    dev = grad_color.device
+    f32 = torch.float32
+    resolve_lazy(pk)
+    grad_color = grad_color.contiguous()
+    accum = torch.empty(P, _capi.SPLAT_GRAD_STRIDE, dtype=f32, device=dev)
+    d_means3D = torch.empty(P, 3, dtype=f32, device=dev)
+    d_means2D = torch.empty(P, 3, dtype=f32, device=dev)
+    d_opac = torch.empty(P, 1, dtype=f32, device=dev)
+    d_colors = None if use_sh else torch.empty(P, Cn, dtype=f32, device=dev)
+    d_scales = torch.empty(P, 3, dtype=f32, device=dev) if need_scale_rot else None
+    d_rots = torch.empty(P, 4, dtype=f32, device=dev) if need_scale_rot else None
+    d_cov = torch.empty(P, 6, dtype=f32, device=dev) if need_cov3D else None
+    d_sh = torch.empty(sh_shape, dtype=f32, device=dev) if use_sh else None
+    gr = _capi.SplatGrads()
+    gr.dL_dcolor, gr.accum = grad_color.data_ptr(), _ptr(accum)
+    gr.dL_dmeans3D, gr.dL_dmeans2D = _ptr(d_means3D), _ptr(d_means2D)
+    gr.dL_dcolors, gr.dL_dopacities = _ptr(d_colors), _ptr(d_opac)
+    gr.dL_dscales, gr.dL_drotations, gr.dL_dcov3D, gr.dL_dshs = _ptr(d_scales), _ptr(d_rots), _ptr(d_cov), _ptr(d_sh)
+    with torch.cuda.device(dev):
+        _capi.check(L.splat_backward(C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), C.byref(gr), _stream(dev)), "splat_backward")
+    return d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rots, d_cov
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        dev = means3D.device
+        means3D = _check_input("means3D", means3D, dev)
+        P = means3D.shape[0]
+        sh = _check_input("shs", sh, dev) if sh.numel() else sh
+        colors = _check_input("colors_precomp", colors_precomp, dev) if colors_precomp.numel() else colors_precomp
+        opac = _check_input("opacities", opacities, dev).reshape(-1) if opacities.numel() else opacities
+        scales_c = _check_input("scales", scales, dev) if scales.numel() else scales
+        rots_c = _check_input("rotations", rotations, dev) if rotations.numel() else rotations
+        cov_c = _check_input("cov3D_precomp", cov3Ds_precomp, dev) if cov3Ds_precomp.numel() else cov3Ds_precomp
+        for name, t, last in (("means3D", means3D, 3), ("scales", scales_c, 3), ("rotations", rots_c, 4), ("cov3D_precomp", cov_c, 6)):
+            if t.numel() and (t.dim() != 2 or t.shape[0] != P or t.shape[1] != last):
+                raise RuntimeError(f"{name} must be [{P}, {last}], got {tuple(t.shape)}")
+        if opac.numel() != P:
+            raise RuntimeError(f"opacities must hold {P} values, got {tuple(opacities.shape)}")
+        if colors.numel() and (colors.dim() != 2 or colors.shape[0] != P):
+            raise RuntimeError(f"colors_precomp must be [{P}, C], got {tuple(colors.shape)}")
+        if sh.numel() and (sh.dim() != 3 or sh.shape[0] != P or sh.shape[2] != 3):
+            raise RuntimeError(f"shs must be [{P}, M, 3], got {tuple(sh.shape)}")
+        color, radii, depth, pk = rasterize_forward(raster_settings, means3D, colors, opac, scales_c, rots_c, cov_c, sh)
+        ctx.pack = pk
+        ctx.use_sh = sh.numel() > 0
+        ctx.sh_shape = tuple(sh.shape)
+        ctx.use_cov = cov_c.numel() > 0
+        ctx.opac_shape = tuple(opacities.shape)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii, _grad_depth):
+        # the rendered depth carries no gradient in the reference either
+        pk = ctx.pack
+        if grad_out_color is None:
+            return (None,) * 9
+        d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rots, d_cov = rasterize_backward(
+            pk, grad_out_color, need_scale_rot=not ctx.use_cov, need_cov3D=ctx.use_cov,
+            use_sh=ctx.use_sh, sh_shape=ctx.sh_shape)
+        return (d_means3D, d_means2D, d_sh, d_colors, d_opac.reshape(ctx.opac_shape), d_scales, d_rots, d_cov, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Boolean mask of the Gaussians in front of the near plane (view-space z > 0.2)."""
+        L = _capi.lib()
+        with torch.no_grad():
+            pos = _check_input("positions", positions, positions.device)
+            view = _cached_contiguous(self.raster_settings.viewmatrix)
+            out = torch.empty(pos.shape[0], dtype=torch.uint8, device=pos.device)
+            with torch.cuda.device(pos.device):
+                _capi.check(L.splat_mark_visible(pos.shape[0], _ptr(pos), view.data_ptr(), _ptr(out), _stream(pos.device)),
+                            "splat_mark_visible")
+        return out.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        raster_settings = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.empty(0, dtype=torch.float32, device=means3D.device)
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, raster_settings)
