@@ -14,9 +14,9 @@ if [ "$mode" != "quick" ]; then
   timeout 900 python bench.py --steps 30 --warmup 10 > gpurun_out/bench.log 2>&1
 fi
 if [ "$mode" = "prof" ]; then
-  cd /tmp
-  timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r1 -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1
-  cd $GRAFT_REPO_ROOT
-  find gpurun_out/prof -name "*stats*" | head -20 > gpurun_out/prof_files.log
+  rm -rf /tmp/prof && mkdir -p /tmp/prof gpurun_out/prof
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r1 -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1)
+  find /tmp/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof/ \;
+  ls -la /tmp/prof/* > gpurun_out/prof_files.log 2>&1
 fi
-tail -5 gpurun_out/*.log
+for f in gpurun_out/*.log; do echo "== $f"; tail -n 5 $f; done
