@@ -1,0 +1,90 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every
+symbol include/splat_hip.h declares, the ctypes structs mirror the header, and the
+Python surface has the reference's shape and error behaviour.  No kernel launches."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, "include", "splat_hip.h")).read()
+
+
+def _declared_functions():
+    body = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
+    return sorted(set(re.findall(r"\b(splat_[a-z_0-9]+)\s*\(", body)))
+
+
+def test_library_exports_every_declared_symbol():
+    from splatam_amd import _capi
+    L = _capi.lib()
+    names = _declared_functions()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/splat_hip.h but not exported"
+    assert set(_capi.EXPORTS) <= set(names)
+    assert L.splat_abi_version() == int(re.search(r"#define SPLAT_ABI_VERSION (\d+)", HEADER).group(1))
+    assert L.splat_error_string(0) == b"ok" and L.splat_error_string(1) == b"invalid argument"
+    assert L.splat_num_tiles(1200, 680) == 75 * 43 and L.splat_num_tiles(0, 10) == 0
+
+
+def _struct_fields(name):
+    m = re.search(r"typedef struct " + name + r" \{(.*?)\} " + name + ";", HEADER, flags=re.S)
+    body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
+    return [re.findall(r"[A-Za-z_0-9]+", s)[-1] for s in body.split(";") if s.strip()]
+
+
+@pytest.mark.parametrize("name", ["SplatCamera", "SplatGaussians", "SplatState", "SplatGrads"])
+def test_ctypes_structs_mirror_header(name):
+    from splatam_amd import _capi
+    assert [f[0] for f in getattr(_capi, name)._fields_] == _struct_fields(name)
+
+
+def test_constants_match_header():
+    from splatam_amd import _capi
+    for k in ("SPLAT_TILE", "SPLAT_MAX_CHANNELS", "SPLAT_GRAD_STRIDE"):
+        assert getattr(_capi, k) == int(re.search(rf"#define {k} (\d+)", HEADER).group(1))
+
+
+def test_invalid_arguments_return_codes_not_crashes():
+    from splatam_amd import _capi
+    L = _capi.lib()
+    cam, g, st = _capi.SplatCamera(), _capi.SplatGaussians(), _capi.SplatState()
+    assert L.splat_preprocess_forward(C.byref(cam), C.byref(g), C.byref(st), None) == 1      # zero-size image
+    cam.image_width, cam.image_height = 64, 64
+    g.P, g.channels = 10, 3
+    assert L.splat_preprocess_forward(C.byref(cam), C.byref(g), C.byref(st), None) == 1      # null matrices
+    assert L.splat_mark_visible(-1, None, None, None, None) == 1
+    g.channels = 99
+    assert L.splat_render_forward(C.byref(cam), C.byref(g), C.byref(st), None, None, None) == 1
+
+
+def test_python_surface_matches_reference_shape():
+    from diff_gaussian_rasterization import GaussianRasterizationSettings as Camera
+    from diff_gaussian_rasterization import GaussianRasterizer as Renderer
+    assert Camera._fields == ('image_height', 'image_width', 'tanfovx', 'tanfovy', 'bg', 'scale_modifier', 'viewmatrix',
+                              'projmatrix', 'sh_degree', 'campos', 'prefiltered')
+    cam = Camera(image_height=8, image_width=8, tanfovx=1.0, tanfovy=1.0, bg=torch.zeros(3), scale_modifier=1.0,
+                 viewmatrix=torch.eye(4), projmatrix=torch.eye(4), sh_degree=0, campos=torch.zeros(3), prefiltered=False)
+    r = Renderer(raster_settings=cam)
+    assert isinstance(r, torch.nn.Module) and r.raster_settings is cam
+    z = torch.zeros(2, 3)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(means3D=z, means2D=z, opacities=torch.ones(2, 1), scales=z, rotations=torch.ones(2, 4))
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair"):
+        r(means3D=z, means2D=z, opacities=torch.ones(2, 1), colors_precomp=z)
+    # no silent CPU path: CPU tensors fail loudly
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        r(means3D=z, means2D=z, opacities=torch.ones(2, 1), colors_precomp=z, scales=z, rotations=torch.ones(2, 4))
+
+
+def test_product_does_not_import_the_oracle():
+    for pkg in ("splatam_amd", "diff_gaussian_rasterization"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, pkg)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h")):
+                    src = open(os.path.join(dirpath, f)).read()
+                    assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                    assert "raster_ref" not in src, f
