@@ -34,6 +34,8 @@ extern "C" {
 #define SPLAT_TILE 16            /* tile edge in pixels (one wave64 = one 16x16 tile, 4 px per lane) */
 #define SPLAT_MAX_CHANNELS 8     /* colour channels per call: 3 for the reference API, up to 8 for fused passes */
 #define SPLAT_GRAD_STRIDE 16     /* floats per Gaussian in the backward accumulator (one 64-byte line) */
+#define SPLAT_COUNTER_STRIDE 32  /* uint32 words between two tile counters: one 128-byte line per counter, so that
+                                    the ~200 atomics a tile receives do not serialise with its neighbours' */
 
 enum {
     SPLAT_OK = 0,
@@ -86,13 +88,14 @@ typedef struct SplatState {
     float *rgb;                  /* [P][3]  colours evaluated from SH (NULL unless shs is used) */
     uint8_t *clamped;            /* [P][3]  SH clamp flags (NULL unless shs is used) */
     /* per-tile */
-    uint32_t *tile_count;        /* [T]     instances per tile */
+    uint32_t *tile_count;        /* [T * SPLAT_COUNTER_STRIDE] instances per tile, counter t at t * SPLAT_COUNTER_STRIDE */
     uint32_t *tile_base;         /* [T+1]   exclusive prefix sum of tile_count */
-    uint32_t *tile_cursor;       /* [T]     scatter cursors */
+    uint32_t *tile_cursor;       /* [T * SPLAT_COUNTER_STRIDE] scatter cursors, same spacing */
     /* per-instance ((Gaussian, tile) pairs) */
     uint64_t *keys;              /* [capacity] (float bits of depth << 32) | Gaussian id, bucketed by tile */
     uint32_t *point_list;        /* [capacity] Gaussian ids, each tile's slice sorted by key */
     int64_t capacity;
+    int32_t max_list_hint;       /* longest tile list if the host knows it (status[2] of an earlier read), 0 = unknown */
     /* per-pixel */
     float *final_T;              /* [H][W] */
     int32_t *n_contrib;          /* [H][W] 1-based list position of the last contributor */
@@ -164,6 +167,10 @@ int splat_mark_visible(int32_t P, const float *means3D, const float *viewmatrix,
  * on that same stream and returns the mean milliseconds per launch in *ms. */
 int splat_time_kernel(int fn, int iters, const SplatCamera *cam, const SplatGaussians *g, SplatState *st,
                       SplatGrads *gr, float *out_color, float *out_depth, void *stream, float *ms);
+
+/* Developer switches used by scripts/ (never by the product path): key 0 = skip the per-tile
+ * count atomics of K1 (timing experiment; results are then invalid).  Returns the previous value. */
+int splat_debug_option(int key, int value);
 
 #ifdef __cplusplus
 }

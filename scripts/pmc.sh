@@ -1,0 +1,33 @@
+#!/bin/bash
+# Counter passes (rocprofv3 --pmc, kernel-trace only) over scripts/kernel_driver.py; per-kernel means land in
+# gpurun_out/pmc_<tag>.txt.   usage: scripts/pmc.sh <tag> [workload]
+tag=${1:-r1}; wl=${2:-B}
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.txt
+: > $out
+pass() {
+  name=$1; shift
+  rm -rf /tmp/pmc_$name
+  (cd /tmp && timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$name -o p -- python $GRAFT_REPO_ROOT/scripts/kernel_driver.py --workload $wl --reps 3 > /tmp/pmc_$name.log 2>&1)
+  f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
+  echo "## pass $name: $*" >> $out
+  if [ -z "$f" ]; then echo "no counter file; log tail:" >> $out; tail -5 /tmp/pmc_$name.log >> $out; return; fi
+  python - "$f" >> $out <<'PY'
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in rows:
+    k = r.get('Kernel_Name', '')
+    if 'splat' not in k:
+        continue
+    acc[k.split('(')[0][-48:]][r['Counter_Name']].append(float(r['Counter_Value']))
+for k, d in acc.items():
+    print(k, ' '.join(f"{c}={sum(v)/len(v):.4g}" for c, v in sorted(d.items())), f"(n={len(next(iter(d.values())))})")
+PY
+}
+pass inst SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM
+pass wait SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_INSTS_BRANCH
+pass fetch FETCH_SIZE GRBM_GUI_ACTIVE
+pass write WRITE_SIZE
+cat $out

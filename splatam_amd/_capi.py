@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libsplat_hip.so")
 SPLAT_TILE = 16
 SPLAT_MAX_CHANNELS = 8
 SPLAT_GRAD_STRIDE = 16
+SPLAT_COUNTER_STRIDE = 32
 ABI_VERSION = 1
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -39,7 +40,7 @@ class SplatState(C.Structure):
     _fields_ = [("depth", _fp), ("xy", _fp), ("conic_opacity", _fp), ("rect", _fp), ("radii", _fp),
                 ("rgb", _fp), ("clamped", _fp),
                 ("tile_count", _fp), ("tile_base", _fp), ("tile_cursor", _fp),
-                ("keys", _fp), ("point_list", _fp), ("capacity", C.c_int64),
+                ("keys", _fp), ("point_list", _fp), ("capacity", C.c_int64), ("max_list_hint", C.c_int32),
                 ("final_T", _fp), ("n_contrib", _fp), ("status", _fp)]
 
 
@@ -53,7 +54,7 @@ EXPORTS = (
     "splat_error_string", "splat_abi_version", "splat_num_tiles",
     "splat_preprocess_forward", "splat_bin_forward", "splat_render_forward", "splat_forward",
     "splat_render_backward", "splat_preprocess_backward", "splat_backward",
-    "splat_mark_visible", "splat_time_kernel",
+    "splat_mark_visible", "splat_time_kernel", "splat_debug_option",
 )
 
 _lib = None
@@ -94,6 +95,8 @@ def lib():
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = args
+    L.splat_debug_option.restype = C.c_int
+    L.splat_debug_option.argtypes = [C.c_int, C.c_int]
     if hasattr(L, "splat_selftest"):
         L.splat_selftest.restype = C.c_int
         L.splat_selftest.argtypes = [C.c_int, _fp, _fp, C.c_int, _fp]

@@ -15,7 +15,9 @@ namespace splat {
 constexpr int kBlock = 256;
 constexpr int kSortLds = 4096;                 // keys sorted in LDS per tile (32 KiB); longer lists spill to HBM
 
-// K3: one lane per Gaussian, one bucket slot per touched tile.
+// K3: one lane per Gaussian, one bucket slot per touched tile.  The slot comes from a
+// returning atomic on the tile cursor (a fabric round trip of a few microseconds under
+// load), so a lane keeps up to four of them in flight instead of chaining them.
 __global__ __launch_bounds__(kBlock) void scatter_kernel(SplatGaussians g, SplatState st, int gx) {
     if ((long long)st.status[0] > st.capacity) return;      // lists would not fit: host re-sizes and retries
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -23,12 +25,22 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(SplatGaussians g, Splat
     if (st.radii[i] <= 0) return;
     const uint2 r = reinterpret_cast<const uint2 *>(st.rect)[i];
     const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff, y1 = r.y >> 16;
+    const int w = x1 - x0, nt = w * (y1 - y0);
     const uint64_t key = ((uint64_t)__float_as_uint(st.depth[i]) << 32) | (uint32_t)i;
-    for (int y = y0; y < y1; ++y)
-        for (int x = x0; x < x1; ++x) {
-            const unsigned slot = atomicAdd(&st.tile_cursor[y * gx + x], 1u);
-            st.keys[slot] = key;
+    for (int t0 = 0; t0 < nt; t0 += 4) {
+        unsigned slot[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u;
+            if (t < nt) {
+                const int yy = t / w, xx = t - yy * w;
+                slot[u] = atomicAdd(&st.tile_cursor[(size_t)((y0 + yy) * gx + x0 + xx) * SPLAT_COUNTER_STRIDE], 1u);
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (t0 + u < nt) st.keys[slot[u]] = key;
+    }
 }
 
 // Bitonic network with ascending-only compare-exchanges ("flip" form), so that
@@ -64,9 +76,15 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr keys, const int n, const int
     }
 }
 
-// K4(+K5): one workgroup per tile.  tile_base already holds the ranges.
-__global__ __launch_bounds__(kBlock) void tile_sort_kernel(SplatState st) {
-    __shared__ uint64_t s_keys[kSortLds];
+// K4(+K5).  tile_base already holds the ranges.  Two kernels:
+//  * short lists (n <= kSortWave, the normal case: ~200 entries at config B): ONE wave per tile,
+//    8 KiB of LDS, the network's barriers degenerate to wave-local waits; every tile of the frame is
+//    resident at once;
+//  * long lists: one 256-thread workgroup per tile, 32 KiB of LDS, or in place in HBM beyond that.
+constexpr int kSortWave = 1024;
+
+__global__ __launch_bounds__(64) void tile_sort_wave_kernel(SplatState st) {
+    __shared__ uint64_t s_keys[kSortWave];
     if ((long long)st.status[0] > st.capacity) {
         if (blockIdx.x == 0 && threadIdx.x == 0) st.status[1] = 1;
         return;
@@ -74,12 +92,26 @@ __global__ __launch_bounds__(kBlock) void tile_sort_kernel(SplatState st) {
     const int tile = blockIdx.x, tid = threadIdx.x;
     const unsigned lo = st.tile_base[tile], hi = st.tile_base[tile + 1];
     const int n = (int)(hi - lo);
-    if (n == 0) return;
+    if (n == 0 || n > kSortWave) return;
+    const uint64_t *gk = st.keys + lo;
+    for (int i = tid; i < n; i += 64) s_keys[i] = gk[i];
+    __syncthreads();
+    if (n > 1) bitonic_sort(s_keys, n, tid, 64);
+    for (int i = tid; i < n; i += 64) st.point_list[lo + i] = (uint32_t)s_keys[i];
+}
+
+__global__ __launch_bounds__(kBlock) void tile_sort_block_kernel(SplatState st) {
+    __shared__ uint64_t s_keys[kSortLds];
+    if ((long long)st.status[0] > st.capacity) return;
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    const unsigned lo = st.tile_base[tile], hi = st.tile_base[tile + 1];
+    const int n = (int)(hi - lo);
+    if (n <= kSortWave) return;
     uint64_t *gk = st.keys + lo;
     if (n <= kSortLds) {
         for (int i = tid; i < n; i += kBlock) s_keys[i] = gk[i];
         __syncthreads();
-        if (n > 1) bitonic_sort(s_keys, n, tid, kBlock);
+        bitonic_sort(s_keys, n, tid, kBlock);
         for (int i = tid; i < n; i += kBlock) st.point_list[lo + i] = (uint32_t)s_keys[i];
     } else {
         // spilled tile list: same network run in place on the HBM bucket (L2-resident)
@@ -92,7 +124,12 @@ hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, S
     const int gx = (cam.image_width + kTile - 1) / kTile;
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
     if (g.P > 0) hipLaunchKernelGGL(scatter_kernel, dim3((g.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, g, st, gx);
-    if (T > 0) hipLaunchKernelGGL(tile_sort_kernel, dim3(T), dim3(kBlock), 0, s, st);
+    if (T > 0) {
+        hipLaunchKernelGGL(tile_sort_wave_kernel, dim3(T), dim3(64), 0, s, st);
+        // the host may know the longest list (status[2]); only then can the long-list kernel be skipped
+        if (st.max_list_hint <= 0 || st.max_list_hint > kSortWave)
+            hipLaunchKernelGGL(tile_sort_block_kernel, dim3(T), dim3(kBlock), 0, s, st);
+    }
     return hipGetLastError();
 }
 

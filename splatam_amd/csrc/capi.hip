@@ -137,6 +137,11 @@ int splat_time_kernel(int fn, int iters, const SplatCamera *cam, const SplatGaus
     return check(err);
 }
 
+int splat_debug_option(int key, int value) {
+    if (key == 0) { const int old = g_debug_skip_count; g_debug_skip_count = value; return old; }
+    return -1;
+}
+
 // test hook (tests/test_gpu_primitives.py): see launch_selftest in binning.hip
 int splat_selftest(int which, const void *in, void *out, int n, void *stream) {
     return check(launch_selftest(which, in, out, n, (hipStream_t)stream));

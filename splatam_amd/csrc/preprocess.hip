@@ -8,9 +8,10 @@
 namespace splat {
 
 constexpr int kBlock = 256;
+int g_debug_skip_count = 0;     // splat_debug_option(0, v): timing experiment only
 
 // K1: Appendix A steps 1-9 + one atomicAdd per touched tile.
-__global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(SplatCamera cam, SplatGaussians g, SplatState st) {
+__global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(SplatCamera cam, SplatGaussians g, SplatState st, int skip_count) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= g.P) return;
     CamConst c;
@@ -48,9 +49,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(SplatCamera 
             st.rgb[3 * i + ch] = fmaxf(v, 0.f);
         }
     }
-    if (vis) {
+    if (vis && !skip_count) {
         for (int y = o.y0; y < o.y1; ++y)
-            for (int x = o.x0; x < o.x1; ++x) atomicAdd(&st.tile_count[y * c.gx + x], 1u);
+            for (int x = o.x0; x < o.x1; ++x) atomicAdd(&st.tile_count[(size_t)(y * c.gx + x) * SPLAT_COUNTER_STRIDE], 1u);
     }
 }
 
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(SplatState st, int T) {
     const int per = (T + 1023) / 1024;
     const int lo = tid * per, hi = min(T, lo + per);
     unsigned sum = 0, mx = 0;
-    for (int t = lo; t < hi; ++t) { const unsigned v = st.tile_count[t]; sum += v; mx = max(mx, v); }
+    for (int t = lo; t < hi; ++t) { const unsigned v = st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE]; sum += v; mx = max(mx, v); }
     unsigned incl = sum;
     for (int d = 1; d < 64; d <<= 1) {
         const unsigned o = (unsigned)__shfl_up((int)incl, d, 64);
@@ -82,8 +83,8 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(SplatState st, int T) {
     unsigned run = wave_off + incl - sum;
     for (int t = lo; t < hi; ++t) {
         st.tile_base[t] = run;
-        st.tile_cursor[t] = run;
-        run += st.tile_count[t];
+        st.tile_cursor[(size_t)t * SPLAT_COUNTER_STRIDE] = run;
+        run += st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE];
     }
     if (tid == 0) {
         st.tile_base[T] = total;
@@ -194,10 +195,10 @@ __global__ __launch_bounds__(kBlock) void mark_visible_kernel(int P, const float
 
 hipError_t launch_preprocess_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s) {
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
-    hipError_t e = hipMemsetAsync(st.tile_count, 0, sizeof(uint32_t) * (size_t)T, s);
+    hipError_t e = hipMemsetAsync(st.tile_count, 0, sizeof(uint32_t) * (size_t)T * SPLAT_COUNTER_STRIDE, s);
     if (e != hipSuccess) return e;
     if (g.P > 0)
-        hipLaunchKernelGGL(preprocess_forward_kernel, dim3((g.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, cam, g, st);
+        hipLaunchKernelGGL(preprocess_forward_kernel, dim3((g.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, cam, g, st, g_debug_skip_count);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, st, T);
     return hipGetLastError();
 }

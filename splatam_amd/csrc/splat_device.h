@@ -24,6 +24,7 @@ hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &
 hipError_t launch_preprocess_backward(const SplatCamera &cam, const SplatGaussians &g, const SplatState &st,
                                       SplatGrads &gr, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
+extern int g_debug_skip_count;
 hipError_t launch_selftest(int which, const void *in, void *out, int n, hipStream_t s);
 
 #if defined(__HIPCC__)

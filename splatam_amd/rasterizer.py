@@ -150,7 +150,8 @@ def _alloc_state(pk: _Pack, dev, P: int, H: int, W: int, use_sh: bool):
     host-side pointer bump."""
     T = ((W + 15) // 16) * ((H + 15) // 16)
     f32, i32 = torch.float32, torch.int32
-    geom = torch.empty(P * 9 + 3 * T + 1 + 4 + 8, dtype=i32, device=dev)   # depth1 xy2 conic4 rect2 | tiles | status
+    CS = _capi.SPLAT_COUNTER_STRIDE
+    geom = torch.empty(P * 9 + (2 * CS + 1) * T + 1 + 4 + 8, dtype=i32, device=dev)   # depth1 xy2 conic4 rect2 | tiles | status
     o = 0
 
     def take(n, align=4):
@@ -163,7 +164,7 @@ def _alloc_state(pk: _Pack, dev, P: int, H: int, W: int, use_sh: bool):
     xy = take(2 * P, 2)
     rect = take(2 * P, 2)
     depth = take(P, 1)
-    tile_count, tile_base, tile_cursor = take(T, 1), take(T + 1, 1), take(T, 1)
+    tile_count, tile_base, tile_cursor = take(T * CS, 1), take(T + 1, 1), take(T * CS, 1)
     status = take(4, 1)
     radii = torch.empty(P, dtype=i32, device=dev)
     final_T = torch.empty(H, W, dtype=f32, device=dev)
@@ -214,8 +215,10 @@ def rasterize_forward(settings, means3D, colors, opacities, scales, rotations, c
         _capi.check(L.splat_preprocess_forward(C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), stream), "splat_preprocess_forward")
         hint_key = (dev.index, P, H, W)
         if _SYNC_MODE == "exact":
-            num_rendered = int(status[0].item())          # the reference's one D2H read per forward
+            stat = status.tolist()                        # the reference's one D2H read per forward
+            num_rendered = int(stat[0])
             _alloc_lists(pk, dev, num_rendered)
+            pk.st.max_list_hint = int(stat[2])            # lets the library skip the long-list sort kernel
             pk.num_rendered = num_rendered
         else:
             cap = _capacity_hint.get(hint_key)

@@ -44,7 +44,7 @@ def test_ctypes_structs_mirror_header(name):
 
 def test_constants_match_header():
     from splatam_amd import _capi
-    for k in ("SPLAT_TILE", "SPLAT_MAX_CHANNELS", "SPLAT_GRAD_STRIDE"):
+    for k in ("SPLAT_TILE", "SPLAT_MAX_CHANNELS", "SPLAT_GRAD_STRIDE", "SPLAT_COUNTER_STRIDE"):
         assert getattr(_capi, k) == int(re.search(rf"#define {k} (\d+)", HEADER).group(1))
 
 
