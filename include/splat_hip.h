@@ -168,8 +168,110 @@ int splat_mark_visible(int32_t P, const float *means3D, const float *viewmatrix,
 int splat_time_kernel(int fn, int iters, const SplatCamera *cam, const SplatGaussians *g, SplatState *st,
                       SplatGrads *gr, float *out_color, float *out_depth, void *stream, float *ms);
 
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused SplaTAM iteration: everything the reference does in Python around the two
+ * rasterizer calls of one optimisation iteration, as a handful of kernels with no host synchronisation:
+ *   transform_to_frame + transformed_params2rendervar + transformed_params2depthplussilhouette
+ *     (/root/reference/utils/slam_helpers.py:252-304, :124-139, :234-249)  -> one per-Gaussian kernel,
+ *   the RGB and the depth/silhouette renders (/root/reference/scripts/splatam.py:249,253)
+ *     -> ONE 6-channel composite (r, g, b, z, 1, z^2) over shared geometry and lists,
+ *   the masked losses of get_loss (/root/reference/scripts/splatam.py:256-290, calc_ssim
+ *     /root/reference/utils/slam_external.py:54-97) and their gradients -> per-pixel kernels,
+ *   loss.backward() through the render variables and the camera pose -> one per-Gaussian kernel,
+ *   optimizer.step() (/root/reference/scripts/splatam.py:160-166,704,860) -> fused Adam kernels,
+ *   the best-candidate pose bookkeeping of the tracking loop (/root/reference/scripts/splatam.py:706-711).
+ * Supported configuration = what every shipped config uses: use_l1, no ignore_outlier_depth_loss, no
+ * densification gradient (means2D.grad of the colour pass alone is not produced); anything else returns
+ * SPLAT_E_UNSUPPORTED and the caller uses the two-call path above.
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* The reference's `params` dict (/root/reference/scripts/splatam.py:120-157).  Adam updates it in place. */
+typedef struct SplatMap {
+    int32_t P;
+    int32_t isotropic;           /* log_scales is [P][1] (1) or [P][3] (0) */
+    float *means3D;              /* [P][3] world frame */
+    float *rgb_colors;           /* [P][3] */
+    float *unnorm_rotations;     /* [P][4] */
+    float *logit_opacities;      /* [P] */
+    float *log_scales;           /* [P][1] or [P][3] */
+    float *cam_unnorm_rots;      /* [1][4][num_frames] */
+    float *cam_trans;            /* [1][3][num_frames] */
+    int32_t num_frames;
+} SplatMap;
+
+/* `curr_data` of get_loss. */
+typedef struct SplatFrameData {
+    const float *im;             /* [3][H][W] */
+    const float *depth;          /* [1][H][W] */
+    const float *w2c;            /* [16] row-major curr_data['w2c'] (first-frame world-to-camera) */
+    int32_t time_idx;            /* iter_time_idx: which camera pose of the map transforms the Gaussians */
+} SplatFrameData;
+
+/* Arguments of get_loss (/root/reference/scripts/splatam.py:214-216). */
+typedef struct SplatLossConfig {
+    int32_t tracking;            /* 1: tracking=True (summed losses); 0: mapping=True (means + SSIM) */
+    int32_t camera_grad;         /* transform_to_frame(camera_grad=...) */
+    int32_t gaussians_grad;      /* transform_to_frame(gaussians_grad=...) */
+    int32_t use_sil_for_loss;
+    float sil_thres;
+    int32_t use_l1;
+    int32_t ignore_outlier_depth_loss;
+    float w_im;                  /* loss_weights['im'] */
+    float w_depth;               /* loss_weights['depth'] */
+} SplatLossConfig;
+
+#define SPLAT_ITER_SUMS 32       /* doubles in SplatIterWorkspace.sums */
+
+/* Device scratch + outputs of one fused iteration; every array is caller-owned. */
+typedef struct SplatIterWorkspace {
+    SplatState st;               /* geometry, lists (fixed capacity; overflow -> st.status[1]) and per-pixel state */
+    float *feat8;                /* [P][8]  r, g, b, z, 1, z^2, 0, 0 */
+    float *out6;                 /* [6][H][W] rendered r, g, b, depth, silhouette, depth^2 */
+    float *dL_dout6;             /* [6][H][W] */
+    float *accum;                /* [P][SPLAT_GRAD_STRIDE] */
+    float *ssim_maps;            /* [9][H][W] mapping only (NULL for tracking) */
+    double *sums;                /* [SPLAT_ITER_SUMS]: [0] masked depth L1 sum, [1] image L1 sum, [2] mask count,
+                                    [3] SSIM map sum, [8..23] camera-pose partial sums */
+    float *max_2D_radius;        /* [P] variables['max_2D_radius'], updated in place, or NULL */
+    /* gradients of the map (written when non-NULL; means3D / unnorm_rotations only with gaussians_grad) */
+    float *d_means3D;            /* [P][3] */
+    float *d_rgb_colors;         /* [P][3] */
+    float *d_unnorm_rotations;   /* [P][4] */
+    float *d_logit_opacities;    /* [P] */
+    float *d_log_scales;         /* [P][1|3] */
+    float *d_cam;                /* [8]: dL/dcam_unnorm_rots[...,t] (4), dL/dcam_trans[...,t] (3), loss (1) */
+} SplatIterWorkspace;
+
+/* get_loss + loss.backward() of one iteration.  On return (stream order) ws->d_* hold the gradients and
+ * ws->d_cam[7] the loss value. */
+int splat_iter_loss_backward(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame,
+                             const SplatLossConfig *cfg, SplatIterWorkspace *ws, void *stream);
+
+/* torch.optim.Adam over the five Gaussian groups (mapping: /root/reference/scripts/splatam.py:160-166 with
+ * eps = 1e-15, lr per group from the config).  step_size[k] = lr_k / (1 - beta1^t) and bc2_sqrt = sqrt(1 - beta2^t)
+ * are formed by the caller in double, as torch does.  Group order: means3D, rgb_colors, unnorm_rotations,
+ * logit_opacities, log_scales.  exp_avg / exp_avg_sq have the shapes of the parameters. */
+typedef struct SplatAdamMap {
+    float beta1, beta2, eps, bc2_sqrt;
+    float step_size[5];
+    const float *grad[5];
+    float *exp_avg[5];
+    float *exp_avg_sq[5];
+} SplatAdamMap;
+int splat_iter_adam_map(const SplatMap *map, const SplatAdamMap *opt, void *stream);
+
+/* Adam step of the camera pose of frame `time_idx` (tracking: default eps 1e-8) followed by the reference's
+ * best-candidate bookkeeping: if loss < min_loss, remember the UPDATED pose.
+ * state [24] floats: exp_avg q(4) t(3), exp_avg_sq q(4) t(3), min_loss, candidate q(4) t(3), 2 spare. */
+#define SPLAT_POSE_STATE 24
+int splat_iter_adam_pose(const SplatMap *map, int32_t time_idx, const float *d_cam, float *state,
+                         float beta1, float beta2, float eps, float bc2_sqrt, float step_size_rot, float step_size_trans,
+                         void *stream);
+
 /* Developer switches used by scripts/ (never by the product path): key 0 = skip the per-tile
- * count atomics of K1 (timing experiment; results are then invalid).  Returns the previous value. */
+ * count atomics of K1 (timing experiment; results are then invalid); key 1 = generation of the composite kernels
+ * (3 = current, 2 = previous, 3-channel calls only; A/B timing).  Returns the previous value. */
 int splat_debug_option(int key, int value);
 
 #ifdef __cplusplus

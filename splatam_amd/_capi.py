@@ -50,11 +50,43 @@ class SplatGrads(C.Structure):
                 ("dL_dcov3D", _fp), ("dL_dshs", _fp)]
 
 
+class SplatMap(C.Structure):
+    _fields_ = [("P", C.c_int32), ("isotropic", C.c_int32),
+                ("means3D", _fp), ("rgb_colors", _fp), ("unnorm_rotations", _fp), ("logit_opacities", _fp),
+                ("log_scales", _fp), ("cam_unnorm_rots", _fp), ("cam_trans", _fp), ("num_frames", C.c_int32)]
+
+
+class SplatFrameData(C.Structure):
+    _fields_ = [("im", _fp), ("depth", _fp), ("w2c", _fp), ("time_idx", C.c_int32)]
+
+
+class SplatLossConfig(C.Structure):
+    _fields_ = [("tracking", C.c_int32), ("camera_grad", C.c_int32), ("gaussians_grad", C.c_int32),
+                ("use_sil_for_loss", C.c_int32), ("sil_thres", C.c_float), ("use_l1", C.c_int32),
+                ("ignore_outlier_depth_loss", C.c_int32), ("w_im", C.c_float), ("w_depth", C.c_float)]
+
+
+class SplatIterWorkspace(C.Structure):
+    _fields_ = [("st", SplatState), ("feat8", _fp), ("out6", _fp), ("dL_dout6", _fp), ("accum", _fp),
+                ("ssim_maps", _fp), ("sums", _fp), ("max_2D_radius", _fp),
+                ("d_means3D", _fp), ("d_rgb_colors", _fp), ("d_unnorm_rotations", _fp), ("d_logit_opacities", _fp),
+                ("d_log_scales", _fp), ("d_cam", _fp)]
+
+
+class SplatAdamMap(C.Structure):
+    _fields_ = [("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("bc2_sqrt", C.c_float),
+                ("step_size", C.c_float * 5), ("grad", _fp * 5), ("exp_avg", _fp * 5), ("exp_avg_sq", _fp * 5)]
+
+
+SPLAT_ITER_SUMS = 32
+SPLAT_POSE_STATE = 24
+
 EXPORTS = (
     "splat_error_string", "splat_abi_version", "splat_num_tiles",
     "splat_preprocess_forward", "splat_bin_forward", "splat_render_forward", "splat_forward",
     "splat_render_backward", "splat_preprocess_backward", "splat_backward",
     "splat_mark_visible", "splat_time_kernel", "splat_debug_option",
+    "splat_iter_loss_backward", "splat_iter_adam_map", "splat_iter_adam_pose",
 )
 
 _lib = None
@@ -95,6 +127,14 @@ def lib():
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = args
+    L.splat_iter_loss_backward.restype = C.c_int
+    L.splat_iter_loss_backward.argtypes = [cam, C.POINTER(SplatMap), C.POINTER(SplatFrameData), C.POINTER(SplatLossConfig),
+                                           C.POINTER(SplatIterWorkspace), _fp]
+    L.splat_iter_adam_map.restype = C.c_int
+    L.splat_iter_adam_map.argtypes = [C.POINTER(SplatMap), C.POINTER(SplatAdamMap), _fp]
+    L.splat_iter_adam_pose.restype = C.c_int
+    L.splat_iter_adam_pose.argtypes = [C.POINTER(SplatMap), C.c_int32, _fp, _fp, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, C.c_float, _fp]
     L.splat_debug_option.restype = C.c_int
     L.splat_debug_option.argtypes = [C.c_int, C.c_int]
     if hasattr(L, "splat_selftest"):

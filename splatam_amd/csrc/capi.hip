@@ -137,8 +137,43 @@ int splat_time_kernel(int fn, int iters, const SplatCamera *cam, const SplatGaus
     return check(err);
 }
 
+int splat_iter_loss_backward(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame,
+                             const SplatLossConfig *cfg, SplatIterWorkspace *ws, void *stream) {
+    if (!cam || !map || !frame || !cfg || !ws) return SPLAT_E_INVALID;
+    if (map->P < 0 || cam->image_width <= 0 || cam->image_height <= 0 || !cam->viewmatrix || !cam->projmatrix) return SPLAT_E_INVALID;
+    if (map->num_frames <= 0 || frame->time_idx < 0 || frame->time_idx >= map->num_frames) return SPLAT_E_INVALID;
+    if (!map->cam_unnorm_rots || !map->cam_trans || !frame->im || !frame->depth || !frame->w2c) return SPLAT_E_INVALID;
+    if (map->P > 0 && (!map->means3D || !map->rgb_colors || !map->unnorm_rotations || !map->logit_opacities || !map->log_scales))
+        return SPLAT_E_INVALID;
+    // what no shipped config uses is not fused: the caller keeps the two-call path for it
+    if (cfg->ignore_outlier_depth_loss) return SPLAT_E_UNSUPPORTED;
+    const SplatState &st = ws->st;
+    if (!st.tile_count || !st.tile_base || !st.tile_cursor || !st.status || !st.final_T || !st.n_contrib) return SPLAT_E_INVALID;
+    if (map->P > 0 && (!st.depth || !st.xy || !st.conic_opacity || !st.rect || !st.radii || !ws->feat8 || !ws->accum)) return SPLAT_E_INVALID;
+    if (st.capacity <= 0 || !st.keys || !st.point_list) return SPLAT_E_INVALID;
+    if (!ws->out6 || !ws->dL_dout6 || !ws->sums || !ws->d_cam) return SPLAT_E_INVALID;
+    if (!cfg->tracking && !ws->ssim_maps) return SPLAT_E_INVALID;
+    return check(launch_iter_loss_backward(*cam, *map, *frame, *cfg, *ws, (hipStream_t)stream));
+}
+
+int splat_iter_adam_map(const SplatMap *map, const SplatAdamMap *opt, void *stream) {
+    if (!map || !opt || map->P < 0) return SPLAT_E_INVALID;
+    for (int k = 0; k < 5; ++k)
+        if (opt->grad[k] && (!opt->exp_avg[k] || !opt->exp_avg_sq[k])) return SPLAT_E_INVALID;
+    return check(launch_iter_adam_map(*map, *opt, (hipStream_t)stream));
+}
+
+int splat_iter_adam_pose(const SplatMap *map, int32_t time_idx, const float *d_cam, float *state, float beta1, float beta2,
+                         float eps, float bc2_sqrt, float step_size_rot, float step_size_trans, void *stream) {
+    if (!map || !d_cam || !state || !map->cam_unnorm_rots || !map->cam_trans) return SPLAT_E_INVALID;
+    if (time_idx < 0 || time_idx >= map->num_frames) return SPLAT_E_INVALID;
+    return check(launch_iter_adam_pose(*map, time_idx, d_cam, state, beta1, beta2, eps, bc2_sqrt, step_size_rot, step_size_trans,
+                                       (hipStream_t)stream));
+}
+
 int splat_debug_option(int key, int value) {
     if (key == 0) { const int old = g_debug_skip_count; g_debug_skip_count = value; return old; }
+    if (key == 1) { const int old = g_debug_composite_version; g_debug_composite_version = value; return old; }
     return -1;
 }
 

@@ -1,0 +1,480 @@
+// fused.hip -- the fused SplaTAM iteration (include/splat_hip.h, "Fused SplaTAM iteration"): the callers on
+// either side of the rasterizer boundary as kernels, so that one optimisation iteration is ~10 launches with no
+// host synchronisation instead of ~150 PyTorch launches + MIOpen convolutions + a GEMM/GEMV pair.
+//
+//   F1 fused_preprocess_kernel   transform_to_frame + both render-variable dicts + K1 (one lane per Gaussian)
+//      K2..K4                    tile scan, scatter, per-tile sort (binning.hip, unchanged)
+//      K6<6 channels>            r, g, b, z, 1, z^2 over shared geometry (render.hip)
+//   F3 track_loss_kernel         tracking: masked L1 sums + dL/d(out6) in one pass over the pixels
+//   F4 ssim_forward_kernel       mapping: separable 11x11 SSIM statistics -> map sum + three partial-derivative maps,
+//                                image L1 sum, masked depth L1 sum and mask count
+//   F5 map_loss_backward_kernel  mapping: blur of the partial maps -> dL/d(rgb), depth gradient with the final count
+//      K7<6 channels>            (render.hip)
+//   F6 fused_backward_kernel     K8+K9 + adjoint of F1's glue + camera-pose partial sums (block reduce, f64 atomics)
+//   F7 pose_finish_kernel        pose partial sums -> dL/d(cam_unnorm_rots[..., t]), dL/d(cam_trans[..., t]), loss value
+//   F8 adam_map_kernel / adam_pose_kernel
+//
+// Arithmetic lives in fused_math.h / splat_math.h (host-testable); reference lines are cited there and in
+// include/splat_hip.h.
+#include "splat_device.h"
+
+#include "fused_math.h"
+
+namespace splat {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct FusedArgs {
+    SplatCamera cam;
+    SplatMap map;
+    SplatFrameData frame;
+    SplatLossConfig cfg;
+    SplatIterWorkspace ws;
+};
+
+__device__ __forceinline__ void load_pose(const SplatMap &m, int time_idx, Pose &P) {
+    pose_from_params(m.cam_unnorm_rots + time_idx, m.cam_trans + time_idx, m.num_frames, P);
+}
+
+__device__ __forceinline__ void load_gaussian(const SplatMap &m, int i, float *p, float *u, float &logit, float *ls) {
+    p[0] = m.means3D[3 * i]; p[1] = m.means3D[3 * i + 1]; p[2] = m.means3D[3 * i + 2];
+    const float4 q = reinterpret_cast<const float4 *>(m.unnorm_rotations)[i];
+    u[0] = q.x; u[1] = q.y; u[2] = q.z; u[3] = q.w;
+    logit = m.logit_opacities[i];
+    if (m.isotropic) {
+        ls[0] = m.log_scales[i]; ls[1] = ls[0]; ls[2] = ls[0];
+    } else {
+        ls[0] = m.log_scales[3 * i]; ls[1] = m.log_scales[3 * i + 1]; ls[2] = m.log_scales[3 * i + 2];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// F1: per Gaussian: pose transform, activations, projection (K1), tile counts, feature record
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void fused_preprocess_kernel(FusedArgs a) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.map.P) return;
+    CamConst c;
+    load_cam(c, a.cam);
+    Pose P;
+    load_pose(a.map, a.frame.time_idx, P);
+    float p[3], u[4], logit, ls[3];
+    load_gaussian(a.map, i, p, u, logit, ls);
+    Glue G;
+    glue_forward(P, a.frame.w2c + 8, p, u, logit, ls, a.map.isotropic != 0, G);
+    float S6[6];
+    cov3d_from_scale_rot(G.s, c.scale_modifier, G.rq, S6);
+    Projected o;
+    const bool vis = project_gaussian(c, G.Xc, S6, o);
+    SplatState &st = a.ws.st;
+    st.depth[i] = o.depth;
+    reinterpret_cast<float2 *>(st.xy)[i] = make_float2(o.px, o.py);
+    reinterpret_cast<float4 *>(st.conic_opacity)[i] = make_float4(o.conic[0], o.conic[1], o.conic[2], G.op);
+    reinterpret_cast<uint2 *>(st.rect)[i] = make_uint2((unsigned)o.x0 | ((unsigned)o.y0 << 16), (unsigned)o.x1 | ((unsigned)o.y1 << 16));
+    st.radii[i] = o.radius;
+    float4 *f = reinterpret_cast<float4 *>(a.ws.feat8) + 2 * (size_t)i;
+    f[0] = make_float4(a.map.rgb_colors[3 * i], a.map.rgb_colors[3 * i + 1], a.map.rgb_colors[3 * i + 2], G.z);
+    f[1] = make_float4(1.0f, G.z * G.z, 0.f, 0.f);
+    if (vis) {
+        if (a.ws.max_2D_radius) a.ws.max_2D_radius[i] = fmaxf(a.ws.max_2D_radius[i], (float)o.radius);
+        for (int y = o.y0; y < o.y1; ++y)
+            for (int x = o.x0; x < o.x1; ++x) atomicAdd(&st.tile_count[(size_t)(y * c.gx + x) * SPLAT_COUNTER_STRIDE], 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// block-level sums -> double atomics
+// ---------------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void block_sum_to(double *dst, const float (&v)[N], double *s_part /* [N][waves] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        float x = v[k];
+        for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+        if (lane == 0) s_part[k * nw + wave] = (double)x;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < N) {
+        double t = 0.0;
+        for (int w = 0; w < nw; ++w) t += s_part[threadIdx.x * nw + w];
+        if (t != 0.0) atomicAdd(dst + threadIdx.x, t);
+    }
+    __syncthreads();
+}
+
+struct Pixel {
+    bool mask;          // the depth (and, for tracking with the silhouette, colour) loss mask
+    float d_err;        // |gt_depth - depth| (finite when mask)
+    float d_sign;       // d|gt - d| / dd = sign(d - gt)
+};
+
+__device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+
+__device__ __forceinline__ Pixel depth_pixel(const SplatLossConfig &cfg, float depth, float sil, float depth_sq, float gt) {
+    Pixel r;
+    const float unc = depth_sq - depth * depth;
+    const bool nan_ok = !(depth != depth) && !(unc != unc);
+    bool m = gt > 0.f && nan_ok;
+    if (cfg.tracking && cfg.use_sil_for_loss) m = m && (sil > cfg.sil_thres);
+    r.mask = m;
+    const float diff = gt - depth;
+    r.d_err = m ? fabsf(diff) : 0.f;
+    r.d_sign = m ? -sgn(diff) : 0.f;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// F3: tracking loss (/root/reference/scripts/splatam.py:256-286 with tracking=True): one pass
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void track_loss_kernel(FusedArgs a, int HW) {
+    __shared__ double s_part[2 * (kBlock / 64)];
+    const float *o = a.ws.out6;
+    float *g = a.ws.dL_dout6;
+    const bool masked_im = a.cfg.use_sil_for_loss || a.cfg.ignore_outlier_depth_loss;
+    float acc[2] = {0.f, 0.f};
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW; i += gridDim.x * kBlock) {
+        const Pixel px = depth_pixel(a.cfg, o[3 * (size_t)HW + i], o[4 * (size_t)HW + i], o[5 * (size_t)HW + i], a.frame.depth[i]);
+        acc[0] += px.d_err;
+        g[3 * (size_t)HW + i] = a.cfg.use_l1 ? a.cfg.w_depth * px.d_sign : 0.f;
+        g[4 * (size_t)HW + i] = 0.f;
+        g[5 * (size_t)HW + i] = 0.f;
+        const bool cm = masked_im ? px.mask : true;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float diff = a.frame.im[ch * (size_t)HW + i] - o[ch * (size_t)HW + i];
+            acc[1] += cm ? fabsf(diff) : 0.f;
+            g[ch * (size_t)HW + i] = cm ? -a.cfg.w_im * sgn(diff) : 0.f;
+        }
+    }
+    block_sum_to<2>(a.ws.sums, acc, s_part);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// F4 / F5: SSIM (11x11, sigma 1.5, zero padding; /root/reference/utils/slam_external.py:54-97)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kSsimR = 5;                   // window radius
+constexpr int kTW = 32, kTH = 16;           // output tile of one 256-thread workgroup (2 pixels per thread)
+constexpr int kHW_ = kTW + 2 * kSsimR;      // halo width 42
+constexpr int kHH_ = kTH + 2 * kSsimR;      // halo height 26
+
+__device__ __forceinline__ void ssim_window(float *g) {
+    // exp(-(x-5)^2 / (2 * 1.5^2)) normalised, as create_window builds it
+    float s = 0.f;
+    for (int k = 0; k < 11; ++k) { g[k] = expf(-(float)((k - 5) * (k - 5)) / 4.5f); s += g[k]; }
+    for (int k = 0; k < 11; ++k) g[k] /= s;
+}
+
+// F4: grid (tiles_x, tiles_y, 3 channels).  Also accumulates the L1 image sum; the z == 0 slice handles the depth plane.
+__global__ __launch_bounds__(kBlock) void ssim_forward_kernel(FusedArgs a, int W, int H) {
+    __shared__ float sx[kHH_][kHW_ + 1], sy[kHH_][kHW_ + 1];
+    __shared__ float sh[5][kHH_][kTW + 1];
+    __shared__ double s_part[4 * (kBlock / 64)];
+    float g[11];
+    ssim_window(g);
+    const int ch = blockIdx.z, tid = threadIdx.x;
+    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
+    const size_t HW = (size_t)H * W;
+    const float *X = a.ws.out6 + ch * HW, *Y = a.frame.im + ch * HW;
+    for (int k = tid; k < kHH_ * kHW_; k += kBlock) {
+        const int r = k / kHW_, c = k - r * kHW_;
+        const int yy = y0 + r - kSsimR, xx = x0 + c - kSsimR;
+        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        sx[r][c] = in ? X[(size_t)yy * W + xx] : 0.f;
+        sy[r][c] = in ? Y[(size_t)yy * W + xx] : 0.f;
+    }
+    __syncthreads();
+    for (int k = tid; k < kHH_ * kTW; k += kBlock) {
+        const int r = k / kTW, c = k - r * kTW;
+        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 11; ++t) {
+            const float xv = sx[r][c + t], yv = sy[r][c + t], w = g[t];
+            m1 += w * xv; m2 += w * yv; e11 += w * xv * xv; e22 += w * yv * yv; e12 += w * xv * yv;
+        }
+        sh[0][r][c] = m1; sh[1][r][c] = m2; sh[2][r][c] = e11; sh[3][r][c] = e22; sh[4][r][c] = e12;
+    }
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};        // depth L1 (masked), image L1, mask count, SSIM map sum
+    float *M = a.ws.ssim_maps + (size_t)(3 * ch) * HW;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int k = tid + rep * kBlock;
+        const int r = k / kTW, c = k - r * kTW;
+        const int yy = y0 + r, xx = x0 + c;
+        if (yy < H && xx < W) {
+            float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 11; ++t)
+#pragma unroll
+                for (int q = 0; q < 5; ++q) v[q] += g[t] * sh[q][r + t][c];
+            float dmu1, de11, de12;
+            acc[3] += ssim_pixel(v[0], v[1], v[2], v[3], v[4], &dmu1, &de11, &de12);
+            const size_t pix = (size_t)yy * W + xx;
+            M[pix] = dmu1; M[HW + pix] = de11; M[2 * HW + pix] = de12;
+            acc[1] += fabsf(sx[r + kSsimR][c + kSsimR] - sy[r + kSsimR][c + kSsimR]);
+            if (ch == 0) {
+                const float *o = a.ws.out6;
+                const Pixel px = depth_pixel(a.cfg, o[3 * HW + pix], o[4 * HW + pix], o[5 * HW + pix], a.frame.depth[pix]);
+                acc[0] += px.d_err;
+                acc[2] += px.mask ? 1.f : 0.f;
+            }
+        }
+    }
+    block_sum_to<4>(a.ws.sums, acc, s_part);
+}
+
+// F5: dL/d(rgb) = w_im * (0.8 sign(x - y) / (3HW) - 0.2 / (3HW) * [blur(dmu1) + 2 x blur(de11) + y blur(de12)]),
+//     depth plane: w_depth * mask * sign(d - gt) / count.
+__global__ __launch_bounds__(kBlock) void map_loss_backward_kernel(FusedArgs a, int W, int H) {
+    __shared__ float sm[3][kHH_][kHW_ + 1];
+    __shared__ float sh[3][kHH_][kTW + 1];
+    float g[11];
+    ssim_window(g);
+    const int ch = blockIdx.z, tid = threadIdx.x;
+    const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
+    const size_t HW = (size_t)H * W;
+    const float *M = a.ws.ssim_maps + (size_t)(3 * ch) * HW;
+    for (int k = tid; k < kHH_ * kHW_; k += kBlock) {
+        const int r = k / kHW_, c = k - r * kHW_;
+        const int yy = y0 + r - kSsimR, xx = x0 + c - kSsimR;
+        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const size_t pix = (size_t)yy * W + xx;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) sm[q][r][c] = in ? M[q * HW + pix] : 0.f;
+    }
+    __syncthreads();
+    for (int k = tid; k < kHH_ * kTW; k += kBlock) {
+        const int r = k / kTW, c = k - r * kTW;
+        float v[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 11; ++t)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) v[q] += g[t] * sm[q][r][c + t];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) sh[q][r][c] = v[q];
+    }
+    __syncthreads();
+    const float inv_n = 1.0f / (3.0f * (float)HW);
+    const float count = (float)a.ws.sums[2];
+    const float *X = a.ws.out6 + ch * HW, *Y = a.frame.im + ch * HW;
+    float *Gout = a.ws.dL_dout6;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int k = tid + rep * kBlock;
+        const int r = k / kTW, c = k - r * kTW;
+        const int yy = y0 + r, xx = x0 + c;
+        if (yy < H && xx < W) {
+            float v[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 11; ++t)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) v[q] += g[t] * sh[q][r + t][c];
+            const size_t pix = (size_t)yy * W + xx;
+            const float xv = X[pix], yv = Y[pix];
+            const float dssim = v[0] + 2.f * xv * v[1] + yv * v[2];
+            Gout[ch * HW + pix] = a.cfg.w_im * (0.8f * sgn(xv - yv) * inv_n - 0.2f * inv_n * dssim);
+            if (ch == 0) {
+                const float *o = a.ws.out6;
+                const Pixel px = depth_pixel(a.cfg, o[3 * HW + pix], o[4 * HW + pix], o[5 * HW + pix], a.frame.depth[pix]);
+                Gout[3 * HW + pix] = a.cfg.use_l1 ? a.cfg.w_depth * px.d_sign / count : 0.f;
+                Gout[4 * HW + pix] = 0.f;
+                Gout[5 * HW + pix] = 0.f;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// F6: per Gaussian adjoint: K8+K9, glue adjoint, pose partial sums
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void fused_backward_kernel(FusedArgs a) {
+    __shared__ double s_part[kPoseSums * (kBlock / 64)];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    float pose[kPoseSums];
+#pragma unroll
+    for (int k = 0; k < kPoseSums; ++k) pose[k] = 0.f;
+    const SplatIterWorkspace &ws = a.ws;
+    const bool iso = a.map.isotropic != 0;
+    if (i < a.map.P) {
+        const bool vis = ws.st.radii[i] > 0;
+        float dp[3] = {0.f, 0.f, 0.f}, du[4] = {0.f, 0.f, 0.f, 0.f}, dlogit = 0.f, dls[3] = {0.f, 0.f, 0.f};
+        float drgb[3] = {0.f, 0.f, 0.f};
+        if (vis) {
+            float acc[SPLAT_GRAD_STRIDE];
+            const float4 *a4 = reinterpret_cast<const float4 *>(ws.accum + (size_t)i * SPLAT_GRAD_STRIDE);
+#pragma unroll
+            for (int k = 0; k < SPLAT_GRAD_STRIDE / 4; ++k) {
+                const float4 v = a4[k];
+                acc[4 * k] = v.x; acc[4 * k + 1] = v.y; acc[4 * k + 2] = v.z; acc[4 * k + 3] = v.w;
+            }
+            CamConst c;
+            load_cam(c, a.cam);
+            Pose P;
+            load_pose(a.map, a.frame.time_idx, P);
+            float p[3], u[4], logit, ls[3];
+            load_gaussian(a.map, i, p, u, logit, ls);
+            Glue G;
+            glue_forward(P, a.frame.w2c + 8, p, u, logit, ls, iso, G);
+            float S6[6];
+            cov3d_from_scale_rot(G.s, c.scale_modifier, G.rq, S6);
+            const float4 co = reinterpret_cast<const float4 *>(ws.st.conic_opacity)[i];
+            const float g_ndc[2] = {-(co.x * acc[0] + co.y * acc[1]) * 0.5f * c.W, -(co.z * acc[1] + co.y * acc[0]) * 0.5f * c.H};
+            const float g_conic[3] = {-0.5f * acc[2], -acc[3], -0.5f * acc[4]};
+            float dXc[3], dS6[6], ds[3], drq[4];
+            project_gaussian_backward(c, G.Xc, S6, g_ndc, g_conic, dXc, dS6);
+            cov3d_backward(G.s, c.scale_modifier, G.rq, dS6, ds, drq);
+            // colour channels: 6..8 rgb, 9 z, 10 silhouette (constant), 11 z^2
+            drgb[0] = acc[6]; drgb[1] = acc[7]; drgb[2] = acc[8];
+            const float dz = acc[9] + 2.f * G.z * acc[11];
+            glue_backward(P, a.frame.w2c + 8, p, iso, G, dXc, dz, acc[5], ds, drq, dp, du, &dlogit, dls, pose);
+        }
+        if (a.cfg.gaussians_grad) {
+            if (ws.d_means3D) { ws.d_means3D[3 * i] = dp[0]; ws.d_means3D[3 * i + 1] = dp[1]; ws.d_means3D[3 * i + 2] = dp[2]; }
+            if (ws.d_unnorm_rotations) reinterpret_cast<float4 *>(ws.d_unnorm_rotations)[i] = make_float4(du[0], du[1], du[2], du[3]);
+        }
+        if (ws.d_rgb_colors) { ws.d_rgb_colors[3 * i] = drgb[0]; ws.d_rgb_colors[3 * i + 1] = drgb[1]; ws.d_rgb_colors[3 * i + 2] = drgb[2]; }
+        if (ws.d_logit_opacities) ws.d_logit_opacities[i] = dlogit;
+        if (ws.d_log_scales) {
+            if (iso) ws.d_log_scales[i] = dls[0];
+            else { ws.d_log_scales[3 * i] = dls[0]; ws.d_log_scales[3 * i + 1] = dls[1]; ws.d_log_scales[3 * i + 2] = dls[2]; }
+        }
+    }
+    if (a.cfg.camera_grad) block_sum_to<kPoseSums>(ws.sums + 8, pose, s_part);
+}
+
+// F7: one thread: pose partial sums -> gradients of the raw camera parameters; loss value
+__global__ void pose_finish_kernel(FusedArgs a, int HW) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double *S = a.ws.sums;
+    float *out = a.ws.d_cam;
+    float dq[4] = {0.f, 0.f, 0.f, 0.f}, dt[3] = {0.f, 0.f, 0.f};
+    if (a.cfg.camera_grad) {
+        Pose P;
+        load_pose(a.map, a.frame.time_idx, P);
+        float sums[kPoseSums];
+        for (int k = 0; k < kPoseSums; ++k) sums[k] = (float)S[8 + k];
+        pose_backward(P, sums, dq, dt);
+    }
+    for (int k = 0; k < 4; ++k) out[k] = dq[k];
+    for (int k = 0; k < 3; ++k) out[4 + k] = dt[k];
+    float loss;
+    const float l_depth = a.cfg.use_l1 ? (float)S[0] : 0.f;
+    if (a.cfg.tracking) {
+        loss = a.cfg.w_depth * l_depth + a.cfg.w_im * (float)S[1];
+    } else {
+        const float n = 3.0f * (float)HW;
+        const float l_im = 0.8f * ((float)S[1] / n) + 0.2f * (1.0f - (float)S[3] / n);
+        loss = a.cfg.w_depth * (a.cfg.use_l1 ? l_depth / (float)S[2] : 0.f) + a.cfg.w_im * l_im;
+    }
+    out[7] = loss;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// F8: Adam
+// ---------------------------------------------------------------------------------------------------------
+struct AdamArgs {
+    SplatMap map;
+    SplatAdamMap opt;
+};
+
+__global__ __launch_bounds__(kBlock) void adam_map_kernel(AdamArgs a) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.map.P) return;
+    float *params[5] = {a.map.means3D, a.map.rgb_colors, a.map.unnorm_rotations, a.map.logit_opacities, a.map.log_scales};
+    const int width[5] = {3, 3, 4, 1, a.map.isotropic ? 1 : 3};
+#pragma unroll
+    for (int gidx = 0; gidx < 5; ++gidx) {
+        const float *grad = a.opt.grad[gidx];
+        if (!grad) continue;                                    // torch skips parameters without a gradient
+        float *m = a.opt.exp_avg[gidx], *v = a.opt.exp_avg_sq[gidx], *p = params[gidx];
+        const int wd = width[gidx];
+        for (int k = 0; k < wd; ++k) {
+            const size_t j = (size_t)i * wd + k;
+            float mm = m[j], vv = v[j];
+            p[j] = adam_update(p[j], grad[j], mm, vv, a.opt.beta1, a.opt.beta2, a.opt.step_size[gidx], a.opt.bc2_sqrt, a.opt.eps);
+            m[j] = mm; v[j] = vv;
+        }
+    }
+}
+
+__global__ void adam_pose_kernel(SplatMap map, int time_idx, const float *d_cam, float *state, float beta1, float beta2,
+                                 float eps, float bc2_sqrt, float ss_rot, float ss_trans) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // state: m_q[0..3] m_t[4..6] v_q[7..10] v_t[11..13] min_loss[14] cand_q[15..18] cand_t[19..21]
+    float q[4], t[3];
+    for (int k = 0; k < 4; ++k) {
+        float *p = map.cam_unnorm_rots + k * map.num_frames + time_idx;
+        q[k] = adam_update(*p, d_cam[k], state[k], state[7 + k], beta1, beta2, ss_rot, bc2_sqrt, eps);
+        *p = q[k];
+    }
+    for (int k = 0; k < 3; ++k) {
+        float *p = map.cam_trans + k * map.num_frames + time_idx;
+        t[k] = adam_update(*p, d_cam[4 + k], state[4 + k], state[11 + k], beta1, beta2, ss_trans, bc2_sqrt, eps);
+        *p = t[k];
+    }
+    // the reference compares the loss of THIS iteration and stores the parameters AFTER the step
+    // (/root/reference/scripts/splatam.py:704-711)
+    const float loss = d_cam[7];
+    if (loss < state[14]) {
+        state[14] = loss;
+        for (int k = 0; k < 4; ++k) state[15 + k] = q[k];
+        for (int k = 0; k < 3; ++k) state[19 + k] = t[k];
+    }
+}
+
+}  // namespace
+
+hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame,
+                                     const SplatLossConfig &cfg, SplatIterWorkspace &ws, hipStream_t s) {
+    FusedArgs a{cam, map, frame, cfg, ws};
+    const int W = cam.image_width, H = cam.image_height, HW = W * H;
+    const int T = (int)splat_num_tiles(W, H);
+    const int P = map.P;
+    hipError_t e = hipMemsetAsync(ws.sums, 0, sizeof(double) * SPLAT_ITER_SUMS, s);
+    if (e != hipSuccess) return e;
+    e = launch_tile_count_reset(ws.st, T, s);
+    if (e != hipSuccess) return e;
+    const int gblocks = (P + kBlock - 1) / kBlock;
+    if (P > 0) hipLaunchKernelGGL(fused_preprocess_kernel, dim3(gblocks), dim3(kBlock), 0, s, a);
+    e = launch_tile_scan(ws.st, T, s);
+    if (e != hipSuccess) return e;
+    SplatGaussians g{};
+    g.P = P;
+    g.channels = 6;
+    e = launch_bin_forward(cam, g, ws.st, s);
+    if (e != hipSuccess) return e;
+    e = launch_render_forward_feat8(cam, ws.feat8, ws.st, ws.out6, s);
+    if (e != hipSuccess) return e;
+    if (cfg.tracking) {
+        const int blocks = min((HW + kBlock - 1) / kBlock, 2048);
+        hipLaunchKernelGGL(track_loss_kernel, dim3(blocks), dim3(kBlock), 0, s, a, HW);
+    } else {
+        const dim3 grid((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, 3);
+        hipLaunchKernelGGL(ssim_forward_kernel, grid, dim3(kBlock), 0, s, a, W, H);
+        hipLaunchKernelGGL(map_loss_backward_kernel, grid, dim3(kBlock), 0, s, a, W, H);
+    }
+    e = launch_render_backward_feat8(cam, ws.feat8, ws.st, ws.dL_dout6, ws.accum, P, s);
+    if (e != hipSuccess) return e;
+    if (P > 0) hipLaunchKernelGGL(fused_backward_kernel, dim3(gblocks), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(64), 0, s, a, HW);
+    return hipGetLastError();
+}
+
+hipError_t launch_iter_adam_map(const SplatMap &map, const SplatAdamMap &opt, hipStream_t s) {
+    if (map.P <= 0) return hipSuccess;
+    AdamArgs a{map, opt};
+    hipLaunchKernelGGL(adam_map_kernel, dim3((map.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_iter_adam_pose(const SplatMap &map, int time_idx, const float *d_cam, float *state, float beta1, float beta2,
+                                 float eps, float bc2_sqrt, float ss_rot, float ss_trans, hipStream_t s) {
+    hipLaunchKernelGGL(adam_pose_kernel, dim3(1), dim3(64), 0, s, map, time_idx, d_cam, state, beta1, beta2, eps, bc2_sqrt, ss_rot,
+                       ss_trans);
+    return hipGetLastError();
+}
+
+}  // namespace splat

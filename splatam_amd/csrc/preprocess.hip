@@ -80,14 +80,17 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(SplatState st, int T) {
         total += wave_tot[w];
         gmax = max(gmax, wave_max[w]);
     }
+    // lists that do not fit the caller's buffers are published as EMPTY (and flagged in status[1]): a composite
+    // launched behind an overflowing binning must never index past keys / point_list
+    const bool overflow = (long long)total > st.capacity;
     unsigned run = wave_off + incl - sum;
     for (int t = lo; t < hi; ++t) {
-        st.tile_base[t] = run;
+        st.tile_base[t] = overflow ? 0u : run;
         st.tile_cursor[(size_t)t * SPLAT_COUNTER_STRIDE] = run;
         run += st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE];
     }
     if (tid == 0) {
-        st.tile_base[T] = total;
+        st.tile_base[T] = overflow ? 0u : total;
         st.status[0] = (int)total;
         st.status[1] = (long long)total > st.capacity ? 1 : 0;
         st.status[2] = (int)gmax;
@@ -193,14 +196,22 @@ __global__ __launch_bounds__(kBlock) void mark_visible_kernel(int P, const float
     present[i] = z > kNearZ;
 }
 
+hipError_t launch_tile_count_reset(SplatState &st, int T, hipStream_t s) {
+    return hipMemsetAsync(st.tile_count, 0, sizeof(uint32_t) * (size_t)T * SPLAT_COUNTER_STRIDE, s);
+}
+
+hipError_t launch_tile_scan(SplatState &st, int T, hipStream_t s) {
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, st, T);
+    return hipGetLastError();
+}
+
 hipError_t launch_preprocess_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s) {
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
-    hipError_t e = hipMemsetAsync(st.tile_count, 0, sizeof(uint32_t) * (size_t)T * SPLAT_COUNTER_STRIDE, s);
+    hipError_t e = launch_tile_count_reset(st, T, s);
     if (e != hipSuccess) return e;
     if (g.P > 0)
         hipLaunchKernelGGL(preprocess_forward_kernel, dim3((g.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, cam, g, st, g_debug_skip_count);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, st, T);
-    return hipGetLastError();
+    return launch_tile_scan(st, T, s);
 }
 
 hipError_t launch_preprocess_backward(const SplatCamera &cam, const SplatGaussians &g, const SplatState &st,

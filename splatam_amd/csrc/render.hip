@@ -1,65 +1,85 @@
 // render.hip -- tile-wise alpha compositing, forward (K6) and backward (K7).
 //
-// MI355X mapping: ONE wave64 per 16x16 tile, FOUR pixels per lane (lane l owns
-// pixel (l&7, l>>3) of each 8x8 quadrant).  Consequences:
-//   * no workgroup barriers and no cross-wave reductions: "is every pixel of
-//     the tile done" and "did anybody in the tile touch this Gaussian" are
-//     single wave-level ballots;
-//   * the tile's depth-sorted list is staged 64 Gaussians at a time through a
-//     wave-private LDS slab (each lane gathers one Gaussian's record from the
-//     L2-resident SoA arrays, next batch prefetched into registers while the
-//     current one is composited); the inner loop reads the slab with
-//     uniform-address (broadcast) ds_read_b128, one Gaussian ahead of use,
-//     amortised over 4 pixels per lane;
-//   * exact quadrant culling: the staging lane computes, per Gaussian, which of
-//     the tile's four 8x8 quadrants can contain a pixel with alpha >= 1/255
-//     (axis-aligned box of the ellipse power >= -ln(255*opacity), inflated by a
-//     rounding margin).  The 4-bit mask is wave-uniform, so a dead quadrant
-//     costs one scalar branch instead of 64 lanes of exp/compare work, and
-//     results are unchanged (a culled pixel would have failed the alpha test);
-//   * backward: a Gaussian's 6+C partial sums are first added over the lane's
-//     4 pixels in registers, then reduced across the 64 lanes four values at a
-//     time with v_permlane32_swap / v_permlane16_swap + 4 DPP adds, and leave
-//     the wave as ONE float atomic per (Gaussian, tile, component).
+// MI355X mapping (third generation; the previous one lives in render_v2.hip for A/B timing):
+//   * one 256-thread workgroup per 16x16 tile, ONE WAVE64 PER 8x8 QUADRANT, one pixel per lane.  A frame of
+//     config B is 3 225 tiles = 12 900 waves = 12.6 per SIMD, so every SIMD always has several waves to
+//     interleave (the one-wave-per-tile kernels were latency bound at ~3 waves per SIMD);
+//   * the tile's depth-sorted list is staged 256 Gaussians at a time into double-buffered LDS (each thread
+//     gathers one Gaussian's record from the L2-resident SoA arrays; the next batch is in flight while the
+//     current one is composited; one barrier per batch);
+//   * exact quadrant culling, resolved at staging time: the gathering thread computes which of the four
+//     quadrants can hold a pixel with alpha >= 1/255 (axis-aligned box of {power >= -ln(255 o)}, inflated by a
+//     rounding margin), the four 64-bit ballots per gathering wave go to LDS, and each compositing wave walks
+//     ONLY the set bits of its own quadrant's 256-bit mask (s_ff1 / s_flbit on SGPRs).  A Gaussian that cannot
+//     touch a quadrant costs that wave nothing; results are unchanged (a culled pixel fails the alpha test);
+//   * inner loop: uniform-address (broadcast) ds_read_b128/b64 of the live entry; the scalar search for the next
+//     set bit overlaps the LDS latency (an explicit one-entry-ahead register prefetch measured slower: +40 VGPRs);
+//   * backward: the 6+C partial sums of a Gaussian are reduced across the 64 lanes four at a time with
+//     v_permlane32_swap / v_permlane16_swap + 4 DPP adds and leave the wave as ONE float atomic per
+//     (Gaussian, quadrant, component);
+//   * blockIdx -> tile map gives each XCD (block b runs on XCD b % 8) a contiguous band of tiles, so that the
+//     Gaussians shared by neighbouring tiles are served by one XCD's L2.
 //
-// Arithmetic: SURVEY.md Appendix A "Forward composite (K6)" / "Backward
-// composite (K7)" -- the callee of /root/reference/scripts/splatam.py:249,253
-// and of the autograd backward reached from :702,854.  exp(power) is evaluated
-// as v_exp_f32(power * log2 e) with log2 e folded into the staged conic.
+// Arithmetic: SURVEY.md Appendix A "Forward composite (K6)" / "Backward composite (K7)" -- the callee of
+// /root/reference/scripts/splatam.py:249,253 and of the autograd backward reached from :702,854.
+// exp(power) is evaluated as v_exp_f32(power * log2 e) with log2 e folded into the staged conic.
 #include "splat_device.h"
 
 namespace splat {
 
-// One staged Gaussian, as the gathering lane holds it in registers.
-template <int C>
+constexpr int kBatch = 256;     // list entries staged per LDS buffer
+
+hipError_t launch_render_forward_v2(const SplatCamera &cam, const float *col, SplatState &st, float *out_color,
+                                    float *out_depth, hipStream_t s);
+hipError_t launch_render_backward_v2(const SplatCamera &cam, const float *col, const SplatState &st, const float *dL_dcolor,
+                                     float *accum, hipStream_t s);
+int g_debug_composite_version = 3;   // splat_debug_option(1, v): 2 = previous generation (3-channel calls only)
+
+// One staged Gaussian as the gathering thread holds it in registers.
+template <int FP>
 struct Staged {
     float4 ga;          // A = -0.5*cxx*log2e, B = -cxy*log2e, Cq = -0.5*cyy*log2e, opacity
-    float4 gb;          // mu_x, mu_y, quadrant mask (bits), Gaussian id (bits)
-    float feat[C + 1];  // colours, then depth (forward only)
+    float2 mu;          // pixel centre
+    float feat[FP];     // colours (then depth in the forward of the reference API), zero padded
+    unsigned mask;      // 4-bit quadrant mask
+    unsigned id;        // Gaussian index
 };
 
-// LDS slab of one wave: 64 staged Gaussians.
-template <int C>
-struct Slab {
-    float4 ga[64];
-    float4 gb[64];
-    float feat[(C + 1) * 64];                // C == 3: one float4 {r,g,b,depth} per Gaussian; otherwise [c][64]
-};
+// colours of Gaussian `id`: C floats at colors + id*CS (CS = record stride in floats; CS % 4 == 0 records are
+// 16-byte aligned and read as float4)
+template <int C, int CS>
+__device__ __forceinline__ void load_colors(const float *colors, unsigned id, float *out) {
+    if constexpr (CS % 4 == 0) {
+        const float4 *p = reinterpret_cast<const float4 *>(colors + (size_t)id * CS);
+#pragma unroll
+        for (int v = 0; v < (C + 3) / 4; ++v) {
+            const float4 t = p[v];
+            if (4 * v < C) out[4 * v] = t.x;
+            if (4 * v + 1 < C) out[4 * v + 1] = t.y;
+            if (4 * v + 2 < C) out[4 * v + 2] = t.z;
+            if (4 * v + 3 < C) out[4 * v + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) out[ch] = colors[(size_t)id * CS + ch];
+    }
+}
 
-template <int C, bool WITH_DEPTH>
-__device__ __forceinline__ void gather(Staged<C> &s, const SplatState &st, const float *colors, unsigned idx, bool valid,
+template <int C, int CS, bool WITH_DEPTH, int FP>
+__device__ __forceinline__ void gather(Staged<FP> &s, const SplatState &st, const float *colors, unsigned idx, bool valid,
                                        float tile_x0, float tile_y0) {
     s.ga = make_float4(0.f, 0.f, 0.f, 0.f);
-    s.gb = make_float4(0.f, 0.f, 0.f, 0.f);
+    s.mu = make_float2(0.f, 0.f);
 #pragma unroll
-    for (int f = 0; f <= C; ++f) s.feat[f] = 0.f;
+    for (int f = 0; f < FP; ++f) s.feat[f] = 0.f;
+    s.mask = 0;
+    s.id = 0;
     if (valid) {
         const unsigned id = st.point_list[idx];
         const float4 co = reinterpret_cast<const float4 *>(st.conic_opacity)[id];
         const float2 mu = reinterpret_cast<const float2 *>(st.xy)[id];
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) s.feat[ch] = colors[(size_t)id * C + ch];
-        if (WITH_DEPTH) s.feat[C] = st.depth[id];
+        load_colors<C, CS>(colors, id, s.feat);
+        if constexpr (WITH_DEPTH) s.feat[C] = st.depth[id];
         // live region {alpha >= 1/255}: (p-mu)^T Q (p-mu) <= 2 tau, tau = ln(255 o); half extents sqrt(2 tau Q^-1_ii)
         unsigned mask = 0;
         const float tau2 = 2.0f * __logf(255.0f * co.w);
@@ -75,264 +95,325 @@ __device__ __forceinline__ void gather(Staged<C> &s, const SplatState &st, const
             if (!(hx == hx) || !(hy == hy)) mask = 15u;     // NaN geometry: no culling, let it propagate as the reference would
         }
         s.ga = make_float4(-0.5f * kLog2e * co.x, -kLog2e * co.y, -0.5f * kLog2e * co.z, co.w);
-        s.gb = make_float4(mu.x, mu.y, __uint_as_float(mask), __uint_as_float(id));
+        s.mu = mu;
+        s.mask = mask;
+        s.id = id;
     }
 }
 
-template <int C>
-__device__ __forceinline__ void commit(Slab<C> &sl, const Staged<C> &s, int lane) {
-    sl.ga[lane] = s.ga;
-    sl.gb[lane] = s.gb;
-    if constexpr (C == 3) {
-        reinterpret_cast<float4 *>(sl.feat)[lane] = make_float4(s.feat[0], s.feat[1], s.feat[2], s.feat[3]);
-    } else {
-#pragma unroll
-        for (int f = 0; f <= C; ++f) sl.feat[f * 64 + lane] = s.feat[f];
-    }
-}
-
-template <int C>
-struct Entry {          // one slab entry as the inner loop holds it (wave-uniform values)
-    float4 ga, gb;
-    float feat[C + 1];
+// LDS image of one batch: one record of R4 = FP/4 + 2 float4 per staged Gaussian
+//   [0] A, B, Cq, opacity   [1 .. FP/4] features   [FP/4 + 1] mu_x, mu_y, id (bits), 0
+// so that the compositing wave needs ONE address register and reads the record with FP/4 + 2 broadcast
+// ds_read_b128 (the 48 / 64-byte record stride keeps the staging ds_write_b128 conflict free).
+template <int FP>
+struct Batch {
+    static constexpr int R4 = FP / 4 + 2;
+    float4 rec[kBatch * R4];
+    unsigned qmask[4][4][2];        // [quadrant][gathering wave][lo, hi]: ballot of "this Gaussian can touch the quadrant"
+    unsigned flag[4];               // forward: wave w had no pixel left when this batch was committed
 };
 
-template <int C>
-__device__ __forceinline__ void read_entry(const Slab<C> &sl, int j, Entry<C> &e) {
-    e.ga = sl.ga[j];
-    e.gb = sl.gb[j];
-    if constexpr (C == 3) {
-        const float4 v = reinterpret_cast<const float4 *>(sl.feat)[j];
-        e.feat[0] = v.x; e.feat[1] = v.y; e.feat[2] = v.z; e.feat[3] = v.w;
-    } else {
+template <int FP>
+__device__ __forceinline__ void commit(Batch<FP> &b, const Staged<FP> &s, int tid, unsigned flag) {
+    constexpr int R4 = Batch<FP>::R4;
+    b.rec[tid * R4] = s.ga;
 #pragma unroll
-        for (int f = 0; f <= C; ++f) e.feat[f] = sl.feat[f * 64 + j];
+    for (int v = 0; v < FP / 4; ++v)
+        b.rec[tid * R4 + 1 + v] = make_float4(s.feat[4 * v], s.feat[4 * v + 1], s.feat[4 * v + 2], s.feat[4 * v + 3]);
+    b.rec[tid * R4 + R4 - 1] = make_float4(s.mu.x, s.mu.y, __uint_as_float(s.id), 0.f);
+    const int wave = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64((s.mask >> q) & 1u);
+        if ((tid & 63) == 0) {
+            b.qmask[q][wave][0] = (unsigned)m;
+            b.qmask[q][wave][1] = (unsigned)(m >> 32);
+        }
     }
+    if ((tid & 63) == 0) b.flag[wave] = flag;
 }
+
+template <int FP>
+struct Entry {          // one staged Gaussian as the compositing wave holds it (wave-uniform values)
+    float4 ga;
+    float mux, muy;
+    unsigned id;
+    float feat[FP];
+};
+
+template <int FP>
+__device__ __forceinline__ void read_entry(const Batch<FP> &b, int e, Entry<FP> &o) {
+    constexpr int R4 = Batch<FP>::R4;
+    const float4 *r = b.rec + e * R4;
+    o.ga = r[0];
+#pragma unroll
+    for (int v = 0; v < FP / 4; ++v) {
+        const float4 t = r[1 + v];
+        o.feat[4 * v] = t.x; o.feat[4 * v + 1] = t.y; o.feat[4 * v + 2] = t.z; o.feat[4 * v + 3] = t.w;
+    }
+    const float4 m = r[R4 - 1];
+    o.mux = m.x; o.muy = m.y; o.id = __float_as_uint(m.z);
+}
+
+// wave-uniform 64-bit word of this wave's quadrant mask
+template <int FP>
+__device__ __forceinline__ unsigned long long mask_word(const Batch<FP> &b, int quadrant, int w) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)b.qmask[quadrant][w][0]);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)b.qmask[quadrant][w][1]);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// blockIdx -> tile: XCD x (blocks with b % 8 == x) owns tiles [x*per, (x+1)*per)
+__device__ __forceinline__ int block_tile(int per_xcd, int T) {
+    const int b = blockIdx.x, slot = b >> 3;
+    const int tile = (b & 7) * per_xcd + slot;
+    return (slot < per_xcd && tile < T) ? tile : -1;
+}
+
+// Per-lane predicates of the inner loops are kept as wave-uniform 64-bit masks in SGPRs (ballot in, inverse
+// ballot out): the kernels are instruction-issue bound, and masks in scalar registers cost one s_and / s_andn2
+// where a per-lane bool in divergent control flow costs the compiler a chain of exec-mask bookkeeping.
+__device__ __forceinline__ bool lane_of(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
 // ---------------------------------------------------------------------------
 // K6 forward composite
 // ---------------------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(64) void render_forward_kernel(SplatCamera cam, const float *colors, SplatState st,
-                                                            float *out_color, float *out_depth) {
-    __shared__ Slab<C> sl;
+template <int C, int CS, bool WITH_DEPTH>
+__global__ __launch_bounds__(256) void render_forward_kernel(SplatCamera cam, const float *colors, SplatState st,
+                                                             float *out_color, float *out_depth, int T, int per_xcd) {
+    constexpr int F = C + (WITH_DEPTH ? 1 : 0);
+    constexpr int FP = (F + 3) / 4 * 4;
+    __shared__ Batch<FP> sb[2];
+    const int tile = block_tile(per_xcd, T);
+    if (tile < 0) return;
     const int W = cam.image_width, H = cam.image_height;
     const int gx = (W + kTile - 1) / kTile;
-    const int tile = blockIdx.x, lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx = tile % gx, ty = tile / gx;
-    const int px0 = tx * kTile + (lane & 7), py0 = ty * kTile + (lane >> 3);
-    const float fpx[2] = {(float)px0, (float)(px0 + 8)}, fpy[2] = {(float)py0, (float)(py0 + 8)};
+    const int px = tx * kTile + (wave & 1) * 8 + (lane & 7), py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
+    const float fpx = (float)px, fpy = (float)py;
     const float tile_x0 = (float)(tx * kTile), tile_y0 = (float)(ty * kTile);
-    bool inside[4], done[4];
-    float T[4], D[4], Cc[4][C];
-    unsigned last[4];
+    const bool inside = px < W && py < H;
+    float Tr = 1.f, D = 0.f, Cc[C];
+    unsigned last = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        inside[k] = (px0 + 8 * (k & 1) < W) && (py0 + 8 * (k >> 1) < H);
-        done[k] = !inside[k];
-        T[k] = 1.f; D[k] = 0.f; last[k] = 0;
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) Cc[k][ch] = 0.f;
-    }
-    // wave-uniform: quadrants that still have a pixel to composite
-    unsigned qalive = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) qalive |= __any(!done[k]) ? (1u << k) : 0u;
+    for (int ch = 0; ch < C; ++ch) Cc[ch] = 0.f;
+    unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside);      // wave-uniform: pixels with nothing left to composite
+    bool wdone = done_m == ~0ull;
 
     const unsigned lo = st.tile_base[tile], hi = st.tile_base[tile + 1];
     const int n = (int)(hi - lo);
+    const int nb = (n + kBatch - 1) / kBatch;
 
-    Staged<C> pre;
-    gather<C, true>(pre, st, colors, lo + lane, lane < n, tile_x0, tile_y0);
-    for (int base = 0; base < n && qalive != 0; base += 64) {
-        commit<C>(sl, pre, lane);
+    if (nb > 0) {
+        Staged<FP> pre;
+        gather<C, CS, WITH_DEPTH, FP>(pre, st, colors, lo + tid, tid < n, tile_x0, tile_y0);
+        commit(sb[0], pre, tid, wdone ? 1u : 0u);
         __syncthreads();
-        if (base + 64 < n) gather<C, true>(pre, st, colors, lo + base + 64 + lane, base + 64 + lane < n, tile_x0, tile_y0);
-        const int cnt = min(64, n - base);
-        Entry<C> cur, nxt;
-        read_entry<C>(sl, 0, cur);
-        for (int j = 0; j < cnt; ++j) {
-            read_entry<C>(sl, (j + 1) & 63, nxt);          // one Gaussian ahead: LDS latency hidden behind the blend
-            const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cur.gb.z)) & qalive;
-            if (mask != 0) {
-                const float dx[2] = {cur.gb.x - fpx[0], cur.gb.x - fpx[1]}, dy[2] = {cur.gb.y - fpy[0], cur.gb.y - fpy[1]};
-                const unsigned pos = (unsigned)(base + j + 1);
+        for (int bi = 0; bi < nb; ++bi) {
+            const Batch<FP> &B = sb[bi & 1];
+            // every wave was finished when this batch was committed: the rest of the list cannot contribute
+            const unsigned alldone = B.flag[0] & B.flag[1] & B.flag[2] & B.flag[3];
+            if (__builtin_amdgcn_readfirstlane((int)alldone)) break;
+            const bool more = bi + 1 < nb;
+            if (more) {                         // next batch's gather stays in flight while this one is composited
+                const int e = (bi + 1) * kBatch + tid;
+                gather<C, CS, WITH_DEPTH, FP>(pre, st, colors, lo + e, e < n, tile_x0, tile_y0);
+            }
+            const unsigned base1 = (unsigned)(bi * kBatch + 1);
+#pragma unroll 1
+            for (int w = 0; w < 4 && !wdone; ++w) {
+                unsigned long long bits = mask_word(B, wave, w);
+                while (bits != 0) {
+                    const int e = w * 64 + __builtin_ctzll(bits);
+                    bits &= bits - 1;
+                    Entry<FP> cur;
+                    read_entry(B, e, cur);
+                    const float dx = cur.mux - fpx, dy = cur.muy - fpy;
+                    const float p2 = dx * (cur.ga.x * dx + cur.ga.y * dy) + cur.ga.z * dy * dy;     // power * log2(e)
+                    const float alpha = fminf(kAlphaMax, cur.ga.w * fast_exp2(p2));
+                    const unsigned long long live_m = __builtin_amdgcn_ballot_w64(p2 <= 0.f) & __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin) & ~done_m;
+                    if (live_m != 0) {
+                        const float test_T = Tr * (1.f - alpha);
+                        const unsigned long long stop_m = __builtin_amdgcn_ballot_w64(test_T < kTStop) & live_m;
+                        const bool upd = lane_of(live_m & ~stop_m);
+                        const float wgt = upd ? alpha * Tr : 0.f;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (mask & (1u << k)) {                // scalar branch
-                        const float ddx = dx[k & 1], ddy = dy[k >> 1];
-                        const float p2 = ddx * (cur.ga.x * ddx + cur.ga.y * ddy) + cur.ga.z * ddy * ddy;   // power * log2(e)
-                        const float alpha = fminf(kAlphaMax, cur.ga.w * fast_exp2(p2));
-                        const bool live = !done[k] && p2 <= 0.f && alpha >= kAlphaMin;
-                        if (__any(live)) {
-                            const float test_T = T[k] * (1.f - alpha);
-                            const bool stop = live && test_T < kTStop;
-                            const bool upd = live && !stop;
-                            const float w = upd ? alpha * T[k] : 0.f;
-#pragma unroll
-                            for (int ch = 0; ch < C; ++ch) Cc[k][ch] += cur.feat[ch] * w;
-                            D[k] += cur.feat[C] * w;
-                            T[k] = upd ? test_T : T[k];
-                            last[k] = upd ? pos : last[k];
-                            if (__any(stop)) {
-                                done[k] = done[k] || stop;
-                                if (!__any(!done[k])) qalive &= ~(1u << k);
-                            }
+                        for (int ch = 0; ch < C; ++ch) Cc[ch] += cur.feat[ch] * wgt;
+                        if constexpr (WITH_DEPTH) D += cur.feat[C] * wgt;
+                        Tr = upd ? test_T : Tr;
+                        last = upd ? base1 + (unsigned)e : last;
+                        done_m |= stop_m;
+                        if (done_m == ~0ull) {
+                            wdone = true;
+                            bits = 0;
                         }
                     }
                 }
             }
-            cur = nxt;
+            if (more) {
+                commit(sb[(bi + 1) & 1], pre, tid, wdone ? 1u : 0u);
+                __syncthreads();
+            }
         }
-        __syncthreads();
     }
-    const size_t HW = (size_t)H * W;
+    if (inside) {
+        const size_t HW = (size_t)H * W;
+        const size_t pix = (size_t)py * W + px;
+        st.final_T[pix] = Tr;
+        st.n_contrib[pix] = (int)last;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (inside[k]) {
-            const size_t pix = (size_t)(py0 + 8 * (k >> 1)) * W + (px0 + 8 * (k & 1));
-            st.final_T[pix] = T[k];
-            st.n_contrib[pix] = (int)last[k];
-#pragma unroll
-            for (int ch = 0; ch < C; ++ch) out_color[ch * HW + pix] = Cc[k][ch] + T[k] * cam.bg[ch];
-            out_depth[pix] = D[k];
-        }
+        for (int ch = 0; ch < C; ++ch) out_color[ch * HW + pix] = Cc[ch] + Tr * cam.bg[ch];
+        if constexpr (WITH_DEPTH) out_depth[pix] = D;
     }
 }
 
 // ---------------------------------------------------------------------------
 // K7 backward composite
 // ---------------------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(64) void render_backward_kernel(SplatCamera cam, const float *colors, SplatState st,
-                                                             const float *dL_dcolor, float *accum) {
+template <int C, int CS>
+__global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, const float *colors, SplatState st,
+                                                              const float *dL_dcolor, float *accum, int T, int per_xcd) {
+    constexpr int FP = (C + 3) / 4 * 4;
     constexpr int NV = 6 + C;                 // partial sums per Gaussian
     constexpr int NG = (NV + 3) / 4;          // packed reduction groups
-    __shared__ Slab<C> sl;
+    __shared__ Batch<FP> sb[2];
+    __shared__ unsigned s_wmax[4];
+    const int tile = block_tile(per_xcd, T);
+    if (tile < 0) return;
     const int W = cam.image_width, H = cam.image_height;
     const int gx = (W + kTile - 1) / kTile;
-    const int tile = blockIdx.x, lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx = tile % gx, ty = tile / gx;
-    const int px0 = tx * kTile + (lane & 7), py0 = ty * kTile + (lane >> 3);
-    const float fpx[2] = {(float)px0, (float)(px0 + 8)}, fpy[2] = {(float)py0, (float)(py0 + 8)};
+    const int px = tx * kTile + (wave & 1) * 8 + (lane & 7), py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
+    const float fpx = (float)px, fpy = (float)py;
     const float tile_x0 = (float)(tx * kTile), tile_y0 = (float)(ty * kTile);
+    const bool inside = px < W && py < H;
     const size_t HW = (size_t)H * W;
+    const size_t pix = (size_t)py * W + px;
 
     // Per pixel: running transmittance, and the scalar form of the "colour behind" recursion:
     // with cdot_i = sum_ch c_i[ch] dL/dC[ch], the reference's accum_rec[ch] only ever enters through
     // behind = sum_ch accum_rec[ch] dL/dC[ch], which obeys behind <- a_prev cdot_prev + (1-a_prev) behind.
-    float T[4], Tfin[4], dpix[4][C], bgdot[4], behind[4], lcdot[4], lalpha[4];
-    unsigned last[4];
-    unsigned max_last = 0;
+    const float Tfin = inside ? st.final_T[pix] : 0.f;
+    float Tr = Tfin;
+    const unsigned last = inside ? (unsigned)st.n_contrib[pix] : 0u;
+    float dpix[C], bgdot = 0.f, behind = 0.f, lcdot = 0.f, lalpha = 0.f;
     bool has_bg = false;
 #pragma unroll
-    for (int ch = 0; ch < C; ++ch) has_bg |= cam.bg[ch] != 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const bool inside = (px0 + 8 * (k & 1) < W) && (py0 + 8 * (k >> 1) < H);
-        const size_t pix = (size_t)(py0 + 8 * (k >> 1)) * W + (px0 + 8 * (k & 1));
-        Tfin[k] = inside ? st.final_T[pix] : 0.f;
-        T[k] = Tfin[k];
-        last[k] = inside ? (unsigned)st.n_contrib[pix] : 0u;
-        max_last = max(max_last, last[k]);
-        bgdot[k] = 0.f; lalpha[k] = 0.f; behind[k] = 0.f; lcdot[k] = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) {
-            dpix[k][ch] = inside ? dL_dcolor[ch * HW + pix] : 0.f;
-            bgdot[k] += cam.bg[ch] * dpix[k][ch];
-        }
+    for (int ch = 0; ch < C; ++ch) {
+        has_bg |= cam.bg[ch] != 0.f;
+        dpix[ch] = inside ? dL_dcolor[ch * HW + pix] : 0.f;
+        bgdot += cam.bg[ch] * dpix[ch];
     }
-    max_last = wave_max_u32(max_last);
-    if (max_last == 0) return;
+    const unsigned wmax = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_max_u32(last));   // deepest contributor of this quadrant
+    if (lane == 0) s_wmax[wave] = wmax;
+    __syncthreads();
+    const unsigned tmax = (unsigned)__builtin_amdgcn_readfirstlane((int)max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])));
+    if (tmax == 0) return;                                     // uniform over the workgroup
     const unsigned lo = st.tile_base[tile];
-    const int nb = (int)((max_last + 63) / 64);
+    const int nb = (int)((tmax + kBatch - 1) / kBatch);
+    // lanes 0 / 16 / 32 / 48 publish the reduced sums: row r holds value row_value(r) of each packed group
+    const int rv = row_value(lane >> 4);
+    const unsigned long long pub_m = 0x0001000100010001ull;
 
-    Staged<C> pre;
-    gather<C, false>(pre, st, colors, lo + (nb - 1) * 64 + lane, (unsigned)((nb - 1) * 64 + lane) < max_last, tile_x0, tile_y0);
-    for (int b = nb - 1; b >= 0; --b) {
-        commit<C>(sl, pre, lane);
-        __syncthreads();
-        if (b > 0) gather<C, false>(pre, st, colors, lo + (b - 1) * 64 + lane, true, tile_x0, tile_y0);
-        const int jhi = min(64, (int)max_last - b * 64);
-        Entry<C> cur, nxt;
-        read_entry<C>(sl, jhi - 1, cur);
-        for (int j = jhi - 1; j >= 0; --j) {
-            read_entry<C>(sl, (j - 1) & 63, nxt);
-            const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(cur.gb.z));
-            if (mask != 0) {
-                const unsigned pos = (unsigned)(b * 64 + j + 1);
-                const float dx[2] = {cur.gb.x - fpx[0], cur.gb.x - fpx[1]}, dy[2] = {cur.gb.y - fpy[0], cur.gb.y - fpy[1]};
-                float s[NG * 4];
+    Staged<FP> pre;
+    {
+        const unsigned e = (unsigned)((nb - 1) * kBatch + tid);
+        gather<C, CS, false, FP>(pre, st, colors, lo + e, e < tmax, tile_x0, tile_y0);
+    }
+    commit(sb[(nb - 1) & 1], pre, tid, 0u);
+    __syncthreads();
+    for (int bi = nb - 1; bi >= 0; --bi) {
+        const Batch<FP> &B = sb[bi & 1];
+        const bool more = bi > 0;
+        if (more) gather<C, CS, false, FP>(pre, st, colors, lo + (unsigned)((bi - 1) * kBatch + tid), true, tile_x0, tile_y0);
+        const int base = bi * kBatch;
+        const int lim = (int)wmax - base;                      // entries [0, lim) of this batch can matter to this wave
+#pragma unroll 1
+        for (int w = 3; w >= 0; --w) {
+            const int k = lim - 64 * w;
+            if (k <= 0) continue;
+            unsigned long long bits = mask_word(B, wave, w);
+            if (k < 64) bits &= (1ull << k) - 1ull;
+            while (bits != 0) {
+                const int j = 63 - __builtin_clzll(bits);
+                bits &= ~(1ull << j);
+                const int e = w * 64 + j;
+                Entry<FP> cur;
+                read_entry(B, e, cur);
+                const unsigned pos = (unsigned)(base + e + 1);
+                const float dx = cur.mux - fpx, dy = cur.muy - fpy;
+                const float p2 = dx * (cur.ga.x * dx + cur.ga.y * dy) + cur.ga.z * dy * dy;
+                const float G = fast_exp2(p2);
+                const float alpha = fminf(kAlphaMax, cur.ga.w * G);
+                const unsigned long long live_m = __builtin_amdgcn_ballot_w64(pos <= last) & __builtin_amdgcn_ballot_w64(p2 <= 0.f) &
+                                                  __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin);
+                if (live_m != 0) {
+                    const bool live = lane_of(live_m);
+                    const float rcp = __builtin_amdgcn_rcpf(1.f - alpha);
+                    const float Tn = Tr * rcp;                     // transmittance in front of this Gaussian
+                    float cdot = 0.f;
 #pragma unroll
-                for (int v = 0; v < NG * 4; ++v) s[v] = 0.f;
-                bool touched = false;
+                    for (int ch = 0; ch < C; ++ch) cdot += cur.feat[ch] * dpix[ch];
+                    const float bh = lalpha * lcdot + (1.f - lalpha) * behind;
+                    float dL_dalpha = (cdot - bh) * Tn;
+                    if (has_bg) dL_dalpha += (-Tfin * rcp) * bgdot;
+                    // selects (not multiplies by 0) so that a non-live lane can never inject inf * 0
+                    const float Gl = live ? G : 0.f;
+                    const float wgt = live ? alpha * Tn : 0.f;
+                    const float q = live ? cur.ga.w * dL_dalpha : 0.f;   // dL/dG
+                    const float gdx = Gl * dx, gdy = Gl * dy;
+                    const float qgx = q * gdx, qgy = q * gdy;
+                    float s[NG * 4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (mask & (1u << k)) {
-                        const float ddx = dx[k & 1], ddy = dy[k >> 1];
-                        const float p2 = ddx * (cur.ga.x * ddx + cur.ga.y * ddy) + cur.ga.z * ddy * ddy;
-                        const float G = fast_exp2(p2);
-                        const float alpha = fminf(kAlphaMax, cur.ga.w * G);
-                        const bool live = pos <= last[k] && p2 <= 0.f && alpha >= kAlphaMin;
-                        if (__any(live)) {
-                            touched = true;
-                            const float rcp = __builtin_amdgcn_rcpf(1.f - alpha);
-                            const float Tn = T[k] * rcp;                     // transmittance in front of this Gaussian
-                            float cdot = 0.f;
+                    for (int v = NV; v < NG * 4; ++v) s[v] = 0.f;
+                    s[0] = qgx;
+                    s[1] = qgy;
+                    s[2] = qgx * dx;
+                    s[3] = qgx * dy;
+                    s[4] = qgy * dy;
+                    s[5] = Gl * dL_dalpha;
 #pragma unroll
-                            for (int ch = 0; ch < C; ++ch) cdot += cur.feat[ch] * dpix[k][ch];
-                            const float bh = lalpha[k] * lcdot[k] + (1.f - lalpha[k]) * behind[k];
-                            float dL_dalpha = (cdot - bh) * Tn;
-                            if (has_bg) dL_dalpha += (-Tfin[k] * rcp) * bgdot[k];
-                            // selects (not multiplies by 0) so that a non-live lane can never inject inf * 0
-                            const float Gl = live ? G : 0.f;
-                            const float w = live ? alpha * Tn : 0.f;
-                            const float q = live ? cur.ga.w * dL_dalpha : 0.f;   // dL/dG
-                            const float gdx = Gl * ddx, gdy = Gl * ddy;
-                            const float qgx = q * gdx, qgy = q * gdy;
-                            s[0] += qgx;
-                            s[1] += qgy;
-                            s[2] += qgx * ddx;
-                            s[3] += qgx * ddy;
-                            s[4] += qgy * ddy;
-                            s[5] += live ? Gl * dL_dalpha : 0.f;
+                    for (int ch = 0; ch < C; ++ch) s[6 + ch] = wgt * dpix[ch];
+                    Tr = live ? Tn : Tr;
+                    behind = live ? bh : behind;
+                    lcdot = live ? cdot : lcdot;
+                    lalpha = live ? alpha : lalpha;
+                    // all packed reductions first (independent chains interleave), then one publish region
+                    float r[NG];
 #pragma unroll
-                            for (int ch = 0; ch < C; ++ch) s[6 + ch] += w * dpix[k][ch];
-                            T[k] = live ? Tn : T[k];
-                            behind[k] = live ? bh : behind[k];
-                            lcdot[k] = live ? cdot : lcdot[k];
-                            lalpha[k] = live ? alpha : lalpha[k];
-                        }
-                    }
-                }
-                if (touched) {
-                    float *dst = accum + (size_t)__float_as_uint(cur.gb.w) * SPLAT_GRAD_STRIDE;
-                    const int rv = row_value(lane >> 4);
+                    for (int grp = 0; grp < NG; ++grp)
+                        r[grp] = wave_reduce4_packed(s[4 * grp], s[4 * grp + 1], s[4 * grp + 2], s[4 * grp + 3]);
+                    if (lane_of(pub_m)) {
+                        float *dst = accum + (size_t)cur.id * SPLAT_GRAD_STRIDE + rv;
 #pragma unroll
-                    for (int grp = 0; grp < NG; ++grp) {
-                        const float r = wave_reduce4_packed(s[4 * grp], s[4 * grp + 1], s[4 * grp + 2], s[4 * grp + 3]);
-                        if ((lane & 15) == 0 && 4 * grp + rv < NV) atomicAdd(dst + 4 * grp + rv, r);
+                        for (int grp = 0; grp < NG; ++grp)
+                            if (4 * grp + 3 < NV || 4 * grp + rv < NV) atomicAdd(dst + 4 * grp, r[grp]);
                     }
                 }
             }
-            cur = nxt;
         }
-        __syncthreads();
+        if (more) {
+            commit(sb[(bi - 1) & 1], pre, tid, 0u);
+            __syncthreads();
+        }
     }
 }
 
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-template <int C>
+template <int C, int CS, bool WITH_DEPTH>
 static void launch_fwd(const SplatCamera &cam, const float *colors, SplatState &st, float *oc, float *od, int T, hipStream_t s) {
-    hipLaunchKernelGGL((render_forward_kernel<C>), dim3(T), dim3(64), 0, s, cam, colors, st, oc, od);
+    const int per = (T + 7) / 8;
+    hipLaunchKernelGGL((render_forward_kernel<C, CS, WITH_DEPTH>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, oc, od, T, per);
 }
-template <int C>
+template <int C, int CS>
 static void launch_bwd(const SplatCamera &cam, const float *colors, const SplatState &st, const float *dl, float *acc, int T,
                        hipStream_t s) {
-    hipLaunchKernelGGL((render_backward_kernel<C>), dim3(T), dim3(64), 0, s, cam, colors, st, dl, acc);
+    const int per = (T + 7) / 8;
+    hipLaunchKernelGGL((render_backward_kernel<C, CS>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
 }
 
 static const float *colour_source(const SplatGaussians &g, const SplatState &st) {
@@ -344,15 +425,16 @@ hipError_t launch_render_forward(const SplatCamera &cam, const SplatGaussians &g
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
     const float *col = colour_source(g, st);
     if (T == 0) return hipSuccess;
+    if (g_debug_composite_version == 2 && g.channels == 3) return launch_render_forward_v2(cam, col, st, out_color, out_depth, s);
     switch (g.channels) {
-        case 1: launch_fwd<1>(cam, col, st, out_color, out_depth, T, s); break;
-        case 2: launch_fwd<2>(cam, col, st, out_color, out_depth, T, s); break;
-        case 3: launch_fwd<3>(cam, col, st, out_color, out_depth, T, s); break;
-        case 4: launch_fwd<4>(cam, col, st, out_color, out_depth, T, s); break;
-        case 5: launch_fwd<5>(cam, col, st, out_color, out_depth, T, s); break;
-        case 6: launch_fwd<6>(cam, col, st, out_color, out_depth, T, s); break;
-        case 7: launch_fwd<7>(cam, col, st, out_color, out_depth, T, s); break;
-        case 8: launch_fwd<8>(cam, col, st, out_color, out_depth, T, s); break;
+        case 1: launch_fwd<1, 1, true>(cam, col, st, out_color, out_depth, T, s); break;
+        case 2: launch_fwd<2, 2, true>(cam, col, st, out_color, out_depth, T, s); break;
+        case 3: launch_fwd<3, 3, true>(cam, col, st, out_color, out_depth, T, s); break;
+        case 4: launch_fwd<4, 4, true>(cam, col, st, out_color, out_depth, T, s); break;
+        case 5: launch_fwd<5, 5, true>(cam, col, st, out_color, out_depth, T, s); break;
+        case 6: launch_fwd<6, 6, true>(cam, col, st, out_color, out_depth, T, s); break;
+        case 7: launch_fwd<7, 7, true>(cam, col, st, out_color, out_depth, T, s); break;
+        case 8: launch_fwd<8, 8, true>(cam, col, st, out_color, out_depth, T, s); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -365,17 +447,36 @@ hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &
     hipError_t e = hipMemsetAsync(gr.accum, 0, sizeof(float) * SPLAT_GRAD_STRIDE * (size_t)g.P, s);
     if (e != hipSuccess) return e;
     if (T == 0 || g.P == 0) return hipSuccess;
+    if (g_debug_composite_version == 2 && g.channels == 3) return launch_render_backward_v2(cam, col, st, gr.dL_dcolor, gr.accum, s);
     switch (g.channels) {
-        case 1: launch_bwd<1>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
-        case 2: launch_bwd<2>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
-        case 3: launch_bwd<3>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
-        case 4: launch_bwd<4>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
-        case 5: launch_bwd<5>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
-        case 6: launch_bwd<6>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
-        case 7: launch_bwd<7>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
-        case 8: launch_bwd<8>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
+        case 1: launch_bwd<1, 1>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
+        case 2: launch_bwd<2, 2>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
+        case 3: launch_bwd<3, 3>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
+        case 4: launch_bwd<4, 4>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
+        case 5: launch_bwd<5, 5>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
+        case 6: launch_bwd<6, 6>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
+        case 7: launch_bwd<7, 7>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
+        case 8: launch_bwd<8, 8>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+// Fused-iteration path (fused.hip): 6 channels (r, g, b, z, 1, z^2) read from 8-float records, no separate depth plane.
+hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat8, SplatState &st, float *out6, hipStream_t s) {
+    const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
+    if (T == 0) return hipSuccess;
+    launch_fwd<6, 8, false>(cam, feat8, st, out6, nullptr, T, s);
+    return hipGetLastError();
+}
+
+hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *feat8, const SplatState &st, const float *dL_dout6,
+                                        float *accum, int P, hipStream_t s) {
+    const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
+    hipError_t e = hipMemsetAsync(accum, 0, sizeof(float) * SPLAT_GRAD_STRIDE * (size_t)P, s);
+    if (e != hipSuccess) return e;
+    if (T == 0 || P == 0) return hipSuccess;
+    launch_bwd<6, 8>(cam, feat8, st, dL_dout6, accum, T, s);
     return hipGetLastError();
 }
 

@@ -16,6 +16,8 @@ constexpr int kWave = 64;
 // launchers (one per .hip file); every one returns hipGetLastError()
 // ---------------------------------------------------------------------------
 hipError_t launch_preprocess_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s);
+hipError_t launch_tile_count_reset(SplatState &st, int T, hipStream_t s);
+hipError_t launch_tile_scan(SplatState &st, int T, hipStream_t s);
 hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s);
 hipError_t launch_render_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st,
                                  float *out_color, float *out_depth, hipStream_t s);
@@ -24,7 +26,16 @@ hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &
 hipError_t launch_preprocess_backward(const SplatCamera &cam, const SplatGaussians &g, const SplatState &st,
                                       SplatGrads &gr, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
+hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat8, SplatState &st, float *out6, hipStream_t s);
+hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *feat8, const SplatState &st, const float *dL_dout6,
+                                        float *accum, int P, hipStream_t s);
+hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame,
+                                     const SplatLossConfig &cfg, SplatIterWorkspace &ws, hipStream_t s);
+hipError_t launch_iter_adam_map(const SplatMap &map, const SplatAdamMap &opt, hipStream_t s);
+hipError_t launch_iter_adam_pose(const SplatMap &map, int time_idx, const float *d_cam, float *state, float beta1, float beta2,
+                                 float eps, float bc2_sqrt, float ss_rot, float ss_trans, hipStream_t s);
 extern int g_debug_skip_count;
+extern int g_debug_composite_version;
 hipError_t launch_selftest(int which, const void *in, void *out, int n, hipStream_t s);
 
 #if defined(__HIPCC__)

@@ -212,25 +212,31 @@ def rasterize_forward(settings, means3D, colors, opacities, scales, rotations, c
     out_depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
     stream = _stream(dev)
     with torch.cuda.device(dev):
-        _capi.check(L.splat_preprocess_forward(C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), stream), "splat_preprocess_forward")
         hint_key = (dev.index, P, H, W)
-        if _SYNC_MODE == "exact":
-            stat = status.tolist()                        # the reference's one D2H read per forward
+        cap = _capacity_hint.get(hint_key) if _SYNC_MODE == "lazy" else None
+        if cap is None:
+            # size the lists from this call's own count: one 16-byte D2H read + stream sync, exactly what the
+            # reference extension does.  (The tile scan publishes EMPTY lists when the count exceeds
+            # st.capacity, so the capacity is "unbounded" until the buffers exist.)
+            pk.st.capacity = 1 << 62
+            _capi.check(L.splat_preprocess_forward(C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), stream), "splat_preprocess_forward")
+            stat = status.tolist()
             num_rendered = int(stat[0])
-            _alloc_lists(pk, dev, num_rendered)
-            pk.st.max_list_hint = int(stat[2])            # lets the library skip the long-list sort kernel
+            if _SYNC_MODE == "exact":
+                _alloc_lists(pk, dev, num_rendered)
+                pk.st.max_list_hint = int(stat[2])        # lets the library skip the long-list sort kernel
+            else:                                         # lazy, first call for this shape: learn the size
+                _capacity_hint[hint_key] = int(num_rendered * 1.5) + 1024
+                _alloc_lists(pk, dev, _capacity_hint[hint_key])
             pk.num_rendered = num_rendered
         else:
-            cap = _capacity_hint.get(hint_key)
-            if cap is None:                               # first call for this shape: learn the size
-                cap = int(int(status[0].item()) * 1.5) + 1024
-                _capacity_hint[hint_key] = cap
             _alloc_lists(pk, dev, cap)
+            _capi.check(L.splat_preprocess_forward(C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), stream), "splat_preprocess_forward")
             pk.num_rendered = None
         _capi.check(L.splat_bin_forward(C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), stream), "splat_bin_forward")
         _capi.check(L.splat_render_forward(C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), out_color.data_ptr(),
                                            out_depth.data_ptr(), stream), "splat_render_forward")
-        if _SYNC_MODE == "lazy":
+        if _SYNC_MODE == "lazy" and pk.num_rendered is None:
             pk.pending_status = _async_status(status, dev)
             pk.hint_key = hint_key
     return out_color, radii, out_depth, pk

@@ -2,6 +2,7 @@
 // per-Gaussian arithmetic the HIP kernels execute can be checked against the
 // oracle on a machine without a GPU (tests/test_host_math.py).
 #include "../splatam_amd/csrc/splat_math.h"
+#include "../splatam_amd/csrc/fused_math.h"
 
 using namespace splat;
 
@@ -55,5 +56,55 @@ void hm_sh(int P, int deg, int M, const float *dirs, const float *sh, const floa
             }
         }
     }
+}
+
+// ---- fused_math.h: the glue around the rasterizer (pose transform, activations) and its adjoint -------------
+// q_raw[4], t_raw[3] contiguous; outputs per Gaussian: Xc(3) z(1) op(1) s(3) rq(4) = 12 floats
+void hm_glue_forward(int P, int iso, const float *q_raw, const float *t_raw, const float *w2c_row2, const float *means,
+                     const float *urot, const float *logit, const float *ls, float *out) {
+    Pose Ps;
+    pose_from_params(q_raw, t_raw, 1, Ps);
+    for (int i = 0; i < P; ++i) {
+        Glue G;
+        glue_forward(Ps, w2c_row2, means + 3 * i, urot + 4 * i, logit[i], ls + (iso ? 1 : 3) * i, iso != 0, G);
+        float *o = out + 12 * i;
+        for (int k = 0; k < 3; ++k) o[k] = G.Xc[k];
+        o[3] = G.z; o[4] = G.op;
+        for (int k = 0; k < 3; ++k) o[5 + k] = G.s[k];
+        for (int k = 0; k < 4; ++k) o[8 + k] = G.rq[k];
+    }
+}
+
+// cotangents per Gaussian in the layout of hm_glue_forward's output; outputs: dmeans(3) durot(4) dlogit(1) dls(1|3),
+// and the camera gradient dq_raw(4), dt_raw(3) (partial sums accumulated in double like the kernel's atomics)
+void hm_glue_backward(int P, int iso, const float *q_raw, const float *t_raw, const float *w2c_row2, const float *means,
+                      const float *urot, const float *logit, const float *ls, const float *cot,
+                      float *dmeans, float *durot, float *dlogit, float *dls, float *dq_raw, float *dt_raw) {
+    Pose Ps;
+    pose_from_params(q_raw, t_raw, 1, Ps);
+    double acc[kPoseSums];
+    for (int k = 0; k < kPoseSums; ++k) acc[k] = 0.0;
+    for (int i = 0; i < P; ++i) {
+        Glue G;
+        glue_forward(Ps, w2c_row2, means + 3 * i, urot + 4 * i, logit[i], ls + (iso ? 1 : 3) * i, iso != 0, G);
+        const float *c = cot + 12 * i;
+        float pose[kPoseSums];
+        glue_backward(Ps, w2c_row2, means + 3 * i, iso != 0, G, c, c[3], c[4], c + 5, c + 8, dmeans + 3 * i, durot + 4 * i,
+                      dlogit + i, dls + (iso ? 1 : 3) * i, pose);
+        for (int k = 0; k < kPoseSums; ++k) acc[k] += pose[k];
+    }
+    float sums[kPoseSums];
+    for (int k = 0; k < kPoseSums; ++k) sums[k] = (float)acc[k];
+    pose_backward(Ps, sums, dq_raw, dt_raw);
+}
+
+void hm_ssim_pixel(int n, const float *mu1, const float *mu2, const float *e11, const float *e22, const float *e12,
+                   float *map, float *dmu1, float *de11, float *de12) {
+    for (int i = 0; i < n; ++i) map[i] = ssim_pixel(mu1[i], mu2[i], e11[i], e22[i], e12[i], dmu1 + i, de11 + i, de12 + i);
+}
+
+void hm_adam(int n, float *param, const float *grad, float *m, float *v, float beta1, float beta2, float step_size,
+             float bc2_sqrt, float eps) {
+    for (int i = 0; i < n; ++i) param[i] = adam_update(param[i], grad[i], m[i], v[i], beta1, beta2, step_size, bc2_sqrt, eps);
 }
 }

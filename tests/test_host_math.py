@@ -19,9 +19,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def shim():
     out = os.path.join(HERE, "_build", "libhost_math_shim.so")
     src = os.path.join(HERE, "host_math_shim.cpp")
-    hdr = os.path.join(HERE, "..", "splatam_amd", "csrc", "splat_math.h")
+    hdrs = [os.path.join(HERE, "..", "splatam_amd", "csrc", h) for h in ("splat_math.h", "fused_math.h")]
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    if not os.path.exists(out) or os.path.getmtime(out) < max([os.path.getmtime(src)] + [os.path.getmtime(h) for h in hdrs]):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", out, src])
     return C.CDLL(out)
 
@@ -98,3 +98,101 @@ def test_sh_basis_and_derivative(shim, deg):
     np.testing.assert_allclose(dsh, sh.grad.numpy(), rtol=1e-4, atol=1e-5)
     dref = np.zeros((P, 3)) if d.grad is None else d.grad.numpy()
     np.testing.assert_allclose(ddir, dref, rtol=1e-3, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fused_math.h: the callers around the rasterizer (splatam_amd/slam.py is the reference-shaped Python, itself
+# pinned to /root/reference by tests/golden/) and their hand-derived adjoints against torch autograd.
+# ---------------------------------------------------------------------------------------------------------------
+
+def _glue_inputs(P, iso, seed):
+    g = torch.Generator().manual_seed(seed)
+    means = torch.randn(P, 3, generator=g) * 2.0
+    urot = torch.randn(P, 4, generator=g)
+    if iso:
+        urot = torch.tensor([[1.0, 0, 0, 0]]).repeat(P, 1) + 0.05 * urot
+    logit = torch.randn(P, 1, generator=g)
+    ls = torch.randn(P, 1 if iso else 3, generator=g) * 0.4 - 3.0
+    q = torch.tensor([[0.9, 0.1, -0.2, 0.05]]) * 1.3          # deliberately un-normalised
+    t = torch.tensor([[0.1, -0.2, 0.3]])
+    w2c = torch.eye(4)
+    w2c[:3, :3] = torch.tensor(tilted_w2c()[:3, :3])
+    w2c[:3, 3] = torch.tensor([0.05, 0.02, -0.1])
+    return means, urot, logit, ls, q, t, w2c
+
+
+def _glue_torch(means, urot, logit, ls, q, t, w2c):
+    """The reference-shaped Python for one frame (time index 0 of a 1-frame pose tensor)."""
+    from splatam_amd import slam
+    params = {'means3D': means, 'unnorm_rotations': urot, 'logit_opacities': logit, 'log_scales': ls,
+              'rgb_colors': torch.zeros_like(means),
+              'cam_unnorm_rots': q.reshape(1, 4, 1), 'cam_trans': t.reshape(1, 3, 1)}
+    tg = slam.transform_to_frame(params, 0, gaussians_grad=True, camera_grad=True)
+    rv = slam.transformed_params2rendervar(params, tg)
+    dv = slam.transformed_params2depthplussilhouette(params, w2c, tg)
+    return torch.cat([rv['means3D'], dv['colors_precomp'][:, 0:1], rv['opacities'], rv['scales'], rv['rotations']], dim=1)
+
+
+@pytest.mark.parametrize("iso", [True, False])
+def test_fused_glue_forward_and_adjoint(shim, iso):
+    P = 500
+    means, urot, logit, ls, q, t, w2c = _glue_inputs(P, iso, seed=3 + int(iso))
+    leaves = [x.clone().requires_grad_(True) for x in (means, urot, logit, ls, q, t)]
+    out = _glue_torch(*leaves, w2c)
+    cot = torch.randn(P, 12, generator=torch.Generator().manual_seed(9))
+    (out * cot).sum().backward()
+
+    args = [_np(x) for x in (q.reshape(-1), t.reshape(-1), w2c[2], means, urot, logit.reshape(-1), ls)]
+    got = np.zeros((P, 12), np.float32)
+    shim.hm_glue_forward(P, int(iso), *[_p(a) for a in args], _p(got))
+    np.testing.assert_allclose(got, out.detach().numpy(), rtol=2e-5, atol=2e-6)
+
+    dmeans = np.zeros((P, 3), np.float32); durot = np.zeros((P, 4), np.float32); dlogit = np.zeros(P, np.float32)
+    dls = np.zeros((P, 1 if iso else 3), np.float32); dq = np.zeros(4, np.float32); dt = np.zeros(3, np.float32)
+    cotn = _np(cot)
+    shim.hm_glue_backward(P, int(iso), *[_p(a) for a in args], _p(cotn), _p(dmeans), _p(durot), _p(dlogit), _p(dls), _p(dq), _p(dt))
+    for got_g, ref, name in ((dmeans, leaves[0].grad, "means3D"), (durot, leaves[1].grad, "unnorm_rotations"),
+                             (dlogit, leaves[2].grad.reshape(-1), "logit_opacities"), (dls, leaves[3].grad, "log_scales"),
+                             (dq, leaves[4].grad.reshape(-1), "cam_unnorm_rots"), (dt, leaves[5].grad.reshape(-1), "cam_trans")):
+        ref = ref.numpy()
+        scale = np.abs(ref).max() + 1e-12
+        assert np.abs(got_g - ref).max() <= 2e-4 * scale, (name, np.abs(got_g - ref).max(), scale)
+
+
+def test_fused_ssim_pixel_against_autograd(shim):
+    from splatam_amd import slam
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(1, 3, 24, 31, generator=g).requires_grad_(True)
+    y = (x.detach() + 0.1 * torch.randn(1, 3, 24, 31, generator=g)).clamp(0, 1)
+    ssim = slam.calc_ssim(x, y)
+    ssim.backward()
+    # the same statistic through ssim_pixel + the three blurred partial maps (what the kernels do)
+    import torch.nn.functional as F
+    win = slam._ssim_window(3, 11, x.device, x.dtype)
+    blur = lambda t: F.conv2d(t, win, padding=5, groups=3)                      # noqa: E731
+    xd = x.detach()
+    stats = [_np(blur(t)).reshape(-1) for t in (xd, y, xd * xd, y * y, xd * y)]
+    n = stats[0].size
+    out = [np.zeros(n, np.float32) for _ in range(4)]
+    shim.hm_ssim_pixel(n, *[_p(a) for a in stats], *[_p(a) for a in out])
+    assert abs(out[0].mean() - float(ssim.detach())) < 2e-6
+    dmu1, de11, de12 = (torch.from_numpy(a).reshape(1, 3, 24, 31) for a in out[1:])
+    grad = (blur(dmu1) + 2 * xd * blur(de11) + y * blur(de12)) / n
+    ref = x.grad
+    assert (grad - ref).abs().max() <= 2e-4 * ref.abs().max()
+
+
+def test_fused_adam_matches_torch(shim):
+    g = torch.Generator().manual_seed(1)
+    p0 = torch.randn(1000, generator=g)
+    p = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([{'params': [p], 'lr': 0.0025}], lr=0.0, eps=1e-15)
+    pn, m, v = _np(p0).copy(), np.zeros(1000, np.float32), np.zeros(1000, np.float32)
+    for step in range(1, 6):
+        grad = torch.randn(1000, generator=g) * 10 ** torch.randint(-6, 1, (1000,), generator=g).float()
+        p.grad = grad.clone()
+        opt.step()
+        bc1, bc2 = 1 - 0.9 ** step, 1 - 0.999 ** step
+        shim.hm_adam(1000, _p(pn), _p(_np(grad)), _p(m), _p(v), C.c_float(0.9), C.c_float(0.999), C.c_float(0.0025 / bc1),
+                     C.c_float(bc2 ** 0.5), C.c_float(1e-15))
+        np.testing.assert_allclose(pn, p.detach().numpy(), rtol=0, atol=3e-7)
