@@ -10,6 +10,13 @@ mix (2 tracking + 3 mapping per 5 steps).  With N > 1 ranks every rank runs the
 same schedule on its own frame / keyframe view (weak scaling); mapping steps
 exchange Gaussian gradients with one RCCL all-reduce, tracking steps are replicas.
 
+Two engines run the same iteration (same loss, same gradients, same Adam update: tests/test_gpu_fused.py):
+  * ``fused``  (default, the headline ``value``): splatam_amd.fused.FusedEngine -- the whole iteration as ~10 kernel
+    launches of libsplat_hip.so (shared geometry, ONE 6-channel composite for the RGB and depth/silhouette renders,
+    fused loss / SSIM / pose-gradient / Adam kernels, no host synchronisation);
+  * ``dropin``: the reference's own Python glue (splatam_amd.slam, PyTorch autograd + torch.optim.Adam) around the
+    drop-in ``GaussianRasterizer`` -- what an unmodified scripts/splatam.py gets; reported as ``dropin_iters_per_s``.
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -84,6 +91,21 @@ def run_steps(params, variables, frames, bucket, rank, world, nsteps, opt_track,
     return variables
 
 
+def run_steps_fused(eng, frames, rank, world, nsteps, start=0):
+    from splatam_amd import slam
+    n_views = len(frames) - 1
+
+    def allreduce(flat):
+        dist.all_reduce(flat)
+        flat.div_(world)
+    for i in range(start, start + nsteps):
+        if i % 5 < 2:
+            eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING)
+        else:
+            view = 2 + (rank + i * world) % n_views
+            eng.mapping_iteration(frames[view], view, slam.REPLICA_MAPPING, allreduce if world > 1 else None)
+
+
 def phase_rate(fn, n, dev):
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -145,6 +167,49 @@ def kernel_roofline(params, frames, shape, dev):
                       "render_backward_ms": round(out["render_backward"], 4), "render_backward_GBps": round(gbs_b, 2),
                       "num_rendered": R, "pairs_per_launch": None}}
     return roof, pk
+
+
+def fused_roofline(eng, frames, shape, dev):
+    """Live HIP-event timing of the two 6-channel composite kernels of the fused iteration on the stream they are
+    launched on (splat_iter_time_kernel), after a tracking iteration has left a valid state in the workspace.
+    Algorithmic bytes (DESIGN.md 5): per instance 4 (id) + 8 (xy) + 16 (conic, opacity) + 24 (six colours) = 52 B;
+    K6: R*52 + HW*32 (six planes + final_T + n_contrib);  K7: R*52 + HW*32 (six gradient planes + final_T + n_contrib)
+    + P*48 (twelve partial sums per Gaussian)."""
+    import ctypes as C
+    from splatam_amd import _capi, slam
+    N, W, H = shape
+    eng.begin_tracking(1)
+    eng.loss_backward(frames[1], 1, slam.REPLICA_TRACKING, tracking=True)
+    torch.cuda.synchronize(dev)
+    R = int(eng.buf['status'][0])
+    ws = eng._workspace(False, False)
+    L = _capi.lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    out = {}
+    for fn, name in ((0, "render_forward"), (1, "render_backward")):
+        ms = C.c_float(0)
+        for iters in (5, 30):     # warm-up, then measure
+            _capi.check(L.splat_iter_time_kernel(fn, iters, C.byref(eng._cam), N, C.byref(ws), stream, C.byref(ms)), "splat_iter_time_kernel")
+        out[name] = ms.value
+    HW = W * H
+    bytes_fwd = R * 52 + HW * 32
+    bytes_bwd = R * 52 + HW * 32 + N * 48
+    gbs_f = bytes_fwd / (out["render_forward"] * 1e-3) / 1e9
+    gbs_b = bytes_bwd / (out["render_backward"] * 1e-3) / 1e9
+    dominant = "render_backward" if out["render_backward"] >= out["render_forward"] else "render_forward"
+    ach = gbs_b if dominant == "render_backward" else gbs_f
+    return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+            "traffic": PMC_TRAFFIC.get(dominant), "kernel": dominant + "_kernel<6,8> (fused iteration)", "kernel_ms": round(out[dominant], 4),
+            "algorithmic_bytes": bytes_bwd if dominant == "render_backward" else bytes_fwd,
+            "other": {"render_forward_ms": round(out["render_forward"], 4), "render_forward_GBps": round(gbs_f, 2),
+                      "render_backward_ms": round(out["render_backward"], 4), "render_backward_GBps": round(gbs_b, 2),
+                      "num_rendered": R, "note": "kernels are VALU-issue bound, not HBM bound (DESIGN.md 5); traffic = PMC "
+                      "FETCH_SIZE*2 + WRITE_SIZE per launch from the last profiled round (profiles/), null if not collected"}}
+
+
+# HBM bytes per launch of the dominant kernels from the most recent rocprofv3 --pmc passes (profiles/r01_*_pmc*.txt), corrected
+# as /opt/skills/guides/MI355X_MICROARCH.md prescribes (FETCH_SIZE in KiB reads 1/2 of wide streaming reads on gfx950 -> x2).
+PMC_TRAFFIC = {}
 
 
 def render_mpix(params, frames, shape, dev, reps=10):
@@ -241,6 +306,7 @@ def main():
     ap.add_argument("--workload", default="B", choices=sorted(WORKLOADS))
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--sync-mode", default="exact", choices=["exact", "lazy"])
+    ap.add_argument("--engine", default="fused", choices=["fused", "dropin"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -248,6 +314,7 @@ def main():
     from splatam_amd import dist as sdist
     from splatam_amd import rasterizer as rz
     from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
     rank, world, local_rank = sdist.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP rasterizer has no CPU path)")
@@ -258,67 +325,103 @@ def main():
     rz.set_sync_mode(args.sync_mode)
 
     params, variables, frames, shape = build_scene(args.workload, dev, args.views)
-    bucket = sdist.GradBucket(params) if world > 1 else None
-    opt_track = slam.initialize_optimizer(params, slam.REPLICA_TRACKING['lrs'], tracking=True)
-    opt_map = slam.initialize_optimizer(params, slam.REPLICA_MAPPING['lrs'], tracking=False)
-    tstate = slam.TrackingState(params, 1)
+    N, W, H = shape
+    fused = args.engine == "fused"
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # kernel-level figures are taken on the seeded initial map (before Adam moves it), so that they are
-    # comparable from run to run and with scripts/stage_times.py
-    roof = None
-    if rank == 0 and not args.no_roofline:
-        roof, _ = kernel_roofline(params, frames, shape, dev)
-        mpix, ms_call = render_mpix(params, frames, shape, dev)
+    # the drop-in path works on its own copy of the map so that both engines start from the seeded scene
+    params_d = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    bucket = sdist.GradBucket(params_d) if world > 1 else None
+    opt_track = slam.initialize_optimizer(params_d, slam.REPLICA_TRACKING['lrs'], tracking=True)
+    opt_map = slam.initialize_optimizer(params_d, slam.REPLICA_MAPPING['lrs'], tracking=False)
+    tstate = slam.TrackingState(params_d, 1)
 
-    variables = run_steps(params, variables, frames, bucket, rank, world, args.warmup, opt_track, opt_map, tstate, 0)
-    barrier()
-    t0 = time.perf_counter()
-    variables = run_steps(params, variables, frames, bucket, rank, world, args.steps, opt_track, opt_map, tstate, args.warmup)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # kernel-level figures are taken on the seeded initial map (before Adam moves it), so that they are
+    # comparable from run to run and with scripts/kernel_driver.py
+    roof = None
+    mpix = ms_call = None
+    if rank == 0 and not args.no_roofline:
+        if fused:
+            probe = FusedEngine({k: v.detach().clone() for k, v in params.items()}, frames[1]['cam'])
+            roof = fused_roofline(probe, frames, shape, dev)
+            del probe
+        else:
+            roof, _ = kernel_roofline(params_d, frames, shape, dev)
+        mpix, ms_call = render_mpix(params_d, frames, shape, dev)
+
+    if fused:
+        eparams = {k: v.detach().clone() for k, v in params.items()}
+        eng = FusedEngine(eparams, frames[1]['cam'], track_max_radius=variables['max_2D_radius'])
+        eng.begin_tracking(1)
+        run_steps_fused(eng, frames, rank, world, args.warmup, 0)
+        barrier()
+        t0 = time.perf_counter()
+        run_steps_fused(eng, frames, rank, world, args.steps, args.warmup)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if eng.check_overflow(grow=False):
+            raise SystemExit("instance lists overflowed during the timed region: the result would be invalid")
+    else:
+        variables = run_steps(params_d, variables, frames, bucket, rank, world, args.warmup, opt_track, opt_map, tstate, 0)
+        barrier()
+        t0 = time.perf_counter()
+        variables = run_steps(params_d, variables, frames, bucket, rank, world, args.steps, opt_track, opt_map, tstate, args.warmup)
+        barrier()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # per-phase rates (rank-local, informational)
-    n_phase = max(5, min(20, args.steps))
-    track_rate = phase_rate(lambda: slam.tracking_iteration(params, frames[1], variables, 1, opt_track, tstate), n_phase, dev)
+    n_phase = max(5, min(40, args.steps))
+    if fused:
+        track_rate = phase_rate(lambda: eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING), n_phase, dev)
+        map_rate = phase_rate(lambda: eng.mapping_iteration(frames[2], 2, slam.REPLICA_MAPPING), n_phase, dev)
+    n_drop = max(5, min(15, args.steps))
+    if fused:       # the drop-in path has not run yet: MIOpen / rocBLAS pick their kernels on the first calls
+        for _ in range(3):
+            slam.tracking_iteration(params_d, frames[1], variables, 1, opt_track, tstate)
+            slam.mapping_iteration(params_d, frames[2], variables, 2, opt_map)
+    track_rate_d = phase_rate(lambda: slam.tracking_iteration(params_d, frames[1], variables, 1, opt_track, tstate), n_drop, dev)
 
     def map_once():
-        loss, _, _ = slam.get_loss(params, frames[2], variables, 2, slam.REPLICA_MAPPING['loss_weights'], False, 0.5, True, False, mapping=True)
+        loss, _, _ = slam.get_loss(params_d, frames[2], variables, 2, slam.REPLICA_MAPPING['loss_weights'], False, 0.5, True, False, mapping=True)
         loss.backward()
         with torch.no_grad():
             opt_map.step()
             opt_map.zero_grad(set_to_none=True)
-    map_rate = phase_rate(map_once, n_phase, dev)
+    map_rate_d = phase_rate(map_once, n_drop, dev)
+    dropin_rate = 5.0 / (2.0 / track_rate_d + 3.0 / map_rate_d)
+    if not fused:
+        track_rate, map_rate = track_rate_d, map_rate_d
 
     result = None
     if rank == 0:
-        N, W, H = shape
-        if roof is None:
-            mpix, ms_call = render_mpix(params, frames, shape, dev)
+        if mpix is None:
+            mpix, ms_call = render_mpix(params_d, frames, shape, dev)
         result = {
             "metric": "track+map iters/sec @300k Gaussians (render+backward Mpix/s alongside)",
             "value": round(args.steps * world / elapsed, 3), "unit": "iters/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {N} Gaussians, {W}x{H}, SplaTAM tracking+mapping loop (2:3 mix), isotropic map",
-                       "gaussians": N, "width": W, "height": H, "views": args.views, "sync_mode": args.sync_mode,
+                       "gaussians": N, "width": W, "height": H, "views": args.views, "sync_mode": args.sync_mode, "engine": args.engine,
                        "parallelism": "1 process/GPU; mapping views sharded, one gradient all-reduce; tracking replicas"},
             "tracking_iters_per_s": round(track_rate, 3), "mapping_iters_per_s": round(map_rate, 3),
+            "dropin_iters_per_s": round(dropin_rate, 3), "dropin_tracking_iters_per_s": round(track_rate_d, 3),
+            "dropin_mapping_iters_per_s": round(map_rate_d, 3),
             "render_fwd_bwd_mpix_per_s": round(mpix, 2), "render_fwd_bwd_ms": round(ms_call, 4),
             "host_cores": os.cpu_count(),
         }
         if roof is not None:
             result["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args.workload, params, frames)
+            result["cpu_baseline"] = cpu_baseline(args.workload, params_d, frames)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -269,6 +269,11 @@ int splat_iter_adam_pose(const SplatMap *map, int32_t time_idx, const float *d_c
                          float beta1, float beta2, float eps, float bc2_sqrt, float step_size_rot, float step_size_trans,
                          void *stream);
 
+/* Kernel-only timing helper for bench.py on the fused path: fn 0 = 6-channel composite forward, 1 = 6-channel composite
+ * backward (incl. its accumulator memset), launched `iters` times on `stream` between two hipEvents; the workspace must hold
+ * the state of a completed splat_iter_loss_backward. */
+int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P, SplatIterWorkspace *ws, void *stream, float *ms);
+
 /* Developer switches used by scripts/ (never by the product path): key 0 = skip the per-tile
  * count atomics of K1 (timing experiment; results are then invalid); key 1 = generation of the composite kernels
  * (3 = current, 2 = previous, 3-channel calls only; A/B timing).  Returns the previous value. */

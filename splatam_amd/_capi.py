@@ -86,7 +86,7 @@ EXPORTS = (
     "splat_preprocess_forward", "splat_bin_forward", "splat_render_forward", "splat_forward",
     "splat_render_backward", "splat_preprocess_backward", "splat_backward",
     "splat_mark_visible", "splat_time_kernel", "splat_debug_option",
-    "splat_iter_loss_backward", "splat_iter_adam_map", "splat_iter_adam_pose",
+    "splat_iter_loss_backward", "splat_iter_adam_map", "splat_iter_adam_pose", "splat_iter_time_kernel",
 )
 
 _lib = None
@@ -135,6 +135,8 @@ def lib():
     L.splat_iter_adam_pose.restype = C.c_int
     L.splat_iter_adam_pose.argtypes = [C.POINTER(SplatMap), C.c_int32, _fp, _fp, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_float, _fp]
+    L.splat_iter_time_kernel.restype = C.c_int
+    L.splat_iter_time_kernel.argtypes = [C.c_int, C.c_int, cam, C.c_int32, C.POINTER(SplatIterWorkspace), _fp, C.POINTER(C.c_float)]
     L.splat_debug_option.restype = C.c_int
     L.splat_debug_option.argtypes = [C.c_int, C.c_int]
     if hasattr(L, "splat_selftest"):

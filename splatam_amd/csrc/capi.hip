@@ -171,6 +171,27 @@ int splat_iter_adam_pose(const SplatMap *map, int32_t time_idx, const float *d_c
                                        (hipStream_t)stream));
 }
 
+int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P, SplatIterWorkspace *ws, void *stream, float *ms) {
+    if (!ms || iters <= 0 || !cam || !ws || (fn != 0 && fn != 1) || P < 0) return SPLAT_E_INVALID;
+    if (!ws->feat8 || !ws->out6 || !ws->dL_dout6 || !ws->accum || !ws->st.tile_base || !ws->st.point_list) return SPLAT_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return SPLAT_E_LAUNCH;
+    hipError_t err = hipSuccess;
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < iters && err == hipSuccess; ++i)
+        err = fn == 0 ? launch_render_forward_feat8(*cam, ws->feat8, ws->st, ws->out6, s)
+                      : launch_render_backward_feat8(*cam, ws->feat8, ws->st, ws->dL_dout6, ws->accum, P, s);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms = t / iters;
+    return check(err);
+}
+
 int splat_debug_option(int key, int value) {
     if (key == 0) { const int old = g_debug_skip_count; g_debug_skip_count = value; return old; }
     if (key == 1) { const int old = g_debug_composite_version; g_debug_composite_version = value; return old; }
