@@ -358,6 +358,8 @@ def main():
         eng = FusedEngine(eparams, frames[1]['cam'], track_max_radius=variables['max_2D_radius'])
         eng.begin_tracking(1)
         run_steps_fused(eng, frames, rank, world, args.warmup, 0)
+        if eng.check_overflow():            # also learns the longest tile list (skips the long-list sort launch from here on)
+            raise SystemExit("instance lists overflowed during warm-up")
         barrier()
         t0 = time.perf_counter()
         run_steps_fused(eng, frames, rank, world, args.steps, args.warmup)

@@ -100,7 +100,8 @@ typedef struct SplatState {
     float *final_T;              /* [H][W] */
     int32_t *n_contrib;          /* [H][W] 1-based list position of the last contributor */
     /* status words: [0] num_rendered  [1] overflow flag (num_rendered > capacity)
-     *               [2] longest tile list  [3] reserved */
+     *               [2] longest tile list  [3] a list longer than the wave-sort limit met a stale max_list_hint
+     *               that had skipped the long-list sort kernel (the lists are then NOT sorted: re-run) */
     int32_t *status;             /* [4] */
 } SplatState;
 
@@ -223,7 +224,9 @@ typedef struct SplatLossConfig {
 
 #define SPLAT_ITER_SUMS 32       /* doubles in SplatIterWorkspace.sums */
 
-/* Device scratch + outputs of one fused iteration; every array is caller-owned. */
+/* Device scratch + outputs of one fused iteration; every array is caller-owned.  The caller ZERO-INITIALISES sums,
+ * st.tile_count, accum and dL_dout6 once; each iteration leaves them zeroed again (the kernels that consume a buffer
+ * reset it), so the steady state has no memset launches. */
 typedef struct SplatIterWorkspace {
     SplatState st;               /* geometry, lists (fixed capacity; overflow -> st.status[1]) and per-pixel state */
     float *feat8;                /* [P][8]  r, g, b, z, 1, z^2, 0, 0 */
@@ -240,7 +243,8 @@ typedef struct SplatIterWorkspace {
     float *d_unnorm_rotations;   /* [P][4] */
     float *d_logit_opacities;    /* [P] */
     float *d_log_scales;         /* [P][1|3] */
-    float *d_cam;                /* [8]: dL/dcam_unnorm_rots[...,t] (4), dL/dcam_trans[...,t] (3), loss (1) */
+    float *d_cam;                /* [12]: dL/dcam_unnorm_rots[...,t] (4), dL/dcam_trans[...,t] (3), loss (1), then the raw
+                                    sums [0..3] of this iteration */
 } SplatIterWorkspace;
 
 /* get_loss + loss.backward() of one iteration.  On return (stream order) ws->d_* hold the gradients and

@@ -37,7 +37,7 @@ def loss_terms(x6):
     return mask, float(ld), float(li)
 m_ref, ld_ref, li_ref = loss_terms(ref6)
 m_eng, ld_eng, li_eng = loss_terms(o)
-S = eng.buf['sums'].cpu().numpy()
+S = eng.buf['d_cam'].cpu().numpy()[8:12]
 print("mask count ref/eng-render:", int(m_ref.sum()), int(m_eng.sum()), " mismatching pixels:", int((m_ref != m_eng).sum()))
 print(f"depth L1: ref-render {ld_ref:.4f}  torch-on-engine-render {ld_eng:.4f}  kernel {S[0]:.4f}")
 print(f"im    L1: ref-render {li_ref:.4f}  torch-on-engine-render {li_eng:.4f}  kernel {S[1]:.4f}")

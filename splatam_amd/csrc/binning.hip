@@ -92,7 +92,13 @@ __global__ __launch_bounds__(64) void tile_sort_wave_kernel(SplatState st) {
     const int tile = blockIdx.x, tid = threadIdx.x;
     const unsigned lo = st.tile_base[tile], hi = st.tile_base[tile + 1];
     const int n = (int)(hi - lo);
-    if (n == 0 || n > kSortWave) return;
+    if (n > kSortWave) {
+        // long list: the workgroup-per-tile kernel sorts it -- unless the host's (possibly stale) hint said that no
+        // list is that long and skipped that launch; flag it so that the host re-runs instead of rendering unsorted
+        if (tid == 0 && st.max_list_hint > 0 && st.max_list_hint <= kSortWave) atomicOr((unsigned *)&st.status[3], 1u);
+        return;
+    }
+    if (n == 0) return;
     const uint64_t *gk = st.keys + lo;
     for (int i = tid; i < n; i += 64) s_keys[i] = gk[i];
     __syncthreads();

@@ -181,7 +181,7 @@ int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P,
     (void)hipEventRecord(e0, s);
     for (int i = 0; i < iters && err == hipSuccess; ++i)
         err = fn == 0 ? launch_render_forward_feat8(*cam, ws->feat8, ws->st, ws->out6, s)
-                      : launch_render_backward_feat8(*cam, ws->feat8, ws->st, ws->dL_dout6, ws->accum, P, s);
+                      : launch_render_backward_feat8(*cam, ws->feat8, ws->st, ws->dL_dout6, ws->accum, P, false, s);
     (void)hipEventRecord(e1, s);
     (void)hipEventSynchronize(e1);
     float t = 0.f;

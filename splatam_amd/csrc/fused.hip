@@ -129,24 +129,48 @@ __device__ __forceinline__ Pixel depth_pixel(const SplatLossConfig &cfg, float d
 // ---------------------------------------------------------------------------------------------------------
 // F3: tracking loss (/root/reference/scripts/splatam.py:256-286 with tracking=True): one pass
 // ---------------------------------------------------------------------------------------------------------
+// Planes 4 (silhouette) and 5 (depth^2) never receive a gradient (the uncertainty is detached, the silhouette only
+// masks): their dL_dout6 planes are zeroed once by the caller and never written.
+template <int V>
 __global__ __launch_bounds__(kBlock) void track_loss_kernel(FusedArgs a, int HW) {
     __shared__ double s_part[2 * (kBlock / 64)];
     const float *o = a.ws.out6;
     float *g = a.ws.dL_dout6;
     const bool masked_im = a.cfg.use_sil_for_loss || a.cfg.ignore_outlier_depth_loss;
     float acc[2] = {0.f, 0.f};
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < HW; i += gridDim.x * kBlock) {
-        const Pixel px = depth_pixel(a.cfg, o[3 * (size_t)HW + i], o[4 * (size_t)HW + i], o[5 * (size_t)HW + i], a.frame.depth[i]);
-        acc[0] += px.d_err;
-        g[3 * (size_t)HW + i] = a.cfg.use_l1 ? a.cfg.w_depth * px.d_sign : 0.f;
-        g[4 * (size_t)HW + i] = 0.f;
-        g[5 * (size_t)HW + i] = 0.f;
-        const bool cm = masked_im ? px.mask : true;
+    const int nvec = HW / V;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < nvec; i += gridDim.x * kBlock) {
+        float in[10][V], out[4][V];
+        auto ld = [&](const float *p, float *dst) {
+            if constexpr (V == 4) {
+                const float4 t = reinterpret_cast<const float4 *>(p)[i];
+                dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+            } else {
+                dst[0] = p[i];
+            }
+        };
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            const float diff = a.frame.im[ch * (size_t)HW + i] - o[ch * (size_t)HW + i];
-            acc[1] += cm ? fabsf(diff) : 0.f;
-            g[ch * (size_t)HW + i] = cm ? -a.cfg.w_im * sgn(diff) : 0.f;
+        for (int ch = 0; ch < 6; ++ch) ld(o + ch * (size_t)HW, in[ch]);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) ld(a.frame.im + ch * (size_t)HW, in[6 + ch]);
+        ld(a.frame.depth, in[9]);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const Pixel px = depth_pixel(a.cfg, in[3][v], in[4][v], in[5][v], in[9][v]);
+            acc[0] += px.d_err;
+            out[3][v] = a.cfg.use_l1 ? a.cfg.w_depth * px.d_sign : 0.f;
+            const bool cm = masked_im ? px.mask : true;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float diff = in[6 + ch][v] - in[ch][v];
+                acc[1] += cm ? fabsf(diff) : 0.f;
+                out[ch][v] = cm ? -a.cfg.w_im * sgn(diff) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            if constexpr (V == 4) reinterpret_cast<float4 *>(g + ch * (size_t)HW)[i] = make_float4(out[ch][0], out[ch][1], out[ch][2], out[ch][3]);
+            else g[ch * (size_t)HW + i] = out[ch][0];
         }
     }
     block_sum_to<2>(a.ws.sums, acc, s_part);
@@ -280,8 +304,6 @@ __global__ __launch_bounds__(kBlock) void map_loss_backward_kernel(FusedArgs a, 
                 const float *o = a.ws.out6;
                 const Pixel px = depth_pixel(a.cfg, o[3 * HW + pix], o[4 * HW + pix], o[5 * HW + pix], a.frame.depth[pix]);
                 Gout[3 * HW + pix] = a.cfg.use_l1 ? a.cfg.w_depth * px.d_sign / count : 0.f;
-                Gout[4 * HW + pix] = 0.f;
-                Gout[5 * HW + pix] = 0.f;
             }
         }
     }
@@ -304,11 +326,12 @@ __global__ __launch_bounds__(kBlock) void fused_backward_kernel(FusedArgs a) {
         float drgb[3] = {0.f, 0.f, 0.f};
         if (vis) {
             float acc[SPLAT_GRAD_STRIDE];
-            const float4 *a4 = reinterpret_cast<const float4 *>(ws.accum + (size_t)i * SPLAT_GRAD_STRIDE);
+            float4 *a4 = reinterpret_cast<float4 *>(ws.accum + (size_t)i * SPLAT_GRAD_STRIDE);
 #pragma unroll
             for (int k = 0; k < SPLAT_GRAD_STRIDE / 4; ++k) {
                 const float4 v = a4[k];
                 acc[4 * k] = v.x; acc[4 * k + 1] = v.y; acc[4 * k + 2] = v.z; acc[4 * k + 3] = v.w;
+                a4[k] = make_float4(0.f, 0.f, 0.f, 0.f);      // consumed: the next iteration's K7 accumulates from zero without a memset
             }
             CamConst c;
             load_cam(c, a.cam);
@@ -348,7 +371,8 @@ __global__ __launch_bounds__(kBlock) void fused_backward_kernel(FusedArgs a) {
 // F7: one thread: pose partial sums -> gradients of the raw camera parameters; loss value
 __global__ void pose_finish_kernel(FusedArgs a, int HW) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const double *S = a.ws.sums;
+    double S[SPLAT_ITER_SUMS];
+    for (int k = 0; k < SPLAT_ITER_SUMS; ++k) S[k] = a.ws.sums[k];
     float *out = a.ws.d_cam;
     float dq[4] = {0.f, 0.f, 0.f, 0.f}, dt[3] = {0.f, 0.f, 0.f};
     if (a.cfg.camera_grad) {
@@ -370,6 +394,9 @@ __global__ void pose_finish_kernel(FusedArgs a, int HW) {
         loss = a.cfg.w_depth * (a.cfg.use_l1 ? l_depth / (float)S[2] : 0.f) + a.cfg.w_im * l_im;
     }
     out[7] = loss;
+    // raw sums for inspection, then reset for the next iteration (no memset launch)
+    for (int k = 0; k < 4; ++k) out[8 + k] = (float)S[k];
+    for (int k = 0; k < SPLAT_ITER_SUMS; ++k) a.ws.sums[k] = 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -380,23 +407,28 @@ struct AdamArgs {
     SplatAdamMap opt;
 };
 
-__global__ __launch_bounds__(kBlock) void adam_map_kernel(AdamArgs a) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= a.map.P) return;
+// one lane per ELEMENT of the five groups laid end to end (coalesced 4-byte streams of param / grad / moments)
+__global__ __launch_bounds__(kBlock) void adam_map_kernel(AdamArgs a, long long total) {
+    const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= total) return;
     float *params[5] = {a.map.means3D, a.map.rgb_colors, a.map.unnorm_rotations, a.map.logit_opacities, a.map.log_scales};
     const int width[5] = {3, 3, 4, 1, a.map.isotropic ? 1 : 3};
+    long long off = 0;
 #pragma unroll
     for (int gidx = 0; gidx < 5; ++gidx) {
-        const float *grad = a.opt.grad[gidx];
-        if (!grad) continue;                                    // torch skips parameters without a gradient
-        float *m = a.opt.exp_avg[gidx], *v = a.opt.exp_avg_sq[gidx], *p = params[gidx];
-        const int wd = width[gidx];
-        for (int k = 0; k < wd; ++k) {
-            const size_t j = (size_t)i * wd + k;
-            float mm = m[j], vv = v[j];
-            p[j] = adam_update(p[j], grad[j], mm, vv, a.opt.beta1, a.opt.beta2, a.opt.step_size[gidx], a.opt.bc2_sqrt, a.opt.eps);
-            m[j] = mm; v[j] = vv;
+        const long long n = (long long)a.map.P * width[gidx];
+        if (e >= off && e < off + n) {
+            const float *grad = a.opt.grad[gidx];
+            if (grad) {                                         // torch skips parameters without a gradient
+                const long long j = e - off;
+                float mm = a.opt.exp_avg[gidx][j], vv = a.opt.exp_avg_sq[gidx][j];
+                float *p = params[gidx];
+                p[j] = adam_update(p[j], grad[j], mm, vv, a.opt.beta1, a.opt.beta2, a.opt.step_size[gidx], a.opt.bc2_sqrt, a.opt.eps);
+                a.opt.exp_avg[gidx][j] = mm;
+                a.opt.exp_avg_sq[gidx][j] = vv;
+            }
         }
+        off += n;
     }
 }
 
@@ -433,10 +465,9 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
     const int W = cam.image_width, H = cam.image_height, HW = W * H;
     const int T = (int)splat_num_tiles(W, H);
     const int P = map.P;
-    hipError_t e = hipMemsetAsync(ws.sums, 0, sizeof(double) * SPLAT_ITER_SUMS, s);
-    if (e != hipSuccess) return e;
-    e = launch_tile_count_reset(ws.st, T, s);
-    if (e != hipSuccess) return e;
+    // no memsets: sums, tile counters and the accumulator rows are zeroed by the kernels that consume them
+    // (pose_finish / tile_scan / fused_backward); the caller zero-initialises the workspace once
+    hipError_t e = hipSuccess;
     const int gblocks = (P + kBlock - 1) / kBlock;
     if (P > 0) hipLaunchKernelGGL(fused_preprocess_kernel, dim3(gblocks), dim3(kBlock), 0, s, a);
     e = launch_tile_scan(ws.st, T, s);
@@ -449,14 +480,19 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
     e = launch_render_forward_feat8(cam, ws.feat8, ws.st, ws.out6, s);
     if (e != hipSuccess) return e;
     if (cfg.tracking) {
-        const int blocks = min((HW + kBlock - 1) / kBlock, 2048);
-        hipLaunchKernelGGL(track_loss_kernel, dim3(blocks), dim3(kBlock), 0, s, a, HW);
+        if (HW % 4 == 0) {
+            const int blocks = min((HW / 4 + kBlock - 1) / kBlock, 2048);
+            hipLaunchKernelGGL(track_loss_kernel<4>, dim3(blocks), dim3(kBlock), 0, s, a, HW);
+        } else {
+            const int blocks = min((HW + kBlock - 1) / kBlock, 2048);
+            hipLaunchKernelGGL(track_loss_kernel<1>, dim3(blocks), dim3(kBlock), 0, s, a, HW);
+        }
     } else {
         const dim3 grid((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, 3);
         hipLaunchKernelGGL(ssim_forward_kernel, grid, dim3(kBlock), 0, s, a, W, H);
         hipLaunchKernelGGL(map_loss_backward_kernel, grid, dim3(kBlock), 0, s, a, W, H);
     }
-    e = launch_render_backward_feat8(cam, ws.feat8, ws.st, ws.dL_dout6, ws.accum, P, s);
+    e = launch_render_backward_feat8(cam, ws.feat8, ws.st, ws.dL_dout6, ws.accum, P, false, s);
     if (e != hipSuccess) return e;
     if (P > 0) hipLaunchKernelGGL(fused_backward_kernel, dim3(gblocks), dim3(kBlock), 0, s, a);
     hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(64), 0, s, a, HW);
@@ -466,7 +502,8 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
 hipError_t launch_iter_adam_map(const SplatMap &map, const SplatAdamMap &opt, hipStream_t s) {
     if (map.P <= 0) return hipSuccess;
     AdamArgs a{map, opt};
-    hipLaunchKernelGGL(adam_map_kernel, dim3((map.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    const long long total = (long long)map.P * (3 + 3 + 4 + 1 + (map.isotropic ? 1 : 3));
+    hipLaunchKernelGGL(adam_map_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a, total);
     return hipGetLastError();
 }
 

@@ -88,6 +88,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(SplatState st, int T) {
         st.tile_base[t] = overflow ? 0u : run;
         st.tile_cursor[(size_t)t * SPLAT_COUNTER_STRIDE] = run;
         run += st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE];
+        st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE] = 0;     // consumed: the next call's K1 starts from zero without a memset
     }
     if (tid == 0) {
         st.tile_base[T] = overflow ? 0u : total;

@@ -471,10 +471,12 @@ hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat
 }
 
 hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *feat8, const SplatState &st, const float *dL_dout6,
-                                        float *accum, int P, hipStream_t s) {
+                                        float *accum, int P, bool zero_accum, hipStream_t s) {
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
-    hipError_t e = hipMemsetAsync(accum, 0, sizeof(float) * SPLAT_GRAD_STRIDE * (size_t)P, s);
-    if (e != hipSuccess) return e;
+    if (zero_accum) {
+        hipError_t e = hipMemsetAsync(accum, 0, sizeof(float) * SPLAT_GRAD_STRIDE * (size_t)P, s);
+        if (e != hipSuccess) return e;
+    }
     if (T == 0 || P == 0) return hipSuccess;
     launch_bwd<6, 8>(cam, feat8, st, dL_dout6, accum, T, s);
     return hipGetLastError();

@@ -28,7 +28,7 @@ hipError_t launch_preprocess_backward(const SplatCamera &cam, const SplatGaussia
 hipError_t launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
 hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat8, SplatState &st, float *out6, hipStream_t s);
 hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *feat8, const SplatState &st, const float *dL_dout6,
-                                        float *accum, int P, hipStream_t s);
+                                        float *accum, int P, bool zero_accum, hipStream_t s);
 hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame,
                                      const SplatLossConfig &cfg, SplatIterWorkspace &ws, hipStream_t s);
 hipError_t launch_iter_adam_map(const SplatMap &map, const SplatAdamMap &opt, hipStream_t s);

@@ -58,7 +58,7 @@ class FusedEngine:
         b['rect'] = torch.empty(P, 2, dtype=i32, **z)
         b['depth'] = torch.empty(P, dtype=f32, **z)
         b['radii'] = torch.zeros(P, dtype=i32, **z)
-        b['tile_count'] = torch.empty(T * CS, dtype=i32, **z)
+        b['tile_count'] = torch.zeros(T * CS, dtype=i32, **z)
         b['tile_base'] = torch.empty(T + 1, dtype=i32, **z)
         b['tile_cursor'] = torch.empty(T * CS, dtype=i32, **z)
         b['status'] = torch.zeros(4, dtype=i32, **z)
@@ -67,10 +67,10 @@ class FusedEngine:
         b['feat8'] = torch.empty(P, 8, dtype=f32, **z)
         b['out6'] = torch.empty(6, H, W, dtype=f32, **z)
         b['dL_dout6'] = torch.zeros(6, H, W, dtype=f32, **z)
-        b['accum'] = torch.empty(P, _capi.SPLAT_GRAD_STRIDE, dtype=f32, **z)
+        b['accum'] = torch.zeros(P, _capi.SPLAT_GRAD_STRIDE, dtype=f32, **z)
         b['ssim_maps'] = torch.empty(9, H, W, dtype=f32, **z)
         b['sums'] = torch.zeros(_capi.SPLAT_ITER_SUMS, dtype=torch.float64, **z)
-        b['d_cam'] = torch.zeros(8, dtype=f32, **z)
+        b['d_cam'] = torch.zeros(12, dtype=f32, **z)
         b['pose_state'] = torch.zeros(_capi.SPLAT_POSE_STATE, dtype=f32, **z)
         self.max_2D_radius = track_max_radius
         # map gradients: ONE flat buffer (the all-reduce bucket of the view-sharded mapping step), viewed per parameter
@@ -85,6 +85,7 @@ class FusedEngine:
         self.map_step = 0
         self.pose_step = 0
         self.track_time_idx = None
+        self.max_list_hint = 0          # longest tile list seen at the last check_overflow(); 0 = unknown
         self._alloc_lists(self.capacity)
         self._cam = self._make_cam(cam)
         self._frame_keep = None
@@ -131,7 +132,7 @@ class FusedEngine:
         st.radii = b['radii'].data_ptr()
         st.tile_count, st.tile_base, st.tile_cursor = b['tile_count'].data_ptr(), b['tile_base'].data_ptr(), b['tile_cursor'].data_ptr()
         st.keys, st.point_list, st.capacity = b['keys'].data_ptr(), b['point_list'].data_ptr(), self.capacity
-        st.max_list_hint = 0
+        st.max_list_hint = self.max_list_hint
         st.final_T, st.n_contrib, st.status = b['final_T'].data_ptr(), b['n_contrib'].data_ptr(), b['status'].data_ptr()
         ws.feat8, ws.out6, ws.dL_dout6, ws.accum = b['feat8'].data_ptr(), b['out6'].data_ptr(), b['dL_dout6'].data_ptr(), b['accum'].data_ptr()
         ws.ssim_maps = b['ssim_maps'].data_ptr() if with_ssim else None
@@ -250,11 +251,15 @@ class FusedEngine:
         """Lists are fixed-size; an iteration whose instances did not fit rendered EMPTY lists and flagged it.
         Call at frame end (one D2H read): returns True when the last iteration overflowed (and grows the lists)."""
         stat = self.buf['status'].tolist()
-        if stat[1] != 0 or stat[0] > self.capacity:
-            if grow:
-                self._alloc_lists(int(stat[0] * 1.5) + 65536)
-            return True
-        return False
+        bad = stat[1] != 0 or stat[0] > self.capacity
+        if bad and grow:
+            self._alloc_lists(int(stat[0] * 1.5) + 65536)
+        if stat[3] != 0:            # a list outgrew the (stale) hint that skipped the long-list sort: forget the hint
+            bad = True
+            self.max_list_hint = 0
+        elif not bad:               # lets the library skip the long-list sort kernel while lists stay well below its limit
+            self.max_list_hint = int(stat[2]) if 0 < stat[2] <= 768 else 0
+        return bad
 
     @property
     def seen(self):
