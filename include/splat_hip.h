@@ -96,6 +96,10 @@ typedef struct SplatState {
     uint32_t *point_list;        /* [capacity] Gaussian ids, each tile's slice sorted by key */
     int64_t capacity;
     int32_t max_list_hint;       /* longest tile list if the host knows it (status[2] of an earlier read), 0 = unknown */
+    int32_t tile_stride;         /* 0: compact lists, tile t = [tile_base[t], tile_base[t+1]) (the exact path);
+                                    > 0: BUCKETED lists (fused iteration only): tile t = [t*stride, t*stride + min(count, stride)),
+                                    filled by the per-Gaussian kernel itself -- no scan, no scatter pass; a tile that
+                                    receives more than `stride` instances sets status[1] and is truncated */
     /* per-pixel */
     float *final_T;              /* [H][W] */
     int32_t *n_contrib;          /* [H][W] 1-based list position of the last contributor */
@@ -222,7 +226,8 @@ typedef struct SplatLossConfig {
     float w_depth;               /* loss_weights['depth'] */
 } SplatLossConfig;
 
-#define SPLAT_ITER_SUMS 32       /* doubles in SplatIterWorkspace.sums */
+#define SPLAT_ITER_SUMS 32       /* doubles per copy of the partial sums */
+#define SPLAT_ITER_SUM_COPIES 64 /* copies: workgroups spread their atomics over them (one hot cache line otherwise) */
 
 /* Device scratch + outputs of one fused iteration; every array is caller-owned.  The caller ZERO-INITIALISES sums,
  * st.tile_count, accum and dL_dout6 once; each iteration leaves them zeroed again (the kernels that consume a buffer
@@ -234,8 +239,8 @@ typedef struct SplatIterWorkspace {
     float *dL_dout6;             /* [6][H][W] */
     float *accum;                /* [P][SPLAT_GRAD_STRIDE] */
     float *ssim_maps;            /* [9][H][W] mapping only (NULL for tracking) */
-    double *sums;                /* [SPLAT_ITER_SUMS]: [0] masked depth L1 sum, [1] image L1 sum, [2] mask count,
-                                    [3] SSIM map sum, [8..23] camera-pose partial sums */
+    double *sums;                /* [SPLAT_ITER_SUM_COPIES][SPLAT_ITER_SUMS]: [0] masked depth L1 sum, [1] image L1 sum,
+                                    [2] mask count, [3] SSIM map sum, [8..23] camera-pose partial sums */
     float *max_2D_radius;        /* [P] variables['max_2D_radius'], updated in place, or NULL */
     /* gradients of the map (written when non-NULL; means3D / unnorm_rotations only with gaussians_grad) */
     float *d_means3D;            /* [P][3] */
@@ -243,8 +248,9 @@ typedef struct SplatIterWorkspace {
     float *d_unnorm_rotations;   /* [P][4] */
     float *d_logit_opacities;    /* [P] */
     float *d_log_scales;         /* [P][1|3] */
-    float *d_cam;                /* [12]: dL/dcam_unnorm_rots[...,t] (4), dL/dcam_trans[...,t] (3), loss (1), then the raw
-                                    sums [0..3] of this iteration */
+    float *d_cam;                /* [16]: dL/dcam_unnorm_rots[...,t] (4), dL/dcam_trans[...,t] (3), loss (1), the raw sums
+                                    [0..3] of this iteration (4), [12] STICKY "lists overflowed / unsorted" flag (set by any
+                                    iteration whose status[1] or status[3] was set; cleared by the host), 3 spare */
 } SplatIterWorkspace;
 
 /* get_loss + loss.backward() of one iteration.  On return (stream order) ws->d_* hold the gradients and

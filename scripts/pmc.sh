@@ -1,7 +1,8 @@
 #!/bin/bash
-# Counter passes (rocprofv3 --pmc, kernel-trace only) over scripts/kernel_driver.py; per-kernel means land in
-# gpurun_out/pmc_<tag>.txt.   usage: scripts/pmc.sh <tag> [workload]
-tag=${1:-r1}; wl=${2:-B}
+# Counter passes (rocprofv3 --pmc, kernel-trace only) over scripts/kernel_driver.py (or scripts/fused_driver.py); per-kernel
+# means land in gpurun_out/pmc_<tag>.txt.   usage: scripts/pmc.sh <tag> [workload] [kernel|fused]
+tag=${1:-r1}; wl=${2:-B}; drv=${3:-kernel}
+if [ "$drv" = "fused" ]; then driver="scripts/fused_driver.py $wl 3"; else driver="scripts/kernel_driver.py --workload $wl --reps 3"; fi
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.txt
@@ -9,7 +10,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.txt
 pass() {
   name=$1; shift
   rm -rf /tmp/pmc_$name
-  (cd /tmp && timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$name -o p -- python $GRAFT_REPO_ROOT/scripts/kernel_driver.py --workload $wl --reps 3 > /tmp/pmc_$name.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$name -o p -- python $GRAFT_REPO_ROOT/$driver > /tmp/pmc_$name.log 2>&1)
   f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
   echo "## pass $name: $*" >> $out
   if [ -z "$f" ]; then echo "no counter file; log tail:" >> $out; tail -5 /tmp/pmc_$name.log >> $out; return; fi

@@ -40,7 +40,7 @@ class SplatState(C.Structure):
     _fields_ = [("depth", _fp), ("xy", _fp), ("conic_opacity", _fp), ("rect", _fp), ("radii", _fp),
                 ("rgb", _fp), ("clamped", _fp),
                 ("tile_count", _fp), ("tile_base", _fp), ("tile_cursor", _fp),
-                ("keys", _fp), ("point_list", _fp), ("capacity", C.c_int64), ("max_list_hint", C.c_int32),
+                ("keys", _fp), ("point_list", _fp), ("capacity", C.c_int64), ("max_list_hint", C.c_int32), ("tile_stride", C.c_int32),
                 ("final_T", _fp), ("n_contrib", _fp), ("status", _fp)]
 
 
@@ -79,6 +79,7 @@ class SplatAdamMap(C.Structure):
 
 
 SPLAT_ITER_SUMS = 32
+SPLAT_ITER_SUM_COPIES = 64
 SPLAT_POSE_STATE = 24
 
 EXPORTS = (

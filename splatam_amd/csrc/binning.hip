@@ -85,13 +85,20 @@ constexpr int kSortWave = 1024;
 
 __global__ __launch_bounds__(64) void tile_sort_wave_kernel(SplatState st) {
     __shared__ uint64_t s_keys[kSortWave];
-    if ((long long)st.status[0] > st.capacity) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) st.status[1] = 1;
-        return;
-    }
     const int tile = blockIdx.x, tid = threadIdx.x;
-    const unsigned lo = st.tile_base[tile], hi = st.tile_base[tile + 1];
-    const int n = (int)(hi - lo);
+    if (st.tile_stride == 0) {
+        if ((long long)st.status[0] > st.capacity) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) st.status[1] = 1;
+            return;
+        }
+    } else if (tile == 0 && tid == 0) {
+        // bucketed lists have no scan kernel: the per-iteration status words are reset here and re-accumulated by the
+        // kernel that consumes the tile counters (fused_backward_kernel)
+        st.status[0] = 0; st.status[2] = 0; st.status[3] = 0;
+    }
+    unsigned lo;
+    int n;
+    tile_range(st, tile, lo, n);
     if (n > kSortWave) {
         // long list: the workgroup-per-tile kernel sorts it -- unless the host's (possibly stale) hint said that no
         // list is that long and skipped that launch; flag it so that the host re-runs instead of rendering unsorted
@@ -108,10 +115,11 @@ __global__ __launch_bounds__(64) void tile_sort_wave_kernel(SplatState st) {
 
 __global__ __launch_bounds__(kBlock) void tile_sort_block_kernel(SplatState st) {
     __shared__ uint64_t s_keys[kSortLds];
-    if ((long long)st.status[0] > st.capacity) return;
+    if (st.tile_stride == 0 && (long long)st.status[0] > st.capacity) return;
     const int tile = blockIdx.x, tid = threadIdx.x;
-    const unsigned lo = st.tile_base[tile], hi = st.tile_base[tile + 1];
-    const int n = (int)(hi - lo);
+    unsigned lo;
+    int n;
+    tile_range(st, tile, lo, n);
     if (n <= kSortWave) return;
     uint64_t *gk = st.keys + lo;
     if (n <= kSortLds) {
@@ -129,7 +137,8 @@ __global__ __launch_bounds__(kBlock) void tile_sort_block_kernel(SplatState st) 
 hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s) {
     const int gx = (cam.image_width + kTile - 1) / kTile;
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
-    if (g.P > 0) hipLaunchKernelGGL(scatter_kernel, dim3((g.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, g, st, gx);
+    // bucketed lists were filled by the per-Gaussian kernel: only the per-tile sort remains
+    if (g.P > 0 && st.tile_stride == 0) hipLaunchKernelGGL(scatter_kernel, dim3((g.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, g, st, gx);
     if (T > 0) {
         hipLaunchKernelGGL(tile_sort_wave_kernel, dim3(T), dim3(64), 0, s, st);
         // the host may know the longest list (status[2]); only then can the long-list kernel be skipped

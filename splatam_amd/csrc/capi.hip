@@ -150,7 +150,9 @@ int splat_iter_loss_backward(const SplatCamera *cam, const SplatMap *map, const 
     const SplatState &st = ws->st;
     if (!st.tile_count || !st.tile_base || !st.tile_cursor || !st.status || !st.final_T || !st.n_contrib) return SPLAT_E_INVALID;
     if (map->P > 0 && (!st.depth || !st.xy || !st.conic_opacity || !st.rect || !st.radii || !ws->feat8 || !ws->accum)) return SPLAT_E_INVALID;
-    if (st.capacity <= 0 || !st.keys || !st.point_list) return SPLAT_E_INVALID;
+    if (st.capacity <= 0 || !st.keys || !st.point_list || st.tile_stride < 0) return SPLAT_E_INVALID;
+    if (st.tile_stride > 0 && (long long)st.tile_stride * (long long)splat_num_tiles(cam->image_width, cam->image_height) > st.capacity)
+        return SPLAT_E_INVALID;
     if (!ws->out6 || !ws->dL_dout6 || !ws->sums || !ws->d_cam) return SPLAT_E_INVALID;
     if (!cfg->tracking && !ws->ssim_maps) return SPLAT_E_INVALID;
     return check(launch_iter_loss_backward(*cam, *map, *frame, *cfg, *ws, (hipStream_t)stream));
@@ -181,7 +183,7 @@ int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P,
     (void)hipEventRecord(e0, s);
     for (int i = 0; i < iters && err == hipSuccess; ++i)
         err = fn == 0 ? launch_render_forward_feat8(*cam, ws->feat8, ws->st, ws->out6, s)
-                      : launch_render_backward_feat8(*cam, ws->feat8, ws->st, ws->dL_dout6, ws->accum, P, false, s);
+                      : launch_render_backward_feat8(*cam, ws->feat8, ws->st, ws->dL_dout6, ws->accum, P, false, true, s);
     (void)hipEventRecord(e1, s);
     (void)hipEventSynchronize(e1);
     float t = 0.f;

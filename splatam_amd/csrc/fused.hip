@@ -32,7 +32,10 @@ struct FusedArgs {
     SplatFrameData frame;
     SplatLossConfig cfg;
     SplatIterWorkspace ws;
+    float win[11];      // SSIM window (host-built the way create_window builds it)
 };
+
+__device__ __forceinline__ int c_num_tiles(int W, int H) { return ((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile); }
 
 __device__ __forceinline__ void load_pose(const SplatMap &m, int time_idx, Pose &P) {
     pose_from_params(m.cam_unnorm_rots + time_idx, m.cam_trans + time_idx, m.num_frames, P);
@@ -79,14 +82,50 @@ __global__ __launch_bounds__(kBlock) void fused_preprocess_kernel(FusedArgs a) {
     f[1] = make_float4(1.0f, G.z * G.z, 0.f, 0.f);
     if (vis) {
         if (a.ws.max_2D_radius) a.ws.max_2D_radius[i] = fmaxf(a.ws.max_2D_radius[i], (float)o.radius);
-        for (int y = o.y0; y < o.y1; ++y)
-            for (int x = o.x0; x < o.x1; ++x) atomicAdd(&st.tile_count[(size_t)(y * c.gx + x) * SPLAT_COUNTER_STRIDE], 1u);
+        if (st.tile_stride == 0) {
+            // exact path: count now, scan + scatter later
+            for (int y = o.y0; y < o.y1; ++y)
+                for (int x = o.x0; x < o.x1; ++x) atomicAdd(&st.tile_count[(size_t)(y * c.gx + x) * SPLAT_COUNTER_STRIDE], 1u);
+        } else {
+            // bucketed path: the returning atomic IS the slot; up to four in flight per lane
+            const unsigned stride = (unsigned)st.tile_stride;
+            const uint64_t key = ((uint64_t)__float_as_uint(o.depth) << 32) | (uint32_t)i;
+            const int w = o.x1 - o.x0, nt = w * (o.y1 - o.y0);
+            bool spilled = false;
+            for (int t0 = 0; t0 < nt; t0 += 4) {
+                unsigned slot[4], tix[4];
+#pragma unroll
+                for (int uu = 0; uu < 4; ++uu) {
+                    const int t = t0 + uu;
+                    if (t < nt) {
+                        const int yy = t / w, xx = t - yy * w;
+                        tix[uu] = (unsigned)((o.y0 + yy) * c.gx + o.x0 + xx);
+                        slot[uu] = atomicAdd(&st.tile_count[(size_t)tix[uu] * SPLAT_COUNTER_STRIDE], 1u);
+                    }
+                }
+#pragma unroll
+                for (int uu = 0; uu < 4; ++uu)
+                    if (t0 + uu < nt) {
+                        if (slot[uu] < stride) st.keys[(size_t)tix[uu] * stride + slot[uu]] = key;
+                        else spilled = true;
+                    }
+            }
+            if (spilled) st.status[1] = 1;
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // block-level sums -> double atomics
 // ---------------------------------------------------------------------------------------------------------
+// ws.sums holds SPLAT_ITER_SUM_COPIES copies of the SPLAT_ITER_SUMS partial sums (one 256-byte pair of lines each):
+// a workgroup adds to copy (its linear id % copies), so that the few thousand workgroups of a launch do not queue
+// their atomics on ONE line (measured: ~12 ns per same-line atomic, i.e. 60 us for 4 900 workgroups).
+__device__ __forceinline__ double *sum_copy(double *sums) {
+    const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    return sums + (size_t)(b % SPLAT_ITER_SUM_COPIES) * SPLAT_ITER_SUMS;
+}
+
 template <int N>
 __device__ __forceinline__ void block_sum_to(double *dst, const float (&v)[N], double *s_part /* [N][waves] */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -103,6 +142,14 @@ __device__ __forceinline__ void block_sum_to(double *dst, const float (&v)[N], d
         if (t != 0.0) atomicAdd(dst + threadIdx.x, t);
     }
     __syncthreads();
+}
+
+// total of one partial sum over the copies: call with a full wave; every lane returns the total
+__device__ __forceinline__ double sum_total(const double *sums, int k) {
+    static_assert(SPLAT_ITER_SUM_COPIES == 64, "one copy per lane");
+    double v = sums[(size_t)(threadIdx.x & 63) * SPLAT_ITER_SUMS + k];
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
 }
 
 struct Pixel {
@@ -173,7 +220,7 @@ __global__ __launch_bounds__(kBlock) void track_loss_kernel(FusedArgs a, int HW)
             else g[ch * (size_t)HW + i] = out[ch][0];
         }
     }
-    block_sum_to<2>(a.ws.sums, acc, s_part);
+    block_sum_to<2>(sum_copy(a.ws.sums), acc, s_part);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -184,10 +231,10 @@ constexpr int kTW = 32, kTH = 16;           // output tile of one 256-thread wor
 constexpr int kHW_ = kTW + 2 * kSsimR;      // halo width 42
 constexpr int kHH_ = kTH + 2 * kSsimR;      // halo height 26
 
-__device__ __forceinline__ void ssim_window(float *g) {
-    // exp(-(x-5)^2 / (2 * 1.5^2)) normalised, as create_window builds it
+// exp(-(x-5)^2 / (2 * 1.5^2)) normalised in float32, as create_window builds it (/root/reference/utils/slam_external.py:54-56)
+void ssim_window_host(float *g) {
     float s = 0.f;
-    for (int k = 0; k < 11; ++k) { g[k] = expf(-(float)((k - 5) * (k - 5)) / 4.5f); s += g[k]; }
+    for (int k = 0; k < 11; ++k) { g[k] = (float)exp(-(double)((k - 5) * (k - 5)) / 4.5); s += g[k]; }
     for (int k = 0; k < 11; ++k) g[k] /= s;
 }
 
@@ -197,7 +244,8 @@ __global__ __launch_bounds__(kBlock) void ssim_forward_kernel(FusedArgs a, int W
     __shared__ float sh[5][kHH_][kTW + 1];
     __shared__ double s_part[4 * (kBlock / 64)];
     float g[11];
-    ssim_window(g);
+#pragma unroll
+    for (int k = 0; k < 11; ++k) g[k] = a.win[k];
     const int ch = blockIdx.z, tid = threadIdx.x;
     const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
     const size_t HW = (size_t)H * W;
@@ -247,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void ssim_forward_kernel(FusedArgs a, int W
             }
         }
     }
-    block_sum_to<4>(a.ws.sums, acc, s_part);
+    block_sum_to<4>(sum_copy(a.ws.sums), acc, s_part);
 }
 
 // F5: dL/d(rgb) = w_im * (0.8 sign(x - y) / (3HW) - 0.2 / (3HW) * [blur(dmu1) + 2 x blur(de11) + y blur(de12)]),
@@ -255,12 +303,18 @@ __global__ __launch_bounds__(kBlock) void ssim_forward_kernel(FusedArgs a, int W
 __global__ __launch_bounds__(kBlock) void map_loss_backward_kernel(FusedArgs a, int W, int H) {
     __shared__ float sm[3][kHH_][kHW_ + 1];
     __shared__ float sh[3][kHH_][kTW + 1];
+    __shared__ float s_count;
     float g[11];
-    ssim_window(g);
+#pragma unroll
+    for (int k = 0; k < 11; ++k) g[k] = a.win[k];
     const int ch = blockIdx.z, tid = threadIdx.x;
     const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
     const size_t HW = (size_t)H * W;
     const float *M = a.ws.ssim_maps + (size_t)(3 * ch) * HW;
+    if (tid < 64) {
+        const double c = sum_total(a.ws.sums, 2);
+        if (tid == 0) s_count = (float)c;
+    }
     for (int k = tid; k < kHH_ * kHW_; k += kBlock) {
         const int r = k / kHW_, c = k - r * kHW_;
         const int yy = y0 + r - kSsimR, xx = x0 + c - kSsimR;
@@ -282,7 +336,7 @@ __global__ __launch_bounds__(kBlock) void map_loss_backward_kernel(FusedArgs a, 
     }
     __syncthreads();
     const float inv_n = 1.0f / (3.0f * (float)HW);
-    const float count = (float)a.ws.sums[2];
+    const float count = s_count;            // written before the first __syncthreads above
     const float *X = a.ws.out6 + ch * HW, *Y = a.frame.im + ch * HW;
     float *Gout = a.ws.dL_dout6;
 #pragma unroll
@@ -365,14 +419,43 @@ __global__ __launch_bounds__(kBlock) void fused_backward_kernel(FusedArgs a) {
             else { ws.d_log_scales[3 * i] = dls[0]; ws.d_log_scales[3 * i + 1] = dls[1]; ws.d_log_scales[3 * i + 2] = dls[2]; }
         }
     }
-    if (a.cfg.camera_grad) block_sum_to<kPoseSums>(ws.sums + 8, pose, s_part);
+    if (ws.st.tile_stride > 0) {
+        // bucketed lists: this is the last kernel that needs the tile counters -- fold them into the status words
+        // (num_rendered, longest list) and reset them for the next iteration's per-Gaussian kernel
+        const int T = c_num_tiles(a.cam.image_width, a.cam.image_height);
+        unsigned sum = 0, mx = 0;
+        for (int t = i; t < T; t += gridDim.x * kBlock) {
+            const unsigned cnt = ws.st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE];
+            ws.st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE] = 0;
+            sum += cnt;
+            mx = max(mx, cnt);
+        }
+        if (blockIdx.x * kBlock < T) {              // uniform per block; later blocks hold no tile
+            for (int m = 32; m >= 1; m >>= 1) { sum += (unsigned)__shfl_xor((int)sum, m, 64); mx = max(mx, (unsigned)__shfl_xor((int)mx, m, 64)); }
+            if ((threadIdx.x & 63) == 0 && sum) { atomicAdd((unsigned *)&ws.st.status[0], sum); atomicMax((unsigned *)&ws.st.status[2], mx); }
+        }
+    }
+    if (a.cfg.camera_grad) block_sum_to<kPoseSums>(sum_copy(ws.sums) + 8, pose, s_part);
 }
 
 // F7: one thread: pose partial sums -> gradients of the raw camera parameters; loss value
-__global__ void pose_finish_kernel(FusedArgs a, int HW) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double S[SPLAT_ITER_SUMS];
-    for (int k = 0; k < SPLAT_ITER_SUMS; ++k) S[k] = a.ws.sums[k];
+__global__ __launch_bounds__(256) void pose_finish_kernel(FusedArgs a, int HW) {
+    static_assert(SPLAT_ITER_SUMS * 8 == 256 && SPLAT_ITER_SUM_COPIES == 64, "thread t: sum k = t / 8, copies (t % 8) * 8 .. + 7");
+    __shared__ double S[SPLAT_ITER_SUMS];
+    const int t = threadIdx.x, k = t >> 3, part = t & 7;
+    double v = 0.0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        double *p = a.ws.sums + (size_t)(part * 8 + c) * SPLAT_ITER_SUMS + k;
+        v += *p;
+        *p = 0.0;                       // reset for the next iteration (no memset launch)
+    }
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    if (part == 0) S[k] = v;
+    __syncthreads();
+    if (t != 0) return;
     float *out = a.ws.d_cam;
     float dq[4] = {0.f, 0.f, 0.f, 0.f}, dt[3] = {0.f, 0.f, 0.f};
     if (a.cfg.camera_grad) {
@@ -394,9 +477,8 @@ __global__ void pose_finish_kernel(FusedArgs a, int HW) {
         loss = a.cfg.w_depth * (a.cfg.use_l1 ? l_depth / (float)S[2] : 0.f) + a.cfg.w_im * l_im;
     }
     out[7] = loss;
-    // raw sums for inspection, then reset for the next iteration (no memset launch)
-    for (int k = 0; k < 4; ++k) out[8 + k] = (float)S[k];
-    for (int k = 0; k < SPLAT_ITER_SUMS; ++k) a.ws.sums[k] = 0.0;
+    for (int k = 0; k < 4; ++k) out[8 + k] = (float)S[k];       // raw sums, for inspection
+    if (a.ws.st.status[1] != 0 || a.ws.st.status[3] != 0) out[12] = 1.0f;     // sticky until the host clears it
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -461,7 +543,8 @@ __global__ void adam_pose_kernel(SplatMap map, int time_idx, const float *d_cam,
 
 hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame,
                                      const SplatLossConfig &cfg, SplatIterWorkspace &ws, hipStream_t s) {
-    FusedArgs a{cam, map, frame, cfg, ws};
+    FusedArgs a{cam, map, frame, cfg, ws, {}};
+    ssim_window_host(a.win);
     const int W = cam.image_width, H = cam.image_height, HW = W * H;
     const int T = (int)splat_num_tiles(W, H);
     const int P = map.P;
@@ -470,8 +553,10 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
     hipError_t e = hipSuccess;
     const int gblocks = (P + kBlock - 1) / kBlock;
     if (P > 0) hipLaunchKernelGGL(fused_preprocess_kernel, dim3(gblocks), dim3(kBlock), 0, s, a);
-    e = launch_tile_scan(ws.st, T, s);
-    if (e != hipSuccess) return e;
+    if (ws.st.tile_stride == 0) {
+        e = launch_tile_scan(ws.st, T, s);
+        if (e != hipSuccess) return e;
+    }
     SplatGaussians g{};
     g.P = P;
     g.channels = 6;
@@ -492,10 +577,10 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
         hipLaunchKernelGGL(ssim_forward_kernel, grid, dim3(kBlock), 0, s, a, W, H);
         hipLaunchKernelGGL(map_loss_backward_kernel, grid, dim3(kBlock), 0, s, a, W, H);
     }
-    e = launch_render_backward_feat8(cam, ws.feat8, ws.st, ws.dL_dout6, ws.accum, P, false, s);
+    e = launch_render_backward_feat8(cam, ws.feat8, ws.st, ws.dL_dout6, ws.accum, P, false, ws.d_rgb_colors != nullptr, s);
     if (e != hipSuccess) return e;
     if (P > 0) hipLaunchKernelGGL(fused_backward_kernel, dim3(gblocks), dim3(kBlock), 0, s, a);
-    hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(64), 0, s, a, HW);
+    hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(256), 0, s, a, HW);
     return hipGetLastError();
 }
 

@@ -92,7 +92,18 @@ __device__ __forceinline__ void gather(Staged<FP> &s, const SplatState &st, cons
             const bool y0 = (mu.y - hy <= tile_y0 + 7.f) && (mu.y + hy >= tile_y0);
             const bool y1 = (mu.y - hy <= tile_y0 + 15.f) && (mu.y + hy >= tile_y0 + 8.f);
             mask = (x0 && y0 ? 1u : 0u) | (x1 && y0 ? 2u : 0u) | (x0 && y1 ? 4u : 0u) | (x1 && y1 ? 8u : 0u);
-            if (!(hx == hx) || !(hy == hy)) mask = 15u;     // NaN geometry: no culling, let it propagate as the reference would
+            // radial test on top of the box test: d^T Q d >= lambda_min |d|^2, with |d| the distance from the centre to the
+            // quadrant's box of pixel centres; exact for round splats (cuts the box's corners), conservative otherwise
+            const float mid = 0.5f * (co.x + co.z);
+            const float lam_min = mid - sqrtf(fmaxf(0.f, mid * mid - det));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float bx0 = tile_x0 + 8.f * (q & 1), by0 = tile_y0 + 8.f * (q >> 1);
+                const float ddx = fmaxf(fmaxf(bx0 - mu.x, mu.x - (bx0 + 7.f)), 0.f);
+                const float ddy = fmaxf(fmaxf(by0 - mu.y, mu.y - (by0 + 7.f)), 0.f);
+                if (lam_min * (ddx * ddx + ddy * ddy) > tau2 * 1.001f + 1e-3f) mask &= ~(1u << q);
+            }
+            if (!(hx == hx) || !(hy == hy) || !(lam_min == lam_min)) mask = 15u;     // NaN geometry: no culling, let it propagate as the reference would
         }
         s.ga = make_float4(-0.5f * kLog2e * co.x, -kLog2e * co.y, -0.5f * kLog2e * co.z, co.w);
         s.mu = mu;
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(256) void render_forward_kernel(SplatCamera cam, co
                                                              float *out_color, float *out_depth, int T, int per_xcd) {
     constexpr int F = C + (WITH_DEPTH ? 1 : 0);
     constexpr int FP = (F + 3) / 4 * 4;
-    __shared__ Batch<FP> sb[2];
+    __shared__ Batch<FP> B;
     const int tile = block_tile(per_xcd, T);
     if (tile < 0) return;
     const int W = cam.image_width, H = cam.image_height;
@@ -201,17 +212,20 @@ __global__ __launch_bounds__(256) void render_forward_kernel(SplatCamera cam, co
     unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside);      // wave-uniform: pixels with nothing left to composite
     bool wdone = done_m == ~0ull;
 
-    const unsigned lo = st.tile_base[tile], hi = st.tile_base[tile + 1];
-    const int n = (int)(hi - lo);
+    unsigned lo;
+    int n;
+    tile_range(st, tile, lo, n);
     const int nb = (n + kBatch - 1) / kBatch;
 
     if (nb > 0) {
+        // One LDS buffer (a tile's list is usually ONE batch; a second buffer would halve the resident workgroups):
+        // the next batch's gather is in flight in registers while this one is composited, then barrier - commit - barrier.
         Staged<FP> pre;
         gather<C, CS, WITH_DEPTH, FP>(pre, st, colors, lo + tid, tid < n, tile_x0, tile_y0);
-        commit(sb[0], pre, tid, wdone ? 1u : 0u);
-        __syncthreads();
         for (int bi = 0; bi < nb; ++bi) {
-            const Batch<FP> &B = sb[bi & 1];
+            if (bi > 0) __syncthreads();            // every wave has finished reading the previous batch
+            commit(B, pre, tid, wdone ? 1u : 0u);
+            __syncthreads();
             // every wave was finished when this batch was committed: the rest of the list cannot contribute
             const unsigned alldone = B.flag[0] & B.flag[1] & B.flag[2] & B.flag[3];
             if (__builtin_amdgcn_readfirstlane((int)alldone)) break;
@@ -251,10 +265,6 @@ __global__ __launch_bounds__(256) void render_forward_kernel(SplatCamera cam, co
                     }
                 }
             }
-            if (more) {
-                commit(sb[(bi + 1) & 1], pre, tid, wdone ? 1u : 0u);
-                __syncthreads();
-            }
         }
     }
     if (inside) {
@@ -271,13 +281,27 @@ __global__ __launch_bounds__(256) void render_forward_kernel(SplatCamera cam, co
 // ---------------------------------------------------------------------------
 // K7 backward composite
 // ---------------------------------------------------------------------------
-template <int C, int CS>
+// DMASK: channels whose incoming gradient can be non-zero (the others are not even loaded);
+// SMASK: channels whose colour sums (dL/dcolour) the caller needs.  The reference API uses all C for both; the fused
+// iteration knows that the silhouette and depth^2 planes carry no gradient, and that tracking never reads dL/drgb.
+constexpr int popcount_c(unsigned m) { return m == 0 ? 0 : (int)(m & 1u) + popcount_c(m >> 1); }
+constexpr int nth_set_bit(unsigned m, int n) {      // index of the n-th (0-based) set bit
+    int idx = 0;
+    while (true) {
+        if (m & 1u) { if (n == 0) return idx; --n; }
+        m >>= 1; ++idx;
+        if (idx > 31) return -1;
+    }
+}
+
+template <int C, int CS, unsigned DMASK, unsigned SMASK>
 __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, const float *colors, SplatState st,
                                                               const float *dL_dcolor, float *accum, int T, int per_xcd) {
     constexpr int FP = (C + 3) / 4 * 4;
-    constexpr int NV = 6 + C;                 // partial sums per Gaussian
+    constexpr int NS = popcount_c(SMASK);
+    constexpr int NV = 6 + NS;                // partial sums per Gaussian
     constexpr int NG = (NV + 3) / 4;          // packed reduction groups
-    __shared__ Batch<FP> sb[2];
+    __shared__ Batch<FP> B;
     __shared__ unsigned s_wmax[4];
     const int tile = block_tile(per_xcd, T);
     if (tile < 0) return;
@@ -302,19 +326,35 @@ __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, c
     bool has_bg = false;
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) {
-        has_bg |= cam.bg[ch] != 0.f;
-        dpix[ch] = inside ? dL_dcolor[ch * HW + pix] : 0.f;
-        bgdot += cam.bg[ch] * dpix[ch];
+        dpix[ch] = 0.f;
+        if ((DMASK >> ch) & 1u) {
+            has_bg |= cam.bg[ch] != 0.f;
+            dpix[ch] = inside ? dL_dcolor[ch * HW + pix] : 0.f;
+            bgdot += cam.bg[ch] * dpix[ch];
+        }
     }
     const unsigned wmax = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_max_u32(last));   // deepest contributor of this quadrant
     if (lane == 0) s_wmax[wave] = wmax;
     __syncthreads();
     const unsigned tmax = (unsigned)__builtin_amdgcn_readfirstlane((int)max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])));
     if (tmax == 0) return;                                     // uniform over the workgroup
-    const unsigned lo = st.tile_base[tile];
+    const unsigned lo = st.tile_stride > 0 ? (unsigned)tile * (unsigned)st.tile_stride : st.tile_base[tile];
     const int nb = (int)((tmax + kBatch - 1) / kBatch);
-    // lanes 0 / 16 / 32 / 48 publish the reduced sums: row r holds value row_value(r) of each packed group
+    // lanes 0 / 16 / 32 / 48 publish the reduced sums: row r holds value row_value(r) of each packed group.  Destination
+    // slot of packed value k: the six geometric sums, then slot 6 + channel for the k-th channel of SMASK.
     const int rv = row_value(lane >> 4);
+    int doff[NG];
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+        doff[grp] = -1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            constexpr int dummy = 0; (void)dummy;
+            const int k = 4 * grp + r;
+            const int slot = k < 6 ? k : (k < NV ? 6 + nth_set_bit(SMASK, k - 6 < 0 ? 0 : k - 6) : -1);
+            if (rv == r) doff[grp] = slot;
+        }
+    }
     const unsigned long long pub_m = 0x0001000100010001ull;
 
     Staged<FP> pre;
@@ -322,10 +362,10 @@ __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, c
         const unsigned e = (unsigned)((nb - 1) * kBatch + tid);
         gather<C, CS, false, FP>(pre, st, colors, lo + e, e < tmax, tile_x0, tile_y0);
     }
-    commit(sb[(nb - 1) & 1], pre, tid, 0u);
-    __syncthreads();
     for (int bi = nb - 1; bi >= 0; --bi) {
-        const Batch<FP> &B = sb[bi & 1];
+        if (bi < nb - 1) __syncthreads();           // every wave has finished reading the previous batch
+        commit(B, pre, tid, 0u);
+        __syncthreads();
         const bool more = bi > 0;
         if (more) gather<C, CS, false, FP>(pre, st, colors, lo + (unsigned)((bi - 1) * kBatch + tid), true, tile_x0, tile_y0);
         const int base = bi * kBatch;
@@ -355,7 +395,8 @@ __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, c
                     const float Tn = Tr * rcp;                     // transmittance in front of this Gaussian
                     float cdot = 0.f;
 #pragma unroll
-                    for (int ch = 0; ch < C; ++ch) cdot += cur.feat[ch] * dpix[ch];
+                    for (int ch = 0; ch < C; ++ch)
+                        if ((DMASK >> ch) & 1u) cdot += cur.feat[ch] * dpix[ch];
                     const float bh = lalpha * lcdot + (1.f - lalpha) * behind;
                     float dL_dalpha = (cdot - bh) * Tn;
                     if (has_bg) dL_dalpha += (-Tfin * rcp) * bgdot;
@@ -375,28 +416,26 @@ __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, c
                     s[4] = qgy * dy;
                     s[5] = Gl * dL_dalpha;
 #pragma unroll
-                    for (int ch = 0; ch < C; ++ch) s[6 + ch] = wgt * dpix[ch];
+                    for (int n = 0; n < NS; ++n) s[6 + n] = wgt * dpix[nth_set_bit(SMASK, n)];
                     Tr = live ? Tn : Tr;
                     behind = live ? bh : behind;
                     lcdot = live ? cdot : lcdot;
                     lalpha = live ? alpha : lalpha;
                     // all packed reductions first (independent chains interleave), then one publish region
+                    // (timing ablation, round 1: without the atomics -11..-23 us, without the cross-lane reduction -40..-60 us,
+                    //  without both -100..-120 us of ~245 us per launch: scripts/ablate_backward.py at commit "ablation")
                     float r[NG];
 #pragma unroll
                     for (int grp = 0; grp < NG; ++grp)
                         r[grp] = wave_reduce4_packed(s[4 * grp], s[4 * grp + 1], s[4 * grp + 2], s[4 * grp + 3]);
                     if (lane_of(pub_m)) {
-                        float *dst = accum + (size_t)cur.id * SPLAT_GRAD_STRIDE + rv;
+                        float *dst = accum + (size_t)cur.id * SPLAT_GRAD_STRIDE;
 #pragma unroll
                         for (int grp = 0; grp < NG; ++grp)
-                            if (4 * grp + 3 < NV || 4 * grp + rv < NV) atomicAdd(dst + 4 * grp, r[grp]);
+                            if (doff[grp] >= 0) atomicAdd(dst + doff[grp], r[grp]);
                     }
                 }
             }
-        }
-        if (more) {
-            commit(sb[(bi - 1) & 1], pre, tid, 0u);
-            __syncthreads();
         }
     }
 }
@@ -409,11 +448,11 @@ static void launch_fwd(const SplatCamera &cam, const float *colors, SplatState &
     const int per = (T + 7) / 8;
     hipLaunchKernelGGL((render_forward_kernel<C, CS, WITH_DEPTH>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, oc, od, T, per);
 }
-template <int C, int CS>
+template <int C, int CS, unsigned DMASK = (1u << C) - 1u, unsigned SMASK = (1u << C) - 1u>
 static void launch_bwd(const SplatCamera &cam, const float *colors, const SplatState &st, const float *dl, float *acc, int T,
                        hipStream_t s) {
     const int per = (T + 7) / 8;
-    hipLaunchKernelGGL((render_backward_kernel<C, CS>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
+    hipLaunchKernelGGL((render_backward_kernel<C, CS, DMASK, SMASK>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
 }
 
 static const float *colour_source(const SplatGaussians &g, const SplatState &st) {
@@ -471,14 +510,17 @@ hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat
 }
 
 hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *feat8, const SplatState &st, const float *dL_dout6,
-                                        float *accum, int P, bool zero_accum, hipStream_t s) {
+                                        float *accum, int P, bool zero_accum, bool rgb_sums, hipStream_t s) {
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
     if (zero_accum) {
         hipError_t e = hipMemsetAsync(accum, 0, sizeof(float) * SPLAT_GRAD_STRIDE * (size_t)P, s);
         if (e != hipSuccess) return e;
     }
     if (T == 0 || P == 0) return hipSuccess;
-    launch_bwd<6, 8>(cam, feat8, st, dL_dout6, accum, T, s);
+    // channels r, g, b, z carry gradient; the silhouette and depth^2 planes never do.  dL/drgb is only summed on request
+    // (tracking does not read it: LR 0 in /root/reference/configs/*/splatam.py, optimizer discarded after the frame).
+    if (rgb_sums) launch_bwd<6, 8, 0xFu, 0xFu>(cam, feat8, st, dL_dout6, accum, T, s);
+    else launch_bwd<6, 8, 0xFu, 0x8u>(cam, feat8, st, dL_dout6, accum, T, s);
     return hipGetLastError();
 }
 

@@ -28,7 +28,7 @@ hipError_t launch_preprocess_backward(const SplatCamera &cam, const SplatGaussia
 hipError_t launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
 hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat8, SplatState &st, float *out6, hipStream_t s);
 hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *feat8, const SplatState &st, const float *dL_dout6,
-                                        float *accum, int P, bool zero_accum, hipStream_t s);
+                                        float *accum, int P, bool zero_accum, bool rgb_sums, hipStream_t s);
 hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame,
                                      const SplatLossConfig &cfg, SplatIterWorkspace &ws, hipStream_t s);
 hipError_t launch_iter_adam_map(const SplatMap &map, const SplatAdamMap &opt, hipStream_t s);
@@ -47,6 +47,17 @@ __device__ __forceinline__ void load_cam(CamConst &c, const SplatCamera &cam) {
 }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// [lo, lo + n) of tile `tile` in keys / point_list: compact (exact path) or bucketed (SplatState.tile_stride)
+__device__ __forceinline__ void tile_range(const SplatState &st, int tile, unsigned &lo, int &n) {
+    if (st.tile_stride > 0) {
+        lo = (unsigned)tile * (unsigned)st.tile_stride;
+        n = min((int)st.tile_count[(size_t)tile * SPLAT_COUNTER_STRIDE], st.tile_stride);
+    } else {
+        lo = st.tile_base[tile];
+        n = (int)(st.tile_base[tile + 1] - lo);
+    }
+}
 
 // ---- DPP helpers -----------------------------------------------------------
 // dpp_ctrl encodings: quad_perm = 0x00..0xFF, row_half_mirror = 0x141, row_mirror = 0x140

@@ -69,8 +69,8 @@ class FusedEngine:
         b['dL_dout6'] = torch.zeros(6, H, W, dtype=f32, **z)
         b['accum'] = torch.zeros(P, _capi.SPLAT_GRAD_STRIDE, dtype=f32, **z)
         b['ssim_maps'] = torch.empty(9, H, W, dtype=f32, **z)
-        b['sums'] = torch.zeros(_capi.SPLAT_ITER_SUMS, dtype=torch.float64, **z)
-        b['d_cam'] = torch.zeros(12, dtype=f32, **z)
+        b['sums'] = torch.zeros(_capi.SPLAT_ITER_SUM_COPIES * _capi.SPLAT_ITER_SUMS, dtype=torch.float64, **z)
+        b['d_cam'] = torch.zeros(16, dtype=f32, **z)
         b['pose_state'] = torch.zeros(_capi.SPLAT_POSE_STATE, dtype=f32, **z)
         self.max_2D_radius = track_max_radius
         # map gradients: ONE flat buffer (the all-reduce bucket of the view-sharded mapping step), viewed per parameter
@@ -86,6 +86,9 @@ class FusedEngine:
         self.pose_step = 0
         self.track_time_idx = None
         self.max_list_hint = 0          # longest tile list seen at the last check_overflow(); 0 = unknown
+        self.tile_stride = 0            # > 0: bucketed lists (no scan / scatter pass), learnt by check_overflow()
+        self.num_tiles = T
+        self.allow_buckets = True
         self._alloc_lists(self.capacity)
         self._cam = self._make_cam(cam)
         self._frame_keep = None
@@ -133,6 +136,7 @@ class FusedEngine:
         st.tile_count, st.tile_base, st.tile_cursor = b['tile_count'].data_ptr(), b['tile_base'].data_ptr(), b['tile_cursor'].data_ptr()
         st.keys, st.point_list, st.capacity = b['keys'].data_ptr(), b['point_list'].data_ptr(), self.capacity
         st.max_list_hint = self.max_list_hint
+        st.tile_stride = self.tile_stride
         st.final_T, st.n_contrib, st.status = b['final_T'].data_ptr(), b['n_contrib'].data_ptr(), b['status'].data_ptr()
         ws.feat8, ws.out6, ws.dL_dout6, ws.accum = b['feat8'].data_ptr(), b['out6'].data_ptr(), b['dL_dout6'].data_ptr(), b['accum'].data_ptr()
         ws.ssim_maps = b['ssim_maps'].data_ptr() if with_ssim else None
@@ -248,18 +252,36 @@ class FusedEngine:
         return float(self.buf['d_cam'][7])
 
     def check_overflow(self, grow=True):
-        """Lists are fixed-size; an iteration whose instances did not fit rendered EMPTY lists and flagged it.
-        Call at frame end (one D2H read): returns True when the last iteration overflowed (and grows the lists)."""
+        """Lists are fixed-size; an iteration whose instances did not fit rendered truncated / empty lists and flagged
+        it (stickily).  Call at frame end (one D2H read): returns True when an iteration since the last call has to
+        be repeated.  Also learns the list statistics: from then on the per-tile lists are BUCKETED at 1.5x the longest
+        list seen (the per-Gaussian kernel writes instances straight into their tile's bucket: no scan kernel, no
+        scatter pass) and the long-list sort launch is skipped while lists stay short."""
         stat = self.buf['status'].tolist()
-        bad = stat[1] != 0 or stat[0] > self.capacity
-        if bad and grow:
-            self._alloc_lists(int(stat[0] * 1.5) + 65536)
-        if stat[3] != 0:            # a list outgrew the (stale) hint that skipped the long-list sort: forget the hint
-            bad = True
+        sticky = float(self.buf['d_cam'][12]) != 0.0
+        bad = sticky or stat[1] != 0 or stat[3] != 0 or (self.tile_stride == 0 and stat[0] > self.capacity)
+        if bad:
+            self.buf['d_cam'][12] = 0.0
+            self.buf['status'].zero_()
+            self.buf['tile_count'].zero_()
+            self.buf['accum'].zero_()
+            self.buf['sums'].zero_()
             self.max_list_hint = 0
-        elif not bad:               # lets the library skip the long-list sort kernel while lists stay well below its limit
-            self.max_list_hint = int(stat[2]) if 0 < stat[2] <= 768 else 0
-        return bad
+            if grow:
+                if self.tile_stride > 0:            # a bucket overflowed: back to exact lists, re-learn
+                    self.tile_stride = 0
+                if stat[0] > self.capacity:
+                    self._alloc_lists(int(stat[0] * 1.5) + 65536)
+            return True
+        longest = int(stat[2])
+        self.max_list_hint = longest if 0 < longest <= 768 else 0
+        if grow and self.allow_buckets and longest > 0:
+            stride = max(256, (int(longest * 1.5) + 63) // 64 * 64)
+            if stride != self.tile_stride and stride * self.num_tiles <= 64 * 1024 * 1024:
+                if stride * self.num_tiles > self.capacity:
+                    self._alloc_lists(stride * self.num_tiles)
+                self.tile_stride = stride
+        return False
 
     @property
     def seen(self):

@@ -190,6 +190,58 @@ def test_tracking_loop_matches_reference_loop():
     assert torch.equal(params['means3D'], ref['means3D']) and torch.equal(params['rgb_colors'], ref['rgb_colors'])
 
 
+@pytest.mark.parametrize("tracking", [True, False])
+def test_bucketed_lists_match_exact_lists(tracking):
+    """check_overflow() teaches the engine the list statistics; from then on the per-tile lists are bucketed (no scan /
+    scatter pass).  Same lists, same results: only the order of float atomics differs."""
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    params, variables, frame, cam = _scene(20000, 320, 240, aniso=not tracking, seed=21)
+    cfg = slam.REPLICA_TRACKING if tracking else slam.REPLICA_MAPPING
+    eng = FusedEngine(params, cam)
+    eng.loss_backward(frame, 1, cfg, tracking=tracking)
+    torch.cuda.synchronize()
+    ref_cam = eng.buf['d_cam'][:8].clone()
+    ref_grads = {k: v.clone() for k, v in eng.grads.items()}
+    ref_lists = None
+    assert eng.tile_stride == 0 and not eng.check_overflow()
+    assert eng.tile_stride >= 256 and eng.tile_stride * eng.num_tiles <= eng.capacity
+    n_exact = int(eng.buf['status'][0])
+    for _ in range(2):                      # twice: the counters must come back to zero by themselves
+        eng.loss_backward(frame, 1, cfg, tracking=tracking)
+        torch.cuda.synchronize()
+        assert float(eng.buf['d_cam'][12]) == 0.0
+        assert int(eng.buf['status'][0]) == n_exact
+        got = eng.buf['d_cam'][:8]
+        assert (got - ref_cam).abs().max() <= 1e-4 * ref_cam.abs().max()
+        if not tracking:
+            for k in ("means3D", "rgb_colors", "logit_opacities", "log_scales", "unnorm_rotations"):
+                assert (eng.grads[k] - ref_grads[k]).abs().max() <= 1e-4 * ref_grads[k].abs().max() + 1e-12, k
+    assert not eng.check_overflow()
+    assert int(eng.buf['tile_count'].abs().max()) == 0
+
+
+def test_bucket_overflow_falls_back_to_exact_lists():
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    params, variables, frame, cam = _scene(20000, 96, 64, seed=23)          # dense: hundreds of instances per tile
+    cfg = slam.REPLICA_TRACKING
+    eng = FusedEngine(params, cam)
+    eng.loss_backward(frame, 1, cfg, tracking=True)
+    torch.cuda.synchronize()
+    loss_exact = eng.loss()
+    assert not eng.check_overflow()
+    eng.tile_stride = 64                                                     # force buckets that are too small
+    eng.loss_backward(frame, 1, cfg, tracking=True)
+    torch.cuda.synchronize()
+    assert eng.check_overflow()                                              # flagged; engine is back on exact lists
+    assert eng.tile_stride == 0
+    eng.loss_backward(frame, 1, cfg, tracking=True)
+    torch.cuda.synchronize()
+    assert abs(eng.loss() - loss_exact) <= 1e-5 * abs(loss_exact)
+    assert not eng.check_overflow(grow=False)
+
+
 def test_list_overflow_is_flagged_not_fatal():
     from splatam_amd import slam
     from splatam_amd.fused import FusedEngine
