@@ -95,9 +95,7 @@ def run_steps_fused(eng, frames, rank, world, nsteps, start=0):
     from splatam_amd import slam
     n_views = len(frames) - 1
 
-    def allreduce(flat):
-        dist.all_reduce(flat)
-        flat.div_(world)
+    from splatam_amd.dist import all_reduce_mean_flat as allreduce
     for i in range(start, start + nsteps):
         if i % 5 < 2:
             eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING)
@@ -209,7 +207,10 @@ def fused_roofline(eng, frames, shape, dev):
 
 # HBM bytes per launch of the dominant kernels from the most recent rocprofv3 --pmc passes (profiles/r01_*_pmc*.txt), corrected
 # as /opt/skills/guides/MI355X_MICROARCH.md prescribes (FETCH_SIZE in KiB reads 1/2 of wide streaming reads on gfx950 -> x2).
-PMC_TRAFFIC = {}
+PMC_TRAFFIC = {     # profiles/r01_v3b_fused_pmc_kernels.txt: (2 * FETCH_SIZE + WRITE_SIZE) KiB * 1024, bytes per launch at workload B
+    "render_backward": int((2 * 66.21e3 + 95.11e3) * 1024),     # render_backward_kernel<6,8,15,15>
+    "render_forward": int((2 * 58.27e3 + 27.0e3) * 1024),       # render_forward_kernel<6,8,false,*>
+}
 
 
 def render_mpix(params, frames, shape, dev, reps=10):

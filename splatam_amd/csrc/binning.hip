@@ -43,39 +43,6 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(SplatGaussians g, Splat
     }
 }
 
-// Bitonic network with ascending-only compare-exchanges ("flip" form), so that
-// virtual +inf padding above n never has to be stored: an exchange whose upper
-// index is >= n is skipped.
-template <typename KeyPtr>
-__device__ __forceinline__ void bitonic_sort(KeyPtr keys, const int n, const int tid, const int nthreads) {
-    int N2 = 2;
-    while (N2 < n) N2 <<= 1;
-    const int half_n = N2 >> 1;
-    for (int k = 2; k <= N2; k <<= 1) {
-        const int hk = k >> 1;
-        for (int i = tid; i < half_n; i += nthreads) {
-            const int blk = i / hk, off = i - blk * hk;
-            const int a = blk * k + off, b = blk * k + k - 1 - off;
-            if (b < n) {
-                const uint64_t ka = keys[a], kb = keys[b];
-                if (ka > kb) { keys[a] = kb; keys[b] = ka; }
-            }
-        }
-        __syncthreads();
-        for (int j = hk >> 1; j >= 1; j >>= 1) {
-            for (int i = tid; i < half_n; i += nthreads) {
-                const int blk = i / j, off = i - blk * j;
-                const int a = blk * 2 * j + off, b = a + j;
-                if (b < n) {
-                    const uint64_t ka = keys[a], kb = keys[b];
-                    if (ka > kb) { keys[a] = kb; keys[b] = ka; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
 // K4(+K5).  tile_base already holds the ranges.  Two kernels:
 //  * short lists (n <= kSortWave, the normal case: ~200 entries at config B): ONE wave per tile,
 //    8 KiB of LDS, the network's barriers degenerate to wave-local waits; every tile of the frame is
@@ -91,10 +58,6 @@ __global__ __launch_bounds__(64) void tile_sort_wave_kernel(SplatState st) {
             if (blockIdx.x == 0 && threadIdx.x == 0) st.status[1] = 1;
             return;
         }
-    } else if (tile == 0 && tid == 0) {
-        // bucketed lists have no scan kernel: the per-iteration status words are reset here and re-accumulated by the
-        // kernel that consumes the tile counters (fused_backward_kernel)
-        st.status[0] = 0; st.status[2] = 0; st.status[3] = 0;
     }
     unsigned lo;
     int n;
@@ -134,12 +97,12 @@ __global__ __launch_bounds__(kBlock) void tile_sort_block_kernel(SplatState st) 
     }
 }
 
-hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s) {
+hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s, bool sort) {
     const int gx = (cam.image_width + kTile - 1) / kTile;
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
     // bucketed lists were filled by the per-Gaussian kernel: only the per-tile sort remains
     if (g.P > 0 && st.tile_stride == 0) hipLaunchKernelGGL(scatter_kernel, dim3((g.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, g, st, gx);
-    if (T > 0) {
+    if (T > 0 && sort) {
         hipLaunchKernelGGL(tile_sort_wave_kernel, dim3(T), dim3(64), 0, s, st);
         // the host may know the longest list (status[2]); only then can the long-list kernel be skipped
         if (st.max_list_hint <= 0 || st.max_list_hint > kSortWave)

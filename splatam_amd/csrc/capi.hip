@@ -182,7 +182,7 @@ int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P,
     hipError_t err = hipSuccess;
     (void)hipEventRecord(e0, s);
     for (int i = 0; i < iters && err == hipSuccess; ++i)
-        err = fn == 0 ? launch_render_forward_feat8(*cam, ws->feat8, ws->st, ws->out6, s)
+        err = fn == 0 ? launch_render_forward_feat8(*cam, ws->feat8, ws->st, ws->out6, false, s)
                       : launch_render_backward_feat8(*cam, ws->feat8, ws->st, ws->dL_dout6, ws->accum, P, false, true, s);
     (void)hipEventRecord(e1, s);
     (void)hipEventSynchronize(e1);

@@ -59,6 +59,11 @@ __device__ __forceinline__ void load_gaussian(const SplatMap &m, int i, float *p
 __global__ __launch_bounds__(kBlock) void fused_preprocess_kernel(FusedArgs a) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.map.P) return;
+    if (i == 0 && a.ws.st.tile_stride > 0) {
+        // bucketed lists have no scan kernel: the per-iteration status words are reset here and re-accumulated by the
+        // kernel that consumes the tile counters (fused_backward_kernel); [1] (overflow) stays sticky for the host
+        a.ws.st.status[0] = 0; a.ws.st.status[2] = 0; a.ws.st.status[3] = 0;
+    }
     CamConst c;
     load_cam(c, a.cam);
     Pose P;
@@ -560,9 +565,11 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
     SplatGaussians g{};
     g.P = P;
     g.channels = 6;
-    e = launch_bin_forward(cam, g, ws.st, s);
+    // lists known (host hint, possibly stale: then flagged) to be short are sorted by the composite kernel itself
+    const bool sort_in_k6 = ws.st.max_list_hint > 0 && ws.st.max_list_hint + ws.st.max_list_hint / 4 <= 1024;
+    e = launch_bin_forward(cam, g, ws.st, s, !sort_in_k6);
     if (e != hipSuccess) return e;
-    e = launch_render_forward_feat8(cam, ws.feat8, ws.st, ws.out6, s);
+    e = launch_render_forward_feat8(cam, ws.feat8, ws.st, ws.out6, sort_in_k6, s);
     if (e != hipSuccess) return e;
     if (cfg.tracking) {
         if (HW % 4 == 0) {

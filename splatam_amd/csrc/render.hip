@@ -67,7 +67,7 @@ __device__ __forceinline__ void load_colors(const float *colors, unsigned id, fl
 
 template <int C, int CS, bool WITH_DEPTH, int FP>
 __device__ __forceinline__ void gather(Staged<FP> &s, const SplatState &st, const float *colors, unsigned idx, bool valid,
-                                       float tile_x0, float tile_y0) {
+                                       float tile_x0, float tile_y0, const uint64_t *lds_keys = nullptr, int lds_idx = 0) {
     s.ga = make_float4(0.f, 0.f, 0.f, 0.f);
     s.mu = make_float2(0.f, 0.f);
 #pragma unroll
@@ -75,7 +75,8 @@ __device__ __forceinline__ void gather(Staged<FP> &s, const SplatState &st, cons
     s.mask = 0;
     s.id = 0;
     if (valid) {
-        const unsigned id = st.point_list[idx];
+        // sorted id: from the tile's keys sorted in LDS by this workgroup (low 32 bits), or from the global list
+        const unsigned id = lds_keys ? (unsigned)lds_keys[lds_idx] : st.point_list[idx];
         const float4 co = reinterpret_cast<const float4 *>(st.conic_opacity)[id];
         const float2 mu = reinterpret_cast<const float2 *>(st.xy)[id];
         load_colors<C, CS>(colors, id, s.feat);
@@ -189,12 +190,18 @@ __device__ __forceinline__ bool lane_of(unsigned long long m) { return __builtin
 // ---------------------------------------------------------------------------
 // K6 forward composite
 // ---------------------------------------------------------------------------
-template <int C, int CS, bool WITH_DEPTH>
+constexpr int kFusedSortMax = 1024;     // longest list the composite sorts itself (8 KiB of LDS)
+
+// SORT: the workgroup first sorts its tile's (depth, id) keys in LDS (256-thread bitonic network, a few microseconds
+// next to ~35 us of compositing) and publishes the ids for the backward pass: no separate sort launch, and the
+// gathers take their ids from LDS instead of a dependent global load.
+template <int C, int CS, bool WITH_DEPTH, bool SORT>
 __global__ __launch_bounds__(256) void render_forward_kernel(SplatCamera cam, const float *colors, SplatState st,
                                                              float *out_color, float *out_depth, int T, int per_xcd) {
     constexpr int F = C + (WITH_DEPTH ? 1 : 0);
     constexpr int FP = (F + 3) / 4 * 4;
     __shared__ Batch<FP> B;
+    __shared__ uint64_t s_keys[SORT ? kFusedSortMax : 1];
     const int tile = block_tile(per_xcd, T);
     if (tile < 0) return;
     const int W = cam.image_width, H = cam.image_height;
@@ -215,13 +222,24 @@ __global__ __launch_bounds__(256) void render_forward_kernel(SplatCamera cam, co
     unsigned lo;
     int n;
     tile_range(st, tile, lo, n);
+    if constexpr (SORT) {
+        if (n > kFusedSortMax) {        // the host's list-length hint was stale: flag it (the host repeats the iteration)
+            if (tid == 0) st.status[3] = 1;
+            n = kFusedSortMax;
+        }
+        for (int i = tid; i < n; i += 256) s_keys[i] = st.keys[lo + i];
+        __syncthreads();
+        if (n > 1) bitonic_sort(s_keys, n, tid, 256);
+        for (int i = tid; i < n; i += 256) st.point_list[lo + i] = (uint32_t)s_keys[i];
+    }
+    const uint64_t *lk = SORT ? s_keys : nullptr;
     const int nb = (n + kBatch - 1) / kBatch;
 
     if (nb > 0) {
         // One LDS buffer (a tile's list is usually ONE batch; a second buffer would halve the resident workgroups):
         // the next batch's gather is in flight in registers while this one is composited, then barrier - commit - barrier.
         Staged<FP> pre;
-        gather<C, CS, WITH_DEPTH, FP>(pre, st, colors, lo + tid, tid < n, tile_x0, tile_y0);
+        gather<C, CS, WITH_DEPTH, FP>(pre, st, colors, lo + tid, tid < n, tile_x0, tile_y0, lk, tid);
         for (int bi = 0; bi < nb; ++bi) {
             if (bi > 0) __syncthreads();            // every wave has finished reading the previous batch
             commit(B, pre, tid, wdone ? 1u : 0u);
@@ -232,7 +250,7 @@ __global__ __launch_bounds__(256) void render_forward_kernel(SplatCamera cam, co
             const bool more = bi + 1 < nb;
             if (more) {                         // next batch's gather stays in flight while this one is composited
                 const int e = (bi + 1) * kBatch + tid;
-                gather<C, CS, WITH_DEPTH, FP>(pre, st, colors, lo + e, e < n, tile_x0, tile_y0);
+                gather<C, CS, WITH_DEPTH, FP>(pre, st, colors, lo + e, e < n, tile_x0, tile_y0, lk, e);
             }
             const unsigned base1 = (unsigned)(bi * kBatch + 1);
 #pragma unroll 1
@@ -443,10 +461,10 @@ __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, c
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-template <int C, int CS, bool WITH_DEPTH>
+template <int C, int CS, bool WITH_DEPTH, bool SORT = false>
 static void launch_fwd(const SplatCamera &cam, const float *colors, SplatState &st, float *oc, float *od, int T, hipStream_t s) {
     const int per = (T + 7) / 8;
-    hipLaunchKernelGGL((render_forward_kernel<C, CS, WITH_DEPTH>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, oc, od, T, per);
+    hipLaunchKernelGGL((render_forward_kernel<C, CS, WITH_DEPTH, SORT>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, oc, od, T, per);
 }
 template <int C, int CS, unsigned DMASK = (1u << C) - 1u, unsigned SMASK = (1u << C) - 1u>
 static void launch_bwd(const SplatCamera &cam, const float *colors, const SplatState &st, const float *dl, float *acc, int T,
@@ -502,10 +520,12 @@ hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &
 }
 
 // Fused-iteration path (fused.hip): 6 channels (r, g, b, z, 1, z^2) read from 8-float records, no separate depth plane.
-hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat8, SplatState &st, float *out6, hipStream_t s) {
+hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat8, SplatState &st, float *out6, bool sort_in_kernel,
+                                       hipStream_t s) {
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
     if (T == 0) return hipSuccess;
-    launch_fwd<6, 8, false>(cam, feat8, st, out6, nullptr, T, s);
+    if (sort_in_kernel) launch_fwd<6, 8, false, true>(cam, feat8, st, out6, nullptr, T, s);
+    else launch_fwd<6, 8, false, false>(cam, feat8, st, out6, nullptr, T, s);
     return hipGetLastError();
 }
 

@@ -18,7 +18,7 @@ constexpr int kWave = 64;
 hipError_t launch_preprocess_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s);
 hipError_t launch_tile_count_reset(SplatState &st, int T, hipStream_t s);
 hipError_t launch_tile_scan(SplatState &st, int T, hipStream_t s);
-hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s);
+hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s, bool sort = true);
 hipError_t launch_render_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st,
                                  float *out_color, float *out_depth, hipStream_t s);
 hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &g, const SplatState &st,
@@ -26,7 +26,8 @@ hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &
 hipError_t launch_preprocess_backward(const SplatCamera &cam, const SplatGaussians &g, const SplatState &st,
                                       SplatGrads &gr, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
-hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat8, SplatState &st, float *out6, hipStream_t s);
+hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat8, SplatState &st, float *out6, bool sort_in_kernel,
+                                       hipStream_t s);
 hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *feat8, const SplatState &st, const float *dL_dout6,
                                         float *accum, int P, bool zero_accum, bool rgb_sums, hipStream_t s);
 hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame,
@@ -105,6 +106,40 @@ __device__ __forceinline__ float wave_reduce4_packed(float v0, float v1, float v
 }
 // value index held by row r after wave_reduce4_packed: {0, 2, 1, 3}
 __device__ __forceinline__ int row_value(int row) { return ((row & 1) << 1) | (row >> 1); }
+
+// Bitonic network with ascending-only compare-exchanges ("flip" form), so that
+// virtual +inf padding above n never has to be stored: an exchange whose upper
+// index is >= n is skipped.  All block sizes are powers of two: index arithmetic is shifts and masks.
+template <typename KeyPtr>
+__device__ __forceinline__ void bitonic_sort(KeyPtr keys, const int n, const int tid, const int nthreads) {
+    int lN2 = 1;
+    while ((1 << lN2) < n) ++lN2;
+    const int half_n = 1 << (lN2 - 1);
+    for (int lk = 1; lk <= lN2; ++lk) {                 // k = 2^lk
+        const int lhk = lk - 1, hk = 1 << lhk, k = 1 << lk;
+        for (int i = tid; i < half_n; i += nthreads) {
+            const int blk = i >> lhk, off = i & (hk - 1);
+            const int a = (blk << lk) + off, b = (blk << lk) + k - 1 - off;
+            if (b < n) {
+                const uint64_t ka = keys[a], kb = keys[b];
+                if (ka > kb) { keys[a] = kb; keys[b] = ka; }
+            }
+        }
+        __syncthreads();
+        for (int lj = lhk - 1; lj >= 0; --lj) {         // j = 2^lj
+            const int j = 1 << lj;
+            for (int i = tid; i < half_n; i += nthreads) {
+                const int blk = i >> lj, off = i & (j - 1);
+                const int a = (blk << (lj + 1)) + off, b = a + j;
+                if (b < n) {
+                    const uint64_t ka = keys[a], kb = keys[b];
+                    if (ka > kb) { keys[a] = kb; keys[b] = ka; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
 
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     for (int m = 32; m >= 1; m >>= 1) {

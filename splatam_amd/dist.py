@@ -72,6 +72,15 @@ class GradBucket:
                     params[k].grad.copy_(v)
 
 
+def all_reduce_mean_flat(flat: torch.Tensor, group=None) -> None:
+    """In-place mean over ranks of ONE flat gradient buffer -- the exchange step of the fused mapping iteration
+    (splatam_amd.fused.FusedEngine.grad_flat is already laid out as the bucket: no packing)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(dist.get_world_size(group))
+
+
 def shard_views(num_views: int, rank: int, world: int):
     """Indices of the keyframe views rank ``rank`` renders (round-robin)."""
     return list(range(rank, num_views, world))

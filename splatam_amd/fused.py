@@ -274,7 +274,7 @@ class FusedEngine:
                     self._alloc_lists(int(stat[0] * 1.5) + 65536)
             return True
         longest = int(stat[2])
-        self.max_list_hint = longest if 0 < longest <= 768 else 0
+        self.max_list_hint = longest            # short lists: sorted inside the composite, no sort launch
         if grow and self.allow_buckets and longest > 0:
             stride = max(256, (int(longest * 1.5) + 63) // 64 * 64)
             if stride != self.tile_stride and stride * self.num_tiles <= 64 * 1024 * 1024:

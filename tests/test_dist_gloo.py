@@ -51,8 +51,12 @@ def _worker(rank, world, port, out_dir):
     mine = [views[i] for i in sdist.shard_views(len(views), rank, world)]
     assert len(mine) == 1
     _view_grads(params, variables, frames[mine[0]], mine[0])
+    # the fused engine's exchange step: the same mean taken directly on a flat gradient buffer (no packing)
+    flat = torch.cat([params[k].grad.reshape(-1) for k in KEYS]).clone()
+    sdist.all_reduce_mean_flat(flat)
     bucket = sdist.GradBucket(params)
     bucket.all_reduce_mean(params)
+    assert torch.equal(flat, torch.cat([params[k].grad.reshape(-1) for k in KEYS]))
     opt = slam.initialize_optimizer(params, slam.REPLICA_MAPPING['lrs'], tracking=False)
     opt.step()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"),
