@@ -266,3 +266,34 @@ def test_unsupported_configuration_raises():
     cfg['ignore_outlier_depth_loss'] = True
     with pytest.raises(RuntimeError, match="unsupported"):
         eng.loss_backward(frame, 1, cfg, tracking=True)
+
+
+def test_edge_shapes_and_empty_map():
+    """Image not a multiple of the tile / SSIM block sizes, odd pixel count (scalar loss path), and a map with no
+    visible Gaussian: finite results, zero gradients where nothing is rendered."""
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    params, variables, frame, cam = _scene(3000, 203, 117, aniso=True, seed=31)          # 203*117 is odd
+    for tracking, cfg in ((True, slam.REPLICA_TRACKING), (False, slam.REPLICA_MAPPING)):
+        cfg2 = _gap_threshold(params, frame, cam, cfg) if tracking else cfg
+        loss_ref, g_ref = _reference_grads(params, variables, frame, cfg2, tracking=tracking)
+        eng = FusedEngine(params, cam)
+        eng.loss_backward(frame, 1, cfg2, tracking=tracking)
+        torch.cuda.synchronize()
+        assert abs(eng.loss() - loss_ref) <= 2e-4 * abs(loss_ref), (tracking, eng.loss(), loss_ref)
+        if tracking:
+            gq = g_ref['cam_unnorm_rots'][0, :, 1]
+            assert (eng.buf['d_cam'][0:4] - gq).abs().max() <= 2e-3 * gq.abs().max()
+        else:
+            _cmp(eng.grads['means3D'], g_ref['means3D'], 'means3D')
+            _cmp(eng.grads['rgb_colors'], g_ref['rgb_colors'], 'rgb_colors')
+    # everything behind the camera: nothing rendered, loss = the empty-image loss, all gradients zero
+    with torch.no_grad():
+        params['means3D'][:, 2] = -1.0
+    eng = FusedEngine(params, cam)
+    eng.loss_backward(frame, 1, slam.REPLICA_MAPPING, tracking=False)
+    torch.cuda.synchronize()
+    assert int(eng.buf['status'][0]) == 0 and not eng.check_overflow()
+    assert float(eng.grad_flat.abs().max()) == 0.0
+    loss_ref, _ = _reference_grads(params, variables, frame, slam.REPLICA_MAPPING, tracking=False)
+    assert abs(eng.loss() - loss_ref) <= 1e-5 * abs(loss_ref)
