@@ -284,6 +284,89 @@ int splat_iter_adam_pose(const SplatMap *map, int32_t time_idx, const float *d_c
  * the state of a completed splat_iter_loss_backward. */
 int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P, SplatIterWorkspace *ws, void *stream, float *ms);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Map growth and maintenance: the per-frame callers that change the NUMBER of Gaussians.
+ * The reference re-allocates every parameter tensor with torch.cat / boolean indexing
+ * (/root/reference/scripts/splatam.py:378-420, /root/reference/utils/slam_external.py:139-188); here the map is a
+ * capacity-managed struct of arrays that is edited in place: rows are appended at the tail / compacted stably, so
+ * that after an edit the first `count` rows hold exactly what the reference's tensors would hold, in the same order.
+ * Every edit leaves its result count in store->counts (device); the host reads it once per edit (the reference
+ * synchronises at the same places: `if torch.sum(non_presence_mask) > 0`, boolean indexing).
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* The map arrays with room for `capacity` rows + what has to move with them. */
+typedef struct SplatMapStore {
+    SplatMap map;                /* map.P = rows in use, as the HOST knows them (it is the launch bound) */
+    int32_t capacity;            /* rows every per-Gaussian array can hold */
+    float *exp_avg[5];           /* Adam moments of the live optimizer, group order of SplatAdamMap; NULL = none */
+    float *exp_avg_sq[5];
+    float *max_2D_radius;        /* variables['max_2D_radius'] [capacity] or NULL */
+    float *means2D_gradient_accum; /* variables['means2D_gradient_accum'] [capacity] or NULL */
+    float *denom;                /* variables['denom'] [capacity] or NULL */
+    float *timestep;             /* variables['timestep'] [capacity] or NULL */
+    int32_t *counts;             /* device [8]: [0] rows after the edit, [1] rows appended / removed by it,
+                                    [2] the append did not fit `capacity` (then nothing was written),
+                                    [3] add_new_gaussians: sum(non_presence_mask) BEFORE the valid-depth mask,
+                                    [4] float bits of the median used by add_new_gaussians, 3 spare */
+} SplatMapStore;
+
+/* Forward-only pass of the fused composite (kernels F1, K2..K4, K6; no loss, no gradients, nothing accumulated):
+ * ws->out6 = r, g, b, depth, silhouette, depth^2 of `map` seen from pose `frame->time_idx`.  This is the render of
+ * add_new_gaussians (/root/reference/scripts/splatam.py:381-385) and of the evaluation / keyframe code.
+ * frame->im / frame->depth may be NULL. */
+int splat_iter_render(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame, SplatIterWorkspace *ws,
+                      void *stream);
+
+/* Which pixels of an RGB-D frame become new Gaussians. */
+enum {
+    SPLAT_ADD_VALID_DEPTH = 0,   /* initialize_first_timestep: mask = depth > 0 (/root/reference/scripts/splatam.py:197-202) */
+    SPLAT_ADD_NON_PRESENCE = 1   /* add_new_gaussians: silhouette < sil_thres, or rendered depth behind the measured one
+                                    by more than 50 x the median depth error; and depth > 0 (:386-408) */
+};
+
+typedef struct SplatAddArgs {
+    int32_t mode;                /* SPLAT_ADD_* */
+    int32_t width, height;
+    const float *im;             /* [3][H][W] curr_data['im'] */
+    const float *depth;          /* [1][H][W] curr_data['depth'] */
+    const float *out6;           /* [6][H][W] render at the tracked pose (planes 3 = depth, 4 = silhouette are read);
+                                    NULL for SPLAT_ADD_VALID_DEPTH */
+    float fx, fy, cx, cy;        /* curr_data['intrinsics'] (the densification intrinsics) */
+    float sil_thres;
+    int32_t time_idx;            /* SPLAT_ADD_NON_PRESENCE: pose of the map that back-projects; value of variables['timestep'] */
+    const float *w2c;            /* SPLAT_ADD_VALID_DEPTH: [16] row-major rigid world-to-camera of the frame (device) */
+    float *err;                  /* scratch [H*W] floats (depth error) */
+    uint32_t *scratch;           /* scratch, splat_map_scratch_words(width*height) uint32 words */
+} SplatAddArgs;
+
+/* uint32 words of SplatAddArgs.scratch / SplatPruneArgs.scratch for `n` pixels / rows */
+size_t splat_map_scratch_words(int64_t n);
+
+/* get_pointcloud + initialize_new_params + the torch.cat of add_new_gaussians / initialize_params
+ * (/root/reference/scripts/splatam.py:67-116, 350-376, 378-420): appends one Gaussian per selected pixel, in pixel
+ * order: means3D = c2w [x z, y z, z, 1] with (x, y) = ((u - cx) / fx, (v - cy) / fy), rgb from `im`, rotation (1,0,0,0),
+ * logit opacity 0, log scale log(sqrt((z / ((fx + fy) / 2))^2)) (1 or 3 columns), timestep = time_idx; when anything was
+ * selected before the valid-depth mask, max_2D_radius / means2D_gradient_accum / denom are zeroed for ALL rows, as the
+ * reference does.  Moments (exp_avg*) of appended rows are zeroed.  counts[0..4] are written. */
+int splat_map_add_new_gaussians(SplatMapStore *store, const SplatAddArgs *args, void *stream);
+
+typedef struct SplatPruneArgs {
+    float removal_opacity_threshold; /* remove rows with sigmoid(logit_opacity) < this */
+    int32_t remove_big;          /* also remove rows whose largest exp(log_scale) > big_scale */
+    float big_scale;             /* 0.1 * variables['scene_radius'] */
+    const uint8_t *to_remove;    /* [P] caller-supplied flags (remove_points); NULL = form them from the two rules above */
+    uint8_t *flags;              /* scratch [capacity] */
+    float *stage;                /* scratch: capacity * splat_map_row_floats(store) floats */
+    uint32_t *scratch;           /* splat_map_scratch_words(capacity) words */
+} SplatPruneArgs;
+
+/* floats per row over every non-NULL array of the store (the staging buffer of a prune holds capacity * this) */
+int32_t splat_map_row_floats(const SplatMapStore *store);
+
+/* prune_gaussians' removal rule + remove_points (/root/reference/utils/slam_external.py:139-188): stable compaction of
+ * the five parameter arrays, the Adam moments and the per-Gaussian variables.  counts[0], counts[1] are written. */
+int splat_map_prune(SplatMapStore *store, const SplatPruneArgs *args, void *stream);
+
 /* Developer switches used by scripts/ (never by the product path): key 0 = skip the per-tile
  * count atomics of K1 (timing experiment; results are then invalid); key 1 = generation of the composite kernels
  * (3 = current, 2 = previous, 3-channel calls only; A/B timing).  Returns the previous value. */

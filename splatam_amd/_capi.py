@@ -78,6 +78,24 @@ class SplatAdamMap(C.Structure):
                 ("step_size", C.c_float * 5), ("grad", _fp * 5), ("exp_avg", _fp * 5), ("exp_avg_sq", _fp * 5)]
 
 
+class SplatMapStore(C.Structure):
+    _fields_ = [("map", SplatMap), ("capacity", C.c_int32), ("exp_avg", _fp * 5), ("exp_avg_sq", _fp * 5),
+                ("max_2D_radius", _fp), ("means2D_gradient_accum", _fp), ("denom", _fp), ("timestep", _fp), ("counts", _fp)]
+
+
+class SplatAddArgs(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("im", _fp), ("depth", _fp), ("out6", _fp),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("sil_thres", C.c_float),
+                ("time_idx", C.c_int32), ("w2c", _fp), ("err", _fp), ("scratch", _fp)]
+
+
+class SplatPruneArgs(C.Structure):
+    _fields_ = [("removal_opacity_threshold", C.c_float), ("remove_big", C.c_int32), ("big_scale", C.c_float),
+                ("to_remove", _fp), ("flags", _fp), ("stage", _fp), ("scratch", _fp)]
+
+
+SPLAT_ADD_VALID_DEPTH = 0
+SPLAT_ADD_NON_PRESENCE = 1
 SPLAT_ITER_SUMS = 32
 SPLAT_ITER_SUM_COPIES = 64
 SPLAT_POSE_STATE = 24
@@ -88,6 +106,7 @@ EXPORTS = (
     "splat_render_backward", "splat_preprocess_backward", "splat_backward",
     "splat_mark_visible", "splat_time_kernel", "splat_debug_option",
     "splat_iter_loss_backward", "splat_iter_adam_map", "splat_iter_adam_pose", "splat_iter_time_kernel",
+    "splat_iter_render", "splat_map_scratch_words", "splat_map_row_floats", "splat_map_add_new_gaussians", "splat_map_prune",
 )
 
 _lib = None
@@ -138,6 +157,16 @@ def lib():
                                        C.c_float, C.c_float, _fp]
     L.splat_iter_time_kernel.restype = C.c_int
     L.splat_iter_time_kernel.argtypes = [C.c_int, C.c_int, cam, C.c_int32, C.POINTER(SplatIterWorkspace), _fp, C.POINTER(C.c_float)]
+    L.splat_iter_render.restype = C.c_int
+    L.splat_iter_render.argtypes = [cam, C.POINTER(SplatMap), C.POINTER(SplatFrameData), C.POINTER(SplatIterWorkspace), _fp]
+    L.splat_map_scratch_words.restype = C.c_size_t
+    L.splat_map_scratch_words.argtypes = [C.c_int64]
+    L.splat_map_row_floats.restype = C.c_int32
+    L.splat_map_row_floats.argtypes = [C.POINTER(SplatMapStore)]
+    L.splat_map_add_new_gaussians.restype = C.c_int
+    L.splat_map_add_new_gaussians.argtypes = [C.POINTER(SplatMapStore), C.POINTER(SplatAddArgs), _fp]
+    L.splat_map_prune.restype = C.c_int
+    L.splat_map_prune.argtypes = [C.POINTER(SplatMapStore), C.POINTER(SplatPruneArgs), _fp]
     L.splat_debug_option.restype = C.c_int
     L.splat_debug_option.argtypes = [C.c_int, C.c_int]
     if hasattr(L, "splat_selftest"):

@@ -194,6 +194,63 @@ int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P,
     return check(err);
 }
 
+static bool valid_iter_common(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame, const SplatIterWorkspace *ws) {
+    if (!cam || !map || !frame || !ws) return false;
+    if (map->P < 0 || cam->image_width <= 0 || cam->image_height <= 0 || !cam->viewmatrix || !cam->projmatrix) return false;
+    if (map->num_frames <= 0 || frame->time_idx < 0 || frame->time_idx >= map->num_frames) return false;
+    if (!map->cam_unnorm_rots || !map->cam_trans || !frame->w2c) return false;
+    if (map->P > 0 && (!map->means3D || !map->rgb_colors || !map->unnorm_rotations || !map->logit_opacities || !map->log_scales))
+        return false;
+    const SplatState &st = ws->st;
+    if (!st.tile_count || !st.tile_base || !st.tile_cursor || !st.status || !st.final_T || !st.n_contrib) return false;
+    if (map->P > 0 && (!st.depth || !st.xy || !st.conic_opacity || !st.rect || !st.radii || !ws->feat8)) return false;
+    if (st.capacity <= 0 || !st.keys || !st.point_list || st.tile_stride < 0) return false;
+    if (st.tile_stride > 0 && (long long)st.tile_stride * (long long)splat_num_tiles(cam->image_width, cam->image_height) > st.capacity)
+        return false;
+    return ws->out6 != nullptr;
+}
+
+int splat_iter_render(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame, SplatIterWorkspace *ws, void *stream) {
+    if (!valid_iter_common(cam, map, frame, ws)) return SPLAT_E_INVALID;
+    return check(launch_iter_render(*cam, *map, *frame, *ws, (hipStream_t)stream));
+}
+
+size_t splat_map_scratch_words(int64_t n) { return map_scratch_words(n < 0 ? 0 : n); }
+
+static bool valid_store(const SplatMapStore *st) {
+    if (!st || !st->counts || st->capacity < 0 || st->map.P < 0 || st->map.P > st->capacity) return false;
+    const SplatMap &m = st->map;
+    if (st->capacity > 0 && (!m.means3D || !m.rgb_colors || !m.unnorm_rotations || !m.logit_opacities || !m.log_scales)) return false;
+    for (int k = 0; k < 5; ++k)
+        if ((st->exp_avg[k] == nullptr) != (st->exp_avg_sq[k] == nullptr)) return false;
+    return true;
+}
+
+int32_t splat_map_row_floats(const SplatMapStore *store) {
+    if (!store) return 0;
+    return map_row_floats(*store);
+}
+
+int splat_map_add_new_gaussians(SplatMapStore *store, const SplatAddArgs *a, void *stream) {
+    if (!valid_store(store) || !a) return SPLAT_E_INVALID;
+    if (a->width < 0 || a->height < 0 || (long long)a->width * a->height > 0x7fffffffLL) return SPLAT_E_INVALID;
+    if (a->mode != SPLAT_ADD_VALID_DEPTH && a->mode != SPLAT_ADD_NON_PRESENCE) return SPLAT_E_INVALID;
+    if (!a->scratch || !a->im || !a->depth || a->fx == 0.f || a->fy == 0.f) return SPLAT_E_INVALID;
+    if (a->mode == SPLAT_ADD_NON_PRESENCE) {
+        if (!a->out6 || !a->err || !store->map.cam_unnorm_rots || !store->map.cam_trans) return SPLAT_E_INVALID;
+        if (a->time_idx < 0 || a->time_idx >= store->map.num_frames) return SPLAT_E_INVALID;
+    } else if (!a->w2c) {
+        return SPLAT_E_INVALID;
+    }
+    return check(launch_map_add(*store, *a, (hipStream_t)stream));
+}
+
+int splat_map_prune(SplatMapStore *store, const SplatPruneArgs *a, void *stream) {
+    if (!valid_store(store) || !a || !a->scratch) return SPLAT_E_INVALID;
+    if (store->map.P > 0 && (!a->flags || !a->stage)) return SPLAT_E_INVALID;
+    return check(launch_map_prune(*store, *a, (hipStream_t)stream));
+}
+
 int splat_debug_option(int key, int value) {
     if (key == 0) { const int old = g_debug_skip_count; g_debug_skip_count = value; return old; }
     if (key == 1) { const int old = g_debug_composite_version; g_debug_composite_version = value; return old; }

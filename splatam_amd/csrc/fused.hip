@@ -591,6 +591,34 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
     return hipGetLastError();
 }
 
+// Forward half only (F1, lists, K6): the render of add_new_gaussians / evaluation.  Leaves every per-iteration
+// scratch word the way a full iteration leaves it (tile counters zero, nothing accumulated).
+hipError_t launch_fold_tile_counters(SplatState &st, int T, hipStream_t s);
+
+hipError_t launch_iter_render(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame, SplatIterWorkspace &ws,
+                              hipStream_t s) {
+    FusedArgs a{cam, map, frame, SplatLossConfig{}, ws, {}};
+    a.ws.max_2D_radius = nullptr;           // only get_loss updates variables['max_2D_radius'] (/root/reference/scripts/splatam.py:342)
+    const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
+    const int P = map.P;
+    hipError_t e = hipSuccess;
+    if (P > 0) hipLaunchKernelGGL(fused_preprocess_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    if (ws.st.tile_stride == 0) {
+        e = launch_tile_scan(ws.st, T, s);
+        if (e != hipSuccess) return e;
+    }
+    SplatGaussians g{};
+    g.P = P;
+    g.channels = 6;
+    const bool sort_in_k6 = ws.st.max_list_hint > 0 && ws.st.max_list_hint + ws.st.max_list_hint / 4 <= 1024;
+    e = launch_bin_forward(cam, g, ws.st, s, !sort_in_k6);
+    if (e != hipSuccess) return e;
+    e = launch_render_forward_feat8(cam, ws.feat8, ws.st, ws.out6, sort_in_k6, s);
+    if (e != hipSuccess) return e;
+    if (ws.st.tile_stride > 0) return launch_fold_tile_counters(ws.st, T, s);
+    return hipGetLastError();
+}
+
 hipError_t launch_iter_adam_map(const SplatMap &map, const SplatAdamMap &opt, hipStream_t s) {
     if (map.P <= 0) return hipSuccess;
     AdamArgs a{map, opt};

@@ -24,14 +24,20 @@ from . import _capi
 from .rasterizer import _cached_contiguous
 
 PARAM_ORDER = ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales")
+VARIABLE_KEYS = ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")
 
 
 class FusedEngine:
-    def __init__(self, params, cam, capacity=None, track_max_radius=None):
+    def __init__(self, params, cam, capacity=None, track_max_radius=None, gaussian_capacity=None, variables=None):
         """params: the reference's dict of float32 CUDA tensors / Parameters (updated in place);
-        cam: a GaussianRasterizationSettings; capacity: (Gaussian, tile) instances the lists can hold."""
+        cam: a GaussianRasterizationSettings; capacity: (Gaussian, tile) instances the lists can hold;
+        gaussian_capacity: rows the map may grow to.  When given, the five Gaussian tensors (and ``variables``' per-Gaussian
+        entries) move into capacity-sized backing arrays owned by the engine and ``params[k]`` / ``variables[k]`` become
+        views of their first P rows, re-made after every ``add_new_gaussians`` / ``prune_gaussians`` -- the reference
+        replaces the dict entries at the same places (/root/reference/scripts/splatam.py:410-411)."""
         self.L = _capi.lib()
         self.params = params
+        self.variables = variables
         self.cam_settings = cam
         dev = params['means3D'].device
         if dev.type != "cuda":
@@ -44,6 +50,14 @@ class FusedEngine:
         P = params['means3D'].shape[0]
         self.P = P
         self.iso = params['log_scales'].shape[1] == 1
+        self.managed = gaussian_capacity is not None
+        self.Pcap = max(int(gaussian_capacity), P) if self.managed else P
+        self.store = None
+        if self.managed:
+            self._adopt(params, variables)
+        elif variables is not None and track_max_radius is None:
+            track_max_radius = variables.get('max_2D_radius')
+        P_alloc = self.Pcap
         self.num_frames = params['cam_unnorm_rots'].shape[-1]
         H, W = int(cam.image_height), int(cam.image_width)
         self.H, self.W = H, W
@@ -53,35 +67,33 @@ class FusedEngine:
         self.capacity = int(capacity) if capacity else 4 * P + 65536
         z = dict(device=dev)
         b = self.buf = {}
-        b['conic'] = torch.empty(P, 4, dtype=f32, **z)
-        b['xy'] = torch.empty(P, 2, dtype=f32, **z)
-        b['rect'] = torch.empty(P, 2, dtype=i32, **z)
-        b['depth'] = torch.empty(P, dtype=f32, **z)
-        b['radii'] = torch.zeros(P, dtype=i32, **z)
+        b['conic'] = torch.empty(P_alloc, 4, dtype=f32, **z)
+        b['xy'] = torch.empty(P_alloc, 2, dtype=f32, **z)
+        b['rect'] = torch.empty(P_alloc, 2, dtype=i32, **z)
+        b['depth'] = torch.empty(P_alloc, dtype=f32, **z)
+        b['radii'] = torch.zeros(P_alloc, dtype=i32, **z)
         b['tile_count'] = torch.zeros(T * CS, dtype=i32, **z)
         b['tile_base'] = torch.empty(T + 1, dtype=i32, **z)
         b['tile_cursor'] = torch.empty(T * CS, dtype=i32, **z)
         b['status'] = torch.zeros(4, dtype=i32, **z)
         b['final_T'] = torch.empty(H, W, dtype=f32, **z)
         b['n_contrib'] = torch.empty(H, W, dtype=i32, **z)
-        b['feat8'] = torch.empty(P, 8, dtype=f32, **z)
+        b['feat8'] = torch.empty(P_alloc, 8, dtype=f32, **z)
         b['out6'] = torch.empty(6, H, W, dtype=f32, **z)
         b['dL_dout6'] = torch.zeros(6, H, W, dtype=f32, **z)
-        b['accum'] = torch.zeros(P, _capi.SPLAT_GRAD_STRIDE, dtype=f32, **z)
+        b['accum'] = torch.zeros(P_alloc, _capi.SPLAT_GRAD_STRIDE, dtype=f32, **z)
         b['ssim_maps'] = torch.empty(9, H, W, dtype=f32, **z)
         b['sums'] = torch.zeros(_capi.SPLAT_ITER_SUM_COPIES * _capi.SPLAT_ITER_SUMS, dtype=torch.float64, **z)
         b['d_cam'] = torch.zeros(16, dtype=f32, **z)
         b['pose_state'] = torch.zeros(_capi.SPLAT_POSE_STATE, dtype=f32, **z)
-        self.max_2D_radius = track_max_radius
+        self.max_2D_radius = self.store['max_2D_radius'] if self.managed else track_max_radius
+        b['counts'] = torch.zeros(8, dtype=i32, **z)
         # map gradients: ONE flat buffer (the all-reduce bucket of the view-sharded mapping step), viewed per parameter
-        sizes = [params[k].numel() for k in PARAM_ORDER]
-        self.grad_flat = torch.zeros(sum(sizes), dtype=f32, **z)
-        self.grads, o = {}, 0
-        for k, n in zip(PARAM_ORDER, sizes):
-            self.grads[k] = self.grad_flat[o:o + n].view_as(params[k])
-            o += n
-        self.exp_avg = {k: torch.zeros_like(params[k].detach()) for k in PARAM_ORDER}
-        self.exp_avg_sq = {k: torch.zeros_like(params[k].detach()) for k in PARAM_ORDER}
+        self._widths = [3, 3, 4, 1, 1 if self.iso else 3]
+        self._grad_store = torch.zeros(sum(self._widths) * P_alloc, dtype=f32, **z)
+        self._m_store = {k: torch.zeros(P_alloc, w, dtype=f32, **z) for k, w in zip(PARAM_ORDER, self._widths)}
+        self._v_store = {k: torch.zeros(P_alloc, w, dtype=f32, **z) for k, w in zip(PARAM_ORDER, self._widths)}
+        self._layout_rows()
         self.map_step = 0
         self.pose_step = 0
         self.track_time_idx = None
@@ -92,6 +104,230 @@ class FusedEngine:
         self._alloc_lists(self.capacity)
         self._cam = self._make_cam(cam)
         self._frame_keep = None
+
+    # ------------------------------------------------------------------ capacity-managed map
+    def _adopt(self, params, variables):
+        """Move the caller's Gaussian tensors into backing arrays of ``self.Pcap`` rows."""
+        dev, P = self.dev, self.P
+        self.store = {}
+        for k in PARAM_ORDER:
+            src = params[k].detach()
+            back = torch.zeros((self.Pcap,) + tuple(src.shape[1:]), dtype=torch.float32, device=dev)
+            back[:P] = src
+            self.store[k] = back
+        for k in VARIABLE_KEYS:
+            back = torch.zeros(self.Pcap, dtype=torch.float32, device=dev)
+            if variables is not None and k in variables:
+                back[:P] = variables[k]
+            self.store[k] = back
+        self._publish()
+
+    def _publish(self):
+        """params[k] / variables[k] = views of the first P rows of the backing arrays."""
+        P = self.P
+        for k in PARAM_ORDER:
+            self.params[k] = torch.nn.Parameter(self.store[k][:P], requires_grad=True)
+        if self.variables is not None:
+            for k in VARIABLE_KEYS:
+                self.variables[k] = self.store[k][:P]
+        self.max_2D_radius = self.store['max_2D_radius']
+
+    def _layout_rows(self):
+        """Views that depend on the number of rows: the flat gradient bucket and the moment views."""
+        P = self.P
+        self.grad_flat = self._grad_store[:sum(self._widths) * P]
+        self.grads, o = {}, 0
+        for k, w in zip(PARAM_ORDER, self._widths):
+            self.grads[k] = self.grad_flat[o:o + w * P].view(P, w)
+            o += w * P
+        self.exp_avg = {k: self._m_store[k][:P] for k in PARAM_ORDER}
+        self.exp_avg_sq = {k: self._v_store[k][:P] for k in PARAM_ORDER}
+
+    def _grow_rows(self, new_cap):
+        """Re-allocate every per-Gaussian array for ``new_cap`` rows (contents of the first P rows kept)."""
+        if not self.managed:
+            raise RuntimeError("this FusedEngine was built without gaussian_capacity: the map cannot grow")
+        dev, P, b = self.dev, self.P, self.buf
+        f32, i32 = torch.float32, torch.int32
+
+        def grown(t, rows):
+            n = torch.zeros((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+            n[:P] = t[:P]
+            return n
+        self.Pcap = int(new_cap)
+        for k in list(self.store):
+            self.store[k] = grown(self.store[k], self.Pcap)
+        for k in PARAM_ORDER:
+            self._m_store[k] = grown(self._m_store[k], self.Pcap)
+            self._v_store[k] = grown(self._v_store[k], self.Pcap)
+        self._grad_store = torch.zeros(sum(self._widths) * self.Pcap, dtype=f32, device=dev)
+        for k, shape, dt in (('conic', (4,), f32), ('xy', (2,), f32), ('rect', (2,), i32), ('depth', (), f32), ('radii', (), i32),
+                             ('feat8', (8,), f32), ('accum', (_capi.SPLAT_GRAD_STRIDE,), f32)):
+            b[k] = torch.zeros((self.Pcap,) + shape, dtype=dt, device=dev)
+        b.pop('flags', None)
+        b.pop('stage', None)
+        b.pop('map_scratch', None)
+        self._publish()
+        self._layout_rows()
+
+    def _store_struct(self, with_moments):
+        st = _capi.SplatMapStore()
+        st.map = self._map_struct()
+        st.capacity = self.Pcap
+        for i, k in enumerate(PARAM_ORDER):
+            st.exp_avg[i] = self._m_store[k].data_ptr() if with_moments else None
+            st.exp_avg_sq[i] = self._v_store[k].data_ptr() if with_moments else None
+        if self.managed:
+            st.max_2D_radius = self.store['max_2D_radius'].data_ptr()
+            st.means2D_gradient_accum = self.store['means2D_gradient_accum'].data_ptr()
+            st.denom = self.store['denom'].data_ptr()
+            st.timestep = self.store['timestep'].data_ptr()
+        st.counts = self.buf['counts'].data_ptr()
+        return st
+
+    def _map_scratch(self, n):
+        words = int(self.L.splat_map_scratch_words(int(n)))
+        sc = self.buf.get('map_scratch')
+        if sc is None or sc.numel() < words:
+            sc = self.buf['map_scratch'] = torch.zeros(words, dtype=torch.int32, device=self.dev)
+        return sc
+
+    def _set_rows(self, P):
+        self.P = int(P)
+        self._publish()
+        self._layout_rows()
+        # the per-tile list statistics were learnt for the old map: back to exact lists until check_overflow() re-learns
+        self.tile_stride = 0
+        self.max_list_hint = 0
+
+    def render(self, curr_data, time_idx):
+        """Forward-only 6-channel render of the map from pose ``time_idx`` (no loss, no gradients): returns
+        ``rendered()``.  The render of add_new_gaussians (/root/reference/scripts/splatam.py:381-385)."""
+        fr = _capi.SplatFrameData()
+        w2c = curr_data['w2c'] if curr_data['w2c'].is_contiguous() else curr_data['w2c'].contiguous()
+        fr.im, fr.depth, fr.w2c, fr.time_idx = None, None, w2c.data_ptr(), int(time_idx)
+        self._frame_keep = (w2c,)
+        ws = self._workspace(False, with_ssim=False)
+        ws.max_2D_radius = None
+        m = self._map_struct()
+        with torch.cuda.device(self.dev):
+            _capi.check(self.L.splat_iter_render(C.byref(self._cam), C.byref(m), C.byref(fr), C.byref(ws), self._stream()),
+                        "splat_iter_render")
+        return self.rendered()
+
+    def relearn_lists(self, curr_data, time_idx):
+        """One probe render with exact lists + ``check_overflow()``: sizes the list capacity and the per-tile buckets
+        for the map as it is now (call after the map was edited; one D2H read)."""
+        self.tile_stride = 0
+        self.max_list_hint = 0
+        for _ in range(3):
+            self.render(curr_data, time_idx)
+            if not self.check_overflow():
+                return
+        raise RuntimeError("per-tile lists could not be sized")
+
+    def _append(self, mode, curr_data, time_idx, sil_thres, w2c=None):
+        if not self.managed:
+            raise RuntimeError("this FusedEngine was built without gaussian_capacity: the map cannot grow")
+        H, W = self.H, self.W
+        im, depth = curr_data['im'].contiguous(), curr_data['depth'].contiguous()
+        if tuple(im.shape) != (3, H, W) or tuple(depth.shape) != (1, H, W):
+            raise RuntimeError("frame size differs from the engine's camera")
+        k = curr_data['intrinsics']
+        fx, fy, cx, cy = float(k[0][0]), float(k[1][1]), float(k[0][2]), float(k[1][2])
+        a = _capi.SplatAddArgs()
+        a.mode, a.width, a.height = mode, W, H
+        a.im, a.depth = im.data_ptr(), depth.data_ptr()
+        a.out6 = self.buf['out6'].data_ptr() if mode == _capi.SPLAT_ADD_NON_PRESENCE else None
+        a.fx, a.fy, a.cx, a.cy, a.sil_thres, a.time_idx = fx, fy, cx, cy, float(sil_thres), int(time_idx)
+        keep = (im, depth)
+        if w2c is not None:
+            w2c = w2c.to(device=self.dev, dtype=torch.float32).contiguous()
+            a.w2c = w2c.data_ptr()
+            keep += (w2c,)
+        a.err = self.buf['ssim_maps'].data_ptr()
+        a.scratch = self._map_scratch(max(H * W, self.Pcap)).data_ptr()
+        while True:
+            st = self._store_struct(with_moments=True)
+            with torch.cuda.device(self.dev):
+                _capi.check(self.L.splat_map_add_new_gaussians(C.byref(st), C.byref(a), self._stream()), "splat_map_add_new_gaussians")
+            counts = self.buf['counts'].tolist()            # the one host sync of the edit
+            if not counts[2]:
+                break
+            self._grow_rows(int((self.P + counts[1]) * 1.5) + 1024)
+            a.scratch = self._map_scratch(max(H * W, self.Pcap)).data_ptr()
+        added = counts[0] - self.P
+        if added or counts[3]:
+            self._set_rows(counts[0])
+        return added
+
+    def add_new_gaussians(self, curr_data, sil_thres, time_idx, mean_sq_dist_method="projective", gaussian_distribution=None,
+                          depth_sil=None):
+        """/root/reference/scripts/splatam.py:378-420 on the device, in place: render at the tracked pose, select the
+        pixels the map does not explain, append one Gaussian per selected pixel (pixel order).  Returns the number added.
+        ``depth_sil`` ([>=2,H,W]: depth, silhouette) replaces the render (tests)."""
+        if mean_sq_dist_method != "projective":
+            raise ValueError(f"Unknown mean_sq_dist_method {mean_sq_dist_method}")
+        if gaussian_distribution is not None and (gaussian_distribution == "isotropic") != self.iso:
+            raise ValueError("gaussian_distribution differs from the map's log_scales layout")
+        if depth_sil is None:
+            self.render(curr_data, time_idx)
+        else:
+            self.buf['out6'][3] = depth_sil[0]
+            self.buf['out6'][4] = depth_sil[1]
+        return self._append(_capi.SPLAT_ADD_NON_PRESENCE, curr_data, time_idx, sil_thres)
+
+    def add_valid_depth_points(self, color, depth, intrinsics, w2c, time_idx=0):
+        """get_pointcloud(mask = depth > 0) + initialize_params' Gaussian rows (/root/reference/scripts/splatam.py:197-206):
+        one Gaussian per valid-depth pixel of the frame, appended to the map."""
+        return self._append(_capi.SPLAT_ADD_VALID_DEPTH, {'im': color, 'depth': depth, 'intrinsics': intrinsics}, time_idx, 0.0, w2c=w2c)
+
+    def remove_points(self, to_remove=None, removal_opacity_threshold=0.0, big_scale=None):
+        """remove_points (/root/reference/utils/slam_external.py:139-162): stable in-place compaction of parameters,
+        Adam moments and per-Gaussian variables.  ``to_remove``: bool[P], or None to form the flags on the device from
+        prune_gaussians' two rules.  Returns the number removed."""
+        if self.P == 0:
+            return 0
+        a = _capi.SplatPruneArgs()
+        a.removal_opacity_threshold = float(removal_opacity_threshold)
+        a.remove_big, a.big_scale = int(big_scale is not None), float(big_scale or 0.0)
+        keep = None
+        if to_remove is not None:
+            keep = to_remove.to(device=self.dev, dtype=torch.uint8).contiguous()
+            a.to_remove = keep.data_ptr()
+        b = self.buf
+        if 'flags' not in b:
+            b['flags'] = torch.empty(self.Pcap, dtype=torch.uint8, device=self.dev)
+        st = self._store_struct(with_moments=True)
+        need = self.Pcap * int(self.L.splat_map_row_floats(C.byref(st)))
+        if 'stage' not in b or b['stage'].numel() < need:
+            b['stage'] = torch.empty(need, dtype=torch.float32, device=self.dev)
+        a.flags, a.stage = b['flags'].data_ptr(), b['stage'].data_ptr()
+        a.scratch = self._map_scratch(max(self.H * self.W, self.Pcap)).data_ptr()
+        with torch.cuda.device(self.dev):
+            _capi.check(self.L.splat_map_prune(C.byref(st), C.byref(a), self._stream()), "splat_map_prune")
+        counts = b['counts'].tolist()
+        if counts[1]:
+            if not self.managed:
+                raise RuntimeError("this FusedEngine was built without gaussian_capacity: rows cannot be removed")
+            self._set_rows(counts[0])
+        return counts[1]
+
+    def prune_gaussians(self, iter, prune_dict, scene_radius):
+        """prune_gaussians (/root/reference/utils/slam_external.py:169-196) on the schedule of ``prune_dict``."""
+        removed = 0
+        if iter <= prune_dict['stop_after']:
+            if iter >= prune_dict['start_after'] and iter % prune_dict['prune_every'] == 0:
+                thr = prune_dict['final_removal_opacity_threshold'] if iter == prune_dict['stop_after'] \
+                    else prune_dict['removal_opacity_threshold']
+                big = 0.1 * float(scene_radius) if iter >= prune_dict['remove_big_after'] else None
+                removed = self.remove_points(None, thr, big)
+            if iter > 0 and iter % prune_dict['reset_opacities_every'] == 0 and prune_dict['reset_opacities']:
+                with torch.no_grad():
+                    self.params['logit_opacities'].fill_(math.log(0.01 / (1 - 0.01)))
+                    self.exp_avg['logit_opacities'].zero_()
+                    self.exp_avg_sq['logit_opacities'].zero_()
+        return removed
 
     # ------------------------------------------------------------------ plumbing
     def _alloc_lists(self, capacity):
@@ -118,6 +354,8 @@ class FusedEngine:
 
     def _map_struct(self):
         p = self.params
+        if self.managed:          # the backing arrays (a zero-row view has no data pointer)
+            p = dict(self.store, cam_unnorm_rots=p['cam_unnorm_rots'], cam_trans=p['cam_trans'])
         m = _capi.SplatMap()
         m.P, m.isotropic = self.P, int(self.iso)
         m.means3D, m.rgb_colors = p['means3D'].data_ptr(), p['rgb_colors'].data_ptr()

@@ -19,6 +19,11 @@ here                                           reference
 ``get_loss``                                   scripts/splatam.py:214-347
 ``initialize_optimizer``                       scripts/splatam.py:160-166
 ``tracking_iteration`` / ``mapping_iteration``  scripts/splatam.py:690-711 / 828-869 (loop bodies)
+``get_pointcloud``                             scripts/splatam.py:67-116
+``initialize_params`` / ``initialize_new_params``  scripts/splatam.py:119-157 / 350-376
+``add_new_gaussians``                          scripts/splatam.py:378-420
+``initialize_camera_pose``                     scripts/splatam.py:423-441
+``remove_points`` / ``prune_gaussians``        utils/slam_external.py:139-188
 =============================================  =============================================
 
 Differences are host-side only and do not change results: masked sums are
@@ -307,6 +312,172 @@ def mapping_iteration(params, iter_data, variables, iter_time_idx, optimizer, cf
         optimizer.step()
         optimizer.zero_grad(set_to_none=True)
     return loss, variables
+
+
+# --------------------------------------------------------------------------
+# map growth and maintenance (the torch formulation; FusedEngine does the same edits in place on the device)
+# --------------------------------------------------------------------------
+
+GAUSSIAN_KEYS = ('means3D', 'rgb_colors', 'unnorm_rotations', 'logit_opacities', 'log_scales')
+
+
+def get_pointcloud(color, depth, intrinsics, w2c, transform_pts=True, mask=None, compute_mean_sq_dist=False,
+                   mean_sq_dist_method="projective"):
+    """Back-projection of an RGB-D frame: rows [x, y, z, r, g, b] in pixel order (world frame when
+    ``transform_pts``), optionally with the projective scale estimate (z / mean focal)^2 per point."""
+    H, W = color.shape[1], color.shape[2]
+    fx, fy, cx, cy = intrinsics[0][0], intrinsics[1][1], intrinsics[0][2], intrinsics[1][2]
+    dev = depth.device
+    u = torch.arange(W, device=dev, dtype=torch.float32)
+    v = torch.arange(H, device=dev, dtype=torch.float32)
+    xx = ((u - cx) / fx).unsqueeze(0).expand(H, W).reshape(-1)
+    yy = ((v - cy) / fy).unsqueeze(1).expand(H, W).reshape(-1)
+    z = depth[0].reshape(-1)
+    pts = torch.stack((xx * z, yy * z, z), dim=-1)
+    if transform_pts:
+        c2w = torch.inverse(w2c)
+        pts = pts @ c2w[:3, :3].t() + c2w[:3, 3]
+    msd = None
+    if compute_mean_sq_dist:
+        if mean_sq_dist_method != "projective":
+            raise ValueError(f"Unknown mean_sq_dist_method {mean_sq_dist_method}")
+        msd = (z / ((fx + fy) / 2)) ** 2
+    cloud = torch.cat((pts, color.permute(1, 2, 0).reshape(-1, 3)), dim=-1)
+    if mask is not None:
+        cloud = cloud[mask]
+        if msd is not None:
+            msd = msd[mask]
+    return (cloud, msd) if compute_mean_sq_dist else cloud
+
+
+def initialize_new_params(new_pt_cld, mean3_sq_dist, gaussian_distribution):
+    """Parameter rows of freshly back-projected Gaussians: identity rotation, logit opacity 0,
+    log scale log(sqrt(mean3_sq_dist)) in one (isotropic) or three (anisotropic) columns."""
+    if gaussian_distribution not in ("isotropic", "anisotropic"):
+        raise ValueError(f"Unknown gaussian_distribution {gaussian_distribution}")
+    n, dev = new_pt_cld.shape[0], new_pt_cld.device
+    rots = torch.zeros(n, 4, device=dev)
+    rots[:, 0] = 1.0
+    ls = torch.log(torch.sqrt(mean3_sq_dist)).unsqueeze(-1)
+    raw = {'means3D': new_pt_cld[:, :3], 'rgb_colors': new_pt_cld[:, 3:6], 'unnorm_rotations': rots,
+           'logit_opacities': torch.zeros(n, 1, device=dev),
+           'log_scales': ls if gaussian_distribution == "isotropic" else ls.expand(-1, 3)}
+    return {k: torch.nn.Parameter(t.float().contiguous().requires_grad_(True)) for k, t in raw.items()}
+
+
+def initialize_params(init_pt_cld, num_frames, mean3_sq_dist, gaussian_distribution):
+    """First-frame map + an identity camera trajectory of ``num_frames`` poses + the per-Gaussian variables."""
+    params = initialize_new_params(init_pt_cld, mean3_sq_dist, gaussian_distribution)
+    dev = init_pt_cld.device
+    rots = torch.zeros(1, 4, num_frames, device=dev)
+    rots[:, 0, :] = 1.0
+    params['cam_unnorm_rots'] = torch.nn.Parameter(rots.requires_grad_(True))
+    params['cam_trans'] = torch.nn.Parameter(torch.zeros(1, 3, num_frames, device=dev).requires_grad_(True))
+    n = params['means3D'].shape[0]
+    variables = {k: torch.zeros(n, device=dev) for k in ('max_2D_radius', 'means2D_gradient_accum', 'denom', 'timestep')}
+    return params, variables
+
+
+def add_new_gaussians(params, variables, curr_data, sil_thres, time_idx, mean_sq_dist_method, gaussian_distribution):
+    """Densification of frame ``time_idx``: pixels the map does not explain yet (low silhouette, or rendered
+    depth behind the measurement by more than 50x the median depth error) become new Gaussians."""
+    with torch.no_grad():
+        tg = transform_to_frame(params, time_idx, gaussians_grad=False, camera_grad=False)
+        dv = transformed_params2depthplussilhouette(params, curr_data['w2c'], tg)
+        depth_sil, _, _ = Renderer(raster_settings=curr_data['cam'])(**{k: v.detach() for k, v in dv.items()})
+    return _add_from_render(params, variables, curr_data, depth_sil, sil_thres, time_idx, mean_sq_dist_method, gaussian_distribution)
+
+
+def _add_from_render(params, variables, curr_data, depth_sil, sil_thres, time_idx, mean_sq_dist_method, gaussian_distribution):
+    silhouette, render_depth = depth_sil[1], depth_sil[0]
+    gt_depth = curr_data['depth'][0]
+    depth_error = torch.abs(gt_depth - render_depth) * (gt_depth > 0)
+    behind = (render_depth > gt_depth) & (depth_error > 50 * depth_error.median())
+    non_presence = ((silhouette < sil_thres) | behind).reshape(-1)
+    if int(non_presence.sum()) > 0:
+        q = F.normalize(params['cam_unnorm_rots'][..., time_idx].detach())
+        w2c = torch.eye(4, device=q.device)
+        w2c[:3, :3] = build_rotation(q)[0]
+        w2c[:3, 3] = params['cam_trans'][0, :, time_idx].detach()
+        pick = non_presence & (gt_depth > 0).reshape(-1)
+        cloud, msd = get_pointcloud(curr_data['im'], curr_data['depth'], curr_data['intrinsics'], w2c, mask=pick,
+                                    compute_mean_sq_dist=True, mean_sq_dist_method=mean_sq_dist_method)
+        new = initialize_new_params(cloud, msd, gaussian_distribution)
+        for k, v in new.items():
+            params[k] = torch.nn.Parameter(torch.cat((params[k].detach(), v.detach()), dim=0).requires_grad_(True))
+        n = params['means3D'].shape[0]
+        dev = params['means3D'].device
+        for k in ('means2D_gradient_accum', 'denom', 'max_2D_radius'):
+            variables[k] = torch.zeros(n, device=dev)
+        variables['timestep'] = torch.cat((variables['timestep'], torch.full((cloud.shape[0],), float(time_idx), device=dev)))
+    return params, variables
+
+
+def initialize_camera_pose(params, curr_time_idx, forward_prop):
+    """Pose of the new frame before tracking: constant-velocity extrapolation of the last two poses, or a copy of
+    the previous one."""
+    with torch.no_grad():
+        q, t = params['cam_unnorm_rots'], params['cam_trans']
+        if curr_time_idx > 1 and forward_prop:
+            q1 = F.normalize(q[..., curr_time_idx - 1].detach())
+            q2 = F.normalize(q[..., curr_time_idx - 2].detach())
+            q[..., curr_time_idx] = F.normalize(q1 + (q1 - q2))
+            t1, t2 = t[..., curr_time_idx - 1].detach(), t[..., curr_time_idx - 2].detach()
+            t[..., curr_time_idx] = t1 + (t1 - t2)
+        else:
+            q[..., curr_time_idx] = q[..., curr_time_idx - 1].detach()
+            t[..., curr_time_idx] = t[..., curr_time_idx - 1].detach()
+    return params
+
+
+def remove_points(to_remove, params, variables, optimizer):
+    """Drop the flagged Gaussians from the parameters, the optimizer's moments and the per-Gaussian variables."""
+    keep = ~to_remove
+    for k in GAUSSIAN_KEYS:
+        group = next(g for g in optimizer.param_groups if g['name'] == k)
+        old = group['params'][0]
+        state = optimizer.state.pop(old, None)
+        new = torch.nn.Parameter(old.detach()[keep].requires_grad_(True))
+        if state:
+            state['exp_avg'] = state['exp_avg'][keep]
+            state['exp_avg_sq'] = state['exp_avg_sq'][keep]
+            optimizer.state[new] = state
+        group['params'][0] = new
+        params[k] = new
+    for k in ('means2D_gradient_accum', 'denom', 'max_2D_radius', 'timestep'):
+        if k in variables:
+            variables[k] = variables[k][keep]
+    return params, variables
+
+
+def prune_gaussians(params, variables, optimizer, iter, prune_dict):
+    """Opacity / size pruning on the schedule of ``prune_dict`` (+ the optional opacity reset)."""
+    if iter <= prune_dict['stop_after']:
+        if iter >= prune_dict['start_after'] and iter % prune_dict['prune_every'] == 0:
+            thr = prune_dict['final_removal_opacity_threshold'] if iter == prune_dict['stop_after'] \
+                else prune_dict['removal_opacity_threshold']
+            to_remove = (torch.sigmoid(params['logit_opacities']) < thr).squeeze(-1)
+            if iter >= prune_dict['remove_big_after']:
+                to_remove = to_remove | (torch.exp(params['log_scales']).max(dim=1).values > 0.1 * variables['scene_radius'])
+            params, variables = remove_points(to_remove, params, variables, optimizer)
+        if iter > 0 and iter % prune_dict['reset_opacities_every'] == 0 and prune_dict['reset_opacities']:
+            group = next(g for g in optimizer.param_groups if g['name'] == 'logit_opacities')
+            old = group['params'][0]
+            state = optimizer.state.pop(old, None)
+            v = torch.full_like(old.detach(), math.log(0.01 / (1 - 0.01)))
+            new = torch.nn.Parameter(v.requires_grad_(True))
+            if state is not None:
+                state['exp_avg'] = torch.zeros_like(v)
+                state['exp_avg_sq'] = torch.zeros_like(v)
+                optimizer.state[new] = state
+            group['params'][0] = new
+            params['logit_opacities'] = new
+    return params, variables
+
+
+REPLICA_PRUNE = dict(start_after=0, remove_big_after=0, stop_after=20, prune_every=20, removal_opacity_threshold=0.005,
+                     final_removal_opacity_threshold=0.005, reset_opacities=False, reset_opacities_every=500)
+"""/root/reference/configs/replica/splatam.py:102-111."""
 
 
 # --------------------------------------------------------------------------

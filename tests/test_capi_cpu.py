@@ -33,10 +33,17 @@ def test_library_exports_every_declared_symbol():
 def _struct_fields(name):
     m = re.search(r"typedef struct " + name + r" \{(.*?)\} " + name + ";", HEADER, flags=re.S)
     body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
-    return [re.findall(r"[A-Za-z_0-9]+", s)[-1] for s in body.split(";") if s.strip()]
+    names = []
+    for decl in body.split(";"):
+        decl = re.sub(r"\[[^\]]*\]", "", decl)                  # array extents
+        if decl.strip():
+            names += [re.findall(r"[A-Za-z_0-9]+", part)[-1] for part in decl.split(",")]
+    return names
 
 
-@pytest.mark.parametrize("name", ["SplatCamera", "SplatGaussians", "SplatState", "SplatGrads"])
+@pytest.mark.parametrize("name", ["SplatCamera", "SplatGaussians", "SplatState", "SplatGrads", "SplatMap", "SplatFrameData",
+                                  "SplatLossConfig", "SplatIterWorkspace", "SplatAdamMap", "SplatMapStore", "SplatAddArgs",
+                                  "SplatPruneArgs"])
 def test_ctypes_structs_mirror_header(name):
     from splatam_amd import _capi
     assert [f[0] for f in getattr(_capi, name)._fields_] == _struct_fields(name)

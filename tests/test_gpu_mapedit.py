@@ -1,0 +1,171 @@
+"""Map growth / maintenance on the device (FusedEngine.add_new_gaussians / add_valid_depth_points / prune_gaussians /
+remove_points over the C ABI's splat_map_* entry points) against
+
+ * the golden vectors produced by the REFERENCE's own code (tests/golden/make_golden_mapedit.py): same inputs,
+   the stored depth/silhouette image in place of the render;
+ * the torch formulation (splatam_amd/slam.py, itself pinned to the same vectors) on a real render, full size.
+
+Row ORDER and counts are exact; float values to 2e-6 (the reference back-projects with torch.inverse + a GEMM, the
+kernel with R^T (p - t) in registers)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_mapedit_mirror import GOLD, PARAM_KEYS, VAR_KEYS, check_add_outputs, load_add_case, load_prune_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _dummy_cam(W, H, f=50.0):
+    from splatam_amd import slam
+    k = [[f, 0, W / 2 - 0.5], [0, f, H / 2 - 0.5], [0, 0, 1]]
+    return slam.setup_camera(W, H, k, np.eye(4, dtype=np.float32), device="cuda")
+
+
+@pytest.mark.parametrize("name", ["add_iso", "add_aniso", "add_nan", "add_nothing"])
+@pytest.mark.parametrize("room", ["exact", "grow"])
+def test_add_new_gaussians_matches_reference_vectors(name, room):
+    from splatam_amd.fused import FusedEngine
+    params, variables, curr, depth_sil, time_idx, sil_thres, dist = load_add_case(name, device="cuda")
+    params = {k: torch.nn.Parameter(v.detach().contiguous()) for k, v in params.items()}
+    W, H = int(GOLD[f"{name}/in/meta"][0]), int(GOLD[f"{name}/in/meta"][1])
+    n0 = params['means3D'].shape[0]
+    n1 = GOLD[f"{name}/out/param/means3D"].shape[0]
+    cap = n1 + 7 if room == "exact" else n0 + 3          # "grow": the first attempt cannot fit, the engine re-allocates
+    eng = FusedEngine(params, _dummy_cam(W, H), gaussian_capacity=cap, variables=variables)
+    added = eng.add_new_gaussians(curr, sil_thres, time_idx, "projective", dist, depth_sil=depth_sil)
+    torch.cuda.synchronize()
+    assert added == n1 - n0 and eng.P == n1
+    if n1 > n0:
+        assert eng.Pcap >= n1
+    med = np.frombuffer(np.int32(eng.buf['counts'][4].item()).tobytes(), dtype=np.float32)[0]
+    ref_med = np.float32(GOLD[f"{name}/median"])
+    assert (np.isnan(med) and np.isnan(ref_med)) or med == ref_med, (med, ref_med)      # torch.median, bit for bit
+    check_add_outputs(name, params, variables)
+    for k in eng.exp_avg:                                   # moments of appended rows start from zero
+        assert float(eng.exp_avg[k][n0:].abs().sum()) == 0.0 and float(eng.exp_avg_sq[k][n0:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("name", ["init_iso", "init_aniso"])
+def test_first_frame_points_match_reference_vectors(name):
+    from splatam_amd.fused import FusedEngine
+    im, depth = torch.tensor(GOLD[f"{name}/in/im"]).cuda(), torch.tensor(GOLD[f"{name}/in/depth"]).cuda()
+    k, w2c = torch.tensor(GOLD[f"{name}/in/intrinsics"]), torch.tensor(GOLD[f"{name}/in/w2c"])
+    H, W = im.shape[1], im.shape[2]
+    cols = GOLD[f"{name}/out/param/log_scales"].shape[1]
+    z = lambda *s: torch.nn.Parameter(torch.zeros(*s, device="cuda"))      # noqa: E731
+    params = {'means3D': z(0, 3), 'rgb_colors': z(0, 3), 'unnorm_rotations': z(0, 4), 'logit_opacities': z(0, 1),
+              'log_scales': z(0, cols), 'cam_unnorm_rots': torch.nn.Parameter(torch.tensor(GOLD[f"{name}/out/param/cam_unnorm_rots"]).cuda()),
+              'cam_trans': z(1, 3, 5)}
+    variables = {kk: torch.zeros(0, device="cuda") for kk in VAR_KEYS}
+    eng = FusedEngine(params, _dummy_cam(W, H), gaussian_capacity=H * W, variables=variables)
+    n = eng.add_valid_depth_points(im, depth, k, w2c)
+    torch.cuda.synchronize()
+    assert n == GOLD[f"{name}/out/param/means3D"].shape[0] == eng.P
+    for kk in PARAM_KEYS:
+        np.testing.assert_allclose(params[kk].detach().cpu().numpy(), GOLD[f"{name}/out/param/{kk}"], rtol=2e-6, atol=2e-6, err_msg=kk)
+    for kk in VAR_KEYS:
+        np.testing.assert_array_equal(variables[kk].cpu().numpy(), GOLD[f"{name}/out/var/{kk}"])
+
+
+@pytest.mark.parametrize("name", ["prune_iso", "prune_aniso"])
+def test_prune_gaussians_matches_reference_vectors(name):
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    params, variables, moments = load_prune_case(name, device="cuda")
+    params = {k: torch.nn.Parameter(v.detach().contiguous()) for k, v in params.items()}
+    scene_radius = variables.pop('scene_radius')
+    eng = FusedEngine(params, _dummy_cam(64, 48), gaussian_capacity=params['means3D'].shape[0] + 100, variables=variables)
+    for k, (m, v) in moments.items():
+        eng.exp_avg[k].copy_(m)
+        eng.exp_avg_sq[k].copy_(v)
+    n0 = eng.P
+    removed = eng.prune_gaussians(0, slam.REPLICA_PRUNE, scene_radius)
+    torch.cuda.synchronize()
+    n1 = GOLD[f"{name}/out/param/means3D"].shape[0]
+    assert removed == n0 - n1 and eng.P == n1
+    for k in PARAM_KEYS:                                    # rows move, values do not change: bit-exact
+        np.testing.assert_array_equal(params[k].detach().cpu().numpy(), GOLD[f"{name}/out/param/{k}"], err_msg=k)
+    for k in slam.GAUSSIAN_KEYS:
+        np.testing.assert_array_equal(eng.exp_avg[k].cpu().numpy(), GOLD[f"{name}/out/exp_avg/{k}"])
+        np.testing.assert_array_equal(eng.exp_avg_sq[k].cpu().numpy(), GOLD[f"{name}/out/exp_avg_sq/{k}"])
+    for k in VAR_KEYS:
+        np.testing.assert_array_equal(variables[k].cpu().numpy(), GOLD[f"{name}/out/var/{k}"], err_msg=k)
+    assert eng.prune_gaussians(7, slam.REPLICA_PRUNE, scene_radius) == 0          # off the schedule
+    # caller-supplied flags (remove_points as densify uses it)
+    flags = torch.zeros(eng.P, dtype=torch.bool, device="cuda")
+    flags[::3] = True
+    before = params['means3D'].detach().clone()
+    assert eng.remove_points(flags) == int(flags.sum())
+    assert torch.equal(params['means3D'].detach(), before[~flags])
+
+
+def test_render_only_pass_matches_full_iteration_and_densification_full_size():
+    """splat_iter_render == the forward half of splat_iter_loss_backward; add_new_gaussians on a REAL render at workload
+    size (1200x680, 300k) == the torch formulation on the same render; the grown map then optimises (bucketed lists are
+    re-learnt) and prunes."""
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    W, H, n = 1200, 680, 300000
+    f, cx, cy = 600.0, 599.5, 339.5
+    params, variables = slam.synthetic_params(n, W, H, f, f, cx, cy, num_frames=3, seed=0, device="cuda")
+    k = torch.tensor([[f, 0, cx], [0, f, cy], [0, 0, 1]])
+    w2c = torch.eye(4, device="cuda")
+    cam = slam.setup_camera(W, H, k.numpy(), np.eye(4, dtype=np.float32), device="cuda")
+    im, depth = slam.synthetic_frame(params, cam, w2c, 1, rot_deg=0.6, trans_m=0.02)
+    depth = depth.clone()
+    depth[:, 100:140, 200:300] *= 0.5                      # a new foreground object in front of the map
+    frame = {'cam': cam, 'im': im.contiguous(), 'depth': depth.contiguous(), 'id': 1, 'w2c': w2c, 'intrinsics': k}
+    with torch.no_grad():                                   # thin the map in one corner: low silhouette there
+        params['logit_opacities'][params['means3D'][:, 0] / params['means3D'][:, 2] > 0.8] = -6.0
+        params['cam_unnorm_rots'][0, :, 1] = torch.tensor([0.9999, 0.0, 0.004, 0.001], device="cuda") * 1.05
+        params['cam_trans'][0, :, 1] = torch.tensor([0.015, -0.008, 0.01], device="cuda")
+    ref_params = {kk: torch.nn.Parameter(v.detach().clone()) for kk, v in params.items()}
+    ref_vars = {kk: v.clone() for kk, v in variables.items()}
+    eng = FusedEngine(params, cam, gaussian_capacity=n + 200000, variables=variables)
+    cfg = slam.REPLICA_MAPPING
+    eng.loss_backward(frame, 1, cfg, tracking=False)
+    full = eng.buf['out6'].clone()
+    out = eng.render(frame, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.buf['out6'], full)
+    assert not eng.check_overflow()
+    eng.render(frame, 1)                                    # bucketed lists now
+    assert eng.tile_stride > 0 and torch.allclose(eng.buf['out6'], full, atol=1e-6)
+    assert int(eng.buf['tile_count'].abs().sum()) == 0      # counters folded and reset
+    depth_sil = torch.stack([out[1][0], out[2]]).clone()
+    added = eng.add_new_gaussians(frame, 0.5, 1, "projective", "isotropic")
+    ref_params, ref_vars = slam._add_from_render(ref_params, ref_vars, frame, depth_sil, 0.5, 1, "projective", "isotropic")
+    n1 = ref_params['means3D'].shape[0]
+    assert added == n1 - n and added > 3000
+    for kk in slam.GAUSSIAN_KEYS:
+        np.testing.assert_allclose(params[kk].detach().cpu().numpy(), ref_params[kk].detach().cpu().numpy(), rtol=3e-6, atol=3e-6,
+                                   err_msg=kk)
+    for kk in VAR_KEYS:
+        assert torch.equal(variables[kk], ref_vars[kk]), kk
+    # the grown map optimises
+    eng.relearn_lists(frame, 1)
+    assert eng.tile_stride > 0
+    eng.reset_map_optimizer()
+    l0 = None
+    for it in range(6):
+        eng.mapping_iteration(frame, 1, cfg)
+        if it == 0:
+            l0 = eng.loss()
+    assert not eng.check_overflow()
+    assert np.isfinite(eng.loss()) and eng.loss() < l0
+    with torch.no_grad():
+        rem = (torch.sigmoid(params['logit_opacities']).squeeze(-1) < 0.005) | \
+              (torch.exp(params['log_scales']).max(dim=1).values > 0.1 * 3.0)
+        kept = {kk: params[kk].detach()[~rem].clone() for kk in slam.GAUSSIAN_KEYS}
+        kept_m = eng.exp_avg['means3D'][~rem].clone()
+    removed = eng.prune_gaussians(0, slam.REPLICA_PRUNE, 3.0)
+    assert removed == int(rem.sum()) and removed > 100 and eng.P == n1 - removed
+    for kk in slam.GAUSSIAN_KEYS:
+        assert torch.equal(params[kk].detach(), kept[kk]), kk
+    assert torch.equal(eng.exp_avg['means3D'], kept_m)
+    eng.relearn_lists(frame, 1)
+    eng.mapping_iteration(frame, 1, cfg)
+    assert not eng.check_overflow() and np.isfinite(eng.loss())
