@@ -33,7 +33,18 @@ hipError_t launch_render_forward_v2(const SplatCamera &cam, const float *col, Sp
                                     float *out_depth, hipStream_t s);
 hipError_t launch_render_backward_v2(const SplatCamera &cam, const float *col, const SplatState &st, const float *dL_dcolor,
                                      float *accum, hipStream_t s);
-int g_debug_composite_version = 3;   // splat_debug_option(1, v): 2 = previous generation (3-channel calls only)
+hipError_t launch_render_forward_v4(const SplatCamera &cam, const float *col, int channels, SplatState &st, float *out_color,
+                                    float *out_depth, hipStream_t s);
+hipError_t launch_render_backward_v4(const SplatCamera &cam, const float *col, int channels, const SplatState &st,
+                                     const float *dL_dcolor, float *accum, hipStream_t s);
+hipError_t launch_render_forward_feat8_v4(const SplatCamera &cam, const float *feat8, SplatState &st, float *out6, bool sort_in_kernel,
+                                          hipStream_t s);
+hipError_t launch_render_backward_feat8_v4(const SplatCamera &cam, const float *feat8, const SplatState &st, const float *dL_dout6,
+                                           float *accum, bool rgb_sums, hipStream_t s);
+// splat_debug_option(1, v): 3 = current (this file: wave per 8x8 quadrant); 4 = experiment (render_v4.hip: one 4x4 block
+// per 16-lane row; fewer VALU instructions but twice the accumulator atomics -- slower);
+// 2 = wave per tile (render_v2.hip, 3-channel calls only).  2 and 4 are kept for A/B timing.
+int g_debug_composite_version = 3;
 
 // One staged Gaussian as the gathering thread holds it in registers.
 template <int FP>
@@ -482,6 +493,7 @@ hipError_t launch_render_forward(const SplatCamera &cam, const SplatGaussians &g
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
     const float *col = colour_source(g, st);
     if (T == 0) return hipSuccess;
+    if (g_debug_composite_version == 4) return launch_render_forward_v4(cam, col, g.channels, st, out_color, out_depth, s);
     if (g_debug_composite_version == 2 && g.channels == 3) return launch_render_forward_v2(cam, col, st, out_color, out_depth, s);
     switch (g.channels) {
         case 1: launch_fwd<1, 1, true>(cam, col, st, out_color, out_depth, T, s); break;
@@ -504,6 +516,7 @@ hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &
     hipError_t e = hipMemsetAsync(gr.accum, 0, sizeof(float) * SPLAT_GRAD_STRIDE * (size_t)g.P, s);
     if (e != hipSuccess) return e;
     if (T == 0 || g.P == 0) return hipSuccess;
+    if (g_debug_composite_version == 4) return launch_render_backward_v4(cam, col, g.channels, st, gr.dL_dcolor, gr.accum, s);
     if (g_debug_composite_version == 2 && g.channels == 3) return launch_render_backward_v2(cam, col, st, gr.dL_dcolor, gr.accum, s);
     switch (g.channels) {
         case 1: launch_bwd<1, 1>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
@@ -524,6 +537,7 @@ hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat
                                        hipStream_t s) {
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
     if (T == 0) return hipSuccess;
+    if (g_debug_composite_version == 4) return launch_render_forward_feat8_v4(cam, feat8, st, out6, sort_in_kernel, s);
     if (sort_in_kernel) launch_fwd<6, 8, false, true>(cam, feat8, st, out6, nullptr, T, s);
     else launch_fwd<6, 8, false, false>(cam, feat8, st, out6, nullptr, T, s);
     return hipGetLastError();
@@ -537,6 +551,7 @@ hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *fea
         if (e != hipSuccess) return e;
     }
     if (T == 0 || P == 0) return hipSuccess;
+    if (g_debug_composite_version == 4) return launch_render_backward_feat8_v4(cam, feat8, st, dL_dout6, accum, rgb_sums, s);
     // channels r, g, b, z carry gradient; the silhouette and depth^2 planes never do.  dL/drgb is only summed on request
     // (tracking does not read it: LR 0 in /root/reference/configs/*/splatam.py, optimizer discarded after the frame).
     if (rgb_sums) launch_bwd<6, 8, 0xFu, 0xFu>(cam, feat8, st, dL_dout6, accum, T, s);

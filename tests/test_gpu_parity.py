@@ -268,9 +268,9 @@ def test_full_size_replica_shape():
     np.testing.assert_allclose(gc2, 2.0 * gc, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("version", [3, 2])
+@pytest.mark.parametrize("version", [3, 2, 4])
 def test_composite_kernel_generations(version):
-    """Both generations of the composite kernels (current; previous, kept for A/B timing) are the same function:
+    """All generations of the composite kernels (3 = current; 2 and 4 kept for A/B timing) are the same function:
     multi-batch lists with early termination (dense scene) and the config-A shape."""
     from splatam_amd import _capi
     L = _capi.lib()
