@@ -369,22 +369,22 @@ __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, c
     if (tmax == 0) return;                                     // uniform over the workgroup
     const unsigned lo = st.tile_stride > 0 ? (unsigned)tile * (unsigned)st.tile_stride : st.tile_base[tile];
     const int nb = (int)((tmax + kBatch - 1) / kBatch);
-    // lanes 0 / 16 / 32 / 48 publish the reduced sums: row r holds value row_value(r) of each packed group.  Destination
-    // slot of packed value k: the six geometric sums, then slot 6 + channel for the k-th channel of SMASK.
-    const int rv = row_value(lane >> 4);
-    int doff[NG];
+    // Publish: after the packed reductions every lane of row r holds value row_value(r) of each group.  Lane 16 r + g takes
+    // group g's value, so that ONE global_atomic_add_f32 carries all 6 + |SMASK| sums of the Gaussian to its 64-byte
+    // accumulator line.  The L2 atomic units retire ~21 line-requests per ns however many floats of the line a request
+    // carries (scripts/micro/atomic_bench.hip): one instruction per visit instead of one per group cuts the kernel's
+    // 2.9 M line-requests per launch to 0.97 M.
+    const int pub_g = lane & 15;
+    int doff = -1;
 #pragma unroll
-    for (int grp = 0; grp < NG; ++grp) {
-        doff[grp] = -1;
+    for (int grp = 0; grp < NG; ++grp)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            constexpr int dummy = 0; (void)dummy;
-            const int k = 4 * grp + r;
+            const int k = 4 * grp + row_value(r);
             const int slot = k < 6 ? k : (k < NV ? 6 + nth_set_bit(SMASK, k - 6 < 0 ? 0 : k - 6) : -1);
-            if (rv == r) doff[grp] = slot;
+            if (pub_g == grp && (lane >> 4) == r) doff = slot;
         }
-    }
-    const unsigned long long pub_m = 0x0001000100010001ull;
+    const unsigned long long pub_m = __builtin_amdgcn_ballot_w64(doff >= 0);
 
     Staged<FP> pre;
     {
@@ -457,12 +457,10 @@ __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, c
 #pragma unroll
                     for (int grp = 0; grp < NG; ++grp)
                         r[grp] = wave_reduce4_packed(s[4 * grp], s[4 * grp + 1], s[4 * grp + 2], s[4 * grp + 3]);
-                    if (lane_of(pub_m)) {
-                        float *dst = accum + (size_t)cur.id * SPLAT_GRAD_STRIDE;
+                    float pv = r[0];
 #pragma unroll
-                        for (int grp = 0; grp < NG; ++grp)
-                            if (doff[grp] >= 0) atomicAdd(dst + doff[grp], r[grp]);
-                    }
+                    for (int grp = 1; grp < NG; ++grp) pv = pub_g == grp ? r[grp] : pv;
+                    if (lane_of(pub_m)) atomicAdd(accum + (size_t)cur.id * SPLAT_GRAD_STRIDE + doff, pv);
                 }
             }
         }

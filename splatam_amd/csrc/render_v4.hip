@@ -354,9 +354,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void r
     constexpr int NS = popcount_c(SMASK);
     constexpr int NV = 6 + NS;                // partial sums per Gaussian
     constexpr int NG = (NV + 3) / 4;          // packed reduction groups
-    constexpr int NA = NV;                    // accumulator floats per entry in LDS
     __shared__ Batch<FP> B;
-    __shared__ float s_acc[kBatch * NA];
     __shared__ unsigned s_wmax[4];
     const int tile = block_tile(per_xcd, T);
     if (tile < 0) return;
@@ -388,7 +386,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void r
             bgdot += cam.bg[ch] * dpix[ch];
         }
     }
-    for (int k = tid; k < kBatch * NA; k += 256) s_acc[k] = 0.f;
     const unsigned rmax = row_max_u32(last);                      // deepest contributor of this block (row-uniform)
     const unsigned wmax = (unsigned)wave_max_of_rows((int)rmax);
     if (lane == 0) s_wmax[wave] = wmax;
@@ -398,8 +395,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void r
     const unsigned lo = st.tile_stride > 0 ? (unsigned)tile * (unsigned)st.tile_stride : st.tile_base[tile];
     const int nb = (int)((tmax + kBatch - 1) / kBatch);
     const bool hi = quad >= 2, odd = (quad & 1) != 0;
-    const int my_value = row_value(quad);                      // value of each packed group this quad ends up holding
-    const bool pub = (l16 & 3) == 0;                           // first lane of the quad publishes
+    // Publish: after the packed row reductions every lane of quad q holds value row_value(q) of each group; lane 4 q + g
+    // of the row takes group g's value, so that ONE global_atomic_add_f32 per step carries all sums of the four rows'
+    // Gaussians to their 64-byte accumulator lines (<= 4 line-requests per step; the L2 atomic units retire ~21
+    // line-requests per ns however many floats of a line a request carries: scripts/micro/atomic_bench.hip).
+    const int pub_g = l16 & 3;
+    int doff = -1;
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 4 * grp + row_value(q);
+            const int slot = k < 6 ? k : (k < NV ? 6 + nth_set_bit(SMASK, k - 6 < 0 ? 0 : k - 6) : -1);
+            if (pub_g == grp && quad == q) doff = slot;
+        }
+    const bool pub = doff >= 0;
 
     Staged<FP> pre;
     {
@@ -407,9 +417,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void r
         gather<C, CS, false, FP>(pre, st, colors, lo + e, e < tmax, tile_x0, tile_y0);
     }
     for (int bi = nb - 1; bi >= 0; --bi) {
-        // the previous iteration ended with a barrier (after its flush)
+        // the previous iteration ended with a barrier
         commit(B, pre, tid, 0u);
-        const unsigned batch_id = pre.id;                       // Gaussian of entry `tid` of THIS batch (for the flush)
         if (bi > 0) gather<C, CS, false, FP>(pre, st, colors, lo + (unsigned)((bi - 1) * kBatch + tid), true, tile_x0, tile_y0);
         const int base = bi * kBatch;
         // entries [0, lim) of this batch can matter to this block: count them in the block's list
@@ -476,55 +485,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void r
 #pragma unroll
                 for (int grp = 0; grp < NG; ++grp)
                     r[grp] = row_reduce4_packed(s[4 * grp], s[4 * grp + 1], s[4 * grp + 2], s[4 * grp + 3], hi, odd);
-                // rows with a live lane add their sums to the Gaussian's LDS accumulator
+                // rows with a live lane add their sums to their Gaussian's accumulator line
                 const bool row_live = ((unsigned)(live_m >> (16 * row)) & 0xffffu) != 0u;
-#if !defined(SPLAT_V4_NO_LDS_ATOMICS)      // (timing ablations: -DSPLAT_V4_NO_LDS_ATOMICS [-DSPLAT_V4_GLOBAL_ATOMICS])
-                if (pub && row_live) {
-                    float *dst = s_acc + e * NA + my_value;
+                float pv = r[0];
 #pragma unroll
-                    for (int grp = 0; grp < NG; ++grp)
-                        if (4 * grp + my_value < NV) atomicAdd(dst + 4 * grp, r[grp]);
-                }
-#elif defined(SPLAT_V4_GLOBAL_ATOMICS)
-                if (pub && row_live) {
-                    float *dst = accum + (size_t)cur.id * SPLAT_GRAD_STRIDE;
-#pragma unroll
-                    for (int grp = 0; grp < NG; ++grp) {
-                        const int k = 4 * grp + my_value;
-                        const int slot = k < 6 ? k : (k < NV ? 6 + nth_set_bit(SMASK, k - 6 < 0 ? 0 : k - 6) : -1);
-                        if (k < NV) atomicAdd(dst + slot, r[grp]);
-                    }
-                }
-#else
-                if (pub && row_live && r[0] == 123.456f) s_acc[e] = r[0] + r[NG - 1];
-#endif
+                for (int grp = 1; grp < NG; ++grp) pv = pub_g == grp ? r[grp] : pv;
+                if (pub && row_live) atomicAdd(accum + (size_t)cur.id * SPLAT_GRAD_STRIDE + doff, pv);
             }
             cur = nxt;
             e = e_nxt;
             e_nxt = e_n2;
         }
-        __syncthreads();
-        // flush: thread t owns entry t of the batch
-        {
-            float a[NA];
-            bool any = false;
-#pragma unroll
-            for (int k = 0; k < NA; ++k) {
-                a[k] = s_acc[tid * NA + k];
-                any |= a[k] != 0.f;
-            }
-            if (any) {
-                float *dst = accum + (size_t)batch_id * SPLAT_GRAD_STRIDE;
-#pragma unroll
-                for (int k = 0; k < NV; ++k) {
-                    const int slot = k < 6 ? k : 6 + nth_set_bit(SMASK, k - 6);
-                    if (a[k] != 0.f) atomicAdd(dst + slot, a[k]);
-                }
-#pragma unroll
-                for (int k = 0; k < NA; ++k) s_acc[tid * NA + k] = 0.f;
-            }
-        }
-        __syncthreads();
+        __syncthreads();            // every wave has finished reading this batch
     }
 }
 
