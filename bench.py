@@ -27,6 +27,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -299,6 +301,29 @@ def cpu_baseline(name, params, frames, budget_s=25.0):
                       f"at full size; C oracle (OpenMP, {os.cpu_count()} threads) + PyTorch-CPU glue; median {med:.3f} s/iter"}
 
 
+def slam_loop_figure(name, dev, frames=4):
+    """Informational: the WHOLE frame loop of scripts/splatam.py:654-905 (pose initialisation, tracking, densification,
+    keyframe selection, mapping with pruning, keyframe list; splatam_amd/pipeline.py) on a synthetic RGB-D sequence of the
+    workload's image size with the reference's Replica iteration counts.  The map is what the loop builds (one Gaussian per
+    valid first-frame pixel, then densification), not the workload's fixed 300k."""
+    from splatam_amd import pipeline
+    N, W, H, fx, fy, cx, cy = WORKLOADS[name]
+    ds = pipeline.SyntheticRGBDSequence(N, W, H, fx, fy, cx, cy, num_frames=frames, seed=3, device=dev)
+    cfg = pipeline.replica_config()
+    torch.manual_seed(0)
+    np.random.seed(0)
+    t0 = time.perf_counter()
+    params, _, st = pipeline.rgbd_slam(ds, cfg, engine="fused")
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    ate = max(float((pipeline._est_w2c(params, t)[:3, 3] - ds.gt_w2c(t)[:3, 3]).norm()) for t in range(frames))
+    return {"frames": frames, "image": f"{W}x{H}", "gaussians_per_frame": st['num_gaussians'],
+            "tracking_iters": st['tracking_iters'], "mapping_iters": st['mapping_iters'],
+            "tracking_iters_per_s": round(st['tracking_iters'] / max(st['tracking_s'], 1e-9), 1),
+            "mapping_iters_per_s_incl_densify_keyframes_prune": round(st['mapping_iters'] / max(st['mapping_s'], 1e-9), 1),
+            "frames_per_s": round(frames / wall, 3), "redone_frames": st['redone_frames'], "max_translation_error_m": round(ate, 5)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -310,6 +335,7 @@ def main():
     ap.add_argument("--engine", default="fused", choices=["fused", "dropin"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-slam-loop", action="store_true", help="skip the informational end-to-end frame-loop figure")
     args = ap.parse_args()
 
     from splatam_amd import dist as sdist
@@ -423,6 +449,8 @@ def main():
         }
         if roof is not None:
             result["roofline"] = roof
+        if world == 1 and fused and not args.no_slam_loop:
+            result["slam_loop"] = slam_loop_figure(args.workload, dev)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.workload, params_d, frames)
     if world > 1:

@@ -50,6 +50,12 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(SplatGaussians g, Splat
 //  * long lists: one 256-thread workgroup per tile, 32 KiB of LDS, or in place in HBM beyond that.
 constexpr int kSortWave = 1024;
 
+// The host may know the longest list (status[2] of an earlier iteration).  The long-list kernel is skipped only when that
+// hint leaves a 1.5x margin (the margin the bucket stride uses): lists grow a little from iteration to iteration.
+__host__ __device__ inline bool long_sort_skipped(int max_list_hint) {
+    return max_list_hint > 0 && max_list_hint + max_list_hint / 2 <= kSortWave;
+}
+
 __global__ __launch_bounds__(64) void tile_sort_wave_kernel(SplatState st) {
     __shared__ uint64_t s_keys[kSortWave];
     const int tile = blockIdx.x, tid = threadIdx.x;
@@ -64,8 +70,12 @@ __global__ __launch_bounds__(64) void tile_sort_wave_kernel(SplatState st) {
     tile_range(st, tile, lo, n);
     if (n > kSortWave) {
         // long list: the workgroup-per-tile kernel sorts it -- unless the host's (possibly stale) hint said that no
-        // list is that long and skipped that launch; flag it so that the host re-runs instead of rendering unsorted
-        if (tid == 0 && st.max_list_hint > 0 && st.max_list_hint <= kSortWave) atomicOr((unsigned *)&st.status[3], 1u);
+        // list is that long and skipped that launch.  Then flag it so that the host re-runs, and publish the ids
+        // UNSORTED so that the composite kernels of this (invalid) iteration still read valid Gaussian indices.
+        if (long_sort_skipped(st.max_list_hint)) {
+            if (tid == 0) atomicOr((unsigned *)&st.status[3], 1u);
+            for (int i = tid; i < n; i += 64) st.point_list[lo + i] = (uint32_t)st.keys[lo + i];
+        }
         return;
     }
     if (n == 0) return;
@@ -105,7 +115,7 @@ hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, S
     if (T > 0 && sort) {
         hipLaunchKernelGGL(tile_sort_wave_kernel, dim3(T), dim3(64), 0, s, st);
         // the host may know the longest list (status[2]); only then can the long-list kernel be skipped
-        if (st.max_list_hint <= 0 || st.max_list_hint > kSortWave)
+        if (!long_sort_skipped(st.max_list_hint))
             hipLaunchKernelGGL(tile_sort_block_kernel, dim3(T), dim3(kBlock), 0, s, st);
     }
     return hipGetLastError();

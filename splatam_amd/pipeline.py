@@ -1,0 +1,403 @@
+"""The per-frame SplaTAM loop on the HIP engine: what ``rgbd_slam`` does between loading a frame and
+storing a keyframe (/root/reference/scripts/splatam.py:654-905), without the reference's I/O, logging and evaluation.
+
+=============================================  =============================================
+here                                           reference
+=============================================  =============================================
+``keyframe_selection_overlap``                 utils/keyframe_selection.py:44-103 (+ its get_pointcloud :10-41)
+``replica_config``                             configs/replica/splatam.py (the values the loop reads)
+``rgbd_slam``                                  scripts/splatam.py:455-905 (frame loop: pose initialisation, tracking with
+                                               best-candidate bookkeeping and the depth-loss retry, densification,
+                                               keyframe selection, mapping with pruning, keyframe list)
+``save_params`` / ``load_params``              utils/common_utils.py:25-52 (``params.npz``)
+``SyntheticRGBDSequence``                      stands in for datasets/gradslam_datasets/* (no datasets offline)
+=============================================  =============================================
+
+``engine="fused"`` runs every iteration through ``FusedEngine`` (C ABI ``splat_iter_*`` / ``splat_map_*``: ~8 kernel
+launches per iteration, map edits in place on the device); ``engine="dropin"`` runs the reference-shaped PyTorch loop
+(``splatam_amd.slam``) on the drop-in rasterizer.  Both follow the reference's control flow line by line, including the
+places where it is surprising: pruning happens between ``backward()`` and ``optimizer.step()``, and ``remove_points``
+re-creates the parameters, so the iterations on the pruning schedule take NO Adam step
+(scripts/splatam.py:857-868, utils/slam_external.py:139-162).
+"""
+from __future__ import annotations
+
+import copy
+import math
+import os
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import slam
+
+
+# --------------------------------------------------------------------------
+# keyframe selection
+# --------------------------------------------------------------------------
+
+def _sampled_cloud(depth, intrinsics, w2c, sampled_indices):
+    """World-frame points of the sampled pixels; points that coincide after rounding to 1e-4 (duplicated samples, or
+    the camera origin) are dropped, all copies of them, as the reference's unique/isin construction does."""
+    fx, fy, cx, cy = intrinsics[0][0], intrinsics[1][1], intrinsics[0][2], intrinsics[1][2]
+    v, u = sampled_indices[:, 0], sampled_indices[:, 1]
+    z = depth[0, v, u]
+    pts_cam = torch.stack(((u - cx) / fx * z, (v - cy) / fy * z, z), dim=-1)
+    c2w = torch.inverse(w2c)
+    pts = pts_cam @ c2w[:3, :3].t() + c2w[:3, 3]
+    key = torch.cat((torch.abs(torch.round(pts, decimals=4)), torch.zeros(1, 3, device=pts.device, dtype=pts.dtype)), dim=0)
+    _, inverse, counts = key.unique(dim=0, return_inverse=True, return_counts=True)
+    keep = (counts[inverse] == 1)[:pts.shape[0]]
+    return pts[keep]
+
+
+def keyframe_selection_overlap(gt_depth, w2c, intrinsics, keyframe_list, k, pixels=1600):
+    """Indices (into ``keyframe_list``) of up to ``k`` keyframes that see part of the current frame: 1600 valid-depth
+    pixels are back-projected and re-projected into every keyframe (one batched product over all keyframes); keyframes with
+    a non-zero share of points inside the image (20 px border) are kept, ordered by that share, then shuffled."""
+    H, W = gt_depth.shape[1], gt_depth.shape[2]
+    valid = torch.stack(torch.where(gt_depth[0] > 0), dim=1)
+    sampled = valid[torch.randint(valid.shape[0], (pixels,))]
+    pts = _sampled_cloud(gt_depth, intrinsics, w2c, sampled)
+    if len(keyframe_list) == 0:
+        return []
+    est = torch.stack([kf['est_w2c'] for kf in keyframe_list])                     # [K,4,4]
+    cam = torch.einsum('kij,nj->kni', est[:, :3, :3], pts) + est[:, None, :3, 3]     # [K,N,3]
+    proj = torch.einsum('ij,knj->kni', intrinsics.to(cam.dtype), cam)
+    zc = proj[..., 2] + 1e-5
+    px, py = proj[..., 0] / zc, proj[..., 1] / zc
+    edge = 20
+    inside = (px < W - edge) & (px > edge) & (py < H - edge) & (py > edge) & (zc > 0)
+    share = (inside.sum(dim=1) / max(pts.shape[0], 1)).tolist()
+    order = sorted(range(len(keyframe_list)), key=lambda i: share[i], reverse=True)      # stable, like the reference's sorted()
+    chosen = [i for i in order if share[i] > 0.0]
+    return list(np.random.permutation(np.array(chosen))[:k])
+
+
+# --------------------------------------------------------------------------
+# configuration, I/O
+# --------------------------------------------------------------------------
+
+def replica_config(tracking_iters=40, mapping_iters=60, map_every=1, keyframe_every=5, mapping_window_size=24):
+    """The entries of /root/reference/configs/replica/splatam.py that the frame loop reads."""
+    return dict(
+        seed=0, map_every=map_every, keyframe_every=keyframe_every, mapping_window_size=mapping_window_size,
+        scene_radius_depth_ratio=3, mean_sq_dist_method="projective", gaussian_distribution="isotropic",
+        tracking=dict(use_gt_poses=False, forward_prop=True, num_iters=tracking_iters, use_sil_for_loss=True, sil_thres=0.99,
+                      use_l1=True, ignore_outlier_depth_loss=False, use_depth_loss_thres=False, depth_loss_thres=100000,
+                      loss_weights=dict(im=0.5, depth=1.0), lrs=dict(slam.REPLICA_TRACKING['lrs'])),
+        mapping=dict(num_iters=mapping_iters, add_new_gaussians=True, sil_thres=0.5, use_l1=True, use_sil_for_loss=False,
+                     ignore_outlier_depth_loss=False, loss_weights=dict(im=0.5, depth=1.0), lrs=dict(slam.REPLICA_MAPPING['lrs']),
+                     prune_gaussians=True, pruning_dict=dict(slam.REPLICA_PRUNE), use_gaussian_splatting_densification=False))
+
+
+def save_params(output_params, output_dir, time_idx=None):
+    """``params.npz`` (or ``params<time_idx>.npz``): one array per entry of the params dict."""
+    os.makedirs(output_dir, exist_ok=True)
+    name = "params.npz" if time_idx is None else f"params{time_idx}.npz"
+    path = os.path.join(output_dir, name)
+    np.savez(path, **{k: (v.detach().cpu().contiguous().numpy() if isinstance(v, torch.Tensor) else v) for k, v in output_params.items()})
+    return path
+
+
+def load_params(path, device="cuda"):
+    """Inverse of ``save_params`` the way the reference's checkpoint loader reads it (scripts/splatam.py:611-613)."""
+    raw = dict(np.load(path, allow_pickle=True))
+    return {k: torch.tensor(v).to(device).float().requires_grad_(True) for k, v in raw.items()}
+
+
+class SyntheticRGBDSequence:
+    """RGB-D frames rendered from a seeded synthetic scene along a smooth trajectory (no datasets offline).  Items look like
+    the reference's gradslam datasets: ``(color[H,W,3] in 0..255, depth[H,W,1], intrinsics[4,4], pose[4,4])`` with the pose
+    (camera-to-world) relative to the first frame.  The scene is a smooth, opaque, textured surface (``n_gaussians`` splats
+    on z = z0 + ripples, colours a sum of low- and mid-frequency waves) so that frame-to-model tracking is well posed --
+    the random per-pixel depth layers of the kernel workloads (bench.build_scene) are not."""
+
+    def __init__(self, n_gaussians, width, height, fx, fy, cx, cy, num_frames, seed=0, device="cuda", step_m=0.01, step_deg=0.3):
+        self.W, self.H, self.num_frames, self.device = width, height, num_frames, device
+        self.k = torch.tensor([[fx, 0, cx, 0], [0, fy, cy, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=torch.float32, device=device)
+        g = torch.Generator().manual_seed(seed)
+        n = int(n_gaussians)
+        m = 0.15                                            # the surface extends past the first view: later frames see new parts
+        u = (torch.rand(n, generator=g, dtype=torch.float64) * (1 + 2 * m) - m) * width - 0.5
+        v = (torch.rand(n, generator=g, dtype=torch.float64) * (1 + 2 * m) - m) * height - 0.5
+        su, sv = u / width * 2 * math.pi, v / height * 2 * math.pi
+        z = 2.5 + 0.35 * torch.sin(1.3 * su + 0.4) * torch.cos(0.9 * sv) + 0.15 * torch.sin(2.7 * sv + 1.0)
+        means = torch.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], dim=-1)
+        rgb = torch.stack([0.5 + 0.25 * torch.sin(3 * su) * torch.cos(2 * sv) + 0.2 * torch.sin(17 * su + 0.3) * torch.sin(13 * sv),
+                           0.5 + 0.25 * torch.cos(2 * su + 1.0) * torch.sin(3 * sv) + 0.2 * torch.sin(11 * su) * torch.cos(19 * sv + 0.7),
+                           0.5 + 0.25 * torch.sin(4 * su + 2.0) + 0.2 * torch.cos(15 * su + 9 * sv)], dim=-1).clamp(0.02, 0.98)
+        spacing = math.sqrt((1 + 2 * m) ** 2 * width * height / n)        # mean distance between neighbouring splats in pixels
+        log_scales = torch.log(1.1 * spacing * z / ((fx + fy) / 2))[:, None]
+        rots = torch.zeros(n, 4, dtype=torch.float64)
+        rots[:, 0] = 1.0
+        cam_rots = torch.zeros(1, 4, num_frames)
+        cam_trans = torch.zeros(1, 3, num_frames)
+        for t in range(num_frames):
+            ang = math.radians(step_deg * t)
+            cam_rots[0, :, t] = torch.tensor([math.cos(ang / 2), 0.0, math.sin(ang / 2), 0.0])
+            cam_trans[0, :, t] = torch.tensor([step_m * t, -0.3 * step_m * t, 0.5 * step_m * t])
+        raw = dict(means3D=means, rgb_colors=rgb, unnorm_rotations=rots, logit_opacities=torch.full((n, 1), 4.0, dtype=torch.float64),
+                   log_scales=log_scales, cam_unnorm_rots=cam_rots, cam_trans=cam_trans)
+        self._scene = {k: t.to(device=device, dtype=torch.float32).contiguous() for k, t in raw.items()}
+        self._cam = slam.setup_camera(width, height, self.k[:3, :3].cpu().numpy(), np.eye(4, dtype=np.float32), device=device)
+        self._w2c0 = torch.eye(4, device=device)
+
+    def __len__(self):
+        return self.num_frames
+
+    def gt_w2c(self, t):
+        q = F.normalize(self._scene['cam_unnorm_rots'][..., t].detach())
+        w2c = torch.eye(4, device=self.device)
+        w2c[:3, :3] = slam.build_rotation(q)[0]
+        w2c[:3, 3] = self._scene['cam_trans'][0, :, t].detach()
+        return w2c
+
+    def __getitem__(self, t):
+        im, depth = self._render(t)
+        pose = torch.inverse(self.gt_w2c(t))
+        return (im.permute(1, 2, 0) * 255.0).contiguous(), depth.permute(1, 2, 0).contiguous(), self.k, pose
+
+    def _render(self, t):
+        with torch.no_grad():
+            p = self._scene
+            tg = slam.transform_to_frame(p, t, gaussians_grad=False, camera_grad=False)
+            rv = slam.transformed_params2rendervar(p, tg)
+            im, _, _ = slam.Renderer(raster_settings=self._cam)(**{k: v.detach() for k, v in rv.items()})
+            dv = slam.transformed_params2depthplussilhouette(p, self._w2c0, tg)
+            ds, _, _ = slam.Renderer(raster_settings=self._cam)(**{k: v.detach() for k, v in dv.items()})
+            sil = ds[1:2]
+            depth = torch.where(sil > 0.5, ds[0:1] / sil.clamp_min(1e-6), torch.zeros_like(sil))
+        return im.clamp(0, 1).contiguous(), depth.contiguous()
+
+
+# --------------------------------------------------------------------------
+# the frame loop
+# --------------------------------------------------------------------------
+
+def _est_w2c(params, time_idx):
+    q = F.normalize(params['cam_unnorm_rots'][..., time_idx].detach())
+    w2c = torch.eye(4, device=q.device)
+    w2c[:3, :3] = slam.build_rotation(q)[0]
+    w2c[:3, 3] = params['cam_trans'][0, :, time_idx].detach()
+    return w2c
+
+
+def initialize_first_timestep(dataset, num_frames, scene_radius_depth_ratio, mean_sq_dist_method, gaussian_distribution, device="cuda"):
+    """Map, variables, intrinsics, first-frame world-to-camera and camera from frame 0."""
+    color, depth, intrinsics, pose = dataset[0]
+    color = color.permute(2, 0, 1) / 255
+    depth = depth.permute(2, 0, 1)
+    intrinsics = intrinsics[:3, :3]
+    w2c = torch.linalg.inv(pose)
+    cam = slam.setup_camera(color.shape[2], color.shape[1], intrinsics.cpu().numpy(), w2c.detach().cpu().numpy(), device=device)
+    mask = (depth > 0).reshape(-1)
+    cloud, msd = slam.get_pointcloud(color, depth, intrinsics, w2c, mask=mask, compute_mean_sq_dist=True,
+                                     mean_sq_dist_method=mean_sq_dist_method)
+    params, variables = slam.initialize_params(cloud, num_frames, msd, gaussian_distribution)
+    variables['scene_radius'] = torch.max(depth) / scene_radius_depth_ratio
+    return params, variables, intrinsics, w2c, cam
+
+
+def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacity=None, verbose=False):
+    """Runs the SplaTAM frame loop over ``dataset``; returns ``(params, variables, stats)`` with
+    ``stats = {keyframe_time_indices, tracking_iters, mapping_iters, tracking_s, mapping_s, num_gaussians, redone_frames}``."""
+    if engine not in ("fused", "dropin"):
+        raise ValueError(engine)
+    fused = engine == "fused"
+    num_frames = len(dataset) if num_frames is None else min(num_frames, len(dataset))
+    tcfg, mcfg = config['tracking'], config['mapping']
+    if mcfg.get('use_gaussian_splatting_densification'):
+        raise NotImplementedError("gradient-based densification (configs/*/gaussian_splatting.py) is outside this loop")
+    dist_kind = config.get('gaussian_distribution', 'isotropic')
+    params, variables, intrinsics, first_frame_w2c, cam = initialize_first_timestep(
+        dataset, num_frames, config['scene_radius_depth_ratio'], config['mean_sq_dist_method'], dist_kind)
+    dev = params['means3D'].device
+    first_frame_w2c = first_frame_w2c.to(dev).float().contiguous()
+    eng = None
+    if fused:
+        from .fused import FusedEngine
+        cap = gaussian_capacity or int(params['means3D'].shape[0] * 2.5) + 65536
+        scene_radius = variables['scene_radius']
+        eng = FusedEngine(params, cam, gaussian_capacity=cap, variables=variables)
+    keyframe_list, keyframe_time_indices = [], []
+    stats = dict(tracking_iters=0, mapping_iters=0, tracking_s=0.0, mapping_s=0.0, redone_frames=0, num_gaussians=[])
+
+    def sync():
+        torch.cuda.synchronize(dev)
+
+    for time_idx in range(num_frames):
+        color, depth, _, gt_pose = dataset[time_idx]
+        color = (color.permute(2, 0, 1) / 255).contiguous()
+        depth = depth.permute(2, 0, 1).contiguous()
+        curr_data = {'cam': cam, 'im': color, 'depth': depth, 'id': time_idx, 'intrinsics': intrinsics, 'w2c': first_frame_w2c}
+        if time_idx > 0:
+            slam.initialize_camera_pose(params, time_idx, forward_prop=tcfg['forward_prop'])
+
+        # ---------------- tracking (scripts/splatam.py:676-744)
+        sync()
+        t0 = time.perf_counter()
+        if time_idx > 0 and not tcfg['use_gt_poses']:
+            pose0 = (params['cam_unnorm_rots'].detach()[..., time_idx].clone(), params['cam_trans'].detach()[..., time_idx].clone())
+            for attempt in range(2):
+                n_track = _track_frame(params, variables, curr_data, time_idx, tcfg, eng)
+                if not fused or not eng.check_overflow():
+                    break
+                # a tile list overflowed its bucket: the engine has re-sized / gone back to exact lists; redo the frame
+                stats['redone_frames'] += 1
+                with torch.no_grad():
+                    params['cam_unnorm_rots'][..., time_idx] = pose0[0]
+                    params['cam_trans'][..., time_idx] = pose0[1]
+            stats['tracking_iters'] += n_track
+        elif time_idx > 0:
+            with torch.no_grad():
+                rel = torch.linalg.inv(gt_pose).to(dev)
+                params['cam_unnorm_rots'][..., time_idx] = _matrix_to_quaternion(rel[:3, :3])
+                params['cam_trans'][..., time_idx] = rel[:3, 3]
+        sync()
+        stats['tracking_s'] += time.perf_counter() - t0
+
+        # ---------------- densification + keyframe mapping (scripts/splatam.py:768-891)
+        if time_idx == 0 or (time_idx + 1) % config['map_every'] == 0:
+            t0 = time.perf_counter()
+            if mcfg['add_new_gaussians'] and time_idx > 0:
+                if fused:
+                    eng.add_new_gaussians(curr_data, mcfg['sil_thres'], time_idx, config['mean_sq_dist_method'], dist_kind)
+                else:
+                    params, variables = slam.add_new_gaussians(params, variables, curr_data, mcfg['sil_thres'], time_idx,
+                                                               config['mean_sq_dist_method'], dist_kind)
+            with torch.no_grad():
+                curr_w2c = _est_w2c(params, time_idx)
+                selected = keyframe_selection_overlap(depth, curr_w2c, intrinsics.to(dev), keyframe_list[:-1],
+                                                      config['mapping_window_size'] - 2)
+                if len(keyframe_list) > 0:
+                    selected.append(len(keyframe_list) - 1)
+                selected.append(-1)
+            if fused:
+                eng.relearn_lists(curr_data, time_idx)
+                snap = {k: eng.store[k][:eng.P].clone() for k in slam.GAUSSIAN_KEYS}
+                snap_vars = {k: eng.store[k][:eng.P].clone() for k in ('max_2D_radius', 'means2D_gradient_accum', 'denom', 'timestep')}
+                rng_state = np.random.get_state()
+            for attempt in range(2):
+                _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, mcfg, eng,
+                           scene_radius if fused else None)
+                if not fused or not eng.check_overflow():
+                    break
+                stats['redone_frames'] += 1
+                np.random.set_state(rng_state)
+                eng._set_rows(snap['means3D'].shape[0])
+                with torch.no_grad():
+                    for k, v in {**snap, **snap_vars}.items():
+                        eng.store[k][:eng.P] = v
+                eng.allow_buckets = False               # exact lists for the repeat: they cannot overflow a bucket
+                eng.relearn_lists(curr_data, time_idx)
+            if fused:
+                eng.allow_buckets = True
+            stats['mapping_iters'] += mcfg['num_iters']
+            sync()
+            stats['mapping_s'] += time.perf_counter() - t0
+
+        # ---------------- keyframe list (scripts/splatam.py:893-905)
+        if time_idx == 0 or (time_idx + 1) % config['keyframe_every'] == 0 or time_idx == num_frames - 2:
+            with torch.no_grad():
+                keyframe_list.append({'id': time_idx, 'est_w2c': _est_w2c(params, time_idx), 'color': color, 'depth': depth})
+                keyframe_time_indices.append(time_idx)
+        stats['num_gaussians'].append(int(params['means3D'].shape[0]))
+        if verbose:
+            print(f"frame {time_idx}: {stats['num_gaussians'][-1]} Gaussians, keyframes {keyframe_time_indices}", flush=True)
+    stats['keyframe_time_indices'] = keyframe_time_indices
+    return params, variables, stats
+
+
+def _track_frame(params, variables, curr_data, time_idx, tcfg, eng):
+    """Tracking iterations of one frame incl. the reference's doubling of the budget when the depth loss stays above
+    ``depth_loss_thres`` (scripts/splatam.py:727-735).  Returns the number of iterations run."""
+    num_iters = tcfg['num_iters']
+    it, doubled = 0, False
+    if eng is not None:
+        eng.begin_tracking(time_idx)
+    else:
+        optimizer = slam.initialize_optimizer(params, tcfg['lrs'], tracking=True)
+        state = slam.TrackingState(params, time_idx)
+    while True:
+        if eng is not None:
+            eng.tracking_iteration(curr_data, tcfg)
+        else:
+            loss, _ = slam.tracking_iteration(params, curr_data, variables, time_idx, optimizer, state, tcfg)
+        it += 1
+        if it == num_iters:
+            if not tcfg.get('use_depth_loss_thres', False):
+                break
+            depth_loss = (tcfg['loss_weights']['depth'] * float(eng.buf['d_cam'][8])) if eng is not None else float(_last_depth_loss(
+                params, curr_data, variables, time_idx, tcfg))
+            if depth_loss < tcfg['depth_loss_thres'] or doubled:
+                break
+            doubled = True
+            num_iters *= 2
+    if eng is not None:
+        eng.end_tracking()
+    else:
+        state.commit(params)
+    return it
+
+
+def _last_depth_loss(params, curr_data, variables, time_idx, tcfg):
+    with torch.no_grad():
+        _, _, wl = slam.get_loss(params, curr_data, dict(variables), time_idx, tcfg['loss_weights'], tcfg['use_sil_for_loss'],
+                                 tcfg['sil_thres'], tcfg['use_l1'], tcfg['ignore_outlier_depth_loss'], tracking=True)
+    return wl['depth']
+
+
+def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, mcfg, eng, scene_radius):
+    """The mapping iterations of one frame over the selected keyframes + the current frame."""
+    cam, intrinsics, w2c0 = curr_data['cam'], curr_data['intrinsics'], curr_data['w2c']
+    prune, pd = mcfg['prune_gaussians'], mcfg['pruning_dict']
+    if eng is not None:
+        eng.reset_map_optimizer()
+    else:
+        optimizer = slam.initialize_optimizer(params, mcfg['lrs'], tracking=False)
+    for it in range(mcfg['num_iters']):
+        sel = selected[np.random.randint(0, len(selected))]
+        if sel == -1:
+            iter_time_idx, iter_color, iter_depth = time_idx, curr_data['im'], curr_data['depth']
+        else:
+            kf = keyframe_list[sel]
+            iter_time_idx, iter_color, iter_depth = kf['id'], kf['color'], kf['depth']
+        iter_data = {'cam': cam, 'im': iter_color, 'depth': iter_depth, 'id': iter_time_idx, 'intrinsics': intrinsics, 'w2c': w2c0}
+        # the reference prunes between backward() and step(); remove_points re-creates the parameters without their
+        # gradients, so an iteration on the pruning schedule takes no Adam step
+        on_schedule = prune and it <= pd['stop_after'] and it >= pd['start_after'] and it % pd['prune_every'] == 0
+        if eng is not None:
+            eng.loss_backward(iter_data, iter_time_idx, mcfg, tracking=False)
+            if prune:
+                if eng.prune_gaussians(it, pd, scene_radius):
+                    eng.relearn_lists(curr_data, time_idx)
+            if not on_schedule:
+                eng.adam_map(mcfg['lrs'])
+        else:
+            loss, _, _ = slam.get_loss(params, iter_data, variables, iter_time_idx, mcfg['loss_weights'], mcfg['use_sil_for_loss'],
+                                       mcfg['sil_thres'], mcfg['use_l1'], mcfg['ignore_outlier_depth_loss'], mapping=True)
+            loss.backward()
+            with torch.no_grad():
+                if prune:
+                    slam.prune_gaussians(params, variables, optimizer, it, pd)
+                optimizer.step()
+                optimizer.zero_grad(set_to_none=True)
+
+
+def _matrix_to_quaternion(R):
+    """Rotation matrix -> (w, x, y, z), the branch-free form the reference imports from pytorch3d-style helpers
+    (utils/slam_external.py: matrix_to_quaternion) for ``use_gt_poses``."""
+    m = R.reshape(3, 3).double()
+    t = torch.stack([1 + m[0, 0] + m[1, 1] + m[2, 2], 1 + m[0, 0] - m[1, 1] - m[2, 2],
+                     1 - m[0, 0] + m[1, 1] - m[2, 2], 1 - m[0, 0] - m[1, 1] + m[2, 2]]).clamp_min(0).sqrt()
+    cand = torch.stack([
+        torch.stack([t[0] ** 2, m[2, 1] - m[1, 2], m[0, 2] - m[2, 0], m[1, 0] - m[0, 1]]),
+        torch.stack([m[2, 1] - m[1, 2], t[1] ** 2, m[1, 0] + m[0, 1], m[0, 2] + m[2, 0]]),
+        torch.stack([m[0, 2] - m[2, 0], m[1, 0] + m[0, 1], t[2] ** 2, m[2, 1] + m[1, 2]]),
+        torch.stack([m[1, 0] - m[0, 1], m[2, 0] + m[0, 2], m[2, 1] + m[1, 2], t[3] ** 2])])
+    best = int(torch.argmax(t))
+    q = cand[best] / (2.0 * t[best].clamp_min(0.1))
+    return q.float().reshape(1, 4)

@@ -196,9 +196,37 @@ def case_pose(ns, out):
         params['cam_trans'].detach().numpy()
 
 
+def case_keyframe_selection(out):
+    """utils/keyframe_selection.py as is (CPU), seeded like the caller seeds everything (utils/common_utils.py:8-22)."""
+    from utils import keyframe_selection as ref_kf
+    g = torch.Generator().manual_seed(11)
+    H, W, f = 120, 160, 110.0
+    depth = 1.0 + 2.0 * torch.rand(1, H, W, generator=g)
+    depth[0, :10, :] = 0.0
+    k = torch.tensor([[f, 0.0, W / 2 - 0.5], [0.0, f, H / 2 - 0.5], [0.0, 0.0, 1.0]])
+    w2c = torch.eye(4)
+    kfs = []
+    for i, (ang, tx) in enumerate([(0.0, 0.0), (0.15, 0.1), (0.6, 0.5), (2.5, 0.0), (-0.3, -0.2), (1.2, 1.0), (0.05, 0.02)]):
+        m = torch.eye(4)
+        m[0, 0], m[0, 2], m[2, 0], m[2, 2] = np.cos(ang), np.sin(ang), -np.sin(ang), np.cos(ang)
+        m[0, 3] = tx
+        kfs.append({'id': i * 5, 'est_w2c': m})
+    out["kfsel/depth"], out["kfsel/intrinsics"], out["kfsel/w2c"] = depth.numpy(), k.numpy(), w2c.numpy()
+    out["kfsel/est_w2c"] = torch.stack([kf['est_w2c'] for kf in kfs]).numpy()
+    for kk in (3, 10):
+        torch.manual_seed(5)
+        np.random.seed(5)
+        sel = ref_kf.keyframe_selection_overlap(depth, w2c, k, kfs, kk)
+        out[f"kfsel/selected_k{kk}"] = np.array([int(x) for x in sel], dtype=np.int64)
+    torch.manual_seed(5)
+    np.random.seed(5)
+    out["kfsel/selected_empty"] = np.array(ref_kf.keyframe_selection_overlap(depth, w2c, k, [], 3), dtype=np.int64)
+
+
 if __name__ == "__main__":
     ns = reference_functions()
     out = {}
+    case_keyframe_selection(out)
     case_add("add_iso", ns, 56, 40, 60.0, 400, "isotropic", 0, out)
     case_add("add_aniso", ns, 40, 33, 45.0, 300, "anisotropic", 1, out)
     case_add("add_nan", ns, 40, 32, 45.0, 100, "isotropic", 2, out, nan_pixel=True)

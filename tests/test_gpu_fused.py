@@ -297,3 +297,31 @@ def test_edge_shapes_and_empty_map():
     assert float(eng.grad_flat.abs().max()) == 0.0
     loss_ref, _ = _reference_grads(params, variables, frame, slam.REPLICA_MAPPING, tracking=False)
     assert abs(eng.loss() - loss_ref) <= 1e-5 * abs(loss_ref)
+
+
+def test_stale_list_length_hint_is_flagged_and_memory_safe():
+    """A list longer than the wave-sort limit meeting a stale host hint (which skipped the long-list sort launch) must be
+    flagged for a re-run AND must not feed unwritten list slots to the composite kernels (found by running the frame loop
+    on re-used allocator memory: garbage ids -> memory fault)."""
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    params, variables, frame, cam = _scene(60000, 96, 64, seed=11)       # dense: several thousand instances per tile
+    eng = FusedEngine(params, cam)
+    eng.allow_buckets = False
+    cfg = slam.REPLICA_MAPPING
+    eng.loss_backward(frame, 1, cfg, tracking=False)
+    torch.cuda.synchronize()
+    assert not eng.check_overflow()
+    assert eng.max_list_hint > 1024
+    good = eng.grads['means3D'].clone()
+    good_loss = eng.loss()
+    eng.buf['point_list'].fill_(0x7f7f7f7f)                              # what re-used allocator memory looks like
+    eng.max_list_hint = 100                                              # stale: claims that no list needs the long-list sort
+    eng.loss_backward(frame, 1, cfg, tracking=False)
+    torch.cuda.synchronize()                                            # no memory fault
+    assert eng.check_overflow()                                          # ... and the iteration is reported as invalid
+    eng.loss_backward(frame, 1, cfg, tracking=False)                     # hint reset by check_overflow: sorted again
+    torch.cuda.synchronize()
+    assert not eng.check_overflow()
+    assert abs(eng.loss() - good_loss) <= 1e-5 * abs(good_loss)
+    _cmp(eng.grads['means3D'], good, "dL/dmeans3D after recovery", tol=1e-4)
