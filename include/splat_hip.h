@@ -186,9 +186,9 @@ int splat_time_kernel(int fn, int iters, const SplatCamera *cam, const SplatGaus
  *   loss.backward() through the render variables and the camera pose -> one per-Gaussian kernel,
  *   optimizer.step() (/root/reference/scripts/splatam.py:160-166,704,860) -> fused Adam kernels,
  *   the best-candidate pose bookkeeping of the tracking loop (/root/reference/scripts/splatam.py:706-711).
- * Supported configuration = what every shipped config uses: use_l1, no ignore_outlier_depth_loss, no
- * densification gradient (means2D.grad of the colour pass alone is not produced); anything else returns
- * SPLAT_E_UNSUPPORTED and the caller uses the two-call path above.
+ * Every argument of get_loss is supported (use_l1, use_sil_for_loss, ignore_outlier_depth_loss with torch.median's
+ * exact lower median, tracking / mapping / do_ba); the one thing the fused path does not produce is the colour pass'
+ * own means2D.grad (gradient-based densification, off in every SLAM config): the caller uses the two-call path for it.
  * ------------------------------------------------------------------------------------------------------------ */
 
 /* The reference's `params` dict (/root/reference/scripts/splatam.py:120-157).  Adam updates it in place. */
@@ -250,7 +250,11 @@ typedef struct SplatIterWorkspace {
     float *d_log_scales;         /* [P][1|3] */
     float *d_cam;                /* [16]: dL/dcam_unnorm_rots[...,t] (4), dL/dcam_trans[...,t] (3), loss (1), the raw sums
                                     [0..3] of this iteration (4), [12] STICKY "lists overflowed / unsorted" flag (set by any
-                                    iteration whose status[1] or status[3] was set; cleared by the host), 3 spare */
+                                    iteration whose status[1] or status[3] was set; cleared by the host), [13] the median
+                                    depth error of this iteration when ignore_outlier_depth_loss is set, 2 spare */
+    /* only read when cfg->ignore_outlier_depth_loss (/root/reference/scripts/splatam.py:266-268), NULL otherwise */
+    float *outlier_err;          /* [H*W] scratch: depth error per pixel */
+    uint32_t *outlier_scratch;   /* splat_map_scratch_words(H*W) words: histograms of the radix selection of torch.median */
 } SplatIterWorkspace;
 
 /* get_loss + loss.backward() of one iteration.  On return (stream order) ws->d_* hold the gradients and

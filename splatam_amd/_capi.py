@@ -70,7 +70,7 @@ class SplatIterWorkspace(C.Structure):
     _fields_ = [("st", SplatState), ("feat8", _fp), ("out6", _fp), ("dL_dout6", _fp), ("accum", _fp),
                 ("ssim_maps", _fp), ("sums", _fp), ("max_2D_radius", _fp),
                 ("d_means3D", _fp), ("d_rgb_colors", _fp), ("d_unnorm_rotations", _fp), ("d_logit_opacities", _fp),
-                ("d_log_scales", _fp), ("d_cam", _fp)]
+                ("d_log_scales", _fp), ("d_cam", _fp), ("outlier_err", _fp), ("outlier_scratch", _fp)]
 
 
 class SplatAdamMap(C.Structure):

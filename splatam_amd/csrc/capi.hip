@@ -145,8 +145,7 @@ int splat_iter_loss_backward(const SplatCamera *cam, const SplatMap *map, const 
     if (!map->cam_unnorm_rots || !map->cam_trans || !frame->im || !frame->depth || !frame->w2c) return SPLAT_E_INVALID;
     if (map->P > 0 && (!map->means3D || !map->rgb_colors || !map->unnorm_rotations || !map->logit_opacities || !map->log_scales))
         return SPLAT_E_INVALID;
-    // what no shipped config uses is not fused: the caller keeps the two-call path for it
-    if (cfg->ignore_outlier_depth_loss) return SPLAT_E_UNSUPPORTED;
+    if (cfg->ignore_outlier_depth_loss && (!ws->outlier_err || !ws->outlier_scratch)) return SPLAT_E_INVALID;
     const SplatState &st = ws->st;
     if (!st.tile_count || !st.tile_base || !st.tile_cursor || !st.status || !st.final_T || !st.n_contrib) return SPLAT_E_INVALID;
     if (map->P > 0 && (!st.depth || !st.xy || !st.conic_opacity || !st.rect || !st.radii || !ws->feat8 || !ws->accum)) return SPLAT_E_INVALID;

@@ -165,11 +165,14 @@ struct Pixel {
 
 __device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 
-__device__ __forceinline__ Pixel depth_pixel(const SplatLossConfig &cfg, float depth, float sil, float depth_sq, float gt) {
+// median: of |gt - d| * (gt > 0) over the frame, only read with ignore_outlier_depth_loss
+// (/root/reference/scripts/splatam.py:264-272: mask = (depth_error < 10 * median) & (gt > 0) & nan_mask [& silhouette])
+__device__ __forceinline__ Pixel depth_pixel(const SplatLossConfig &cfg, float depth, float sil, float depth_sq, float gt, float median) {
     Pixel r;
     const float unc = depth_sq - depth * depth;
     const bool nan_ok = !(depth != depth) && !(unc != unc);
     bool m = gt > 0.f && nan_ok;
+    if (cfg.ignore_outlier_depth_loss) m = m && (fabsf(gt - depth) < 10.f * median);
     if (cfg.tracking && cfg.use_sil_for_loss) m = m && (sil > cfg.sil_thres);
     r.mask = m;
     const float diff = gt - depth;
@@ -189,6 +192,7 @@ __global__ __launch_bounds__(kBlock) void track_loss_kernel(FusedArgs a, int HW)
     const float *o = a.ws.out6;
     float *g = a.ws.dL_dout6;
     const bool masked_im = a.cfg.use_sil_for_loss || a.cfg.ignore_outlier_depth_loss;
+    const float median = a.cfg.ignore_outlier_depth_loss ? a.ws.d_cam[13] : 0.f;
     float acc[2] = {0.f, 0.f};
     const int nvec = HW / V;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < nvec; i += gridDim.x * kBlock) {
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void track_loss_kernel(FusedArgs a, int HW)
         ld(a.frame.depth, in[9]);
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            const Pixel px = depth_pixel(a.cfg, in[3][v], in[4][v], in[5][v], in[9][v]);
+            const Pixel px = depth_pixel(a.cfg, in[3][v], in[4][v], in[5][v], in[9][v], median);
             acc[0] += px.d_err;
             out[3][v] = a.cfg.use_l1 ? a.cfg.w_depth * px.d_sign : 0.f;
             const bool cm = masked_im ? px.mask : true;
@@ -274,6 +278,7 @@ __global__ __launch_bounds__(kBlock) void ssim_forward_kernel(FusedArgs a, int W
         sh[0][r][c] = m1; sh[1][r][c] = m2; sh[2][r][c] = e11; sh[3][r][c] = e22; sh[4][r][c] = e12;
     }
     __syncthreads();
+    const float median = a.cfg.ignore_outlier_depth_loss ? a.ws.d_cam[13] : 0.f;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};        // depth L1 (masked), image L1, mask count, SSIM map sum
     float *M = a.ws.ssim_maps + (size_t)(3 * ch) * HW;
 #pragma unroll
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void ssim_forward_kernel(FusedArgs a, int W
             acc[1] += fabsf(sx[r + kSsimR][c + kSsimR] - sy[r + kSsimR][c + kSsimR]);
             if (ch == 0) {
                 const float *o = a.ws.out6;
-                const Pixel px = depth_pixel(a.cfg, o[3 * HW + pix], o[4 * HW + pix], o[5 * HW + pix], a.frame.depth[pix]);
+                const Pixel px = depth_pixel(a.cfg, o[3 * HW + pix], o[4 * HW + pix], o[5 * HW + pix], a.frame.depth[pix], median);
                 acc[0] += px.d_err;
                 acc[2] += px.mask ? 1.f : 0.f;
             }
@@ -341,6 +346,7 @@ __global__ __launch_bounds__(kBlock) void map_loss_backward_kernel(FusedArgs a, 
     }
     __syncthreads();
     const float inv_n = 1.0f / (3.0f * (float)HW);
+    const float median = a.cfg.ignore_outlier_depth_loss ? a.ws.d_cam[13] : 0.f;
     const float count = s_count;            // written before the first __syncthreads above
     const float *X = a.ws.out6 + ch * HW, *Y = a.frame.im + ch * HW;
     float *Gout = a.ws.dL_dout6;
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(kBlock) void map_loss_backward_kernel(FusedArgs a, 
             Gout[ch * HW + pix] = a.cfg.w_im * (0.8f * sgn(xv - yv) * inv_n - 0.2f * inv_n * dssim);
             if (ch == 0) {
                 const float *o = a.ws.out6;
-                const Pixel px = depth_pixel(a.cfg, o[3 * HW + pix], o[4 * HW + pix], o[5 * HW + pix], a.frame.depth[pix]);
+                const Pixel px = depth_pixel(a.cfg, o[3 * HW + pix], o[4 * HW + pix], o[5 * HW + pix], a.frame.depth[pix], median);
                 Gout[3 * HW + pix] = a.cfg.use_l1 ? a.cfg.w_depth * px.d_sign / count : 0.f;
             }
         }
@@ -546,6 +552,9 @@ __global__ void adam_pose_kernel(SplatMap map, int time_idx, const float *d_cam,
 
 }  // namespace
 
+hipError_t launch_depth_error_median(const float *out6, const float *depth, float *err, uint32_t *scratch, int HW, int32_t *counts,
+                                     hipStream_t s);
+
 hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame,
                                      const SplatLossConfig &cfg, SplatIterWorkspace &ws, hipStream_t s) {
     FusedArgs a{cam, map, frame, cfg, ws, {}};
@@ -571,6 +580,12 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
     if (e != hipSuccess) return e;
     e = launch_render_forward_feat8(cam, ws.feat8, ws.st, ws.out6, sort_in_k6, s);
     if (e != hipSuccess) return e;
+    if (cfg.ignore_outlier_depth_loss) {
+        // torch.median of the depth error (exact radix selection, mapedit.hip) -> d_cam[13] (its bits through counts[4])
+        e = launch_depth_error_median(ws.out6, frame.depth, ws.outlier_err, ws.outlier_scratch, HW,
+                                      reinterpret_cast<int32_t *>(ws.d_cam) + 9, s);
+        if (e != hipSuccess) return e;
+    }
     if (cfg.tracking) {
         if (HW % 4 == 0) {
             const int blocks = min((HW / 4 + kBlock - 1) / kBlock, 2048);

@@ -429,6 +429,27 @@ int map_row_floats(const SplatMapStore &st) {
     return w;
 }
 
+// torch.median(|gt - d| * (gt > 0)) of one render (exact lower median, NaN if any NaN): err[HW] and the bits of the median
+// in counts[4].  Used by add_new_gaussians and by get_loss(ignore_outlier_depth_loss=True).
+hipError_t launch_depth_error_median(const float *out6, const float *depth, float *err, uint32_t *scratch, int HW, int32_t *counts,
+                                     hipStream_t s) {
+    SplatAddArgs a{};
+    a.out6 = out6;
+    a.depth = depth;
+    a.err = err;
+    a.scratch = scratch;
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(uint32_t) * kWBlocks, s);
+    if (e != hipSuccess || HW <= 0) return e;
+    const int sblocks = min((HW + kBlock - 1) / kBlock, 1024);
+    hipLaunchKernelGGL(depth_error_hist_kernel, dim3(sblocks), dim3(kBlock), 0, s, a, HW);
+    hipLaunchKernelGGL(select_bin_kernel, dim3(1), dim3(kBlock), 0, s, scratch, 2048, 11, 1, HW, counts);
+    hipLaunchKernelGGL(refine_hist_kernel, dim3(sblocks), dim3(kBlock), 0, s, a, HW, 21, 10, 2048);
+    hipLaunchKernelGGL(select_bin_kernel, dim3(1), dim3(kBlock), 0, s, scratch, 2048, 11, 0, HW, counts);
+    hipLaunchKernelGGL(refine_hist_kernel, dim3(sblocks), dim3(kBlock), 0, s, a, HW, 10, 0, 1024);
+    hipLaunchKernelGGL(select_bin_kernel, dim3(1), dim3(kBlock), 0, s, scratch, 1024, 10, 0, HW, counts);
+    return hipGetLastError();
+}
+
 hipError_t launch_map_add(const SplatMapStore &st, const SplatAddArgs &a, hipStream_t s) {
     const int HW = a.width * a.height;
     const int nblocks = (HW + kPerBlock - 1) / kPerBlock;
@@ -438,13 +459,8 @@ hipError_t launch_map_add(const SplatMapStore &st, const SplatAddArgs &a, hipStr
     if (e != hipSuccess) return e;
     if (HW > 0) {
         if (a.mode == SPLAT_ADD_NON_PRESENCE) {
-            const int sblocks = min((HW + kBlock - 1) / kBlock, 1024);
-            hipLaunchKernelGGL(depth_error_hist_kernel, dim3(sblocks), dim3(kBlock), 0, s, a, HW);
-            hipLaunchKernelGGL(select_bin_kernel, dim3(1), dim3(kBlock), 0, s, a.scratch, 2048, 11, 1, HW, st.counts);
-            hipLaunchKernelGGL(refine_hist_kernel, dim3(sblocks), dim3(kBlock), 0, s, a, HW, 21, 10, 2048);
-            hipLaunchKernelGGL(select_bin_kernel, dim3(1), dim3(kBlock), 0, s, a.scratch, 2048, 11, 0, HW, st.counts);
-            hipLaunchKernelGGL(refine_hist_kernel, dim3(sblocks), dim3(kBlock), 0, s, a, HW, 10, 0, 1024);
-            hipLaunchKernelGGL(select_bin_kernel, dim3(1), dim3(kBlock), 0, s, a.scratch, 1024, 10, 0, HW, st.counts);
+            e = launch_depth_error_median(a.out6, a.depth, a.err, a.scratch, HW, st.counts, s);
+            if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL(add_count_kernel, dim3(nblocks), dim3(kBlock), 0, s, a, HW, st.counts);
     }

@@ -6,9 +6,9 @@ and :828-869) as ~10 kernel launches of libsplat_hip.so with no host synchronisa
 render, loss gradients, Adam moments) and updates the caller's ``params`` tensors
 IN PLACE, exactly as ``torch.optim.Adam`` does for the reference.  Results are the
 same function of the same inputs as ``splatam_amd.slam.get_loss`` + autograd +
-``torch.optim.Adam`` (tests/test_gpu_fused.py); what no shipped config uses
-(``ignore_outlier_depth_loss``, densification from ``means2D.grad``) is not fused
-and raises, so that the caller keeps the two-call path for it.
+``torch.optim.Adam`` (tests/test_gpu_fused.py), for every argument of ``get_loss``
+(incl. ``ignore_outlier_depth_loss``: ``torch.median`` by exact radix selection); only
+the colour pass' own ``means2D.grad`` (gradient-based densification) is not produced.
 
 Everything is computed by the C ABI (include/splat_hip.h, "Fused SplaTAM
 iteration"); PyTorch only owns the memory and the stream.
@@ -386,6 +386,8 @@ class FusedEngine:
             ws.d_unnorm_rotations, ws.d_logit_opacities = g['unnorm_rotations'].data_ptr(), g['logit_opacities'].data_ptr()
             ws.d_log_scales = g['log_scales'].data_ptr()
         ws.d_cam = b['d_cam'].data_ptr()
+        if 'outlier_err' in b:
+            ws.outlier_err, ws.outlier_scratch = b['outlier_err'].data_ptr(), b['outlier_scratch'].data_ptr()
         return ws
 
     def _stream(self):
@@ -416,6 +418,10 @@ class FusedEngine:
         fr.im, fr.depth, fr.w2c, fr.time_idx = im.data_ptr(), depth.data_ptr(), w2c.data_ptr(), int(time_idx)
         self._frame_keep = (im, depth, w2c)
         lc = self.loss_config(cfg, tracking, do_ba)
+        if lc.ignore_outlier_depth_loss and 'outlier_err' not in self.buf:       # scratch of the median selection, on first use
+            self.buf['outlier_err'] = torch.empty(self.H * self.W, dtype=torch.float32, device=self.dev)
+            self.buf['outlier_scratch'] = torch.zeros(int(self.L.splat_map_scratch_words(self.H * self.W)), dtype=torch.int32,
+                                                      device=self.dev)
         ws = self._workspace(map_grads, with_ssim=not tracking)
         m = self._map_struct()
         with torch.cuda.device(self.dev):

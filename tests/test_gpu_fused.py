@@ -257,15 +257,25 @@ def test_list_overflow_is_flagged_not_fatal():
     assert np.isfinite(eng.loss()) and eng.loss() > 0
 
 
-def test_unsupported_configuration_raises():
-    from splatam_amd import slam
+def test_missing_outlier_scratch_is_an_invalid_argument():
+    """ignore_outlier_depth_loss needs its two scratch arrays at the C ABI (the engine allocates them on first use)."""
+    import ctypes as C
+    from splatam_amd import _capi, slam
     from splatam_amd.fused import FusedEngine
     params, variables, frame, cam = _scene(1000, 96, 64, seed=17)
     eng = FusedEngine(params, cam)
     cfg = copy.deepcopy(slam.REPLICA_TRACKING)
     cfg['ignore_outlier_depth_loss'] = True
-    with pytest.raises(RuntimeError, match="unsupported"):
-        eng.loss_backward(frame, 1, cfg, tracking=True)
+    lc = eng.loss_config(cfg, True)
+    ws = eng._workspace(False, with_ssim=False)            # no outlier scratch yet
+    fr = _capi.SplatFrameData()
+    fr.im, fr.depth, fr.w2c, fr.time_idx = frame['im'].data_ptr(), frame['depth'].data_ptr(), frame['w2c'].data_ptr(), 1
+    m = eng._map_struct()
+    rc = eng.L.splat_iter_loss_backward(C.byref(eng._cam), C.byref(m), C.byref(fr), C.byref(lc), C.byref(ws), eng._stream())
+    assert rc == 1
+    eng.loss_backward(frame, 1, cfg, tracking=True)        # the engine path allocates them
+    torch.cuda.synchronize()
+    assert np.isfinite(eng.loss())
 
 
 def test_edge_shapes_and_empty_map():
@@ -325,3 +335,43 @@ def test_stale_list_length_hint_is_flagged_and_memory_safe():
     assert not eng.check_overflow()
     assert abs(eng.loss() - good_loss) <= 1e-5 * abs(good_loss)
     _cmp(eng.grads['means3D'], good, "dL/dmeans3D after recovery", tol=1e-4)
+
+
+@pytest.mark.parametrize("tracking", [True, False])
+def test_ignore_outlier_depth_loss(tracking):
+    """get_loss(ignore_outlier_depth_loss=True): mask = (depth_error < 10 * depth_error.median()) & (gt_depth > 0)
+    (/root/reference/scripts/splatam.py:264-272).  The median is torch.median's, bit for bit (exact radix selection on the
+    device); loss and gradients match the reference-shaped path."""
+    import copy
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    params, variables, frame, cam = _scene(20000, 320, 240, seed=13)
+    frame['depth'] = frame['depth'].clone()
+    frame['depth'][:, 100:140, 60:140] *= 4.0                  # regions of gross depth outliers
+    frame['depth'][:, 10:20, 200:260] += 6.0
+    base = slam.REPLICA_TRACKING if tracking else slam.REPLICA_MAPPING
+    cfg = copy.deepcopy(_gap_threshold(params, frame, cam, base) if tracking else base)
+    cfg['ignore_outlier_depth_loss'] = True
+    loss_ref, g_ref = _reference_grads(params, variables, frame, cfg, tracking=tracking)
+    cfg_off = copy.deepcopy(cfg)
+    cfg_off['ignore_outlier_depth_loss'] = False
+    loss_off, _ = _reference_grads(params, variables, frame, cfg_off, tracking=tracking)
+    assert abs(loss_off - loss_ref) > 1e-2 * abs(loss_ref), (loss_off, loss_ref)    # the outliers matter in this scene
+    eng = FusedEngine(params, cam)
+    eng.loss_backward(frame, 1, cfg, tracking=tracking)
+    torch.cuda.synchronize()
+    assert not eng.check_overflow(grow=False)
+    _, depth, _, _ = eng.rendered()
+    gt = frame['depth']
+    med_ref = (torch.abs(gt - depth) * (gt > 0)).median()
+    assert float(eng.buf['d_cam'][13]) == float(med_ref)      # bit-exact on the engine's own render
+    assert abs(eng.loss() - loss_ref) <= 3e-4 * abs(loss_ref), (eng.loss(), loss_ref)
+    if tracking:
+        d = eng.buf['d_cam'].cpu().numpy()
+        gq = g_ref['cam_unnorm_rots'][0, :, 1].cpu().numpy()
+        gtr = g_ref['cam_trans'][0, :, 1].cpu().numpy()
+        assert np.abs(d[0:4] - gq).max() <= 3e-3 * np.abs(gq).max(), (d[0:4], gq)
+        assert np.abs(d[4:7] - gtr).max() <= 3e-3 * np.abs(gtr).max(), (d[4:7], gtr)
+    else:
+        for k in ("means3D", "rgb_colors", "logit_opacities", "log_scales"):
+            _cmp(eng.grads[k], g_ref[k], k)
