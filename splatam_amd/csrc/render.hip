@@ -202,6 +202,7 @@ __device__ __forceinline__ bool lane_of(unsigned long long m) { return __builtin
 // K6 forward composite
 // ---------------------------------------------------------------------------
 constexpr int kFusedSortMax = 1024;     // longest list the composite sorts itself (8 KiB of LDS)
+constexpr int kRankSortMax = 512;       // lists up to this length are rank sorted (into the upper half of those 8 KiB)
 
 // SORT: the workgroup first sorts its tile's (depth, id) keys in LDS (256-thread bitonic network, a few microseconds
 // next to ~35 us of compositing) and publishes the ids for the backward pass: no separate sort launch, and the
@@ -233,17 +234,47 @@ __global__ __launch_bounds__(256) void render_forward_kernel(SplatCamera cam, co
     unsigned lo;
     int n;
     tile_range(st, tile, lo, n);
+    const uint64_t *lk = SORT ? s_keys : nullptr;
     if constexpr (SORT) {
         if (n > kFusedSortMax) {        // the host's list-length hint was stale: flag it (the host repeats the iteration)
             if (tid == 0) st.status[3] = 1;
             n = kFusedSortMax;
         }
         for (int i = tid; i < n; i += 256) s_keys[i] = st.keys[lo + i];
-        __syncthreads();
-        if (n > 1) bitonic_sort(s_keys, n, tid, 256);
-        for (int i = tid; i < n; i += 256) st.point_list[lo + i] = (uint32_t)s_keys[i];
+        if (n <= kRankSortMax) {
+            // Short list (the normal case: ~220 entries at workload B): RANK sort.  Keys are unique, so the rank of a key
+            // -- the number of smaller keys -- is its sorted position: every thread counts it for its (at most two) keys
+            // against broadcast reads of the whole list, one barrier instead of the ~36 barrier-separated
+            // compare-exchange stages of the bitonic network.  Sorted keys go to the upper half of s_keys.
+            if (tid == 0 && (n & 1)) s_keys[n] = ~0ull;                  // pad to an even count
+            __syncthreads();
+            const uint64_t k0 = tid < n ? s_keys[tid] : ~0ull;
+            const uint64_t k1 = tid + 256 < n ? s_keys[tid + 256] : ~0ull;
+            unsigned r0 = 0, r1 = 0;
+            const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(s_keys);
+            const int np = (n + 1) >> 1;
+            if (n <= 256) {
+                for (int j = 0; j < np; ++j) {
+                    const ulonglong2 ab = pairs[j];
+                    r0 += (ab.x < k0 ? 1u : 0u) + (ab.y < k0 ? 1u : 0u);
+                }
+            } else {
+                for (int j = 0; j < np; ++j) {
+                    const ulonglong2 ab = pairs[j];
+                    r0 += (ab.x < k0 ? 1u : 0u) + (ab.y < k0 ? 1u : 0u);
+                    r1 += (ab.x < k1 ? 1u : 0u) + (ab.y < k1 ? 1u : 0u);
+                }
+            }
+            if (tid < n) s_keys[kRankSortMax + r0] = k0;
+            if (tid + 256 < n) s_keys[kRankSortMax + r1] = k1;
+            __syncthreads();
+            lk = s_keys + kRankSortMax;
+        } else {
+            __syncthreads();
+            bitonic_sort(s_keys, n, tid, 256);
+        }
+        for (int i = tid; i < n; i += 256) st.point_list[lo + i] = (uint32_t)lk[i];
     }
-    const uint64_t *lk = SORT ? s_keys : nullptr;
     const int nb = (n + kBatch - 1) / kBatch;
 
     if (nb > 0) {
