@@ -267,41 +267,68 @@ __global__ __launch_bounds__(kBlock) void ssim_forward_kernel(FusedArgs a, int W
         sy[r][c] = in ? Y[(size_t)yy * W + xx] : 0.f;
     }
     __syncthreads();
-    for (int k = tid; k < kHH_ * kTW; k += kBlock) {
-        const int r = k / kTW, c = k - r * kTW;
-        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    // horizontal pass: one thread per (halo row, group of 4 columns): 14 + 14 LDS reads feed 4 outputs x 5 statistics
+    if (tid < kHH_ * (kTW / 4)) {
+        const int r = tid / (kTW / 4), c0 = (tid - r * (kTW / 4)) * 4;
+        float xv[14], yv[14];
 #pragma unroll
-        for (int t = 0; t < 11; ++t) {
-            const float xv = sx[r][c + t], yv = sy[r][c + t], w = g[t];
-            m1 += w * xv; m2 += w * yv; e11 += w * xv * xv; e22 += w * yv * yv; e12 += w * xv * yv;
+        for (int t = 0; t < 14; ++t) { xv[t] = sx[r][c0 + t]; yv[t] = sy[r][c0 + t]; }
+        float o[5][4];
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[q][j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 14; ++t) {
+            const float xx = xv[t] * xv[t], yy = yv[t] * yv[t], xy = xv[t] * yv[t];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tap = t - j;
+                if (tap >= 0 && tap < 11) {
+                    const float w = g[tap];
+                    o[0][j] += w * xv[t]; o[1][j] += w * yv[t]; o[2][j] += w * xx; o[3][j] += w * yy; o[4][j] += w * xy;
+                }
+            }
         }
-        sh[0][r][c] = m1; sh[1][r][c] = m2; sh[2][r][c] = e11; sh[3][r][c] = e22; sh[4][r][c] = e12;
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sh[q][r][c0 + j] = o[q][j];
     }
     __syncthreads();
     const float median = a.cfg.ignore_outlier_depth_loss ? a.ws.d_cam[13] : 0.f;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};        // depth L1 (masked), image L1, mask count, SSIM map sum
     float *M = a.ws.ssim_maps + (size_t)(3 * ch) * HW;
+    // vertical pass: one thread per (column, pair of rows): 12 LDS reads per statistic feed 2 outputs
+    {
+        const int c = tid & (kTW - 1), r0 = (tid / kTW) * 2;
+        float v[2][5];
 #pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-        const int k = tid + rep * kBlock;
-        const int r = k / kTW, c = k - r * kTW;
-        const int yy = y0 + r, xx = x0 + c;
-        if (yy < H && xx < W) {
-            float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 5; ++q) { v[0][q] = 0.f; v[1][q] = 0.f; }
 #pragma unroll
-            for (int t = 0; t < 11; ++t)
+        for (int t = 0; t < 12; ++t)
 #pragma unroll
-                for (int q = 0; q < 5; ++q) v[q] += g[t] * sh[q][r + t][c];
-            float dmu1, de11, de12;
-            acc[3] += ssim_pixel(v[0], v[1], v[2], v[3], v[4], &dmu1, &de11, &de12);
-            const size_t pix = (size_t)yy * W + xx;
-            M[pix] = dmu1; M[HW + pix] = de11; M[2 * HW + pix] = de12;
-            acc[1] += fabsf(sx[r + kSsimR][c + kSsimR] - sy[r + kSsimR][c + kSsimR]);
-            if (ch == 0) {
-                const float *o = a.ws.out6;
-                const Pixel px = depth_pixel(a.cfg, o[3 * HW + pix], o[4 * HW + pix], o[5 * HW + pix], a.frame.depth[pix], median);
-                acc[0] += px.d_err;
-                acc[2] += px.mask ? 1.f : 0.f;
+            for (int q = 0; q < 5; ++q) {
+                const float val = sh[q][r0 + t][c];
+                if (t < 11) v[0][q] += g[t] * val;
+                if (t >= 1) v[1][q] += g[t - 1] * val;
+            }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = r0 + j;
+            const int yy = y0 + r, xx = x0 + c;
+            if (yy < H && xx < W) {
+                float dmu1, de11, de12;
+                acc[3] += ssim_pixel(v[j][0], v[j][1], v[j][2], v[j][3], v[j][4], &dmu1, &de11, &de12);
+                const size_t pix = (size_t)yy * W + xx;
+                M[pix] = dmu1; M[HW + pix] = de11; M[2 * HW + pix] = de12;
+                acc[1] += fabsf(sx[r + kSsimR][c + kSsimR] - sy[r + kSsimR][c + kSsimR]);
+                if (ch == 0) {
+                    const float *o = a.ws.out6;
+                    const Pixel px = depth_pixel(a.cfg, o[3 * HW + pix], o[4 * HW + pix], o[5 * HW + pix], a.frame.depth[pix], median);
+                    acc[0] += px.d_err;
+                    acc[2] += px.mask ? 1.f : 0.f;
+                }
             }
         }
     }
@@ -334,15 +361,26 @@ __global__ __launch_bounds__(kBlock) void map_loss_backward_kernel(FusedArgs a, 
         for (int q = 0; q < 3; ++q) sm[q][r][c] = in ? M[q * HW + pix] : 0.f;
     }
     __syncthreads();
-    for (int k = tid; k < kHH_ * kTW; k += kBlock) {
-        const int r = k / kTW, c = k - r * kTW;
-        float v[3] = {0.f, 0.f, 0.f};
+    if (tid < kHH_ * (kTW / 4)) {            // horizontal pass: (halo row, group of 4 columns) per thread
+        const int r = tid / (kTW / 4), c0 = (tid - r * (kTW / 4)) * 4;
+        float o[3][4];
 #pragma unroll
-        for (int t = 0; t < 11; ++t)
+        for (int q = 0; q < 3; ++q)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) v[q] += g[t] * sm[q][r][c + t];
+            for (int j = 0; j < 4; ++j) o[q][j] = 0.f;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) sh[q][r][c] = v[q];
+        for (int t = 0; t < 14; ++t) {
+            const float m0 = sm[0][r][c0 + t], m1 = sm[1][r][c0 + t], m2 = sm[2][r][c0 + t];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tap = t - j;
+                if (tap >= 0 && tap < 11) { o[0][j] += g[tap] * m0; o[1][j] += g[tap] * m1; o[2][j] += g[tap] * m2; }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sh[q][r][c0 + j] = o[q][j];
     }
     __syncthreads();
     const float inv_n = 1.0f / (3.0f * (float)HW);
@@ -350,25 +388,32 @@ __global__ __launch_bounds__(kBlock) void map_loss_backward_kernel(FusedArgs a, 
     const float count = s_count;            // written before the first __syncthreads above
     const float *X = a.ws.out6 + ch * HW, *Y = a.frame.im + ch * HW;
     float *Gout = a.ws.dL_dout6;
+    {                                        // vertical pass: (column, pair of rows) per thread
+        const int c = tid & (kTW - 1), r0 = (tid / kTW) * 2;
+        float v[2][3];
 #pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-        const int k = tid + rep * kBlock;
-        const int r = k / kTW, c = k - r * kTW;
-        const int yy = y0 + r, xx = x0 + c;
-        if (yy < H && xx < W) {
-            float v[3] = {0.f, 0.f, 0.f};
+        for (int q = 0; q < 3; ++q) { v[0][q] = 0.f; v[1][q] = 0.f; }
 #pragma unroll
-            for (int t = 0; t < 11; ++t)
+        for (int t = 0; t < 12; ++t)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) v[q] += g[t] * sh[q][r + t][c];
-            const size_t pix = (size_t)yy * W + xx;
-            const float xv = X[pix], yv = Y[pix];
-            const float dssim = v[0] + 2.f * xv * v[1] + yv * v[2];
-            Gout[ch * HW + pix] = a.cfg.w_im * (0.8f * sgn(xv - yv) * inv_n - 0.2f * inv_n * dssim);
-            if (ch == 0) {
-                const float *o = a.ws.out6;
-                const Pixel px = depth_pixel(a.cfg, o[3 * HW + pix], o[4 * HW + pix], o[5 * HW + pix], a.frame.depth[pix], median);
-                Gout[3 * HW + pix] = a.cfg.use_l1 ? a.cfg.w_depth * px.d_sign / count : 0.f;
+            for (int q = 0; q < 3; ++q) {
+                const float val = sh[q][r0 + t][c];
+                if (t < 11) v[0][q] += g[t] * val;
+                if (t >= 1) v[1][q] += g[t - 1] * val;
+            }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int yy = y0 + r0 + j, xx = x0 + c;
+            if (yy < H && xx < W) {
+                const size_t pix = (size_t)yy * W + xx;
+                const float xv = X[pix], yv = Y[pix];
+                const float dssim = v[j][0] + 2.f * xv * v[j][1] + yv * v[j][2];
+                Gout[ch * HW + pix] = a.cfg.w_im * (0.8f * sgn(xv - yv) * inv_n - 0.2f * inv_n * dssim);
+                if (ch == 0) {
+                    const float *o = a.ws.out6;
+                    const Pixel px = depth_pixel(a.cfg, o[3 * HW + pix], o[4 * HW + pix], o[5 * HW + pix], a.frame.depth[pix], median);
+                    Gout[3 * HW + pix] = a.cfg.use_l1 ? a.cfg.w_depth * px.d_sign / count : 0.f;
+                }
             }
         }
     }
