@@ -24,6 +24,8 @@ here                                           reference
 ``add_new_gaussians``                          scripts/splatam.py:378-420
 ``initialize_camera_pose``                     scripts/splatam.py:423-441
 ``remove_points`` / ``prune_gaussians``        utils/slam_external.py:139-188
+``accumulate_mean2d_gradient`` / ``densify``   utils/slam_external.py:100-104 / 191-240 (gradient-based densification of the
+                                               gaussian_splatting / post_splatam_opt configs; torch formulation only)
 =============================================  =============================================
 
 Differences are host-side only and do not change results: masked sums are
@@ -461,18 +463,90 @@ def prune_gaussians(params, variables, optimizer, iter, prune_dict):
                 to_remove = to_remove | (torch.exp(params['log_scales']).max(dim=1).values > 0.1 * variables['scene_radius'])
             params, variables = remove_points(to_remove, params, variables, optimizer)
         if iter > 0 and iter % prune_dict['reset_opacities_every'] == 0 and prune_dict['reset_opacities']:
-            group = next(g for g in optimizer.param_groups if g['name'] == 'logit_opacities')
-            old = group['params'][0]
-            state = optimizer.state.pop(old, None)
-            v = torch.full_like(old.detach(), math.log(0.01 / (1 - 0.01)))
-            new = torch.nn.Parameter(v.requires_grad_(True))
-            if state is not None:
-                state['exp_avg'] = torch.zeros_like(v)
-                state['exp_avg_sq'] = torch.zeros_like(v)
-                optimizer.state[new] = state
-            group['params'][0] = new
-            params['logit_opacities'] = new
+            params = _reset_opacities(params, optimizer)
     return params, variables
+
+
+def accumulate_mean2d_gradient(variables):
+    """Running sum of the screen-space gradient norm of the Gaussians seen by the last colour render."""
+    seen = variables['seen']
+    variables['means2D_gradient_accum'][seen] += torch.norm(variables['means2D'].grad[seen, :2], dim=-1)
+    variables['denom'][seen] += 1
+    return variables
+
+
+def _cat_rows(new_rows, params, optimizer):
+    """Append rows to the Gaussian parameters (and zero moments to the optimizer's state, where it has one)."""
+    for k, v in new_rows.items():
+        group = next(g for g in optimizer.param_groups if g['name'] == k)
+        old = group['params'][0]
+        state = optimizer.state.pop(old, None)
+        new = torch.nn.Parameter(torch.cat((old.detach(), v.detach()), dim=0).requires_grad_(True))
+        if state:
+            state['exp_avg'] = torch.cat((state['exp_avg'], torch.zeros_like(v)), dim=0)
+            state['exp_avg_sq'] = torch.cat((state['exp_avg_sq'], torch.zeros_like(v)), dim=0)
+            optimizer.state[new] = state
+        group['params'][0] = new
+        params[k] = new
+    return params
+
+
+def densify(params, variables, optimizer, iter, densify_dict):
+    """Gradient-based densification (3D Gaussian Splatting's): clone the small Gaussians with a large accumulated
+    screen-space gradient, split the large ones into ``num_to_split_into`` samples of themselves, then prune by opacity
+    and size; optional opacity reset.  Draws from the global torch RNG exactly where the reference does."""
+    if iter > densify_dict['stop_after']:
+        return params, variables
+    variables = accumulate_mean2d_gradient(variables)
+    thr = densify_dict['grad_thresh']
+    if iter >= densify_dict['start_after'] and iter % densify_dict['densify_every'] == 0:
+        grads = variables['means2D_gradient_accum'] / variables['denom']
+        grads[grads.isnan()] = 0.0
+        small = torch.exp(params['log_scales']).max(dim=1).values <= 0.01 * variables['scene_radius']
+        to_clone = (grads >= thr) & small
+        params = _cat_rows({k: params[k].detach()[to_clone] for k in GAUSSIAN_KEYS}, params, optimizer)
+        n_pts = params['means3D'].shape[0]
+        dev = params['means3D'].device
+        padded = torch.zeros(n_pts, device=dev)
+        padded[:grads.shape[0]] = grads
+        to_split = (padded >= thr) & (torch.exp(params['log_scales']).max(dim=1).values > 0.01 * variables['scene_radius'])
+        n = densify_dict['num_to_split_into']
+        rows = {k: params[k].detach()[to_split].repeat(n, 1) for k in GAUSSIAN_KEYS}
+        stds = torch.exp(params['log_scales'].detach())[to_split].repeat(n, 3)
+        samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=dev), std=stds)
+        rots = build_rotation(params['unnorm_rotations'].detach()[to_split]).repeat(n, 1, 1)
+        rows['means3D'] = rows['means3D'] + torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1)
+        rows['log_scales'] = torch.log(torch.exp(rows['log_scales']) / (0.8 * n))
+        params = _cat_rows(rows, params, optimizer)
+        n_pts = params['means3D'].shape[0]
+        for k in ('means2D_gradient_accum', 'denom', 'max_2D_radius'):
+            variables[k] = torch.zeros(n_pts, device=dev)
+        to_remove = torch.cat((to_split, torch.zeros(n * int(to_split.sum()), dtype=torch.bool, device=dev)))
+        params, variables = remove_points(to_remove, params, variables, optimizer)
+        op_thr = densify_dict['final_removal_opacity_threshold'] if iter == densify_dict['stop_after'] \
+            else densify_dict['removal_opacity_threshold']
+        to_remove = (torch.sigmoid(params['logit_opacities']) < op_thr).squeeze(-1)
+        if iter >= densify_dict['remove_big_after']:
+            to_remove = to_remove | (torch.exp(params['log_scales']).max(dim=1).values > 0.1 * variables['scene_radius'])
+        params, variables = remove_points(to_remove, params, variables, optimizer)
+    if iter > 0 and iter % densify_dict['reset_opacities_every'] == 0 and densify_dict['reset_opacities']:
+        params = _reset_opacities(params, optimizer)
+    return params, variables
+
+
+def _reset_opacities(params, optimizer):
+    group = next(g for g in optimizer.param_groups if g['name'] == 'logit_opacities')
+    old = group['params'][0]
+    state = optimizer.state.pop(old, None)
+    v = torch.full_like(old.detach(), math.log(0.01 / (1 - 0.01)))
+    new = torch.nn.Parameter(v.requires_grad_(True))
+    if state is not None:
+        state['exp_avg'] = torch.zeros_like(v)
+        state['exp_avg_sq'] = torch.zeros_like(v)
+        optimizer.state[new] = state
+    group['params'][0] = new
+    params['logit_opacities'] = new
+    return params
 
 
 REPLICA_PRUNE = dict(start_after=0, remove_big_after=0, stop_after=20, prune_every=20, removal_opacity_threshold=0.005,

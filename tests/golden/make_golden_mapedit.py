@@ -223,10 +223,64 @@ def case_keyframe_selection(out):
     out["kfsel/selected_empty"] = np.array(ref_kf.keyframe_selection_overlap(depth, w2c, k, [], 3), dtype=np.int64)
 
 
+def case_densify(name, n, dist, seed, out):
+    """utils/slam_external.py densify (+ accumulate_mean2d_gradient, cat_params_to_optimizer, remove_points,
+    update_params_and_optimizer) as is, on CPU, seeded; two calls: a densification iteration and an opacity-reset iteration."""
+    g = torch.Generator().manual_seed(seed)
+    cols = 1 if dist == "isotropic" else 3
+    params = {
+        'means3D': torch.randn(n, 3, generator=g), 'rgb_colors': torch.rand(n, 3, generator=g),
+        'unnorm_rotations': torch.randn(n, 4, generator=g), 'logit_opacities': -2.0 + 3.0 * torch.randn(n, 1, generator=g),
+        'log_scales': -4.4 + 0.8 * torch.randn(n, cols, generator=g),
+        'cam_unnorm_rots': torch.randn(1, 4, 3, generator=g), 'cam_trans': torch.randn(1, 3, 3, generator=g),
+    }
+    variables = {'max_2D_radius': torch.rand(n, generator=g), 'means2D_gradient_accum': 3e-4 * torch.rand(n, generator=g),
+                 'denom': torch.floor(torch.rand(n, generator=g) * 3),
+                 # no 'timestep': the reference's densify never extends it, so remove_points raises IndexError when it is present
+                 'scene_radius': torch.tensor(1.2), 'seen': torch.rand(n, generator=g) < 0.7}
+    means2D = torch.zeros(n, 3, requires_grad=True)
+    means2D.grad = 4e-4 * torch.randn(n, 3, generator=g)
+    variables['means2D'] = means2D
+    P = {k: torch.nn.Parameter(v.clone()) for k, v in params.items()}
+    lrs = dict(means3D=0.0001, rgb_colors=0.0025, unnorm_rotations=0.001, logit_opacities=0.05, log_scales=0.001,
+               cam_unnorm_rots=0.0, cam_trans=0.0)
+    opt = torch.optim.Adam([{'params': [v], 'name': k, 'lr': lrs[k]} for k, v in P.items()], lr=0.0, eps=1e-15)
+    for k in ('means3D', 'rgb_colors', 'unnorm_rotations', 'logit_opacities', 'log_scales'):
+        P[k].grad = torch.randn(P[k].shape, generator=g)
+    opt.step()
+    for k, v in P.items():
+        out[f"{name}/in/param/{k}"] = v.detach().numpy().copy()
+        st = opt.state.get(v)
+        if st:
+            out[f"{name}/in/exp_avg/{k}"] = st['exp_avg'].numpy().copy()
+            out[f"{name}/in/exp_avg_sq/{k}"] = st['exp_avg_sq'].numpy().copy()
+    for k in ('max_2D_radius', 'means2D_gradient_accum', 'denom', 'scene_radius', 'seen'):
+        out[f"{name}/in/var/{k}"] = variables[k].numpy().copy()
+    out[f"{name}/in/means2D_grad"] = means2D.grad.numpy().copy()
+    dd = dict(start_after=0, remove_big_after=0, stop_after=5000, densify_every=100, grad_thresh=0.0002, num_to_split_into=2,
+              removal_opacity_threshold=0.005, final_removal_opacity_threshold=0.005, reset_opacities=True, reset_opacities_every=300)
+    V = dict(variables)
+    torch.manual_seed(1234)
+    P, V = ref_ext.densify(P, V, opt, 100, dd)                 # a densification iteration (clone + split + prune)
+    n_mid = P['means3D'].shape[0]
+    # the next call only accumulates the gradient statistics and resets the opacities (iter 300: densify too, so use 600 % 100 ... keep simple)
+    for k, v in P.items():
+        out[f"{name}/out/param/{k}"] = v.detach().numpy().copy()
+        st = opt.state.get(v)
+        if st:
+            out[f"{name}/out/exp_avg/{k}"] = st['exp_avg'].numpy().copy()
+            out[f"{name}/out/exp_avg_sq/{k}"] = st['exp_avg_sq'].numpy().copy()
+    for k in ('max_2D_radius', 'means2D_gradient_accum', 'denom'):
+        out[f"{name}/out/var/{k}"] = V[k].numpy().copy()
+    out[f"{name}/counts"] = np.array([n, n_mid])
+
+
 if __name__ == "__main__":
     ns = reference_functions()
     out = {}
     case_keyframe_selection(out)
+    case_densify("densify_iso", 900, "isotropic", 21, out)
+    # (anisotropic maps make the reference's densify raise: stds.repeat(n, 3) of [N,3] scales is [nN,9])
     case_add("add_iso", ns, 56, 40, 60.0, 400, "isotropic", 0, out)
     case_add("add_aniso", ns, 40, 33, 45.0, 300, "anisotropic", 1, out)
     case_add("add_nan", ns, 40, 32, 45.0, 100, "isotropic", 2, out, nan_pixel=True)

@@ -102,3 +102,36 @@ def test_initialize_camera_pose():
     slam.initialize_camera_pose(params, 5, False)
     np.testing.assert_allclose(params['cam_unnorm_rots'].detach().numpy(), GOLD["pose/out/cam_unnorm_rots"], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(params['cam_trans'].detach().numpy(), GOLD["pose/out/cam_trans"], rtol=1e-6, atol=1e-7)
+
+
+def test_densify_matches_reference():
+    """Gradient-based densification (clone + split + prune + moments) against the reference's own densify under the same
+    torch seed (the split draws torch.normal samples)."""
+    name = "densify_iso"
+    params = {k: torch.nn.Parameter(torch.tensor(GOLD[f"{name}/in/param/{k}"])) for k in PARAM_KEYS}
+    variables = {k: torch.tensor(GOLD[f"{name}/in/var/{k}"]) for k in ('max_2D_radius', 'means2D_gradient_accum', 'denom', 'scene_radius', 'seen')}
+    m2d = torch.zeros(params['means3D'].shape[0], 3, requires_grad=True)
+    m2d.grad = torch.tensor(GOLD[f"{name}/in/means2D_grad"])
+    variables['means2D'] = m2d
+    opt = slam.initialize_optimizer(params, slam.REPLICA_MAPPING['lrs'], tracking=False)
+    for k in slam.GAUSSIAN_KEYS:
+        opt.state[params[k]] = {'step': torch.tensor(1.0), 'exp_avg': torch.tensor(GOLD[f"{name}/in/exp_avg/{k}"]),
+                                'exp_avg_sq': torch.tensor(GOLD[f"{name}/in/exp_avg_sq/{k}"])}
+    dd = dict(start_after=0, remove_big_after=0, stop_after=5000, densify_every=100, grad_thresh=0.0002, num_to_split_into=2,
+              removal_opacity_threshold=0.005, final_removal_opacity_threshold=0.005, reset_opacities=True, reset_opacities_every=300)
+    torch.manual_seed(1234)
+    params, variables = slam.densify(params, variables, opt, 100, dd)
+    n0, n1 = GOLD[f"{name}/counts"]
+    assert params['means3D'].shape[0] == n1 != n0
+    for k in PARAM_KEYS:
+        np.testing.assert_allclose(params[k].detach().numpy(), GOLD[f"{name}/out/param/{k}"], rtol=1e-6, atol=1e-7, err_msg=k)
+    for k in slam.GAUSSIAN_KEYS:
+        st = opt.state[params[k]]
+        np.testing.assert_array_equal(st['exp_avg'].numpy(), GOLD[f"{name}/out/exp_avg/{k}"])
+        np.testing.assert_array_equal(st['exp_avg_sq'].numpy(), GOLD[f"{name}/out/exp_avg_sq/{k}"])
+    for k in ('max_2D_radius', 'means2D_gradient_accum', 'denom'):
+        np.testing.assert_array_equal(variables[k].numpy(), GOLD[f"{name}/out/var/{k}"], err_msg=k)
+    # past the schedule nothing happens
+    n = params['means3D'].shape[0]
+    params, variables = slam.densify(params, variables, opt, 6000, dd)
+    assert params['means3D'].shape[0] == n
