@@ -360,11 +360,12 @@ typedef struct SplatPruneArgs {
     float big_scale;             /* 0.1 * variables['scene_radius'] */
     const uint8_t *to_remove;    /* [P] caller-supplied flags (remove_points); NULL = form them from the two rules above */
     uint8_t *flags;              /* scratch [capacity] */
-    float *stage;                /* scratch: capacity * splat_map_row_floats(store) floats */
+    float *stage;                /* scratch: ((capacity + 3) & ~3) * splat_map_row_floats(store) floats */
     uint32_t *scratch;           /* splat_map_scratch_words(capacity) words */
 } SplatPruneArgs;
 
-/* floats per row over every non-NULL array of the store (the staging buffer of a prune holds capacity * this) */
+/* floats per row over every non-NULL array of the store (the staging buffer of a prune holds capacity, rounded up to a
+ * multiple of 4, times this) */
 int32_t splat_map_row_floats(const SplatMapStore *store);
 
 /* prune_gaussians' removal rule + remove_points (/root/reference/utils/slam_external.py:139-188): stable compaction of

@@ -405,7 +405,7 @@ MapArrays map_arrays(const SplatMapStore &st) {
         a.ptr[a.n] = p;
         a.width[a.n] = w;
         a.stage_off[a.n] = off;
-        off += (long long)st.capacity * w;
+        off += (long long)((st.capacity + 3) & ~3) * w;      // regions start 16-byte aligned
         ++a.n;
     };
     for (int g = 0; g < 5; ++g) push(params[g], width[g]);

@@ -286,6 +286,8 @@ class FusedEngine:
         """remove_points (/root/reference/utils/slam_external.py:139-162): stable in-place compaction of parameters,
         Adam moments and per-Gaussian variables.  ``to_remove``: bool[P], or None to form the flags on the device from
         prune_gaussians' two rules.  Returns the number removed."""
+        if not self.managed:
+            raise RuntimeError("this FusedEngine was built without gaussian_capacity: rows cannot be removed")
         if self.P == 0:
             return 0
         a = _capi.SplatPruneArgs()
@@ -299,7 +301,7 @@ class FusedEngine:
         if 'flags' not in b:
             b['flags'] = torch.empty(self.Pcap, dtype=torch.uint8, device=self.dev)
         st = self._store_struct(with_moments=True)
-        need = self.Pcap * int(self.L.splat_map_row_floats(C.byref(st)))
+        need = ((self.Pcap + 3) // 4 * 4) * int(self.L.splat_map_row_floats(C.byref(st)))
         if 'stage' not in b or b['stage'].numel() < need:
             b['stage'] = torch.empty(need, dtype=torch.float32, device=self.dev)
         a.flags, a.stage = b['flags'].data_ptr(), b['stage'].data_ptr()
@@ -308,8 +310,6 @@ class FusedEngine:
             _capi.check(self.L.splat_map_prune(C.byref(st), C.byref(a), self._stream()), "splat_map_prune")
         counts = b['counts'].tolist()
         if counts[1]:
-            if not self.managed:
-                raise RuntimeError("this FusedEngine was built without gaussian_capacity: rows cannot be removed")
             self._set_rows(counts[0])
         return counts[1]
 
@@ -320,7 +320,8 @@ class FusedEngine:
             if iter >= prune_dict['start_after'] and iter % prune_dict['prune_every'] == 0:
                 thr = prune_dict['final_removal_opacity_threshold'] if iter == prune_dict['stop_after'] \
                     else prune_dict['removal_opacity_threshold']
-                big = 0.1 * float(scene_radius) if iter >= prune_dict['remove_big_after'] else None
+                # 0.1 * variables['scene_radius'] as the reference forms it (a float32 tensor product when given a tensor)
+                big = float(0.1 * scene_radius) if iter >= prune_dict['remove_big_after'] else None
                 removed = self.remove_points(None, thr, big)
             if iter > 0 and iter % prune_dict['reset_opacities_every'] == 0 and prune_dict['reset_opacities']:
                 with torch.no_grad():
