@@ -268,10 +268,12 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
         t0 = time.perf_counter()
         if time_idx > 0 and not tcfg['use_gt_poses']:
             pose0 = (params['cam_unnorm_rots'].detach()[..., time_idx].clone(), params['cam_trans'].detach()[..., time_idx].clone())
-            for attempt in range(2):
+            for attempt in range(3):
                 n_track = _track_frame(params, variables, curr_data, time_idx, tcfg, eng)
                 if not fused or not eng.check_overflow():
                     break
+                if attempt == 2:
+                    raise RuntimeError(f"frame {time_idx}: the per-tile lists overflowed three times in a row")
                 # a tile list overflowed its bucket: the engine has re-sized / gone back to exact lists; redo the frame
                 stats['redone_frames'] += 1
                 with torch.no_grad():
@@ -307,11 +309,13 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
                 snap = {k: eng.store[k][:eng.P].clone() for k in slam.GAUSSIAN_KEYS}
                 snap_vars = {k: eng.store[k][:eng.P].clone() for k in ('max_2D_radius', 'means2D_gradient_accum', 'denom', 'timestep')}
                 rng_state = np.random.get_state()
-            for attempt in range(2):
+            for attempt in range(3):
                 _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, mcfg, eng,
                            scene_radius if fused else None)
                 if not fused or not eng.check_overflow():
                     break
+                if attempt == 2:
+                    raise RuntimeError(f"frame {time_idx}: the per-tile lists overflowed three times in a row")
                 stats['redone_frames'] += 1
                 np.random.set_state(rng_state)
                 eng._set_rows(snap['means3D'].shape[0])
