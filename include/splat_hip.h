@@ -374,7 +374,8 @@ int splat_map_prune(SplatMapStore *store, const SplatPruneArgs *args, void *stre
 
 /* Developer switches used by scripts/ (never by the product path): key 0 = skip the per-tile
  * count atomics of K1 (timing experiment; results are then invalid); key 1 = generation of the composite kernels
- * (3 = current, 2 = previous, 3-channel calls only; A/B timing).  Returns the previous value. */
+ * (3 = current, 2 = previous, 3-channel calls only, 4 = experiment; A/B timing); key 2 = list entries per loop trip of the
+ * backward composite (2 = current, 1 = previous).  Returns the previous value. */
 int splat_debug_option(int key, int value);
 
 #ifdef __cplusplus

@@ -354,13 +354,17 @@ constexpr int nth_set_bit(unsigned m, int n) {      // index of the n-th (0-base
     }
 }
 
-template <int C, int CS, unsigned DMASK, unsigned SMASK>
+// NE: list entries per loop trip.  With NE = 2 the 2 x NV partial sums of two consecutive entries are reduced together
+// (2 x 10 sums = five full packed groups instead of 2 x 3 padded ones; 2 x 7 = four instead of 2 x 2), leave the wave in
+// ONE atomic instruction (two accumulator lines) and share the scalar loop overhead.
+template <int C, int CS, unsigned DMASK, unsigned SMASK, int NE>
 __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, const float *colors, SplatState st,
                                                               const float *dL_dcolor, float *accum, int T, int per_xcd) {
     constexpr int FP = (C + 3) / 4 * 4;
     constexpr int NS = popcount_c(SMASK);
     constexpr int NV = 6 + NS;                // partial sums per Gaussian
-    constexpr int NG = (NV + 3) / 4;          // packed reduction groups
+    constexpr int NVT = NE * NV;              // partial sums per loop trip
+    constexpr int NG = (NVT + 3) / 4;         // packed reduction groups per loop trip
     __shared__ Batch<FP> B;
     __shared__ unsigned s_wmax[4];
     const int tile = block_tile(per_xcd, T);
@@ -406,16 +410,20 @@ __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, c
     // carries (scripts/micro/atomic_bench.hip): one instruction per visit instead of one per group cuts the kernel's
     // 2.9 M line-requests per launch to 0.97 M.
     const int pub_g = lane & 15;
-    int doff = -1;
+    int doff = -1;                            // accumulator slot this lane publishes
+    int pub_e = 0;                            // ... of which entry of the trip
 #pragma unroll
     for (int grp = 0; grp < NG; ++grp)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int k = 4 * grp + row_value(r);
-            const int slot = k < 6 ? k : (k < NV ? 6 + nth_set_bit(SMASK, k - 6 < 0 ? 0 : k - 6) : -1);
-            if (pub_g == grp && (lane >> 4) == r) doff = slot;
+            const int kt = 4 * grp + row_value(r);          // index into the trip's NVT sums
+            const int ent = kt / NV, k = kt - ent * NV;
+            const int slot = kt >= NVT ? -1 : (k < 6 ? k : 6 + nth_set_bit(SMASK, k - 6 < 0 ? 0 : k - 6));
+            if (pub_g == grp && (lane >> 4) == r) { doff = slot; pub_e = ent; }
         }
-    const unsigned long long pub_m = __builtin_amdgcn_ballot_w64(doff >= 0);
+    unsigned long long pub_m[NE];             // publishing lanes of each entry
+#pragma unroll
+    for (int t = 0; t < NE; ++t) pub_m[t] = __builtin_amdgcn_ballot_w64(doff >= 0 && pub_e == t);
 
     Staged<FP> pre;
     {
@@ -437,19 +445,31 @@ __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, c
             unsigned long long bits = mask_word(B, wave, w);
             if (k < 64) bits &= (1ull << k) - 1ull;
             while (bits != 0) {
-                const int j = 63 - __builtin_clzll(bits);
-                bits &= ~(1ull << j);
-                const int e = w * 64 + j;
-                Entry<FP> cur;
-                read_entry(B, e, cur);
-                const unsigned pos = (unsigned)(base + e + 1);
-                const float dx = cur.mux - fpx, dy = cur.muy - fpy;
-                const float p2 = dx * (cur.ga.x * dx + cur.ga.y * dy) + cur.ga.z * dy * dy;
-                const float G = fast_exp2(p2);
-                const float alpha = fminf(kAlphaMax, cur.ga.w * G);
-                const unsigned long long live_m = __builtin_amdgcn_ballot_w64(pos <= last) & __builtin_amdgcn_ballot_w64(p2 <= 0.f) &
-                                                  __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin);
-                if (live_m != 0) {
+                float s[NG * 4];
+                unsigned ids[NE];
+                unsigned long long any_m = 0, exec_m = 0;
+#pragma unroll
+                for (int v = 0; v < NG * 4; ++v) s[v] = 0.f;
+#pragma unroll
+                for (int t = 0; t < NE; ++t) {
+                    ids[t] = 0;
+                    if (bits == 0) continue;                    // odd number of entries: the second half of the trip is empty
+                    const int j = 63 - __builtin_clzll(bits);
+                    bits &= ~(1ull << j);
+                    const int e = w * 64 + j;
+                    Entry<FP> cur;
+                    read_entry(B, e, cur);
+                    ids[t] = cur.id;
+                    const unsigned pos = (unsigned)(base + e + 1);
+                    const float dx = cur.mux - fpx, dy = cur.muy - fpy;
+                    const float p2 = dx * (cur.ga.x * dx + cur.ga.y * dy) + cur.ga.z * dy * dy;
+                    const float G = fast_exp2(p2);
+                    const float alpha = fminf(kAlphaMax, cur.ga.w * G);
+                    const unsigned long long live_m = __builtin_amdgcn_ballot_w64(pos <= last) & __builtin_amdgcn_ballot_w64(p2 <= 0.f) &
+                                                      __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin);
+                    if (live_m == 0) continue;
+                    any_m |= live_m;
+                    exec_m |= pub_m[t];
                     const bool live = lane_of(live_m);
                     const float rcp = __builtin_amdgcn_rcpf(1.f - alpha);
                     const float Tn = Tr * rcp;                     // transmittance in front of this Gaussian
@@ -466,24 +486,24 @@ __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, c
                     const float q = live ? cur.ga.w * dL_dalpha : 0.f;   // dL/dG
                     const float gdx = Gl * dx, gdy = Gl * dy;
                     const float qgx = q * gdx, qgy = q * gdy;
-                    float s[NG * 4];
+                    float *sv = s + t * NV;
+                    sv[0] = qgx;
+                    sv[1] = qgy;
+                    sv[2] = qgx * dx;
+                    sv[3] = qgx * dy;
+                    sv[4] = qgy * dy;
+                    sv[5] = Gl * dL_dalpha;
 #pragma unroll
-                    for (int v = NV; v < NG * 4; ++v) s[v] = 0.f;
-                    s[0] = qgx;
-                    s[1] = qgy;
-                    s[2] = qgx * dx;
-                    s[3] = qgx * dy;
-                    s[4] = qgy * dy;
-                    s[5] = Gl * dL_dalpha;
-#pragma unroll
-                    for (int n = 0; n < NS; ++n) s[6 + n] = wgt * dpix[nth_set_bit(SMASK, n)];
+                    for (int n = 0; n < NS; ++n) sv[6 + n] = wgt * dpix[nth_set_bit(SMASK, n)];
                     Tr = live ? Tn : Tr;
                     behind = live ? bh : behind;
                     lcdot = live ? cdot : lcdot;
                     lalpha = live ? alpha : lalpha;
-                    // all packed reductions first (independent chains interleave), then one publish region
+                }
+                if (any_m != 0) {
+                    // all packed reductions first (independent chains interleave), then one publish
                     // (timing ablation, round 1: without the atomics -11..-23 us, without the cross-lane reduction -40..-60 us,
-                    //  without both -100..-120 us of ~245 us per launch: scripts/ablate_backward.py at commit "ablation")
+                    //  without both -100..-120 us of ~245 us per launch)
                     float r[NG];
 #pragma unroll
                     for (int grp = 0; grp < NG; ++grp)
@@ -491,7 +511,9 @@ __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, c
                     float pv = r[0];
 #pragma unroll
                     for (int grp = 1; grp < NG; ++grp) pv = pub_g == grp ? r[grp] : pv;
-                    if (lane_of(pub_m)) atomicAdd(accum + (size_t)cur.id * SPLAT_GRAD_STRIDE + doff, pv);
+                    unsigned id = ids[0];
+                    if constexpr (NE > 1) id = pub_e == 1 ? ids[1] : ids[0];
+                    if (lane_of(exec_m)) atomicAdd(accum + (size_t)id * SPLAT_GRAD_STRIDE + doff, pv);
                 }
             }
         }
@@ -506,11 +528,19 @@ static void launch_fwd(const SplatCamera &cam, const float *colors, SplatState &
     const int per = (T + 7) / 8;
     hipLaunchKernelGGL((render_forward_kernel<C, CS, WITH_DEPTH, SORT>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, oc, od, T, per);
 }
+int g_debug_entries_per_trip = 2;      // splat_debug_option(2, v): 1 = always one list entry per loop trip of K7 (A/B timing)
 template <int C, int CS, unsigned DMASK = (1u << C) - 1u, unsigned SMASK = (1u << C) - 1u>
 static void launch_bwd(const SplatCamera &cam, const float *colors, const SplatState &st, const float *dl, float *acc, int T,
                        hipStream_t s) {
     const int per = (T + 7) / 8;
-    hipLaunchKernelGGL((render_backward_kernel<C, CS, DMASK, SMASK>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
+    // two entries per trip pay when they save a packed reduction group: 2 x 10 sums -> 5 groups instead of 6 (mapping form:
+    // 207 -> 187 us at B); with 2 x 7 sums (tracking form) there is nothing to save and the pair bookkeeping costs 5 %
+    constexpr int NV = 6 + popcount_c(SMASK);
+    constexpr bool kPairPays = (2 * NV + 3) / 4 < 2 * ((NV + 3) / 4);
+    if (kPairPays && g_debug_entries_per_trip != 1)
+        hipLaunchKernelGGL((render_backward_kernel<C, CS, DMASK, SMASK, 2>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
+    else
+        hipLaunchKernelGGL((render_backward_kernel<C, CS, DMASK, SMASK, 1>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
 }
 
 static const float *colour_source(const SplatGaussians &g, const SplatState &st) {
