@@ -623,7 +623,11 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
     const bool sort_in_k6 = ws.st.max_list_hint > 0 && ws.st.max_list_hint + ws.st.max_list_hint / 4 <= 1024;
     e = launch_bin_forward(cam, g, ws.st, s, !sort_in_k6);
     if (e != hipSuccess) return e;
-    e = launch_render_forward_feat8(cam, ws.feat8, ws.st, ws.out6, sort_in_k6, s);
+    // tracking without outlier rejection: the loss and its gradient planes are formed in the composite's epilogue
+    TrackLossEpilogue ep{frame.im, frame.depth, ws.dL_dout6, ws.sums, cfg.sil_thres, cfg.w_im, cfg.w_depth, cfg.use_sil_for_loss, cfg.use_l1};
+    bool loss_done = false;
+    const bool fuse_loss = cfg.tracking && !cfg.ignore_outlier_depth_loss;
+    e = launch_render_forward_feat8(cam, ws.feat8, ws.st, ws.out6, sort_in_k6, s, fuse_loss ? &ep : nullptr, fuse_loss ? &loss_done : nullptr);
     if (e != hipSuccess) return e;
     if (cfg.ignore_outlier_depth_loss) {
         // torch.median of the depth error (exact radix selection, mapedit.hip) -> d_cam[13] (its bits through counts[4])
@@ -631,7 +635,9 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
                                       reinterpret_cast<int32_t *>(ws.d_cam) + 9, s);
         if (e != hipSuccess) return e;
     }
-    if (cfg.tracking) {
+    if (cfg.tracking && loss_done) {
+        // nothing: see the epilogue above
+    } else if (cfg.tracking) {
         if (HW % 4 == 0) {
             const int blocks = min((HW / 4 + kBlock - 1) / kBlock, 2048);
             hipLaunchKernelGGL(track_loss_kernel<4>, dim3(blocks), dim3(kBlock), 0, s, a, HW);

@@ -207,9 +207,11 @@ constexpr int kRankSortMax = 512;       // lists up to this length are rank sort
 // SORT: the workgroup first sorts its tile's (depth, id) keys in LDS (256-thread bitonic network, a few microseconds
 // next to ~35 us of compositing) and publishes the ids for the backward pass: no separate sort launch, and the
 // gathers take their ids from LDS instead of a dependent global load.
-template <int C, int CS, bool WITH_DEPTH, bool SORT>
+template <int C, int CS, bool WITH_DEPTH, bool SORT, bool TRACK = false>
 __global__ __launch_bounds__(256) void render_forward_kernel(SplatCamera cam, const float *colors, SplatState st,
-                                                             float *out_color, float *out_depth, int T, int per_xcd) {
+                                                             float *out_color, float *out_depth, int T, int per_xcd,
+                                                             TrackLossEpilogue ep = TrackLossEpilogue{}) {
+    static_assert(!TRACK || (C == 6 && !WITH_DEPTH), "the tracking-loss epilogue reads the six fused channels");
     constexpr int F = C + (WITH_DEPTH ? 1 : 0);
     constexpr int FP = (F + 3) / 4 * 4;
     __shared__ Batch<FP> B;
@@ -327,14 +329,49 @@ __global__ __launch_bounds__(256) void render_forward_kernel(SplatCamera cam, co
             }
         }
     }
+    float acc_depth = 0.f, acc_im = 0.f;
     if (inside) {
         const size_t HW = (size_t)H * W;
         const size_t pix = (size_t)py * W + px;
         st.final_T[pix] = Tr;
         st.n_contrib[pix] = (int)last;
+        float o[C];
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) out_color[ch * HW + pix] = Cc[ch] + Tr * cam.bg[ch];
+        for (int ch = 0; ch < C; ++ch) {
+            o[ch] = Cc[ch] + Tr * cam.bg[ch];
+            out_color[ch * HW + pix] = o[ch];
+        }
         if constexpr (WITH_DEPTH) out_depth[pix] = D;
+        if constexpr (TRACK) {
+            // channels: r, g, b, depth, silhouette, depth^2; mask = (gt > 0) & ~isnan(depth) & ~isnan(uncertainty) [& sil > thres]
+            const float gt = ep.depth[pix];
+            const float unc = o[5] - o[3] * o[3];
+            bool m = gt > 0.f && !(o[3] != o[3]) && !(unc != unc);
+            if (ep.use_sil_for_loss) m = m && (o[4] > ep.sil_thres);
+            const float dd = gt - o[3];
+            acc_depth = m ? fabsf(dd) : 0.f;
+            const float dsign = m ? ((dd > 0.f) ? -1.f : ((dd < 0.f) ? 1.f : 0.f)) : 0.f;
+            ep.dL_dout6[3 * HW + pix] = ep.use_l1 ? ep.w_depth * dsign : 0.f;
+            const bool cm = ep.use_sil_for_loss ? m : true;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float di = ep.im[ch * HW + pix] - o[ch];
+                acc_im += cm ? fabsf(di) : 0.f;
+                ep.dL_dout6[ch * HW + pix] = cm ? -ep.w_im * ((di > 0.f) ? 1.f : ((di < 0.f) ? -1.f : 0.f)) : 0.f;
+            }
+        }
+    }
+    if constexpr (TRACK) {
+        // workgroup sums -> one of the SPLAT_ITER_SUM_COPIES copies of the partial sums (double atomics)
+        __shared__ double s_loss[2][4];
+        float a0 = acc_depth, a1 = acc_im;
+        for (int msk = 32; msk >= 1; msk >>= 1) { a0 += __shfl_xor(a0, msk, 64); a1 += __shfl_xor(a1, msk, 64); }
+        if (lane == 0) { s_loss[0][wave] = (double)a0; s_loss[1][wave] = (double)a1; }
+        __syncthreads();
+        if (tid < 2) {
+            const double t = s_loss[tid][0] + s_loss[tid][1] + s_loss[tid][2] + s_loss[tid][3];
+            if (t != 0.0) atomicAdd(ep.sums + (size_t)(blockIdx.x % SPLAT_ITER_SUM_COPIES) * SPLAT_ITER_SUMS + tid, t);
+        }
     }
 }
 
@@ -526,7 +563,8 @@ __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, c
 template <int C, int CS, bool WITH_DEPTH, bool SORT = false>
 static void launch_fwd(const SplatCamera &cam, const float *colors, SplatState &st, float *oc, float *od, int T, hipStream_t s) {
     const int per = (T + 7) / 8;
-    hipLaunchKernelGGL((render_forward_kernel<C, CS, WITH_DEPTH, SORT>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, oc, od, T, per);
+    hipLaunchKernelGGL((render_forward_kernel<C, CS, WITH_DEPTH, SORT, false>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, oc, od, T, per,
+                       TrackLossEpilogue{});
 }
 int g_debug_entries_per_trip = 2;      // splat_debug_option(2, v): 1 = always one list entry per loop trip of K7 (A/B timing)
 template <int C, int CS, unsigned DMASK = (1u << C) - 1u, unsigned SMASK = (1u << C) - 1u>
@@ -593,10 +631,22 @@ hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &
 
 // Fused-iteration path (fused.hip): 6 channels (r, g, b, z, 1, z^2) read from 8-float records, no separate depth plane.
 hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat8, SplatState &st, float *out6, bool sort_in_kernel,
-                                       hipStream_t s) {
+                                       hipStream_t s, const TrackLossEpilogue *ep, bool *ep_done) {
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
+    if (ep_done) *ep_done = false;
     if (T == 0) return hipSuccess;
     if (g_debug_composite_version == 4) return launch_render_forward_feat8_v4(cam, feat8, st, out6, sort_in_kernel, s);
+    const int per = (T + 7) / 8;
+    if (ep && ep_done) {
+        if (sort_in_kernel)
+            hipLaunchKernelGGL((render_forward_kernel<6, 8, false, true, true>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6,
+                               (float *)nullptr, T, per, *ep);
+        else
+            hipLaunchKernelGGL((render_forward_kernel<6, 8, false, false, true>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6,
+                               (float *)nullptr, T, per, *ep);
+        *ep_done = true;
+        return hipGetLastError();
+    }
     if (sort_in_kernel) launch_fwd<6, 8, false, true>(cam, feat8, st, out6, nullptr, T, s);
     else launch_fwd<6, 8, false, false>(cam, feat8, st, out6, nullptr, T, s);
     return hipGetLastError();

@@ -26,8 +26,20 @@ hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &
 hipError_t launch_preprocess_backward(const SplatCamera &cam, const SplatGaussians &g, const SplatState &st,
                                       SplatGrads &gr, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
+// Optional epilogue of the 6-channel forward composite for the fused TRACKING iteration: the masked L1 losses of get_loss
+// (/root/reference/scripts/splatam.py:256-286, tracking=True, no outlier rejection) and their gradient planes, formed from
+// the pixel's six channels while they are still in registers (saves the separate loss kernel and its re-read of six planes).
+struct TrackLossEpilogue {
+    const float *im;        // [3][H][W] curr_data['im']
+    const float *depth;     // [1][H][W] curr_data['depth']
+    float *dL_dout6;        // [6][H][W]: planes 0..3 are written
+    double *sums;           // [SPLAT_ITER_SUM_COPIES][SPLAT_ITER_SUMS]: [0] += masked depth L1, [1] += (masked) image L1
+    float sil_thres, w_im, w_depth;
+    int use_sil_for_loss, use_l1;
+};
+// *ep_done tells the caller whether the epilogue ran (generation-3 kernels) or the separate loss kernel is still needed.
 hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat8, SplatState &st, float *out6, bool sort_in_kernel,
-                                       hipStream_t s);
+                                       hipStream_t s, const TrackLossEpilogue *ep = nullptr, bool *ep_done = nullptr);
 hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *feat8, const SplatState &st, const float *dL_dout6,
                                         float *accum, int P, bool zero_accum, bool rgb_sums, hipStream_t s);
 hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame,
