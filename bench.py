@@ -209,9 +209,9 @@ def fused_roofline(eng, frames, shape, dev):
 
 # HBM bytes per launch of the dominant kernels from the most recent rocprofv3 --pmc passes (profiles/r01_*_pmc*.txt), corrected
 # as /opt/skills/guides/MI355X_MICROARCH.md prescribes (FETCH_SIZE in KiB reads 1/2 of wide streaming reads on gfx950 -> x2).
-PMC_TRAFFIC = {     # profiles/r01_v5_fused_pmc_kernels.txt: (2 * FETCH_SIZE + WRITE_SIZE) KiB * 1024, bytes per launch at workload B
-    "render_backward": int((2 * 66.04e3 + 63.41e3) * 1024),     # render_backward_kernel<6,8,15,15>
-    "render_forward": int((2 * 58.28e3 + 27.02e3) * 1024),      # render_forward_kernel<6,8,false,*>
+PMC_TRAFFIC = {     # profiles/r01_v7_fused_pmc_kernels.txt: (2 * FETCH_SIZE + WRITE_SIZE) KiB * 1024, bytes per launch at workload B
+    "render_backward": int((2 * 66.60e3 + 63.41e3) * 1024),     # render_backward_kernel<6,8,15,15,2>
+    "render_forward": int((2 * 58.76e3 + 27.05e3) * 1024),      # render_forward_kernel<6,8,false,*,false>
 }
 
 
