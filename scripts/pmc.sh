@@ -15,14 +15,15 @@ pass() {
   echo "## pass $name: $*" >> $out
   if [ -z "$f" ]; then echo "no counter file; log tail:" >> $out; tail -5 /tmp/pmc_$name.log >> $out; return; fi
   python - "$f" >> $out <<'PY'
-import csv, sys, collections
+import csv, sys, collections, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     k = r.get('Kernel_Name', '')
     if 'splat' not in k:
         continue
-    acc[k.split('(')[0][-48:]][r['Counter_Name']].append(float(r['Counter_Value']))
+    m = re.search(r'([A-Za-z_0-9]+_kernel(?:<[^>]*>)?)', k)
+    acc[m.group(1) if m else k[:56]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in acc.items():
     print(k, ' '.join(f"{c}={sum(v)/len(v):.4g}" for c, v in sorted(d.items())), f"(n={len(next(iter(d.values())))})")
 PY
