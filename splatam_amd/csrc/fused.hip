@@ -466,7 +466,10 @@ __global__ __launch_bounds__(kBlock) void fused_backward_kernel(FusedArgs a) {
         }
         if (a.cfg.gaussians_grad) {
             if (ws.d_means3D) { ws.d_means3D[3 * i] = dp[0]; ws.d_means3D[3 * i + 1] = dp[1]; ws.d_means3D[3 * i + 2] = dp[2]; }
-            if (ws.d_unnorm_rotations) reinterpret_cast<float4 *>(ws.d_unnorm_rotations)[i] = make_float4(du[0], du[1], du[2], du[3]);
+            // isotropic map: Sigma = s^2 I does not depend on the quaternion -- the derivative is exactly zero (what autograd
+            // leaves there is rounding noise); writing the exact zero lets the gradient exchange skip the four rotation floats
+            if (ws.d_unnorm_rotations)
+                reinterpret_cast<float4 *>(ws.d_unnorm_rotations)[i] = iso ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(du[0], du[1], du[2], du[3]);
         }
         if (ws.d_rgb_colors) { ws.d_rgb_colors[3 * i] = drgb[0]; ws.d_rgb_colors[3 * i + 1] = drgb[1]; ws.d_rgb_colors[3 * i + 2] = drgb[2]; }
         if (ws.d_logit_opacities) ws.d_logit_opacities[i] = dlogit;

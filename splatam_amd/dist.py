@@ -3,7 +3,8 @@
 The reference is single-GPU.  Mapping optimises the SAME replicated Gaussian map
 against independent keyframe views, so the views shard across ranks with one
 exchange step per iteration: a sum all-reduce of the Gaussian gradients
-(12 floats per isotropic Gaussian, one flat bucket), followed by the identical
+(one flat bucket: 12 floats per isotropic Gaussian on the drop-in path, 8 on the fused path, which knows that the
+rotation gradient of an isotropic map is exactly zero), followed by the identical
 Adam step on every rank.  One process per GPU; backend "nccl" is RCCL over xGMI
 on ROCm, "gloo" is used by the CPU tests.  Tracking has no exchange step
 (replicas only).

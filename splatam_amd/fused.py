@@ -136,10 +136,14 @@ class FusedEngine:
         """Views that depend on the number of rows: the flat gradient bucket and the moment views."""
         P = self.P
         self.grad_flat = self._grad_store[:sum(self._widths) * P]
+        # the rotations go last: for an isotropic map their gradient is exactly zero and the exchange skips them
+        order = [k for k in PARAM_ORDER if k != "unnorm_rotations"] + ["unnorm_rotations"]
+        widths = dict(zip(PARAM_ORDER, self._widths))
         self.grads, o = {}, 0
-        for k, w in zip(PARAM_ORDER, self._widths):
-            self.grads[k] = self.grad_flat[o:o + w * P].view(P, w)
-            o += w * P
+        for k in order:
+            self.grads[k] = self.grad_flat[o:o + widths[k] * P].view(P, widths[k])
+            o += widths[k] * P
+        self.reduce_flat = self.grad_flat[:(sum(self._widths) - 4) * P] if self.iso else self.grad_flat
         self.exp_avg = {k: self._m_store[k][:P] for k in PARAM_ORDER}
         self.exp_avg_sq = {k: self._v_store[k][:P] for k in PARAM_ORDER}
 
@@ -489,7 +493,7 @@ class FusedEngine:
         """Loop body of /root/reference/scripts/splatam.py:828-869 (without pruning / densification)."""
         self.loss_backward(iter_data, iter_time_idx, cfg, tracking=False)
         if bucket_allreduce is not None:
-            bucket_allreduce(self.grad_flat)
+            bucket_allreduce(self.reduce_flat)      # one collective: 8 (isotropic) or 14 floats per Gaussian
         self.adam_map(cfg['lrs'])
 
     # ------------------------------------------------------------------ read-backs (host sync)

@@ -375,3 +375,36 @@ def test_ignore_outlier_depth_loss(tracking):
     else:
         for k in ("means3D", "rgb_colors", "logit_opacities", "log_scales"):
             _cmp(eng.grads[k], g_ref[k], k)
+
+
+def test_view_sharded_exchange_keeps_replicas_identical():
+    """The exchange step of view-sharded mapping on the fused path, emulated in one process: two replicas render different
+    keyframe views, average the exchanged prefix of their flat gradient buffers (8 floats per isotropic Gaussian: the rotation
+    gradient is exactly zero and stays out of the collective) and take the same Adam step."""
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    params, variables, frame, cam = _scene(8000, 208, 160, seed=23, num_frames=4)
+    frame2 = dict(frame)
+    frame2['im'] = (frame['im'] * 0.9 + 0.03).contiguous()
+    cfg = slam.REPLICA_MAPPING
+    reps = []
+    for fr, t in ((frame, 1), (frame2, 2)):
+        p = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+        eng = FusedEngine(p, cam)
+        eng.loss_backward(fr, t, cfg, tracking=False)
+        reps.append((p, eng))
+    torch.cuda.synchronize()
+    (p1, e1), (p2, e2) = reps
+    assert e1.reduce_flat.numel() == 8 * e1.P and e1.grad_flat.numel() == 12 * e1.P
+    assert float(e1.grads['unnorm_rotations'].abs().max()) == 0.0
+    assert e1.reduce_flat.data_ptr() == e1.grad_flat.data_ptr()
+    mean = 0.5 * (e1.reduce_flat + e2.reduce_flat)
+    assert float((e1.reduce_flat - e2.reduce_flat).abs().max()) > 0.0        # the views really differ
+    for e in (e1, e2):
+        e.reduce_flat.copy_(mean)
+        e.adam_map(cfg['lrs'])
+    torch.cuda.synchronize()
+    for k in ('means3D', 'rgb_colors', 'logit_opacities', 'log_scales', 'unnorm_rotations'):
+        assert torch.equal(p1[k].detach(), p2[k].detach()), k
+    assert torch.equal(p1['unnorm_rotations'].detach(), params['unnorm_rotations'].detach())      # untouched
+    assert not torch.equal(p1['means3D'].detach(), params['means3D'].detach())
