@@ -79,8 +79,11 @@ def all_reduce_mean_flat(flat: torch.Tensor, group=None) -> None:
     (splatam_amd.fused.FusedEngine.grad_flat is already laid out as the bucket: no packing)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    flat.div_(dist.get_world_size(group))
+    if dist.get_backend(group) == "nccl":            # RCCL averages inside the collective: no separate scaling kernel
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(dist.get_world_size(group))
 
 
 def shard_views(num_views: int, rank: int, world: int):
