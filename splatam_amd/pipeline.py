@@ -239,16 +239,40 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
     if mcfg.get('use_gaussian_splatting_densification'):
         raise NotImplementedError("gradient-based densification (configs/*/gaussian_splatting.py) is outside this loop")
     dist_kind = config.get('gaussian_distribution', 'isotropic')
-    params, variables, intrinsics, first_frame_w2c, cam = initialize_first_timestep(
-        dataset, num_frames, config['scene_radius_depth_ratio'], config['mean_sq_dist_method'], dist_kind)
-    dev = params['means3D'].device
-    first_frame_w2c = first_frame_w2c.to(dev).float().contiguous()
     eng = None
     if fused:
+        # first frame on the device: an empty capacity-managed map + one append of every valid-depth pixel
+        # (splat_map_add_new_gaussians, SPLAT_ADD_VALID_DEPTH) = get_pointcloud + initialize_params of the reference
         from .fused import FusedEngine
-        cap = gaussian_capacity or int(params['means3D'].shape[0] * 2.5) + 65536
-        scene_radius = variables['scene_radius']
+        color0, depth0, intr0, pose0 = dataset[0]
+        color0 = (color0.permute(2, 0, 1) / 255).contiguous()
+        depth0 = depth0.permute(2, 0, 1).contiguous()
+        dev = depth0.device
+        intrinsics = intr0[:3, :3]
+        first_frame_w2c = torch.linalg.inv(pose0).to(dev).float().contiguous()
+        H, W = color0.shape[1], color0.shape[2]
+        cam = slam.setup_camera(W, H, intrinsics.cpu().numpy(), first_frame_w2c.detach().cpu().numpy(), device=dev)
+        cols = 1 if dist_kind == "isotropic" else 3
+        if dist_kind not in ("isotropic", "anisotropic"):
+            raise ValueError(f"Unknown gaussian_distribution {dist_kind}")
+        rots = torch.zeros(1, 4, num_frames, device=dev)
+        rots[:, 0, :] = 1.0
+        z = lambda *shape: torch.nn.Parameter(torch.zeros(*shape, device=dev))      # noqa: E731
+        params = {'means3D': z(0, 3), 'rgb_colors': z(0, 3), 'unnorm_rotations': z(0, 4), 'logit_opacities': z(0, 1),
+                  'log_scales': z(0, cols), 'cam_unnorm_rots': torch.nn.Parameter(rots), 'cam_trans': z(1, 3, num_frames)}
+        variables = {k: torch.zeros(0, device=dev) for k in ('max_2D_radius', 'means2D_gradient_accum', 'denom', 'timestep')}
+        variables['scene_radius'] = torch.max(depth0) / config['scene_radius_depth_ratio']
+        cap = gaussian_capacity or int(H * W * 2.5) + 65536
         eng = FusedEngine(params, cam, gaussian_capacity=cap, variables=variables)
+        if config['mean_sq_dist_method'] != "projective":
+            raise ValueError(f"Unknown mean_sq_dist_method {config['mean_sq_dist_method']}")
+        eng.add_valid_depth_points(color0, depth0, intrinsics, first_frame_w2c)
+        scene_radius = variables['scene_radius']
+    else:
+        params, variables, intrinsics, first_frame_w2c, cam = initialize_first_timestep(
+            dataset, num_frames, config['scene_radius_depth_ratio'], config['mean_sq_dist_method'], dist_kind)
+        dev = params['means3D'].device
+        first_frame_w2c = first_frame_w2c.to(dev).float().contiguous()
     keyframe_list, keyframe_time_indices = [], []
     stats = dict(tracking_iters=0, mapping_iters=0, tracking_s=0.0, mapping_s=0.0, redone_frames=0, num_gaussians=[])
 
