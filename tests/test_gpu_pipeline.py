@@ -48,3 +48,27 @@ def test_params_survive_a_checkpoint_round_trip(tmp_path):
     back = pipeline.load_params(path)
     for k, v in params.items():
         assert torch.equal(back[k].detach(), v.detach())
+
+
+def test_ground_truth_poses_and_depth_loss_retry():
+    """use_gt_poses (scripts/splatam.py:745-756): no tracking, the dataset pose goes into the trajectory;
+    use_depth_loss_thres (:727-735): an unreachable threshold doubles the tracking budget once."""
+    from splatam_amd import pipeline
+    W, H, f = 160, 112, 140.0
+    ds = pipeline.SyntheticRGBDSequence(6000, W, H, f, f, W / 2 - 0.5, H / 2 - 0.5, num_frames=3, seed=4, step_m=0.012, step_deg=0.4)
+    cfg = pipeline.replica_config(tracking_iters=6, mapping_iters=8, keyframe_every=2)
+    cfg['tracking']['use_gt_poses'] = True
+    torch.manual_seed(0)
+    np.random.seed(0)
+    params, _, stats = pipeline.rgbd_slam(ds, cfg, engine="fused")
+    assert stats['tracking_iters'] == 0 and stats['mapping_iters'] == 3 * 8
+    for t in range(3):
+        assert float((pipeline._est_w2c(params, t) - ds.gt_w2c(t)).abs().max()) < 1e-5, t
+    cfg = pipeline.replica_config(tracking_iters=6, mapping_iters=8, keyframe_every=2)
+    cfg['tracking']['use_depth_loss_thres'] = True
+    cfg['tracking']['depth_loss_thres'] = -1.0            # never met: the budget doubles once (12 iterations per frame)
+    _, _, stats = pipeline.rgbd_slam(ds, cfg, engine="fused")
+    assert stats['tracking_iters'] == 2 * 12
+    cfg['tracking']['depth_loss_thres'] = 1e9             # met at once: the plain budget
+    _, _, stats = pipeline.rgbd_slam(ds, cfg, engine="fused")
+    assert stats['tracking_iters'] == 2 * 6
