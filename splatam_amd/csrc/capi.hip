@@ -253,7 +253,7 @@ int splat_map_prune(SplatMapStore *store, const SplatPruneArgs *a, void *stream)
 int splat_debug_option(int key, int value) {
     if (key == 0) { const int old = g_debug_skip_count; g_debug_skip_count = value; return old; }
     if (key == 1) { const int old = g_debug_composite_version; g_debug_composite_version = value; return old; }
-    if (key == 2) { const int old = g_debug_entries_per_trip; g_debug_entries_per_trip = value == 1 ? 1 : 2; return old; }
+    if (key == 2) { const int old = g_debug_entries_per_trip; g_debug_entries_per_trip = (value == 1 || value == 3) ? value : 2; return old; }
     return -1;
 }
 

@@ -653,7 +653,8 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
         hipLaunchKernelGGL(ssim_forward_kernel, grid, dim3(kBlock), 0, s, a, W, H);
         hipLaunchKernelGGL(map_loss_backward_kernel, grid, dim3(kBlock), 0, s, a, W, H);
     }
-    e = launch_render_backward_feat8(cam, ws.feat8, ws.st, ws.dL_dout6, ws.accum, P, false, ws.d_rgb_colors != nullptr, s);
+    e = launch_render_backward_feat8(cam, ws.feat8, ws.st, ws.dL_dout6, ws.accum, P, false, ws.d_rgb_colors != nullptr, s,
+                                     ws.d_logit_opacities != nullptr);
     if (e != hipSuccess) return e;
     if (P > 0) hipLaunchKernelGGL(fused_backward_kernel, dim3(gblocks), dim3(kBlock), 0, s, a);
     hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(256), 0, s, a, HW);

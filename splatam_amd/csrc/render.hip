@@ -394,12 +394,15 @@ constexpr int nth_set_bit(unsigned m, int n) {      // index of the n-th (0-base
 // NE: list entries per loop trip.  With NE = 2 the 2 x NV partial sums of two consecutive entries are reduced together
 // (2 x 10 sums = five full packed groups instead of 2 x 3 padded ones; 2 x 7 = four instead of 2 x 2), leave the wave in
 // ONE atomic instruction (two accumulator lines) and share the scalar loop overhead.
-template <int C, int CS, unsigned DMASK, unsigned SMASK, int NE>
+// OPAC: the caller needs S6 = sum G dL/dalpha (dL/dopacity); the fused tracking iteration does not (opacities get no update
+// while the camera is tracked), and 2 x (5 + 1) sums are three full packed groups with two entries per trip.
+template <int C, int CS, unsigned DMASK, unsigned SMASK, int NE, bool OPAC = true>
 __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, const float *colors, SplatState st,
                                                               const float *dL_dcolor, float *accum, int T, int per_xcd) {
     constexpr int FP = (C + 3) / 4 * 4;
     constexpr int NS = popcount_c(SMASK);
-    constexpr int NV = 6 + NS;                // partial sums per Gaussian
+    constexpr int NB = OPAC ? 6 : 5;          // geometric sums: S1..S5 (+ S6)
+    constexpr int NV = NB + NS;               // partial sums per Gaussian
     constexpr int NVT = NE * NV;              // partial sums per loop trip
     constexpr int NG = (NVT + 3) / 4;         // packed reduction groups per loop trip
     __shared__ Batch<FP> B;
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, c
         for (int r = 0; r < 4; ++r) {
             const int kt = 4 * grp + row_value(r);          // index into the trip's NVT sums
             const int ent = kt / NV, k = kt - ent * NV;
-            const int slot = kt >= NVT ? -1 : (k < 6 ? k : 6 + nth_set_bit(SMASK, k - 6 < 0 ? 0 : k - 6));
+            const int slot = kt >= NVT ? -1 : (k < NB ? k : 6 + nth_set_bit(SMASK, k - NB < 0 ? 0 : k - NB));
             if (pub_g == grp && (lane >> 4) == r) { doff = slot; pub_e = ent; }
         }
     unsigned long long pub_m[NE];             // publishing lanes of each entry
@@ -529,9 +532,9 @@ __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, c
                     sv[2] = qgx * dx;
                     sv[3] = qgx * dy;
                     sv[4] = qgy * dy;
-                    sv[5] = Gl * dL_dalpha;
+                    if constexpr (OPAC) sv[5] = Gl * dL_dalpha;
 #pragma unroll
-                    for (int n = 0; n < NS; ++n) sv[6 + n] = wgt * dpix[nth_set_bit(SMASK, n)];
+                    for (int n = 0; n < NS; ++n) sv[NB + n] = wgt * dpix[nth_set_bit(SMASK, n)];
                     Tr = live ? Tn : Tr;
                     behind = live ? bh : behind;
                     lcdot = live ? cdot : lcdot;
@@ -567,18 +570,19 @@ static void launch_fwd(const SplatCamera &cam, const float *colors, SplatState &
                        TrackLossEpilogue{});
 }
 int g_debug_entries_per_trip = 2;      // splat_debug_option(2, v): 1 = always one list entry per loop trip of K7 (A/B timing)
-template <int C, int CS, unsigned DMASK = (1u << C) - 1u, unsigned SMASK = (1u << C) - 1u>
+template <int C, int CS, unsigned DMASK = (1u << C) - 1u, unsigned SMASK = (1u << C) - 1u, bool OPAC = true>
 static void launch_bwd(const SplatCamera &cam, const float *colors, const SplatState &st, const float *dl, float *acc, int T,
                        hipStream_t s) {
     const int per = (T + 7) / 8;
     // two entries per trip pay when they save a packed reduction group: 2 x 10 sums -> 5 groups instead of 6 (mapping form:
-    // 207 -> 187 us at B); with 2 x 7 sums (tracking form) there is nothing to save and the pair bookkeeping costs 5 %
-    constexpr int NV = 6 + popcount_c(SMASK);
+    // 207 -> 187 us at B), 2 x 6 -> 3 instead of 4 (tracking form without the opacity sum); with 2 x 7 sums there is nothing
+    // to save and the pair bookkeeping costs 5 %
+    constexpr int NV = (OPAC ? 6 : 5) + popcount_c(SMASK);
     constexpr bool kPairPays = (2 * NV + 3) / 4 < 2 * ((NV + 3) / 4);
     if (kPairPays && g_debug_entries_per_trip != 1)
-        hipLaunchKernelGGL((render_backward_kernel<C, CS, DMASK, SMASK, 2>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
+        hipLaunchKernelGGL((render_backward_kernel<C, CS, DMASK, SMASK, 2, OPAC>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
     else
-        hipLaunchKernelGGL((render_backward_kernel<C, CS, DMASK, SMASK, 1>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
+        hipLaunchKernelGGL((render_backward_kernel<C, CS, DMASK, SMASK, 1, OPAC>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
 }
 
 static const float *colour_source(const SplatGaussians &g, const SplatState &st) {
@@ -653,7 +657,7 @@ hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat
 }
 
 hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *feat8, const SplatState &st, const float *dL_dout6,
-                                        float *accum, int P, bool zero_accum, bool rgb_sums, hipStream_t s) {
+                                        float *accum, int P, bool zero_accum, bool rgb_sums, hipStream_t s, bool opacity_sum) {
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
     if (zero_accum) {
         hipError_t e = hipMemsetAsync(accum, 0, sizeof(float) * SPLAT_GRAD_STRIDE * (size_t)P, s);
@@ -664,7 +668,8 @@ hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *fea
     // channels r, g, b, z carry gradient; the silhouette and depth^2 planes never do.  dL/drgb is only summed on request
     // (tracking does not read it: LR 0 in /root/reference/configs/*/splatam.py, optimizer discarded after the frame).
     if (rgb_sums) launch_bwd<6, 8, 0xFu, 0xFu>(cam, feat8, st, dL_dout6, accum, T, s);
-    else launch_bwd<6, 8, 0xFu, 0x8u>(cam, feat8, st, dL_dout6, accum, T, s);
+    else if (opacity_sum || g_debug_entries_per_trip == 3) launch_bwd<6, 8, 0xFu, 0x8u, true>(cam, feat8, st, dL_dout6, accum, T, s);
+    else launch_bwd<6, 8, 0xFu, 0x8u, false>(cam, feat8, st, dL_dout6, accum, T, s);      // camera tracking: no dL/dopacity wanted
     return hipGetLastError();
 }
 
