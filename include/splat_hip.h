@@ -283,6 +283,16 @@ int splat_iter_adam_pose(const SplatMap *map, int32_t time_idx, const float *d_c
                          float beta1, float beta2, float eps, float bc2_sqrt, float step_size_rot, float step_size_trans,
                          void *stream);
 
+/* One whole tracking iteration (/root/reference/scripts/splatam.py:690-711) in one call: splat_iter_loss_backward with
+ * cfg->tracking set, with the pose's Adam step and the best-candidate bookkeeping of splat_iter_adam_pose folded into its last
+ * kernel (one launch less per iteration).  `state` and the step sizes as for splat_iter_adam_pose. */
+typedef struct SplatPoseAdam {
+    float *state;                /* [SPLAT_POSE_STATE] */
+    float beta1, beta2, eps, bc2_sqrt, step_size_rot, step_size_trans;
+} SplatPoseAdam;
+int splat_iter_tracking_step(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame,
+                             const SplatLossConfig *cfg, SplatIterWorkspace *ws, const SplatPoseAdam *adam, void *stream);
+
 /* Kernel-only timing helper for bench.py on the fused path: fn 0 = 6-channel composite forward, 1 = 6-channel composite
  * backward (incl. its accumulator memset), launched `iters` times on `stream` between two hipEvents; the workspace must hold
  * the state of a completed splat_iter_loss_backward. */

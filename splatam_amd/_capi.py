@@ -94,6 +94,11 @@ class SplatPruneArgs(C.Structure):
                 ("to_remove", _fp), ("flags", _fp), ("stage", _fp), ("scratch", _fp)]
 
 
+class SplatPoseAdam(C.Structure):
+    _fields_ = [("state", _fp), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("bc2_sqrt", C.c_float),
+                ("step_size_rot", C.c_float), ("step_size_trans", C.c_float)]
+
+
 SPLAT_ADD_VALID_DEPTH = 0
 SPLAT_ADD_NON_PRESENCE = 1
 SPLAT_ITER_SUMS = 32
@@ -106,7 +111,7 @@ EXPORTS = (
     "splat_render_backward", "splat_preprocess_backward", "splat_backward",
     "splat_mark_visible", "splat_time_kernel", "splat_debug_option",
     "splat_iter_loss_backward", "splat_iter_adam_map", "splat_iter_adam_pose", "splat_iter_time_kernel",
-    "splat_iter_render", "splat_map_scratch_words", "splat_map_row_floats", "splat_map_add_new_gaussians", "splat_map_prune",
+    "splat_iter_tracking_step", "splat_iter_render", "splat_map_scratch_words", "splat_map_row_floats", "splat_map_add_new_gaussians", "splat_map_prune",
 )
 
 _lib = None
@@ -157,6 +162,9 @@ def lib():
                                        C.c_float, C.c_float, _fp]
     L.splat_iter_time_kernel.restype = C.c_int
     L.splat_iter_time_kernel.argtypes = [C.c_int, C.c_int, cam, C.c_int32, C.POINTER(SplatIterWorkspace), _fp, C.POINTER(C.c_float)]
+    L.splat_iter_tracking_step.restype = C.c_int
+    L.splat_iter_tracking_step.argtypes = [cam, C.POINTER(SplatMap), C.POINTER(SplatFrameData), C.POINTER(SplatLossConfig),
+                                           C.POINTER(SplatIterWorkspace), C.POINTER(SplatPoseAdam), _fp]
     L.splat_iter_render.restype = C.c_int
     L.splat_iter_render.argtypes = [cam, C.POINTER(SplatMap), C.POINTER(SplatFrameData), C.POINTER(SplatIterWorkspace), _fp]
     L.splat_map_scratch_words.restype = C.c_size_t

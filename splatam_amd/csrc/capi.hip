@@ -137,8 +137,8 @@ int splat_time_kernel(int fn, int iters, const SplatCamera *cam, const SplatGaus
     return check(err);
 }
 
-int splat_iter_loss_backward(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame,
-                             const SplatLossConfig *cfg, SplatIterWorkspace *ws, void *stream) {
+static int iter_loss_backward_impl(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame,
+                                   const SplatLossConfig *cfg, SplatIterWorkspace *ws, const SplatPoseAdam *adam, void *stream) {
     if (!cam || !map || !frame || !cfg || !ws) return SPLAT_E_INVALID;
     if (map->P < 0 || cam->image_width <= 0 || cam->image_height <= 0 || !cam->viewmatrix || !cam->projmatrix) return SPLAT_E_INVALID;
     if (map->num_frames <= 0 || frame->time_idx < 0 || frame->time_idx >= map->num_frames) return SPLAT_E_INVALID;
@@ -154,7 +154,18 @@ int splat_iter_loss_backward(const SplatCamera *cam, const SplatMap *map, const 
         return SPLAT_E_INVALID;
     if (!ws->out6 || !ws->dL_dout6 || !ws->sums || !ws->d_cam) return SPLAT_E_INVALID;
     if (!cfg->tracking && !ws->ssim_maps) return SPLAT_E_INVALID;
-    return check(launch_iter_loss_backward(*cam, *map, *frame, *cfg, *ws, (hipStream_t)stream));
+    return check(launch_iter_loss_backward(*cam, *map, *frame, *cfg, *ws, (hipStream_t)stream, adam));
+}
+
+int splat_iter_loss_backward(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame,
+                             const SplatLossConfig *cfg, SplatIterWorkspace *ws, void *stream) {
+    return iter_loss_backward_impl(cam, map, frame, cfg, ws, nullptr, stream);
+}
+
+int splat_iter_tracking_step(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame,
+                             const SplatLossConfig *cfg, SplatIterWorkspace *ws, const SplatPoseAdam *adam, void *stream) {
+    if (!cfg || !cfg->tracking || !cfg->camera_grad || !adam || !adam->state) return SPLAT_E_INVALID;
+    return iter_loss_backward_impl(cam, map, frame, cfg, ws, adam, stream);
 }
 
 int splat_iter_adam_map(const SplatMap *map, const SplatAdamMap *opt, void *stream) {

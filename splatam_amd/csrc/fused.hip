@@ -497,8 +497,37 @@ __global__ __launch_bounds__(kBlock) void fused_backward_kernel(FusedArgs a) {
     if (a.cfg.camera_grad) block_sum_to<kPoseSums>(sum_copy(ws.sums) + 8, pose, s_part);
 }
 
-// F7: one thread: pose partial sums -> gradients of the raw camera parameters; loss value
-__global__ __launch_bounds__(256) void pose_finish_kernel(FusedArgs a, int HW) {
+// Adam step of the camera pose of one frame + the reference's best-candidate bookkeeping
+// (/root/reference/scripts/splatam.py:704-711); state: m_q[0..3] m_t[4..6] v_q[7..10] v_t[11..13] min_loss[14] cand_q[15..18] cand_t[19..21]
+struct PoseAdam {
+    float *state;               // nullptr: no step (the separate splat_iter_adam_pose call takes it)
+    float beta1, beta2, eps, bc2_sqrt, ss_rot, ss_trans;
+};
+
+__device__ __forceinline__ void pose_adam_step(const SplatMap &map, int time_idx, const float *g, float loss, const PoseAdam &pa) {
+    float *state = pa.state;
+    float q[4], t[3];
+    for (int k = 0; k < 4; ++k) {
+        float *p = map.cam_unnorm_rots + k * map.num_frames + time_idx;
+        q[k] = adam_update(*p, g[k], state[k], state[7 + k], pa.beta1, pa.beta2, pa.ss_rot, pa.bc2_sqrt, pa.eps);
+        *p = q[k];
+    }
+    for (int k = 0; k < 3; ++k) {
+        float *p = map.cam_trans + k * map.num_frames + time_idx;
+        t[k] = adam_update(*p, g[4 + k], state[4 + k], state[11 + k], pa.beta1, pa.beta2, pa.ss_trans, pa.bc2_sqrt, pa.eps);
+        *p = t[k];
+    }
+    // the reference compares the loss of THIS iteration and stores the parameters AFTER the step
+    if (loss < state[14]) {
+        state[14] = loss;
+        for (int k = 0; k < 4; ++k) state[15 + k] = q[k];
+        for (int k = 0; k < 3; ++k) state[19 + k] = t[k];
+    }
+}
+
+// F7: one thread: pose partial sums -> gradients of the raw camera parameters; loss value (+ the pose's Adam step when the
+// caller asked for the whole tracking step in one call: one launch less per iteration)
+__global__ __launch_bounds__(256) void pose_finish_kernel(FusedArgs a, int HW, PoseAdam pa) {
     static_assert(SPLAT_ITER_SUMS * 8 == 256 && SPLAT_ITER_SUM_COPIES == 64, "thread t: sum k = t / 8, copies (t % 8) * 8 .. + 7");
     __shared__ double S[SPLAT_ITER_SUMS];
     const int t = threadIdx.x, k = t >> 3, part = t & 7;
@@ -538,6 +567,12 @@ __global__ __launch_bounds__(256) void pose_finish_kernel(FusedArgs a, int HW) {
     out[7] = loss;
     for (int k = 0; k < 4; ++k) out[8 + k] = (float)S[k];       // raw sums, for inspection
     if (a.ws.st.status[1] != 0 || a.ws.st.status[3] != 0) out[12] = 1.0f;     // sticky until the host clears it
+    if (pa.state) {
+        float g[7];
+        for (int k = 0; k < 4; ++k) g[k] = dq[k];
+        for (int k = 0; k < 3; ++k) g[4 + k] = dt[k];
+        pose_adam_step(a.map, a.frame.time_idx, g, loss, pa);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -576,26 +611,8 @@ __global__ __launch_bounds__(kBlock) void adam_map_kernel(AdamArgs a, long long 
 __global__ void adam_pose_kernel(SplatMap map, int time_idx, const float *d_cam, float *state, float beta1, float beta2,
                                  float eps, float bc2_sqrt, float ss_rot, float ss_trans) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    // state: m_q[0..3] m_t[4..6] v_q[7..10] v_t[11..13] min_loss[14] cand_q[15..18] cand_t[19..21]
-    float q[4], t[3];
-    for (int k = 0; k < 4; ++k) {
-        float *p = map.cam_unnorm_rots + k * map.num_frames + time_idx;
-        q[k] = adam_update(*p, d_cam[k], state[k], state[7 + k], beta1, beta2, ss_rot, bc2_sqrt, eps);
-        *p = q[k];
-    }
-    for (int k = 0; k < 3; ++k) {
-        float *p = map.cam_trans + k * map.num_frames + time_idx;
-        t[k] = adam_update(*p, d_cam[4 + k], state[4 + k], state[11 + k], beta1, beta2, ss_trans, bc2_sqrt, eps);
-        *p = t[k];
-    }
-    // the reference compares the loss of THIS iteration and stores the parameters AFTER the step
-    // (/root/reference/scripts/splatam.py:704-711)
-    const float loss = d_cam[7];
-    if (loss < state[14]) {
-        state[14] = loss;
-        for (int k = 0; k < 4; ++k) state[15 + k] = q[k];
-        for (int k = 0; k < 3; ++k) state[19 + k] = t[k];
-    }
+    const PoseAdam pa{state, beta1, beta2, eps, bc2_sqrt, ss_rot, ss_trans};
+    pose_adam_step(map, time_idx, d_cam, d_cam[7], pa);
 }
 
 }  // namespace
@@ -604,7 +621,7 @@ hipError_t launch_depth_error_median(const float *out6, const float *depth, floa
                                      hipStream_t s);
 
 hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame,
-                                     const SplatLossConfig &cfg, SplatIterWorkspace &ws, hipStream_t s) {
+                                     const SplatLossConfig &cfg, SplatIterWorkspace &ws, hipStream_t s, const SplatPoseAdam *pose_adam) {
     FusedArgs a{cam, map, frame, cfg, ws, {}};
     ssim_window_host(a.win);
     const int W = cam.image_width, H = cam.image_height, HW = W * H;
@@ -657,7 +674,11 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
                                      ws.d_logit_opacities != nullptr);
     if (e != hipSuccess) return e;
     if (P > 0) hipLaunchKernelGGL(fused_backward_kernel, dim3(gblocks), dim3(kBlock), 0, s, a);
-    hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(256), 0, s, a, HW);
+    PoseAdam pa{};
+    if (pose_adam)
+        pa = PoseAdam{pose_adam->state, pose_adam->beta1, pose_adam->beta2, pose_adam->eps, pose_adam->bc2_sqrt, pose_adam->step_size_rot,
+                      pose_adam->step_size_trans};
+    hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(256), 0, s, a, HW, pa);
     return hipGetLastError();
 }
 

@@ -410,9 +410,10 @@ class FusedEngine:
         return c
 
     # ------------------------------------------------------------------ one iteration
-    def loss_backward(self, curr_data, time_idx, cfg, tracking, map_grads=None, do_ba=False):
+    def loss_backward(self, curr_data, time_idx, cfg, tracking, map_grads=None, do_ba=False, pose_adam=None):
         """get_loss + backward.  Afterwards (stream order): ``self.grads`` (mapping) and
-        ``self.buf['d_cam']`` = [dL/dq_raw(4), dL/dt_raw(3), loss]."""
+        ``self.buf['d_cam']`` = [dL/dq_raw(4), dL/dt_raw(3), loss].  ``pose_adam`` (a SplatPoseAdam): the pose's Adam step
+        rides in the last kernel (splat_iter_tracking_step)."""
         if map_grads is None:
             map_grads = not tracking
         fr = _capi.SplatFrameData()
@@ -430,8 +431,12 @@ class FusedEngine:
         ws = self._workspace(map_grads, with_ssim=not tracking)
         m = self._map_struct()
         with torch.cuda.device(self.dev):
-            _capi.check(self.L.splat_iter_loss_backward(C.byref(self._cam), C.byref(m), C.byref(fr), C.byref(lc), C.byref(ws),
-                                                        self._stream()), "splat_iter_loss_backward")
+            if pose_adam is not None:
+                _capi.check(self.L.splat_iter_tracking_step(C.byref(self._cam), C.byref(m), C.byref(fr), C.byref(lc), C.byref(ws),
+                                                            C.byref(pose_adam), self._stream()), "splat_iter_tracking_step")
+            else:
+                _capi.check(self.L.splat_iter_loss_backward(C.byref(self._cam), C.byref(m), C.byref(fr), C.byref(lc), C.byref(ws),
+                                                            self._stream()), "splat_iter_loss_backward")
 
     def adam_map(self, lrs, beta1=0.9, beta2=0.999, eps=1e-15):
         """torch.optim.Adam(param_groups, lr=0.0, eps=1e-15).step() over the five Gaussian groups
@@ -486,8 +491,13 @@ class FusedEngine:
 
     def tracking_iteration(self, curr_data, cfg):
         """Loop body of /root/reference/scripts/splatam.py:690-711 for frame ``begin_tracking`` named."""
-        self.loss_backward(curr_data, self.track_time_idx, cfg, tracking=True)
-        self.adam_pose(cfg['lrs']['cam_unnorm_rots'], cfg['lrs']['cam_trans'])
+        self.pose_step += 1                     # one C call: loss + backward + the pose's Adam step (default betas / eps of torch.optim.Adam)
+        t, beta1, beta2 = self.pose_step, 0.9, 0.999
+        bc1, bc2 = 1.0 - beta1 ** t, 1.0 - beta2 ** t
+        pa = _capi.SplatPoseAdam()
+        pa.state, pa.beta1, pa.beta2, pa.eps, pa.bc2_sqrt = self.buf['pose_state'].data_ptr(), beta1, beta2, 1e-8, math.sqrt(bc2)
+        pa.step_size_rot, pa.step_size_trans = cfg['lrs']['cam_unnorm_rots'] / bc1, cfg['lrs']['cam_trans'] / bc1
+        self.loss_backward(curr_data, self.track_time_idx, cfg, tracking=True, pose_adam=pa)
 
     def mapping_iteration(self, iter_data, iter_time_idx, cfg, bucket_allreduce=None):
         """Loop body of /root/reference/scripts/splatam.py:828-869 (without pruning / densification)."""

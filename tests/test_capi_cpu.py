@@ -43,7 +43,7 @@ def _struct_fields(name):
 
 @pytest.mark.parametrize("name", ["SplatCamera", "SplatGaussians", "SplatState", "SplatGrads", "SplatMap", "SplatFrameData",
                                   "SplatLossConfig", "SplatIterWorkspace", "SplatAdamMap", "SplatMapStore", "SplatAddArgs",
-                                  "SplatPruneArgs"])
+                                  "SplatPruneArgs", "SplatPoseAdam"])
 def test_ctypes_structs_mirror_header(name):
     from splatam_amd import _capi
     assert [f[0] for f in getattr(_capi, name)._fields_] == _struct_fields(name)
