@@ -258,7 +258,8 @@ typedef struct SplatIterWorkspace {
 } SplatIterWorkspace;
 
 /* get_loss + loss.backward() of one iteration.  On return (stream order) ws->d_* hold the gradients and
- * ws->d_cam[7] the loss value. */
+ * ws->d_cam[7] the loss value.  The fused iteration renders on a ZERO background, as setup_camera builds it
+ * (/root/reference/utils/recon_helpers.py:17): cam->bg must point at six zeros (the backward composite drops the term). */
 int splat_iter_loss_backward(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame,
                              const SplatLossConfig *cfg, SplatIterWorkspace *ws, void *stream);
 

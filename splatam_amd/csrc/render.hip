@@ -396,7 +396,8 @@ constexpr int nth_set_bit(unsigned m, int n) {      // index of the n-th (0-base
 // ONE atomic instruction (two accumulator lines) and share the scalar loop overhead.
 // OPAC: the caller needs S6 = sum G dL/dalpha (dL/dopacity); the fused tracking iteration does not (opacities get no update
 // while the camera is tracked), and 2 x (5 + 1) sums are three full packed groups with two entries per trip.
-template <int C, int CS, unsigned DMASK, unsigned SMASK, int NE, bool OPAC = true>
+// BG: the background colour can be non-zero (the fused iteration renders on a zero background and drops that term).
+template <int C, int CS, unsigned DMASK, unsigned SMASK, int NE, bool OPAC = true, bool BG = true>
 __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, const float *colors, SplatState st,
                                                               const float *dL_dcolor, float *accum, int T, int per_xcd) {
     constexpr int FP = (C + 3) / 4 * 4;
@@ -432,9 +433,11 @@ __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, c
     for (int ch = 0; ch < C; ++ch) {
         dpix[ch] = 0.f;
         if ((DMASK >> ch) & 1u) {
-            has_bg |= cam.bg[ch] != 0.f;
             dpix[ch] = inside ? dL_dcolor[ch * HW + pix] : 0.f;
-            bgdot += cam.bg[ch] * dpix[ch];
+            if constexpr (BG) {
+                has_bg |= cam.bg[ch] != 0.f;
+                bgdot += cam.bg[ch] * dpix[ch];
+            }
         }
     }
     const unsigned wmax = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_max_u32(last));   // deepest contributor of this quadrant
@@ -513,13 +516,16 @@ __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, c
                     const bool live = lane_of(live_m);
                     const float rcp = __builtin_amdgcn_rcpf(1.f - alpha);
                     const float Tn = Tr * rcp;                     // transmittance in front of this Gaussian
-                    float cdot = 0.f;
+                    // sum_ch colour[ch] * dL/dC[ch], summed pairwise (packed multiplies / adds)
+                    float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ch = 0; ch < C; ++ch)
-                        if ((DMASK >> ch) & 1u) cdot += cur.feat[ch] * dpix[ch];
+                        if ((DMASK >> ch) & 1u) part[ch & 3] += cur.feat[ch] * dpix[ch];
+                    const float cdot = (part[0] + part[2]) + (part[1] + part[3]);
                     const float bh = lalpha * lcdot + (1.f - lalpha) * behind;
                     float dL_dalpha = (cdot - bh) * Tn;
-                    if (has_bg) dL_dalpha += (-Tfin * rcp) * bgdot;
+                    if constexpr (BG)
+                        if (has_bg) dL_dalpha += (-Tfin * rcp) * bgdot;
                     // selects (not multiplies by 0) so that a non-live lane can never inject inf * 0
                     const float Gl = live ? G : 0.f;
                     const float wgt = live ? alpha * Tn : 0.f;
@@ -570,7 +576,7 @@ static void launch_fwd(const SplatCamera &cam, const float *colors, SplatState &
                        TrackLossEpilogue{});
 }
 int g_debug_entries_per_trip = 2;      // splat_debug_option(2, v): 1 = always one list entry per loop trip of K7 (A/B timing)
-template <int C, int CS, unsigned DMASK = (1u << C) - 1u, unsigned SMASK = (1u << C) - 1u, bool OPAC = true>
+template <int C, int CS, unsigned DMASK = (1u << C) - 1u, unsigned SMASK = (1u << C) - 1u, bool OPAC = true, bool BG = true>
 static void launch_bwd(const SplatCamera &cam, const float *colors, const SplatState &st, const float *dl, float *acc, int T,
                        hipStream_t s) {
     const int per = (T + 7) / 8;
@@ -580,9 +586,9 @@ static void launch_bwd(const SplatCamera &cam, const float *colors, const SplatS
     constexpr int NV = (OPAC ? 6 : 5) + popcount_c(SMASK);
     constexpr bool kPairPays = (2 * NV + 3) / 4 < 2 * ((NV + 3) / 4);
     if (kPairPays && g_debug_entries_per_trip != 1)
-        hipLaunchKernelGGL((render_backward_kernel<C, CS, DMASK, SMASK, 2, OPAC>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
+        hipLaunchKernelGGL((render_backward_kernel<C, CS, DMASK, SMASK, 2, OPAC, BG>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
     else
-        hipLaunchKernelGGL((render_backward_kernel<C, CS, DMASK, SMASK, 1, OPAC>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
+        hipLaunchKernelGGL((render_backward_kernel<C, CS, DMASK, SMASK, 1, OPAC, BG>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
 }
 
 static const float *colour_source(const SplatGaussians &g, const SplatState &st) {
@@ -667,9 +673,10 @@ hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *fea
     if (g_debug_composite_version == 4) return launch_render_backward_feat8_v4(cam, feat8, st, dL_dout6, accum, rgb_sums, s);
     // channels r, g, b, z carry gradient; the silhouette and depth^2 planes never do.  dL/drgb is only summed on request
     // (tracking does not read it: LR 0 in /root/reference/configs/*/splatam.py, optimizer discarded after the frame).
-    if (rgb_sums) launch_bwd<6, 8, 0xFu, 0xFu>(cam, feat8, st, dL_dout6, accum, T, s);
-    else if (opacity_sum || g_debug_entries_per_trip == 3) launch_bwd<6, 8, 0xFu, 0x8u, true>(cam, feat8, st, dL_dout6, accum, T, s);
-    else launch_bwd<6, 8, 0xFu, 0x8u, false>(cam, feat8, st, dL_dout6, accum, T, s);      // camera tracking: no dL/dopacity wanted
+    // (zero background: FusedEngine refuses anything else, as setup_camera builds it)
+    if (rgb_sums) launch_bwd<6, 8, 0xFu, 0xFu, true, false>(cam, feat8, st, dL_dout6, accum, T, s);
+    else if (opacity_sum || g_debug_entries_per_trip == 3) launch_bwd<6, 8, 0xFu, 0x8u, true, false>(cam, feat8, st, dL_dout6, accum, T, s);
+    else launch_bwd<6, 8, 0xFu, 0x8u, false, false>(cam, feat8, st, dL_dout6, accum, T, s);      // camera tracking: no dL/dopacity wanted
     return hipGetLastError();
 }
 
