@@ -30,8 +30,8 @@
 extern "C" {
 #endif
 
-#define SPLAT_ABI_VERSION 1
-#define SPLAT_TILE 16            /* tile edge in pixels (one wave64 = one 16x16 tile, 4 px per lane) */
+#define SPLAT_ABI_VERSION 2        /* 2: map edits, splat_iter_render / _tracking_step, outlier scratch in SplatIterWorkspace */
+#define SPLAT_TILE 16            /* tile edge in pixels (one 256-thread workgroup per tile, one wave64 per 8x8 quadrant) */
 #define SPLAT_MAX_CHANNELS 8     /* colour channels per call: 3 for the reference API, up to 8 for fused passes */
 #define SPLAT_GRAD_STRIDE 16     /* floats per Gaussian in the backward accumulator (one 64-byte line) */
 #define SPLAT_COUNTER_STRIDE 32  /* uint32 words between two tile counters: one 128-byte line per counter, so that

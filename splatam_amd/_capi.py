@@ -16,7 +16,7 @@ SPLAT_TILE = 16
 SPLAT_MAX_CHANNELS = 8
 SPLAT_GRAD_STRIDE = 16
 SPLAT_COUNTER_STRIDE = 32
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _fp = C.c_void_p  # device pointers travel as integers
 
