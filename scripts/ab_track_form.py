@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""A/B of the tracking form of the backward composite (splat_debug_option(2, 3) = with the opacity sum, one list entry per
+loop trip; 2 = without it, two entries per trip): fused tracking iterations per second at workload B.  Developer tool."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, bench
