@@ -295,8 +295,9 @@ int splat_iter_tracking_step(const SplatCamera *cam, const SplatMap *map, const 
                              const SplatLossConfig *cfg, SplatIterWorkspace *ws, const SplatPoseAdam *adam, void *stream);
 
 /* Kernel-only timing helper for bench.py on the fused path: fn 0 = 6-channel composite forward, 1 = 6-channel composite
- * backward (incl. its accumulator memset), launched `iters` times on `stream` between two hipEvents; the workspace must hold
- * the state of a completed splat_iter_loss_backward. */
+ * backward (the kernel alone: the launches accumulate on top of each other and the accumulator is zeroed again AFTER the
+ * timed bracket, so the workspace stays usable), launched `iters` times on `stream` between two hipEvents; the workspace
+ * must hold the state of a completed splat_iter_loss_backward. */
 int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P, SplatIterWorkspace *ws, void *stream, float *ms);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -385,8 +386,9 @@ int splat_map_prune(SplatMapStore *store, const SplatPruneArgs *args, void *stre
 
 /* Developer switches used by scripts/ (never by the product path): key 0 = skip the per-tile
  * count atomics of K1 (timing experiment; results are then invalid); key 1 = generation of the composite kernels
- * (3 = current, 2 = previous, 3-channel calls only, 4 = experiment; A/B timing); key 2 = list entries per loop trip of the
- * backward composite (2 = current, 1 = previous).  Returns the previous value. */
+ * (3 = current; 2 = previous, 3-channel calls only, and 4 = rejected experiment exist only in a library built with
+ * `make EXPERIMENTS=1`: the product library answers -1 for them); key 2 = list entries per loop trip of the
+ * backward composite (2 = current, 1 = previous).  Returns the previous value, -1 for an unknown key / unavailable value. */
 int splat_debug_option(int key, int value);
 
 #ifdef __cplusplus

@@ -146,3 +146,50 @@ def mark_visible(means3D, view):
     out = np.zeros(m.shape[0], np.uint8)
     lib().ref_mark_visible(m.shape[0], _p(m), _p(_f(np.reshape(view, -1))), out.ctypes.data_as(C.POINTER(C.c_ubyte)))
     return out.astype(bool)
+
+
+# --------------------------------------------------------------------------
+# The C oracle behind the reference's Renderer call surface, with autograd (CPU tensors).  Lets the tests run the
+# reference-shaped get_loss (both renders + loss.backward()) end to end on the oracle at full size, where the dense
+# torch oracle (raster_ref.py) is too slow.
+# --------------------------------------------------------------------------
+try:
+    import torch
+
+    class _CRasterize(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, means3D, means2D, colors, opacities, scales, rotations, settings):
+            cr = CRef()
+            s = settings
+            col, radii, dep = cr.forward(means3D.detach().numpy(), colors.detach().numpy(), opacities.detach().numpy(),
+                                         scales.detach().numpy(), rotations.detach().numpy(),
+                                         s.viewmatrix.detach().numpy(), s.projmatrix.detach().numpy(), float(s.tanfovx),
+                                         float(s.tanfovy), int(s.image_width), int(s.image_height), s.bg.detach().numpy(),
+                                         scale_modifier=float(s.scale_modifier))
+            ctx.cr = cr
+            ctx.opac_shape = tuple(opacities.shape)
+            radii_t = torch.from_numpy(radii)
+            ctx.mark_non_differentiable(radii_t)
+            return torch.from_numpy(col), radii_t, torch.from_numpy(dep)
+
+        @staticmethod
+        def backward(ctx, g_color, _g_radii, _g_depth):
+            g = ctx.cr.backward(g_color.contiguous().numpy())
+            t = torch.from_numpy
+            return (t(g['means3D']), t(g['means2D']), t(g['colors']), t(g['opacities']).reshape(ctx.opac_shape),
+                    t(g['scales']), t(g['rotations']), None)
+
+    class CRasterizer(torch.nn.Module):
+        """``Renderer(raster_settings=cam)(**rendervar)`` (/root/reference/scripts/splatam.py:249) on the C oracle."""
+
+        def __init__(self, raster_settings):
+            super().__init__()
+            self.raster_settings = raster_settings
+
+        def forward(self, means3D, means2D, opacities, colors_precomp=None, scales=None, rotations=None, shs=None,
+                    cov3D_precomp=None):
+            if shs is not None or cov3D_precomp is not None or colors_precomp is None or scales is None or rotations is None:
+                raise NotImplementedError("the C oracle wrapper takes colors_precomp + scales + rotations")
+            return _CRasterize.apply(means3D, means2D, colors_precomp, opacities, scales, rotations, self.raster_settings)
+except ImportError:                     # numpy-only users of CRef
+    pass

@@ -364,12 +364,18 @@ def make_camera(width, height, fx, fy, cx, cy, w2c=None, near=0.01, far=100.0, b
                     campos=cam_center, prefiltered=False)
 
 
-def synthetic_cloud(n, width, height, fx, fy, cx, cy, seed=0, anisotropic=False, dtype=torch.float32):
+def synthetic_cloud(n, width, height, fx, fy, cx, cy, seed=0, anisotropic=False, dtype=torch.float32, region=None):
     """Seeded SplaTAM-like cloud: one Gaussian per random (sub-)pixel back-projected
-    at z~U[1,4] (mirrors /root/reference/scripts/splatam.py:76-99,120-128)."""
+    at z~U[1,4] (mirrors /root/reference/scripts/splatam.py:76-99,120-128).
+    ``region`` = (u0, v0, u1, v1) as fractions of the image: all Gaussians project inside that window (the
+    clustered variant of SURVEY.md 8d: per-tile lists far longer than LDS)."""
     g = torch.Generator().manual_seed(seed)
     u = torch.rand(n, generator=g, dtype=torch.float64) * width - 0.5
     v = torch.rand(n, generator=g, dtype=torch.float64) * height - 0.5
+    if region is not None:
+        u0, v0, u1, v1 = region
+        u = (u + 0.5) * (u1 - u0) + u0 * width - 0.5
+        v = (v + 0.5) * (v1 - v0) + v0 * height - 0.5
     z = 1.0 + 3.0 * torch.rand(n, generator=g, dtype=torch.float64)
     means = torch.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], dim=-1)
     log_s = torch.log(z / ((fx + fy) / 2)) + 0.3 * torch.randn(n, generator=g, dtype=torch.float64)

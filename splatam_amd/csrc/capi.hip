@@ -195,6 +195,9 @@ int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P,
         err = fn == 0 ? launch_render_forward_feat8(*cam, ws->feat8, ws->st, ws->out6, false, s)
                       : launch_render_backward_feat8(*cam, ws->feat8, ws->st, ws->dL_dout6, ws->accum, P, false, true, s);
     (void)hipEventRecord(e1, s);
+    // the timed backward launches accumulated into ws->accum: restore the workspace invariant (every iteration leaves the
+    // accumulator zeroed; fused_backward_kernel relies on it) outside the timed bracket
+    if (fn == 1 && err == hipSuccess && P > 0) err = hipMemsetAsync(ws->accum, 0, sizeof(float) * SPLAT_GRAD_STRIDE * (size_t)P, s);
     (void)hipEventSynchronize(e1);
     float t = 0.f;
     (void)hipEventElapsedTime(&t, e0, e1);
@@ -263,7 +266,13 @@ int splat_map_prune(SplatMapStore *store, const SplatPruneArgs *a, void *stream)
 
 int splat_debug_option(int key, int value) {
     if (key == 0) { const int old = g_debug_skip_count; g_debug_skip_count = value; return old; }
-    if (key == 1) { const int old = g_debug_composite_version; g_debug_composite_version = value; return old; }
+    if (key == 1) {
+#if defined(SPLAT_EXPERIMENTS)
+        const int old = g_debug_composite_version; g_debug_composite_version = value; return old;
+#else
+        return value == 3 ? 3 : -1;     // the product library holds generation 3 only
+#endif
+    }
     if (key == 2) { const int old = g_debug_entries_per_trip; g_debug_entries_per_trip = (value == 1 || value == 3) ? value : 2; return old; }
     return -1;
 }

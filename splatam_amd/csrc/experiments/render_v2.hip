@@ -27,7 +27,7 @@
 // composite (K7)" -- the callee of /root/reference/scripts/splatam.py:249,253
 // and of the autograd backward reached from :702,854.  exp(power) is evaluated
 // as v_exp_f32(power * log2 e) with log2 e folded into the staged conic.
-#include "splat_device.h"
+#include "../splat_device.h"
 
 namespace splat {
 namespace v2 {

@@ -29,7 +29,7 @@
 //
 // Arithmetic and its order per pixel are those of generation 3 (render.hip): results are identical up to the
 // summation order of the per-Gaussian partial sums.
-#include "splat_device.h"
+#include "../splat_device.h"
 
 namespace splat {
 

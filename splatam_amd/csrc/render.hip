@@ -1,6 +1,6 @@
 // render.hip -- tile-wise alpha compositing, forward (K6) and backward (K7).
 //
-// MI355X mapping (third generation; the previous one lives in render_v2.hip for A/B timing):
+// MI355X mapping (third generation; earlier / rejected ones live in experiments/, built only with EXPERIMENTS=1):
 //   * one 256-thread workgroup per 16x16 tile, ONE WAVE64 PER 8x8 QUADRANT, one pixel per lane.  A frame of
 //     config B is 3 225 tiles = 12 900 waves = 12.6 per SIMD, so every SIMD always has several waves to
 //     interleave (the one-wave-per-tile kernels were latency bound at ~3 waves per SIMD);
@@ -29,6 +29,10 @@ namespace splat {
 
 constexpr int kBatch = 256;     // list entries staged per LDS buffer
 
+#if defined(SPLAT_EXPERIMENTS)
+// Superseded / rejected generations of these kernels (experiments/render_v2.hip, experiments/render_v4.hip), built only with
+// `make EXPERIMENTS=1` and selected with splat_debug_option(1, v) for A/B timing: 2 = wave per tile (3-channel calls only),
+// 4 = one 4x4 block per 16-lane row (fewer VALU instructions but twice the accumulator atomics).
 hipError_t launch_render_forward_v2(const SplatCamera &cam, const float *col, SplatState &st, float *out_color,
                                     float *out_depth, hipStream_t s);
 hipError_t launch_render_backward_v2(const SplatCamera &cam, const float *col, const SplatState &st, const float *dL_dcolor,
@@ -41,9 +45,7 @@ hipError_t launch_render_forward_feat8_v4(const SplatCamera &cam, const float *f
                                           hipStream_t s);
 hipError_t launch_render_backward_feat8_v4(const SplatCamera &cam, const float *feat8, const SplatState &st, const float *dL_dout6,
                                            float *accum, bool rgb_sums, hipStream_t s);
-// splat_debug_option(1, v): 3 = current (this file: wave per 8x8 quadrant); 4 = experiment (render_v4.hip: one 4x4 block
-// per 16-lane row; fewer VALU instructions but twice the accumulator atomics -- slower);
-// 2 = wave per tile (render_v2.hip, 3-channel calls only).  2 and 4 are kept for A/B timing.
+#endif
 int g_debug_composite_version = 3;
 
 // One staged Gaussian as the gathering thread holds it in registers.
@@ -600,8 +602,10 @@ hipError_t launch_render_forward(const SplatCamera &cam, const SplatGaussians &g
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
     const float *col = colour_source(g, st);
     if (T == 0) return hipSuccess;
+#if defined(SPLAT_EXPERIMENTS)
     if (g_debug_composite_version == 4) return launch_render_forward_v4(cam, col, g.channels, st, out_color, out_depth, s);
     if (g_debug_composite_version == 2 && g.channels == 3) return launch_render_forward_v2(cam, col, st, out_color, out_depth, s);
+#endif
     switch (g.channels) {
         case 1: launch_fwd<1, 1, true>(cam, col, st, out_color, out_depth, T, s); break;
         case 2: launch_fwd<2, 2, true>(cam, col, st, out_color, out_depth, T, s); break;
@@ -623,8 +627,10 @@ hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &
     hipError_t e = hipMemsetAsync(gr.accum, 0, sizeof(float) * SPLAT_GRAD_STRIDE * (size_t)g.P, s);
     if (e != hipSuccess) return e;
     if (T == 0 || g.P == 0) return hipSuccess;
+#if defined(SPLAT_EXPERIMENTS)
     if (g_debug_composite_version == 4) return launch_render_backward_v4(cam, col, g.channels, st, gr.dL_dcolor, gr.accum, s);
     if (g_debug_composite_version == 2 && g.channels == 3) return launch_render_backward_v2(cam, col, st, gr.dL_dcolor, gr.accum, s);
+#endif
     switch (g.channels) {
         case 1: launch_bwd<1, 1>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
         case 2: launch_bwd<2, 2>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
@@ -645,7 +651,9 @@ hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
     if (ep_done) *ep_done = false;
     if (T == 0) return hipSuccess;
+#if defined(SPLAT_EXPERIMENTS)
     if (g_debug_composite_version == 4) return launch_render_forward_feat8_v4(cam, feat8, st, out6, sort_in_kernel, s);
+#endif
     const int per = (T + 7) / 8;
     if (ep && ep_done) {
         if (sort_in_kernel)
@@ -670,7 +678,9 @@ hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *fea
         if (e != hipSuccess) return e;
     }
     if (T == 0 || P == 0) return hipSuccess;
+#if defined(SPLAT_EXPERIMENTS)
     if (g_debug_composite_version == 4) return launch_render_backward_feat8_v4(cam, feat8, st, dL_dout6, accum, rgb_sums, s);
+#endif
     // channels r, g, b, z carry gradient; the silhouette and depth^2 planes never do.  dL/drgb is only summed on request
     // (tracking does not read it: LR 0 in /root/reference/configs/*/splatam.py, optimizer discarded after the frame).
     // (zero background: FusedEngine refuses anything else, as setup_camera builds it)

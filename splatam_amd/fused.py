@@ -103,6 +103,7 @@ class FusedEngine:
         self.allow_buckets = True
         self._alloc_lists(self.capacity)
         self._cam = self._make_cam(cam)
+        self._cam_ok = {}
         self._frame_keep = None
 
     # ------------------------------------------------------------------ capacity-managed map
@@ -207,6 +208,7 @@ class FusedEngine:
     def render(self, curr_data, time_idx):
         """Forward-only 6-channel render of the map from pose ``time_idx`` (no loss, no gradients): returns
         ``rendered()``.  The render of add_new_gaussians (/root/reference/scripts/splatam.py:381-385)."""
+        self._check_cam(curr_data)
         fr = _capi.SplatFrameData()
         w2c = curr_data['w2c'] if curr_data['w2c'].is_contiguous() else curr_data['w2c'].contiguous()
         fr.im, fr.depth, fr.w2c, fr.time_idx = None, None, w2c.data_ptr(), int(time_idx)
@@ -275,7 +277,14 @@ class FusedEngine:
         if gaussian_distribution is not None and (gaussian_distribution == "isotropic") != self.iso:
             raise ValueError("gaussian_distribution differs from the map's log_scales layout")
         if depth_sil is None:
-            self.render(curr_data, time_idx)
+            # the densification render must come from complete, sorted lists: a spilled bucket / stale list-length hint would
+            # permanently add wrong Gaussians (the status words are overwritten by the next relearn_lists)
+            for _ in range(3):
+                self.render(curr_data, time_idx)
+                if not self.check_overflow():
+                    break
+            else:
+                raise RuntimeError("add_new_gaussians: the per-tile lists could not be sized for the densification render")
         else:
             self.buf['out6'][3] = depth_sil[0]
             self.buf['out6'][4] = depth_sil[1]
@@ -357,6 +366,24 @@ class FusedEngine:
         self._cam_keep = (bg6, view, proj, campos)
         return cam
 
+    def _check_cam(self, curr_data):
+        """The engine bakes the camera into its launch arguments at construction; the reference's get_loss reads
+        curr_data['cam'] on every call (/root/reference/scripts/splatam.py:249).  A different camera is an error here, not a
+        silently ignored argument."""
+        cam = curr_data.get('cam') if hasattr(curr_data, 'get') else None
+        if cam is None or cam is self.cam_settings or id(cam) in self._cam_ok:
+            return
+        ref = self.cam_settings
+        same = (int(cam.image_height) == int(ref.image_height) and int(cam.image_width) == int(ref.image_width)
+                and float(cam.tanfovx) == float(ref.tanfovx) and float(cam.tanfovy) == float(ref.tanfovy)
+                and float(cam.scale_modifier) == float(ref.scale_modifier)
+                and all(torch.equal(getattr(cam, f).to(self.dev).float().reshape(-1), getattr(ref, f).to(self.dev).float().reshape(-1))
+                        for f in ("viewmatrix", "projmatrix", "bg")))
+        if not same:
+            raise RuntimeError("curr_data['cam'] differs from the camera this FusedEngine was built for "
+                               "(build one engine per camera / resolution)")
+        self._cam_ok[id(cam)] = cam          # keeps the tuple alive, so the id stays unique
+
     def _map_struct(self):
         p = self.params
         if self.managed:          # the backing arrays (a zero-row view has no data pointer)
@@ -416,6 +443,7 @@ class FusedEngine:
         rides in the last kernel (splat_iter_tracking_step)."""
         if map_grads is None:
             map_grads = not tracking
+        self._check_cam(curr_data)
         fr = _capi.SplatFrameData()
         im, depth = curr_data['im'], curr_data['depth']
         w2c = curr_data['w2c']
@@ -544,7 +572,8 @@ class FusedEngine:
 
     @property
     def seen(self):
-        return self.buf['radii'] > 0
+        """variables['seen'] of the last iteration ([P], /root/reference/scripts/splatam.py:343)."""
+        return self.buf['radii'][:self.P] > 0
 
     def rendered(self):
         """(im[3,H,W], depth[1,H,W], silhouette[H,W], depth_sq[1,H,W]) of the last iteration."""

@@ -198,8 +198,30 @@ def _stream(dev) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
 
-def rasterize_forward(settings, means3D, colors, opacities, scales, rotations, cov3D, shs):
-    """One forward through the C ABI.  Returns (color, radii, depth, pack)."""
+class LazyOverflow(RuntimeError):
+    """Lazy sync mode: the (Gaussian, tile) instances did not fit the lists sized from the high-water mark."""
+
+
+def rasterize_forward(settings, means3D, colors, opacities, scales, rotations, cov3D, shs, will_backward=True):
+    """One forward through the C ABI.  Returns (color, radii, depth, pack).
+
+    ``will_backward=False`` (no input requires grad: torch.no_grad renders such as add_new_gaussians, evaluation,
+    keyframe selection): in lazy sync mode nothing downstream would ever look at the device-side status words, and an
+    overflow publishes EMPTY lists (a background-only image).  The status is therefore resolved here (one D2H read, as
+    the exact mode does) and the render is repeated with the raised capacity."""
+    for _ in range(4):
+        out = _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotations, cov3D, shs)
+        if will_backward or getattr(out[3], "pending_status", None) is None:
+            return out
+        try:
+            resolve_lazy(out[3])
+            return out
+        except LazyOverflow:
+            continue                    # resolve_lazy has raised the capacity hint: render again
+    raise RuntimeError("lazy sync mode: the instance lists could not be sized")
+
+
+def _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotations, cov3D, shs):
     L = _capi.lib()
     dev = means3D.device
     H, W = int(settings.image_height), int(settings.image_width)
@@ -264,7 +286,7 @@ def resolve_lazy(pk) -> None:
     pk.num_rendered = n
     _capacity_hint[pk.hint_key] = max(_capacity_hint.get(pk.hint_key, 0), int(n * 1.5) + 1024)
     if int(host[1]) != 0 or n > pk.st.capacity:
-        raise RuntimeError(
+        raise LazyOverflow(
             f"lazy sync mode: {n} (Gaussian, tile) instances did not fit the {pk.st.capacity}-entry lists; "
             "the capacity hint has been raised -- re-run the forward (or use set_sync_mode('exact'))")
 
@@ -316,7 +338,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             raise RuntimeError(f"colors_precomp must be [{P}, C], got {tuple(colors.shape)}")
         if sh.numel() and (sh.dim() != 3 or sh.shape[0] != P or sh.shape[2] != 3):
             raise RuntimeError(f"shs must be [{P}, M, 3], got {tuple(sh.shape)}")
-        color, radii, depth, pk = rasterize_forward(raster_settings, means3D, colors, opac, scales_c, rots_c, cov_c, sh)
+        color, radii, depth, pk = rasterize_forward(raster_settings, means3D, colors, opac, scales_c, rots_c, cov_c, sh,
+                                                    will_backward=any(ctx.needs_input_grad))
         ctx.pack = pk
         ctx.use_sh = sh.numel() > 0
         ctx.sh_shape = tuple(sh.shape)

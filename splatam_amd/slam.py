@@ -558,12 +558,18 @@ REPLICA_PRUNE = dict(start_after=0, remove_big_after=0, stop_after=20, prune_eve
 # synthetic RGB-D scene (datasets are not available offline)
 # --------------------------------------------------------------------------
 
-def synthetic_params(n, width, height, fx, fy, cx, cy, num_frames=2, seed=0, device="cuda", anisotropic=False):
+def synthetic_params(n, width, height, fx, fy, cx, cy, num_frames=2, seed=0, device="cuda", anisotropic=False, region=None):
     """Seeded SplaTAM-like map: one Gaussian per random sub-pixel, back-projected at
-    z~U[1,4] with the reference's projective scale init (scripts/splatam.py:76-99,120-157)."""
+    z~U[1,4] with the reference's projective scale init (scripts/splatam.py:76-99,120-157).
+    ``region`` = (u0, v0, u1, v1) as fractions of the image: every Gaussian projects inside that window (the clustered
+    stress workload: per-tile lists far longer than LDS)."""
     g = torch.Generator().manual_seed(seed)
     u = torch.rand(n, generator=g, dtype=torch.float64) * width - 0.5
     v = torch.rand(n, generator=g, dtype=torch.float64) * height - 0.5
+    if region is not None:
+        u0, v0, u1, v1 = region
+        u = (u + 0.5) * (u1 - u0) + u0 * width - 0.5
+        v = (v + 0.5) * (v1 - v0) + v0 * height - 0.5
     z = 1.0 + 3.0 * torch.rand(n, generator=g, dtype=torch.float64)
     means = torch.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], dim=-1)
     log_s = torch.log(z / ((fx + fy) / 2)) + 0.3 * torch.randn(n, generator=g, dtype=torch.float64)
