@@ -13,44 +13,42 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libraster_ref.so")
-_lib = None
+_SO64 = os.path.join(_HERE, "_build", "libraster_ref_f64.so")      # the same statements in float64 (-DREF_DOUBLE)
+_libs = {}
 
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "raster_ref.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    stale = any(not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src) for so in (_SO, _SO64))
+    if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_SO):
+def lib(precision: str = "f32"):
+    if precision not in ("f32", "f64"):
+        raise ValueError(precision)
+    if precision not in _libs:
+        so = _SO if precision == "f32" else _SO64
+        if not os.path.exists(so):
             build()
-        L = C.CDLL(_SO)
+        L = C.CDLL(so)
+        rt_real = C.c_float if precision == "f32" else C.c_double
+        assert L.ref_real_bytes() == C.sizeof(rt_real)
         L.ref_create.restype = C.c_void_p
         L.ref_destroy.argtypes = [C.c_void_p]
         L.ref_num_rendered.restype = C.c_int64
         L.ref_num_rendered.argtypes = [C.c_void_p]
-        for name, rt in (("ref_ranges", C.c_int), ("ref_list", C.c_int), ("ref_final_T", C.c_float),
-                         ("ref_n_contrib", C.c_int), ("ref_geom_xy", C.c_float),
-                         ("ref_geom_conic_op", C.c_float), ("ref_geom_depth", C.c_float)):
+        for name, rt in (("ref_ranges", C.c_int), ("ref_list", C.c_int), ("ref_final_T", rt_real),
+                         ("ref_n_contrib", C.c_int), ("ref_geom_xy", rt_real),
+                         ("ref_geom_conic_op", rt_real), ("ref_geom_depth", rt_real)):
             f = getattr(L, name)
             f.restype = C.POINTER(rt)
             f.argtypes = [C.c_void_p]
         L.ref_forward.restype = C.c_int
         L.ref_backward.restype = C.c_int
-        _lib = L
-    return _lib
-
-
-def _f(a):
-    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
-
-
-def _p(a, t=C.c_float):
-    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+        _libs[precision] = L
+    return _libs[precision]
 
 
 class CRef:
@@ -58,10 +56,13 @@ class CRef:
 
     Matrices are passed exactly as the settings tuple holds them
     (/root/reference/utils/recon_helpers.py:8-13): viewmatrix = w2c^T,
-    projmatrix = (P w2c)^T, flattened row-major (== column-major of w2c)."""
+    projmatrix = (P w2c)^T, flattened row-major (== column-major of w2c).
+    ``precision="f64"``: the float64 build of the same statements (inputs are the float32 values, widened)."""
 
-    def __init__(self):
-        self.L = lib()
+    def __init__(self, precision: str = "f32"):
+        self.L = lib(precision)
+        self.dt = np.float32 if precision == "f32" else np.float64
+        self.ct = C.c_float if precision == "f32" else C.c_double
         self.ctx = C.c_void_p(self.L.ref_create())
 
     def __del__(self):
@@ -70,22 +71,30 @@ class CRef:
         except Exception:
             pass
 
+    def _f(self, a):
+        # float32 inputs widen exactly for the f64 build; float64 inputs (a float64 caller-side chain) pass unrounded
+        return None if a is None else np.ascontiguousarray(a, dtype=self.dt)
+
+    def _p(self, a, t=None):
+        return None if a is None else a.ctypes.data_as(C.POINTER(t or self.ct))
+
     def forward(self, means3D, colors, opacities, scales, rotations, view, proj, tanfovx, tanfovy,
                 W, H, bg, scale_modifier=1.0, cov3D_precomp=None):
+        _f, _p = self._f, self._p
         self.a = dict(means3D=_f(means3D), colors=_f(colors), opac=_f(np.reshape(opacities, -1)),
                       scales=_f(scales), rot=_f(rotations), view=_f(np.reshape(view, -1)),
                       proj=_f(np.reshape(proj, -1)), bg=_f(bg), cov=_f(cov3D_precomp))
         a = self.a
         P, Cc = a['means3D'].shape[0], a['colors'].shape[1]
         self.P, self.C, self.W, self.H = P, Cc, W, H
-        self.tan = (float(tanfovx), float(tanfovy))
-        self.mod = float(scale_modifier)
-        color = np.zeros((Cc, H, W), np.float32)
-        depth = np.zeros((1, H, W), np.float32)
+        self.tan = (float(np.float32(tanfovx)), float(np.float32(tanfovy)))
+        self.mod = float(np.float32(scale_modifier))
+        color = np.zeros((Cc, H, W), self.dt)
+        depth = np.zeros((1, H, W), self.dt)
         radii = np.zeros(P, np.int32)
         rc = self.L.ref_forward(self.ctx, P, Cc, W, H, _p(a['bg']), _p(a['means3D']), _p(a['colors']),
-                                _p(a['opac']), _p(a['scales']), C.c_float(self.mod), _p(a['rot']), _p(a['cov']),
-                                _p(a['view']), _p(a['proj']), C.c_float(self.tan[0]), C.c_float(self.tan[1]),
+                                _p(a['opac']), _p(a['scales']), self.ct(self.mod), _p(a['rot']), _p(a['cov']),
+                                _p(a['view']), _p(a['proj']), self.ct(self.tan[0]), self.ct(self.tan[1]),
                                 _p(color), _p(depth), _p(radii, C.c_int))
         if rc != 0:
             raise RuntimeError(f"ref_forward failed: {rc}")
@@ -100,7 +109,7 @@ class CRef:
         return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True)
 
     def final_T(self):
-        return self._arr("ref_final_T", self.W * self.H, np.float32).reshape(self.H, self.W)
+        return self._arr("ref_final_T", self.W * self.H, self.dt).reshape(self.H, self.W)
 
     def n_contrib(self):
         return self._arr("ref_n_contrib", self.W * self.H, np.int32).reshape(self.H, self.W)
@@ -114,25 +123,25 @@ class CRef:
         return self._arr("ref_list", n, np.int32) if n else np.zeros(0, np.int32)
 
     def geom(self):
-        return dict(xy=self._arr("ref_geom_xy", 2 * self.P, np.float32).reshape(-1, 2),
-                    conic_op=self._arr("ref_geom_conic_op", 4 * self.P, np.float32).reshape(-1, 4),
-                    depth=self._arr("ref_geom_depth", self.P, np.float32))
+        return dict(xy=self._arr("ref_geom_xy", 2 * self.P, self.dt).reshape(-1, 2),
+                    conic_op=self._arr("ref_geom_conic_op", 4 * self.P, self.dt).reshape(-1, 4),
+                    depth=self._arr("ref_geom_depth", self.P, self.dt))
 
     def backward(self, dL_dcolor):
         a = self.a
+        _f, _p = self._f, self._p
         P, Cc = self.P, self.C
         g = _f(dL_dcolor)
-        out = dict(means3D=np.zeros((P, 3), np.float32), means2D=np.zeros((P, 3), np.float32),
-                   colors=np.zeros((P, Cc), np.float32), opacities=np.zeros((P, 1), np.float32),
-                   cov3D=np.zeros((P, 6), np.float32))
+        z = lambda *shape: np.zeros(shape, self.dt)      # noqa: E731
+        out = dict(means3D=z(P, 3), means2D=z(P, 3), colors=z(P, Cc), opacities=z(P, 1), cov3D=z(P, 6))
         use_sr = a['cov'] is None
         if use_sr:
-            out['scales'] = np.zeros((P, 3), np.float32)
-            out['rotations'] = np.zeros((P, 4), np.float32)
+            out['scales'] = z(P, 3)
+            out['rotations'] = z(P, 4)
         rc = self.L.ref_backward(self.ctx, _p(a['bg']), _p(a['means3D']), _p(a['colors']),
-                                 _p(a['scales']) if use_sr else None, C.c_float(self.mod),
+                                 _p(a['scales']) if use_sr else None, self.ct(self.mod),
                                  _p(a['rot']) if use_sr else None,
-                                 _p(a['view']), _p(a['proj']), C.c_float(self.tan[0]), C.c_float(self.tan[1]),
+                                 _p(a['view']), _p(a['proj']), self.ct(self.tan[0]), self.ct(self.tan[1]),
                                  _p(g), _p(out['means3D']), _p(out['means2D']), _p(out['colors']),
                                  _p(out['opacities']), _p(out.get('scales')), _p(out.get('rotations')),
                                  _p(out['cov3D']))
@@ -142,9 +151,11 @@ class CRef:
 
 
 def mark_visible(means3D, view):
-    m = _f(means3D)
+    m = np.ascontiguousarray(means3D, dtype=np.float32)
+    v = np.ascontiguousarray(np.reshape(view, -1), dtype=np.float32)
     out = np.zeros(m.shape[0], np.uint8)
-    lib().ref_mark_visible(m.shape[0], _p(m), _p(_f(np.reshape(view, -1))), out.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    fp = C.POINTER(C.c_float)
+    lib().ref_mark_visible(m.shape[0], m.ctypes.data_as(fp), v.ctypes.data_as(fp), out.ctypes.data_as(C.POINTER(C.c_ubyte)))
     return out.astype(bool)
 
 
@@ -159,7 +170,7 @@ try:
     class _CRasterize(torch.autograd.Function):
         @staticmethod
         def forward(ctx, means3D, means2D, colors, opacities, scales, rotations, settings):
-            cr = CRef()
+            cr = CRef("f64" if means3D.dtype == torch.float64 else "f32")      # float64 tensors -> the float64 build
             s = settings
             col, radii, dep = cr.forward(means3D.detach().numpy(), colors.detach().numpy(), opacities.detach().numpy(),
                                          scales.detach().numpy(), rotations.detach().numpy(),

@@ -27,17 +27,40 @@
 #define TILE 16
 #define MAXC 8
 
+/* Working precision.  Default: float32, the arithmetic type of the path (every operation of Appendix A rounds as the
+ * reference's float kernels round).  -DREF_DOUBLE builds the SAME statements in float64 (library
+ * _build/libraster_ref_f64.so): the "exact" evaluation of the algorithm that the tests use to calibrate how far two correct
+ * float32 implementations may differ (pixel coordinates of ~1e3 carry 1e-4 px of float32 rounding, which the backward
+ * chain amplifies through cancelling sums).  Threshold constants keep their float32 VALUES in both builds (0.99f, 1.f/255.f,
+ * 0.0001f, 0.2f, 0.3f ... are float literals promoted exactly), and the depth sort key is always the float32 bit pattern. */
+#ifdef REF_DOUBLE
+typedef double real;
+#define R_EXP exp
+#define R_SQRT sqrt
+#define R_MIN fmin
+#define R_MAX fmax
+#define R_CEIL ceil
+#else
+typedef float real;
+#define R_EXP expf
+#define R_SQRT sqrtf
+#define R_MIN fminf
+#define R_MAX fmaxf
+#define R_CEIL ceilf
+#endif
+int ref_real_bytes(void) { return (int)sizeof(real); }
+
 typedef struct {
     int P, C, W, H, gx, gy;
     /* per-Gaussian geometry (Appendix A, preprocess outputs) */
-    float *depth, *xy, *conic_op, *cov3d, *cov2d;
+    real *depth, *xy, *conic_op, *cov3d, *cov2d;
     int *radii, *rect;          /* rect: minx,miny,maxx,maxy (tiles) */
     /* binning */
     int64_t R;
     int *range;                 /* [tiles+1] */
     int *list;                  /* [R] Gaussian ids, per tile sorted by (depth bits, id) */
     /* per-pixel */
-    float *final_T;
+    real *final_T;
     int *n_contrib;
 } ref_ctx;
 
@@ -53,30 +76,30 @@ void ref_destroy(ref_ctx *c) { if (c) { ctx_release(c); free(c); } }
 int64_t ref_num_rendered(const ref_ctx *c) { return c->R; }
 const int *ref_ranges(const ref_ctx *c) { return c->range; }
 const int *ref_list(const ref_ctx *c) { return c->list; }
-const float *ref_final_T(const ref_ctx *c) { return c->final_T; }
+const real *ref_final_T(const ref_ctx *c) { return c->final_T; }
 const int *ref_n_contrib(const ref_ctx *c) { return c->n_contrib; }
-const float *ref_geom_xy(const ref_ctx *c) { return c->xy; }
-const float *ref_geom_conic_op(const ref_ctx *c) { return c->conic_op; }
-const float *ref_geom_depth(const ref_ctx *c) { return c->depth; }
+const real *ref_geom_xy(const ref_ctx *c) { return c->xy; }
+const real *ref_geom_conic_op(const ref_ctx *c) { return c->conic_op; }
+const real *ref_geom_depth(const ref_ctx *c) { return c->depth; }
 
 /* 4x4 given as 16 floats, element (row r, col c) at m[c*4+r] (Appendix A conventions). */
-static inline float m4(const float *m, int r, int c) { return m[c * 4 + r]; }
+static inline real m4(const real *m, int r, int c) { return m[c * 4 + r]; }
 
-static void quat_rot(const float *q, float R[3][3]) {
+static void quat_rot(const real *q, real R[3][3]) {
     /* same polynomial as /root/reference/utils/slam_external.py:33-41, no renormalisation */
-    float r = q[0], x = q[1], y = q[2], z = q[3];
+    real r = q[0], x = q[1], y = q[2], z = q[3];
     R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
     R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
     R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
 }
 
-static void cov3d_of(const float *scale, float mod, const float *q, float *out6) {
-    float R[3][3], M[3][3];
+static void cov3d_of(const real *scale, real mod, const real *q, real *out6) {
+    real R[3][3], M[3][3];
     quat_rot(q, R);
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[i][j] = R[i][j] * (mod * scale[j]);
-    float S[3][3];
+    real S[3][3];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
-        float a = 0.f; for (int k = 0; k < 3; k++) a += M[i][k] * M[j][k]; S[i][j] = a;
+        real a = 0.f; for (int k = 0; k < 3; k++) a += M[i][k] * M[j][k]; S[i][j] = a;
     }
     out6[0] = S[0][0]; out6[1] = S[0][1]; out6[2] = S[0][2]; out6[3] = S[1][1]; out6[4] = S[1][2]; out6[5] = S[2][2];
 }
@@ -90,61 +113,61 @@ static int kv_cmp(const void *a, const void *b) {
 
 /* Forward.  cov3D_precomp may be NULL.  Returns 0. */
 int ref_forward(ref_ctx *c, int P, int C, int W, int H,
-                const float *bg, const float *means3D, const float *colors, const float *opac,
-                const float *scales, float mod, const float *rot, const float *cov3D_precomp,
-                const float *view, const float *proj, float tanfovx, float tanfovy,
-                float *out_color, float *out_depth, int *out_radii)
+                const real *bg, const real *means3D, const real *colors, const real *opac,
+                const real *scales, real mod, const real *rot, const real *cov3D_precomp,
+                const real *view, const real *proj, real tanfovx, real tanfovy,
+                real *out_color, real *out_depth, int *out_radii)
 {
     if (C > MAXC) return 1;
     ctx_release(c);
     int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, tiles = gx * gy;
     c->P = P; c->C = C; c->W = W; c->H = H; c->gx = gx; c->gy = gy;
-    c->depth = (float *)calloc(P, 4); c->xy = (float *)calloc(P, 8); c->conic_op = (float *)calloc(P, 16);
-    c->cov3d = (float *)calloc(P, 24); c->cov2d = (float *)calloc(P, 12);
+    c->depth = (real *)calloc(P, sizeof(real)); c->xy = (real *)calloc(P, 2 * sizeof(real)); c->conic_op = (real *)calloc(P, 4 * sizeof(real));
+    c->cov3d = (real *)calloc(P, 6 * sizeof(real)); c->cov2d = (real *)calloc(P, 3 * sizeof(real));
     c->radii = (int *)calloc(P, 4); c->rect = (int *)calloc(P, 16);
     c->range = (int *)calloc(tiles + 1, 4);
-    c->final_T = (float *)malloc((size_t)W * H * 4); c->n_contrib = (int *)calloc((size_t)W * H, 4);
-    const float fx = W / (2.f * tanfovx), fy = H / (2.f * tanfovy);
+    c->final_T = (real *)malloc((size_t)W * H * sizeof(real)); c->n_contrib = (int *)calloc((size_t)W * H, 4);
+    const real fx = W / (2.f * tanfovx), fy = H / (2.f * tanfovy);
     int *count = (int *)calloc(tiles, 4);
 
     /* ---- preprocess (Appendix A steps 1-9) ---- */
     for (int i = 0; i < P; i++) {
-        const float *p = means3D + 3 * i;
-        float tv[3];
+        const real *p = means3D + 3 * i;
+        real tv[3];
         for (int r = 0; r < 3; r++) tv[r] = m4(view, r, 0) * p[0] + m4(view, r, 1) * p[1] + m4(view, r, 2) * p[2] + m4(view, r, 3);
         out_radii[i] = 0;
         if (tv[2] <= 0.2f) continue;
-        float hom[4];
+        real hom[4];
         for (int r = 0; r < 4; r++) hom[r] = m4(proj, r, 0) * p[0] + m4(proj, r, 1) * p[1] + m4(proj, r, 2) * p[2] + m4(proj, r, 3);
-        float pw = 1.f / (hom[3] + 0.0000001f);
-        float ndcx = hom[0] * pw, ndcy = hom[1] * pw;
-        float *S6 = c->cov3d + 6 * i;
-        if (cov3D_precomp) memcpy(S6, cov3D_precomp + 6 * i, 24);
+        real pw = 1.f / (hom[3] + 0.0000001f);
+        real ndcx = hom[0] * pw, ndcy = hom[1] * pw;
+        real *S6 = c->cov3d + 6 * i;
+        if (cov3D_precomp) memcpy(S6, cov3D_precomp + 6 * i, 6 * sizeof(real));
         else cov3d_of(scales + 3 * i, mod, rot + 4 * i, S6);
         /* EWA */
-        float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
-        float txtz = tv[0] / tv[2], tytz = tv[1] / tv[2];
-        float tx = fminf(limx, fmaxf(-limx, txtz)) * tv[2];
-        float ty = fminf(limy, fmaxf(-limy, tytz)) * tv[2];
-        float tz = tv[2];
-        float J[2][3] = {{fx / tz, 0.f, -(fx * tx) / (tz * tz)}, {0.f, fy / tz, -(fy * ty) / (tz * tz)}};
-        float T[2][3];
+        real limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+        real txtz = tv[0] / tv[2], tytz = tv[1] / tv[2];
+        real tx = R_MIN(limx, R_MAX(-limx, txtz)) * tv[2];
+        real ty = R_MIN(limy, R_MAX(-limy, tytz)) * tv[2];
+        real tz = tv[2];
+        real J[2][3] = {{fx / tz, 0.f, -(fx * tx) / (tz * tz)}, {0.f, fy / tz, -(fy * ty) / (tz * tz)}};
+        real T[2][3];
         for (int r = 0; r < 2; r++) for (int k = 0; k < 3; k++)
             T[r][k] = J[r][0] * m4(view, 0, k) + J[r][1] * m4(view, 1, k) + J[r][2] * m4(view, 2, k);
-        float Sg[3][3] = {{S6[0], S6[1], S6[2]}, {S6[1], S6[3], S6[4]}, {S6[2], S6[4], S6[5]}};
-        float TS[2][3];
+        real Sg[3][3] = {{S6[0], S6[1], S6[2]}, {S6[1], S6[3], S6[4]}, {S6[2], S6[4], S6[5]}};
+        real TS[2][3];
         for (int r = 0; r < 2; r++) for (int k = 0; k < 3; k++) TS[r][k] = T[r][0] * Sg[0][k] + T[r][1] * Sg[1][k] + T[r][2] * Sg[2][k];
-        float a = TS[0][0] * T[0][0] + TS[0][1] * T[0][1] + TS[0][2] * T[0][2] + 0.3f;
-        float b = TS[0][0] * T[1][0] + TS[0][1] * T[1][1] + TS[0][2] * T[1][2];
-        float cc = TS[1][0] * T[1][0] + TS[1][1] * T[1][1] + TS[1][2] * T[1][2] + 0.3f;
-        float det = a * cc - b * b;
+        real a = TS[0][0] * T[0][0] + TS[0][1] * T[0][1] + TS[0][2] * T[0][2] + 0.3f;
+        real b = TS[0][0] * T[1][0] + TS[0][1] * T[1][1] + TS[0][2] * T[1][2];
+        real cc = TS[1][0] * T[1][0] + TS[1][1] * T[1][1] + TS[1][2] * T[1][2] + 0.3f;
+        real det = a * cc - b * b;
         if (det == 0.f) continue;
-        float di = 1.f / det;
-        float mid = 0.5f * (a + cc);
-        float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
-        float lam = fmaxf(mid + disc, mid - disc);
-        float radius = ceilf(3.f * sqrtf(lam));
-        float px = ((ndcx + 1.f) * W - 1.f) * 0.5f, py = ((ndcy + 1.f) * H - 1.f) * 0.5f;
+        real di = 1.f / det;
+        real mid = 0.5f * (a + cc);
+        real disc = R_SQRT(R_MAX(0.1f, mid * mid - det));
+        real lam = R_MAX(mid + disc, mid - disc);
+        real radius = R_CEIL(3.f * R_SQRT(lam));
+        real px = ((ndcx + 1.f) * W - 1.f) * 0.5f, py = ((ndcy + 1.f) * H - 1.f) * 0.5f;
         int x0 = (int)((px - radius) / TILE), y0 = (int)((py - radius) / TILE);
         int x1 = (int)((px + radius + TILE - 1) / TILE), y1 = (int)((py + radius + TILE - 1) / TILE);
         x0 = x0 < 0 ? 0 : (x0 > gx ? gx : x0); x1 = x1 < 0 ? 0 : (x1 > gx ? gx : x1);
@@ -157,7 +180,7 @@ int ref_forward(ref_ctx *c, int P, int C, int W, int H,
         int *rc = c->rect + 4 * i; rc[0] = x0; rc[1] = y0; rc[2] = x1; rc[3] = y1;
         for (int y = y0; y < y1; y++) for (int x = x0; x < x1; x++) count[y * gx + x]++;
     }
-    /* ---- binning: per tile, ascending (float bits of depth, id) ---- */
+    /* ---- binning: per tile, ascending (real bits of depth, id) ---- */
     for (int t = 0; t < tiles; t++) c->range[t + 1] = c->range[t] + count[t];
     c->R = c->range[tiles];
     c->list = (int *)malloc((size_t)(c->R ? c->R : 1) * 4);
@@ -166,7 +189,7 @@ int ref_forward(ref_ctx *c, int P, int C, int W, int H,
     for (int i = 0; i < P; i++) {
         if (c->radii[i] <= 0) continue;
         const int *rc = c->rect + 4 * i;
-        uint32_t key; memcpy(&key, &c->depth[i], 4);
+        uint32_t key; { const float d32 = (float)c->depth[i]; memcpy(&key, &d32, 4); }
         for (int y = rc[1]; y < rc[3]; y++) for (int x = rc[0]; x < rc[2]; x++) {
             int t = y * gx + x; kv_t *e = kv + c->range[t] + count[t]++;
             e->key = key; e->id = i;
@@ -187,17 +210,17 @@ int ref_forward(ref_ctx *c, int P, int C, int W, int H,
         for (int ly = 0; ly < TILE; ly++) for (int lx = 0; lx < TILE; lx++) {
             int px = tx * TILE + lx, py = ty * TILE + ly;
             if (px >= W || py >= H) continue;
-            float T = 1.f, D = 0.f, Cc[MAXC] = {0};
+            real T = 1.f, D = 0.f, Cc[MAXC] = {0};
             int contributor = 0, last = 0;
             for (int k = s; k < e; k++) {
                 int id = c->list[k]; contributor++;
-                float dx = c->xy[2 * id] - (float)px, dy = c->xy[2 * id + 1] - (float)py;
-                const float *co = c->conic_op + 4 * id;
-                float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                real dx = c->xy[2 * id] - (real)px, dy = c->xy[2 * id + 1] - (real)py;
+                const real *co = c->conic_op + 4 * id;
+                real power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
                 if (power > 0.f) continue;
-                float alpha = fminf(0.99f, co[3] * expf(power));
+                real alpha = R_MIN(0.99f, co[3] * R_EXP(power));
                 if (alpha < 1.f / 255.f) continue;
-                float test_T = T * (1.f - alpha);
+                real test_T = T * (1.f - alpha);
                 if (test_T < 0.0001f) break;
                 for (int ch = 0; ch < C; ch++) Cc[ch] += colors[(size_t)id * C + ch] * alpha * T;
                 D += c->depth[id] * alpha * T;
@@ -215,15 +238,15 @@ int ref_forward(ref_ctx *c, int P, int C, int W, int H,
 /* Backward.  dL_dpix: [C,H,W].  Outputs (all overwritten):
  * dmeans3D[P,3] dmeans2D[P,3] dcolors[P,C] dopac[P] dscales[P,3] drot[P,4] dcov3D[P,6]
  * (dscales/drot are skipped when scales==NULL, i.e. cov3D_precomp was used). */
-int ref_backward(const ref_ctx *c, const float *bg, const float *means3D, const float *colors,
-                 const float *scales, float mod, const float *rot,
-                 const float *view, const float *proj, float tanfovx, float tanfovy,
-                 const float *dL_dpix,
-                 float *dmeans3D, float *dmeans2D, float *dcolors, float *dopac,
-                 float *dscales, float *drot, float *dcov3D)
+int ref_backward(const ref_ctx *c, const real *bg, const real *means3D, const real *colors,
+                 const real *scales, real mod, const real *rot,
+                 const real *view, const real *proj, real tanfovx, real tanfovy,
+                 const real *dL_dpix,
+                 real *dmeans3D, real *dmeans2D, real *dcolors, real *dopac,
+                 real *dscales, real *drot, real *dcov3D)
 {
     const int P = c->P, C = c->C, W = c->W, H = c->H, gx = c->gx, tiles = c->gx * c->gy;
-    /* double accumulators keep the OpenMP result order-independent to float precision */
+    /* double accumulators keep the OpenMP result order-independent to real precision */
     double *acc = (double *)calloc((size_t)P * (6 + C), sizeof(double));
     const int NA = 6 + C; /* 0,1 mean2D(ndc)  2,3,4 conic (true derivative)  5 opacity  6.. colour */
 
@@ -234,25 +257,25 @@ int ref_backward(const ref_ctx *c, const float *bg, const float *means3D, const 
             int px = tx * TILE + lx, py = ty * TILE + ly;
             if (px >= W || py >= H) continue;
             size_t pix = (size_t)py * W + px;
-            const float T_final = c->final_T[pix];
-            float T = T_final;
+            const real T_final = c->final_T[pix];
+            real T = T_final;
             int last = c->n_contrib[pix];
-            float dpix[MAXC], accum[MAXC] = {0}, last_col[MAXC] = {0}, last_alpha = 0.f, bgdot = 0.f;
+            real dpix[MAXC], accum[MAXC] = {0}, last_col[MAXC] = {0}, last_alpha = 0.f, bgdot = 0.f;
             for (int ch = 0; ch < C; ch++) { dpix[ch] = dL_dpix[(size_t)ch * W * H + pix]; bgdot += bg[ch] * dpix[ch]; }
             for (int k = s + last - 1; k >= s; k--) {
                 int id = c->list[k];
-                float dx = c->xy[2 * id] - (float)px, dy = c->xy[2 * id + 1] - (float)py;
-                const float *co = c->conic_op + 4 * id;
-                float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                real dx = c->xy[2 * id] - (real)px, dy = c->xy[2 * id + 1] - (real)py;
+                const real *co = c->conic_op + 4 * id;
+                real power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
                 if (power > 0.f) continue;
-                float G = expf(power);
-                float alpha = fminf(0.99f, co[3] * G);
+                real G = R_EXP(power);
+                real alpha = R_MIN(0.99f, co[3] * G);
                 if (alpha < 1.f / 255.f) continue;
                 T = T / (1.f - alpha);
-                float w = alpha * T, dL_dalpha = 0.f;
+                real w = alpha * T, dL_dalpha = 0.f;
                 double *a = acc + (size_t)id * NA;
                 for (int ch = 0; ch < C; ch++) {
-                    float col = colors[(size_t)id * C + ch];
+                    real col = colors[(size_t)id * C + ch];
                     accum[ch] = last_alpha * last_col[ch] + (1.f - last_alpha) * accum[ch];
                     last_col[ch] = col;
                     dL_dalpha += (col - accum[ch]) * dpix[ch];
@@ -262,9 +285,9 @@ int ref_backward(const ref_ctx *c, const float *bg, const float *means3D, const 
                 dL_dalpha *= T;
                 last_alpha = alpha;
                 dL_dalpha += (-T_final / (1.f - alpha)) * bgdot;
-                float dL_dG = co[3] * dL_dalpha;
-                float gdx = G * dx, gdy = G * dy;
-                float dG_ddx = -gdx * co[0] - gdy * co[1], dG_ddy = -gdy * co[2] - gdx * co[1];
+                real dL_dG = co[3] * dL_dalpha;
+                real gdx = G * dx, gdy = G * dy;
+                real dG_ddx = -gdx * co[0] - gdy * co[1], dG_ddy = -gdy * co[2] - gdx * co[1];
                 #pragma omp atomic
                 a[0] += (double)(dL_dG * dG_ddx * 0.5f * W);
                 #pragma omp atomic
@@ -282,9 +305,9 @@ int ref_backward(const ref_ctx *c, const float *bg, const float *means3D, const 
     }
 
     /* ---- per-Gaussian backward (Appendix A "Backward preprocess (K8+K9)") ---- */
-    const float fx = W / (2.f * tanfovx), fy = H / (2.f * tanfovy);
+    const real fx = W / (2.f * tanfovx), fy = H / (2.f * tanfovy);
     for (int i = 0; i < P; i++) {
-        float *gm = dmeans3D + 3 * i; gm[0] = gm[1] = gm[2] = 0.f;
+        real *gm = dmeans3D + 3 * i; gm[0] = gm[1] = gm[2] = 0.f;
         dmeans2D[3 * i] = dmeans2D[3 * i + 1] = dmeans2D[3 * i + 2] = 0.f;
         for (int ch = 0; ch < C; ch++) dcolors[(size_t)i * C + ch] = 0.f;
         dopac[i] = 0.f;
@@ -292,76 +315,76 @@ int ref_backward(const ref_ctx *c, const float *bg, const float *means3D, const 
         if (dcov3D) for (int k = 0; k < 6; k++) dcov3D[6 * i + k] = 0.f;
         if (c->radii[i] <= 0) continue;
         const double *a = acc + (size_t)i * NA;
-        float g2x = (float)a[0], g2y = (float)a[1], gcx = (float)a[2], gcy = (float)a[3], gcz = (float)a[4];
+        real g2x = (real)a[0], g2y = (real)a[1], gcx = (real)a[2], gcy = (real)a[3], gcz = (real)a[4];
         dmeans2D[3 * i] = g2x; dmeans2D[3 * i + 1] = g2y;
-        dopac[i] = (float)a[5];
-        for (int ch = 0; ch < C; ch++) dcolors[(size_t)i * C + ch] = (float)a[6 + ch];
+        dopac[i] = (real)a[5];
+        for (int ch = 0; ch < C; ch++) dcolors[(size_t)i * C + ch] = (real)a[6 + ch];
 
-        const float *p = means3D + 3 * i;
-        float tv[3];
+        const real *p = means3D + 3 * i;
+        real tv[3];
         for (int r = 0; r < 3; r++) tv[r] = m4(view, r, 0) * p[0] + m4(view, r, 1) * p[1] + m4(view, r, 2) * p[2] + m4(view, r, 3);
-        float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
-        float txtz = tv[0] / tv[2], tytz = tv[1] / tv[2];
-        float tx = fminf(limx, fmaxf(-limx, txtz)) * tv[2], ty = fminf(limy, fmaxf(-limy, tytz)) * tv[2], tz = tv[2];
-        float xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f, ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
-        float J[2][3] = {{fx / tz, 0.f, -(fx * tx) / (tz * tz)}, {0.f, fy / tz, -(fy * ty) / (tz * tz)}};
-        float T[2][3];
+        real limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+        real txtz = tv[0] / tv[2], tytz = tv[1] / tv[2];
+        real tx = R_MIN(limx, R_MAX(-limx, txtz)) * tv[2], ty = R_MIN(limy, R_MAX(-limy, tytz)) * tv[2], tz = tv[2];
+        real xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f, ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+        real J[2][3] = {{fx / tz, 0.f, -(fx * tx) / (tz * tz)}, {0.f, fy / tz, -(fy * ty) / (tz * tz)}};
+        real T[2][3];
         for (int r = 0; r < 2; r++) for (int k = 0; k < 3; k++)
             T[r][k] = J[r][0] * m4(view, 0, k) + J[r][1] * m4(view, 1, k) + J[r][2] * m4(view, 2, k);
-        const float *S6 = c->cov3d + 6 * i;
-        float Sg[3][3] = {{S6[0], S6[1], S6[2]}, {S6[1], S6[3], S6[4]}, {S6[2], S6[4], S6[5]}};
-        float ca = c->cov2d[3 * i], cb = c->cov2d[3 * i + 1], cc = c->cov2d[3 * i + 2];
-        float det = ca * cc - cb * cb;
-        float d2 = 1.f / (det * det + 0.0000001f);
-        float dLa = d2 * (-cc * cc * gcx + cb * cc * gcy - cb * cb * gcz);
-        float dLc = d2 * (-cb * cb * gcx + ca * cb * gcy - ca * ca * gcz);
-        float dLb = d2 * (2.f * cb * cc * gcx - (det + 2.f * cb * cb) * gcy + 2.f * ca * cb * gcz);
+        const real *S6 = c->cov3d + 6 * i;
+        real Sg[3][3] = {{S6[0], S6[1], S6[2]}, {S6[1], S6[3], S6[4]}, {S6[2], S6[4], S6[5]}};
+        real ca = c->cov2d[3 * i], cb = c->cov2d[3 * i + 1], cc = c->cov2d[3 * i + 2];
+        real det = ca * cc - cb * cb;
+        real d2 = 1.f / (det * det + 0.0000001f);
+        real dLa = d2 * (-cc * cc * gcx + cb * cc * gcy - cb * cb * gcz);
+        real dLc = d2 * (-cb * cb * gcx + ca * cb * gcy - ca * ca * gcz);
+        real dLb = d2 * (2.f * cb * cc * gcx - (det + 2.f * cb * cb) * gcy + 2.f * ca * cb * gcz);
         /* symmetric gradient of the 2x2 covariance */
-        float G2[2][2] = {{dLa, 0.5f * dLb}, {0.5f * dLb, dLc}};
+        real G2[2][2] = {{dLa, 0.5f * dLb}, {0.5f * dLb, dLc}};
         /* dL/dSigma = T^T G2 T */
-        float GT[2][3];
+        real GT[2][3];
         for (int r = 0; r < 2; r++) for (int k = 0; k < 3; k++) GT[r][k] = G2[r][0] * T[0][k] + G2[r][1] * T[1][k];
-        float dS[3][3];
+        real dS[3][3];
         for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) dS[r][k] = T[0][r] * GT[0][k] + T[1][r] * GT[1][k];
-        float g6[6] = {dS[0][0], 2.f * dS[0][1], 2.f * dS[0][2], dS[1][1], 2.f * dS[1][2], dS[2][2]};
-        if (dcov3D) memcpy(dcov3D + 6 * i, g6, 24);
+        real g6[6] = {dS[0][0], 2.f * dS[0][1], 2.f * dS[0][2], dS[1][1], 2.f * dS[1][2], dS[2][2]};
+        if (dcov3D) memcpy(dcov3D + 6 * i, g6, 6 * sizeof(real));
         /* dL/dT = 2 G2 T Sigma */
-        float TS[2][3], dT[2][3];
+        real TS[2][3], dT[2][3];
         for (int r = 0; r < 2; r++) for (int k = 0; k < 3; k++) TS[r][k] = T[r][0] * Sg[0][k] + T[r][1] * Sg[1][k] + T[r][2] * Sg[2][k];
         for (int r = 0; r < 2; r++) for (int k = 0; k < 3; k++) dT[r][k] = 2.f * (G2[r][0] * TS[0][k] + G2[r][1] * TS[1][k]);
         /* dL/dJ = dT W3^T */
-        float dJ[2][3];
+        real dJ[2][3];
         for (int r = 0; r < 2; r++) for (int k = 0; k < 3; k++)
             dJ[r][k] = dT[r][0] * m4(view, k, 0) + dT[r][1] * m4(view, k, 1) + dT[r][2] * m4(view, k, 2);
-        float iz = 1.f / tz, iz2 = iz * iz, iz3 = iz2 * iz;
-        float dtx = xmul * -fx * iz2 * dJ[0][2];
-        float dty = ymul * -fy * iz2 * dJ[1][2];
-        float dtz = -fx * iz2 * dJ[0][0] - fy * iz2 * dJ[1][1] + 2.f * fx * tx * iz3 * dJ[0][2] + 2.f * fy * ty * iz3 * dJ[1][2];
+        real iz = 1.f / tz, iz2 = iz * iz, iz3 = iz2 * iz;
+        real dtx = xmul * -fx * iz2 * dJ[0][2];
+        real dty = ymul * -fy * iz2 * dJ[1][2];
+        real dtz = -fx * iz2 * dJ[0][0] - fy * iz2 * dJ[1][1] + 2.f * fx * tx * iz3 * dJ[0][2] + 2.f * fy * ty * iz3 * dJ[1][2];
         for (int k = 0; k < 3; k++) gm[k] = m4(view, 0, k) * dtx + m4(view, 1, k) * dty + m4(view, 2, k) * dtz;
         /* projection: NDC gradient -> centre */
-        float hom[4];
+        real hom[4];
         for (int r = 0; r < 4; r++) hom[r] = m4(proj, r, 0) * p[0] + m4(proj, r, 1) * p[1] + m4(proj, r, 2) * p[2] + m4(proj, r, 3);
-        float pw = 1.f / (hom[3] + 0.0000001f);
+        real pw = 1.f / (hom[3] + 0.0000001f);
         for (int k = 0; k < 3; k++) {
-            float dndcx = m4(proj, 0, k) * pw - hom[0] * pw * pw * m4(proj, 3, k);
-            float dndcy = m4(proj, 1, k) * pw - hom[1] * pw * pw * m4(proj, 3, k);
+            real dndcx = m4(proj, 0, k) * pw - hom[0] * pw * pw * m4(proj, 3, k);
+            real dndcy = m4(proj, 1, k) * pw - hom[1] * pw * pw * m4(proj, 3, k);
             gm[k] += dndcx * g2x + dndcy * g2y;
         }
         /* Sigma = M M^T, M = R diag(mod*s)  ->  scale and quaternion */
         if (dscales && scales) {
-            float R[3][3], Gs[3][3] = {{g6[0], 0.5f * g6[1], 0.5f * g6[2]}, {0.5f * g6[1], g6[3], 0.5f * g6[4]}, {0.5f * g6[2], 0.5f * g6[4], g6[5]}};
-            const float *q = rot + 4 * i; quat_rot(q, R);
-            float sv[3] = {mod * scales[3 * i], mod * scales[3 * i + 1], mod * scales[3 * i + 2]};
-            float dM[3][3], A[3][3];
+            real R[3][3], Gs[3][3] = {{g6[0], 0.5f * g6[1], 0.5f * g6[2]}, {0.5f * g6[1], g6[3], 0.5f * g6[4]}, {0.5f * g6[2], 0.5f * g6[4], g6[5]}};
+            const real *q = rot + 4 * i; quat_rot(q, R);
+            real sv[3] = {mod * scales[3 * i], mod * scales[3 * i + 1], mod * scales[3 * i + 2]};
+            real dM[3][3], A[3][3];
             for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) {
-                float v = 0.f; for (int m = 0; m < 3; m++) v += Gs[r][m] * R[m][k] * sv[k];
+                real v = 0.f; for (int m = 0; m < 3; m++) v += Gs[r][m] * R[m][k] * sv[k];
                 dM[r][k] = 2.f * v;
             }
             for (int k = 0; k < 3; k++) {
                 dscales[3 * i + k] = mod * (dM[0][k] * R[0][k] + dM[1][k] * R[1][k] + dM[2][k] * R[2][k]);
                 for (int r = 0; r < 3; r++) A[r][k] = dM[r][k] * sv[k];
             }
-            float r_ = q[0], x = q[1], y = q[2], z = q[3];
+            real r_ = q[0], x = q[1], y = q[2], z = q[3];
             drot[4 * i + 0] = 2.f * (-z * A[0][1] + y * A[0][2] + z * A[1][0] - x * A[1][2] - y * A[2][0] + x * A[2][1]);
             drot[4 * i + 1] = 2.f * (y * A[0][1] + z * A[0][2] + y * A[1][0] - 2.f * x * A[1][1] - r_ * A[1][2] + z * A[2][0] + r_ * A[2][1] - 2.f * x * A[2][2]);
             drot[4 * i + 2] = 2.f * (-2.f * y * A[0][0] + x * A[0][1] + r_ * A[0][2] + x * A[1][0] + z * A[1][2] - r_ * A[2][0] + z * A[2][1] - 2.f * y * A[2][2]);
@@ -373,10 +396,10 @@ int ref_backward(const ref_ctx *c, const float *bg, const float *means3D, const 
 }
 
 /* markVisible of the boundary */
-void ref_mark_visible(int P, const float *means3D, const float *view, unsigned char *present) {
+void ref_mark_visible(int P, const real *means3D, const real *view, unsigned char *present) {
     for (int i = 0; i < P; i++) {
-        const float *p = means3D + 3 * i;
-        float z = m4(view, 2, 0) * p[0] + m4(view, 2, 1) * p[1] + m4(view, 2, 2) * p[2] + m4(view, 2, 3);
+        const real *p = means3D + 3 * i;
+        real z = m4(view, 2, 0) * p[0] + m4(view, 2, 1) * p[1] + m4(view, 2, 2) * p[2] + m4(view, 2, 3);
         present[i] = z > 0.2f;
     }
 }

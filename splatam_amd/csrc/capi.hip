@@ -274,6 +274,7 @@ int splat_debug_option(int key, int value) {
 #endif
     }
     if (key == 2) { const int old = g_debug_entries_per_trip; g_debug_entries_per_trip = (value == 1 || value == 3) ? value : 2; return old; }
+    if (key == 3) { const int old = g_debug_k7_generation; if (value == 3 || value == 5) g_debug_k7_generation = value; return old; }
     return -1;
 }
 

@@ -569,6 +569,252 @@ __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, c
 }
 
 // ---------------------------------------------------------------------------
+// K7 backward composite, generation 5: no cross-lane reduction per Gaussian visit
+// ---------------------------------------------------------------------------
+// Generation 3 above spends ~95 VALU wave-instructions per (Gaussian, 8x8 quadrant) visit, ~40 of them on reducing the
+// 6 + |SMASK| partial sums across the 64 pixel lanes (packed permlane / DPP trees, zero fills, publish selects) -- while only
+// ~21 % of the lanes of a visited quadrant hold a live pixel.  This generation splits the visit into two phases and turns
+// the reduction over PIXELS into a loop, not a lane tree:
+//   phase 1 (lane = pixel): the back-to-front recursion in its running-sum form
+//         T_i = T_{i+1} / (1 - a_i),   dL/da_i = T_i c_i.dL/dC - R_i / (1 - a_i),   R_{i-1} = R_i + (c_i.dL/dC) a_i T_i,
+//     (R_i = sum_{j>i} (c_j.dL/dC) a_j T_j, started at T_final (bg.dL/dC): the reference's recursion on accum_rec /
+//     last_alpha, /root/reference callee of scripts/splatam.py:702,854, summed instead of blended) gives per live pixel just
+//     TWO numbers, v = G dL/da and w = a T, which go to a per-wave LDS pair buffer [visit slot][pixel]; ~28 VALU;
+//   phase 2 (every kChunk = 8 visits; lane = (visit, pixel ROW of the quadrant)): each lane walks the 8 pixels of its row and
+//     accumulates the moments of v about the row's centre (sum v, sum v k, sum v k^2, k = column - 3.5: compile-time
+//     constants) and the colour sums sum w dL/dC[ch] in registers -- dense FMAs, 3 + |SMASK| per pixel -- converts them to
+//     the centred sums S1..S6 with the visit's (mu - quadrant centre) and opacity, reduces over its visit's 8 lanes with three
+//     DPP adds per value, and publishes.  ~14 VALU per visit.
+// All 6 + |SMASK| sums of one visit still leave the wave in ONE atomic instruction per accumulator line: a visit's values
+// 0..7 sit in its own 8 lanes, values 8.. are rotated (DPP row_ror:8) into the lanes of its row partner, so that even visits
+// publish in one instruction and odd visits in the next (4 lines each).
+constexpr int kChunk = 8;               // visits per phase-2 pass (8 lanes each)
+constexpr int kPairRow = 72;            // float2 per visit slot: 64 pixels + 4 (rows 4..7 shifted) + 3 (slot & 3) + 1 spare
+
+// (v, w) of (slot, pixel): conflict-free for the phase-1 ds_write_b64 (lane = pixel) and the phase-2 ds_read_b64
+// (lane = (slot, row), same column): 8-byte unit index mod 32 is a bijection of (slot & 3, row) for every column
+__device__ __forceinline__ int pair_index(int slot, int pixel) { return slot * kPairRow + pixel + 4 * (pixel >> 5) + (slot & 3); }
+
+template <int NX>
+struct PairBuf {
+    float2 vw[4][kChunk * kPairRow];    // [wave][...]
+    float4 info[4][kChunk];             // [wave][slot]: mu_x - (quadrant x0 + 3.5), mu_y - quadrant y0, opacity, id (bits)
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f32(float v) { return dpp_f32<CTRL>(v); }
+
+__device__ __forceinline__ float group8_allreduce_add(float v) {
+    v += dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);   // row_half_mirror: the other quad of the 8-lane group
+    return v;
+}
+
+template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC = true, bool BG = true>
+__global__ __launch_bounds__(256) void render_backward_kernel5(SplatCamera cam, const float *colors, SplatState st,
+                                                               const float *dL_dcolor, float *accum, int T, int per_xcd) {
+    constexpr int FP = (C + 3) / 4 * 4;
+    constexpr int NS = popcount_c(SMASK);
+    constexpr int NB = OPAC ? 6 : 5;          // published geometric sums: S1..S5 (+ S6)
+    constexpr int NV = NB + NS;               // published values per visit
+    static_assert(NV <= 16, "two publish instructions carry at most 16 values");
+    constexpr int NX = NV > 8 ? NV - 8 : 0;   // values 8.. travel in the row partner's lanes
+    __shared__ Batch<FP> B;
+    __shared__ PairBuf<NX> PB;
+    __shared__ unsigned s_wmax[4];
+    const int tile = block_tile(per_xcd, T);
+    if (tile < 0) return;
+    const int W = cam.image_width, H = cam.image_height;
+    const int gx = (W + kTile - 1) / kTile;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tx = tile % gx, ty = tile / gx;
+    const int qx0 = tx * kTile + (wave & 1) * 8, qy0 = ty * kTile + (wave >> 1) * 8;      // this wave's quadrant
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const float fpx = (float)px, fpy = (float)py;
+    const float tile_x0 = (float)(tx * kTile), tile_y0 = (float)(ty * kTile);
+    const bool inside = px < W && py < H;
+    const size_t HW = (size_t)H * W;
+    const size_t pix = (size_t)py * W + px;
+
+    // ---- phase-1 state of this lane's pixel
+    const float Tfin = inside ? st.final_T[pix] : 0.f;
+    float Tr = Tfin;
+    const unsigned last = inside ? (unsigned)st.n_contrib[pix] : 0u;
+    float dpix[C], R = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+        dpix[ch] = 0.f;
+        if ((DMASK >> ch) & 1u) {
+            dpix[ch] = inside ? dL_dcolor[ch * HW + pix] : 0.f;
+            if constexpr (BG) R += Tfin * cam.bg[ch] * dpix[ch];      // the background term of dL/dalpha: -T_final bg.dL/dC / (1 - alpha)
+        }
+    }
+    // ---- phase-2 constants of this lane: the incoming gradient of the 8 pixels of row s2 = lane & 7, channels in SMASK
+    const int v2 = lane >> 3, s2 = lane & 7;
+    float drow[NS > 0 ? NS : 1][8];
+    {
+        const int ry = qy0 + s2;
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int rx = qx0 + k;
+                drow[n][k] = (rx < W && ry < H) ? dL_dcolor[(size_t)nth_set_bit(SMASK, n) * HW + (size_t)ry * W + rx] : 0.f;
+            }
+    }
+    const unsigned wmax = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_max_u32(last));   // deepest contributor of this quadrant
+    if (lane == 0) s_wmax[wave] = wmax;
+    __syncthreads();
+    const unsigned tmax = (unsigned)__builtin_amdgcn_readfirstlane((int)max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])));
+    if (tmax == 0) return;                                     // uniform over the workgroup
+    const unsigned lo = st.tile_stride > 0 ? (unsigned)tile * (unsigned)st.tile_stride : st.tile_base[tile];
+    const int nb = (int)((tmax + kBatch - 1) / kBatch);
+
+    // accumulator slot of published value k: S1..S5 (S6) -> 0..5, colour sums -> 6 + channel
+    auto slot_of = [](int k) { return k < NB ? k : 6 + nth_set_bit(SMASK, k - NB); };
+    int doff_own = 0, doff_x = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (k < NV && s2 == k) doff_own = slot_of(k);
+#pragma unroll
+    for (int k = 0; k < NX; ++k)
+        if (s2 == k) doff_x = slot_of(8 + k);
+    float2 *const my_vw = PB.vw[wave];
+    float4 *const my_info = PB.info[wave];
+    const int wr_lane = lane + 4 * (lane >> 5);                          // pair_index(slot, lane) - slot * kPairRow - (slot & 3)
+    const int rd_base = v2 * kPairRow + s2 * 8 + 4 * (s2 >> 2) + (v2 & 3);   // pair_index(v2, s2 * 8 + k) - k
+    const float qcx = (float)qx0 + 3.5f, qcy = (float)qy0;
+    const float ay_off = (float)s2;
+
+    // ---- phase 2: nvis (wave-uniform) visits are waiting in the pair buffer
+    auto phase2 = [&](int nvis) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float4 inf = my_info[v2];
+        float R0 = 0.f, RX = 0.f, RXX = 0.f, Cs[NS > 0 ? NS : 1];
+#pragma unroll
+        for (int n = 0; n < NS; ++n) Cs[n] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float2 vw = my_vw[rd_base + k];
+            const float kc = (float)k - 3.5f;
+            R0 += vw.x;
+            RX = fmaf(vw.x, kc, RX);
+            RXX = fmaf(vw.x, kc * kc, RXX);
+#pragma unroll
+            for (int n = 0; n < NS; ++n) Cs[n] = fmaf(vw.y, drow[n][k], Cs[n]);
+        }
+        const float ax = inf.x, ay = inf.y - ay_off;
+        const float Sdx = fmaf(ax, R0, -RX);                   // sum v dx      (this row)
+        const float Sdxx = fmaf(ax, Sdx - RX, RXX);            // sum v dx^2
+        float val[NV > 8 ? NV : 8];
+        val[0] = Sdx;
+        val[1] = ay * R0;                                      // sum v dy
+        val[2] = Sdxx;
+        val[3] = ay * Sdx;                                     // sum v dx dy
+        val[4] = ay * val[1];                                  // sum v dy^2
+        if constexpr (OPAC) val[5] = R0;
+#pragma unroll
+        for (int n = 0; n < NS; ++n) val[NB + n] = Cs[n];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) val[k] = group8_allreduce_add(val[k]);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) val[k] *= inf.z;           // q = opacity * dL/dalpha
+        const unsigned id = __float_as_uint(inf.w);
+        float pv = val[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            if (k < NV) pv = s2 == k ? val[k] : pv;
+        const bool valid = v2 < nvis;
+        if constexpr (NX == 0) {
+            if (valid && s2 < NV) atomicAdd(accum + (size_t)id * SPLAT_GRAD_STRIDE + doff_own, pv);
+        } else {
+            float px_ = val[8];
+#pragma unroll
+            for (int k = 1; k < NX; ++k) px_ = s2 == k ? val[8 + k] : px_;
+            // the row partner's (visit v2 ^ 1) extra values, id and validity
+            const float xr = dpp_f32<0x128>(px_);                                 // row_ror:8
+            const unsigned idr = dpp_u32<0x128>(id);
+            const bool pvalid = (v2 ^ 1) < nvis;
+            const bool odd = (v2 & 1) != 0;
+            // instruction 1: even visits (own 8 lanes + the first NX lanes of the odd partner); instruction 2: odd visits
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const bool own = odd == (pass == 1);
+                const bool act = own ? valid : (pvalid && s2 < NX);
+                const unsigned tid_ = own ? id : idr;
+                const int off = own ? doff_own : doff_x;
+                const float x = own ? pv : xr;
+                if (act) atomicAdd(accum + (size_t)tid_ * SPLAT_GRAD_STRIDE + off, x);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    int nslot = 0;                                              // wave-uniform
+    Staged<FP> pre;
+    {
+        const unsigned e = (unsigned)((nb - 1) * kBatch + tid);
+        gather<C, CS, false, FP>(pre, st, colors, lo + e, e < tmax, tile_x0, tile_y0);
+    }
+    for (int bi = nb - 1; bi >= 0; --bi) {
+        if (bi < nb - 1) __syncthreads();           // every wave has finished reading the previous batch
+        commit(B, pre, tid, 0u);
+        __syncthreads();
+        const bool more = bi > 0;
+        if (more) gather<C, CS, false, FP>(pre, st, colors, lo + (unsigned)((bi - 1) * kBatch + tid), true, tile_x0, tile_y0);
+        const int base = bi * kBatch;
+        const int lim = (int)wmax - base;                      // entries [0, lim) of this batch can matter to this wave
+#pragma unroll 1
+        for (int w = 3; w >= 0; --w) {
+            const int kk = lim - 64 * w;
+            if (kk <= 0) continue;
+            unsigned long long bits = mask_word(B, wave, w);
+            if (kk < 64) bits &= (1ull << kk) - 1ull;
+            while (bits != 0) {
+                const int j = 63 - __builtin_clzll(bits);
+                bits &= ~(1ull << j);
+                const int e = w * 64 + j;
+                Entry<FP> cur;
+                read_entry(B, e, cur);
+                const unsigned pos = (unsigned)(base + e + 1);
+                const float dx = cur.mux - fpx, dy = cur.muy - fpy;
+                const float p2 = dx * (cur.ga.x * dx + cur.ga.y * dy) + cur.ga.z * dy * dy;
+                const float G = fast_exp2(p2);
+                const float alpha = fminf(kAlphaMax, cur.ga.w * G);
+                const unsigned long long live_m = __builtin_amdgcn_ballot_w64(pos <= last) & __builtin_amdgcn_ballot_w64(p2 <= 0.f) &
+                                                  __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin);
+                if (live_m == 0) continue;
+                const bool live = lane_of(live_m);
+                const float rcp = __builtin_amdgcn_rcpf(1.f - alpha);
+                const float Tn = Tr * rcp;                     // transmittance in front of this Gaussian
+                float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch)
+                    if ((DMASK >> ch) & 1u) part[ch & 3] += cur.feat[ch] * dpix[ch];
+                const float cdot = (part[0] + part[2]) + (part[1] + part[3]);
+                const float dL_dalpha = fmaf(cdot, Tn, -(R * rcp));
+                // selects (not multiplies by 0) so that a non-live lane can never inject inf * 0
+                const float vv = live ? G * dL_dalpha : 0.f;
+                const float ww = live ? alpha * Tn : 0.f;
+                R = fmaf(cdot, ww, R);
+                Tr = live ? Tn : Tr;
+                my_vw[nslot * kPairRow + (nslot & 3) + wr_lane] = make_float2(vv, ww);
+                if (lane == 0) my_info[nslot] = make_float4(cur.mux - qcx, cur.muy - qcy, cur.ga.w, __uint_as_float(cur.id));
+                if (++nslot == kChunk) {
+                    phase2(kChunk);
+                    nslot = 0;
+                }
+            }
+        }
+    }
+    if (nslot > 0) phase2(nslot);
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 template <int C, int CS, bool WITH_DEPTH, bool SORT = false>
@@ -577,6 +823,7 @@ static void launch_fwd(const SplatCamera &cam, const float *colors, SplatState &
     hipLaunchKernelGGL((render_forward_kernel<C, CS, WITH_DEPTH, SORT, false>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, oc, od, T, per,
                        TrackLossEpilogue{});
 }
+int g_debug_k7_generation = 5;         // splat_debug_option(3, v): 5 = two-phase backward composite (current), 3 = previous (A/B timing)
 int g_debug_entries_per_trip = 2;      // splat_debug_option(2, v): 1 = always one list entry per loop trip of K7 (A/B timing)
 template <int C, int CS, unsigned DMASK = (1u << C) - 1u, unsigned SMASK = (1u << C) - 1u, bool OPAC = true, bool BG = true>
 static void launch_bwd(const SplatCamera &cam, const float *colors, const SplatState &st, const float *dl, float *acc, int T,
@@ -587,7 +834,9 @@ static void launch_bwd(const SplatCamera &cam, const float *colors, const SplatS
     // to save and the pair bookkeeping costs 5 %
     constexpr int NV = (OPAC ? 6 : 5) + popcount_c(SMASK);
     constexpr bool kPairPays = (2 * NV + 3) / 4 < 2 * ((NV + 3) / 4);
-    if (kPairPays && g_debug_entries_per_trip != 1)
+    if (g_debug_k7_generation == 5)
+        hipLaunchKernelGGL((render_backward_kernel5<C, CS, DMASK, SMASK, OPAC, BG>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
+    else if (kPairPays && g_debug_entries_per_trip != 1)
         hipLaunchKernelGGL((render_backward_kernel<C, CS, DMASK, SMASK, 2, OPAC, BG>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
     else
         hipLaunchKernelGGL((render_backward_kernel<C, CS, DMASK, SMASK, 1, OPAC, BG>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);

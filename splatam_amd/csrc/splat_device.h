@@ -56,6 +56,7 @@ int map_row_floats(const SplatMapStore &st);
 extern int g_debug_skip_count;
 extern int g_debug_composite_version;
 extern int g_debug_entries_per_trip;
+extern int g_debug_k7_generation;
 hipError_t launch_selftest(int which, const void *in, void *out, int n, hipStream_t s);
 
 #if defined(__HIPCC__)

@@ -11,15 +11,17 @@ through (1) the drop-in surface (GaussianRasterizer: forward + all six gradients
 two backward passes through the reference-shaped get_loss (splatam_amd.slam.get_loss running on CPU tensors with the C
 oracle as its Renderer), not with the HIP drop-in path.
 
-Tolerances: 1e-4 colour / depth; gradients per element at 1e-3 of max(|ref_i|, 1e-3 max|ref|) (tests/util.py:
-assert_grad_close); lists / radii exact."""
+Tolerances: 1e-4 colour / depth; lists / radii exact; gradients: the north star's 1e-3 of the tensor's maximum AND, per
+element, no further from the float64 evaluation of the oracle than 2x the float32 oracle itself is (tests/util.py:
+assert_grad_calibrated -- a flat per-element 1e-3 is not attainable by ANY float32 evaluation of this backward pass: the
+float32 and float64 builds of the oracle differ by more than that on 0.2-0.7 % of the elements)."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import c_ref
 from oracle import raster_ref as R
-from tests.util import assert_close_outliers, assert_grad_close
+from tests.util import assert_close_outliers, assert_grad_calibrated
 
 pytestmark = pytest.mark.gpu
 
@@ -60,8 +62,8 @@ def _dropin(cam, rv, gout):
     return color.detach().cpu().numpy(), radii.cpu().numpy(), depth.detach().cpu().numpy(), {k: inp[k].grad.cpu().numpy() for k in KEYS}
 
 
-def _oracle(cam, rv, gout):
-    cr = c_ref.CRef()
+def _oracle(cam, rv, gout, precision="f32"):
+    cr = c_ref.CRef(precision)
     col, radii, dep = cr.forward(rv['means3D'].numpy(), rv['colors_precomp'].numpy(), rv['opacities'].numpy(), rv['scales'].numpy(),
                                  rv['rotations'].numpy(), cam.viewmatrix.numpy(), cam.projmatrix.numpy(), cam.tanfovx, cam.tanfovy,
                                  cam.image_width, cam.image_height, cam.bg.numpy(), scale_modifier=cam.scale_modifier)
@@ -76,6 +78,14 @@ def _check_images(gc, gr, gd, oc, orad, od):
     assert_close_outliers(gd, od, 1e-4, rtol=1e-4, max_outlier_frac=1e-4, outlier_atol=0.1, what="depth")
 
 
+def _check_dropin_grads(gg, og32, og64, what, aniso):
+    for k, ok in GRAD_MAP:
+        if ok == 'rotations' and not aniso:
+            # isotropic scales: Sigma = s^2 I does not depend on the quaternion; all three evaluations give rounding noise
+            continue
+        assert_grad_calibrated(gg[k].reshape(og32[ok].shape), og32[ok], og64[ok], what=f"{what} grad {k}")
+
+
 @pytest.mark.parametrize("cfg,aniso", [('D', False), ('D', True), ('B', True), ('E', False), ('E', True)])
 def test_dropin_full_size(cfg, aniso):
     """Drop-in forward + backward vs the C oracle at the BASELINE configurations round 1 left uncovered."""
@@ -84,14 +94,13 @@ def test_dropin_full_size(cfg, aniso):
     gc, gr, gd, gg = _dropin(cam, rv, gout)
     oc, orad, od, og, _ = _oracle(cam, rv, gout)
     _check_images(gc, gr, gd, oc, orad, od)
-    for k, ok in GRAD_MAP:
-        assert_grad_close(gg[k].reshape(og[ok].shape), og[ok], what=f"{cfg}{'-aniso' if aniso else ''} grad {k}")
+    og64 = _oracle(cam, rv, gout, "f64")[3]
+    _check_dropin_grads(gg, og, og64, f"{cfg}{'-aniso' if aniso else ''}", aniso)
 
 
 def test_dropin_clustered_lists_beyond_lds():
     """Config E, clustered: 1 M Gaussians inside 5 % of the image.  The longest per-tile lists are far beyond what one
     workgroup sorts in LDS; the sorted lists must still be the oracle's, bit for bit."""
-    import ctypes as C  # noqa: F401
     from splatam_amd import rasterizer as rz
     cam, rv = _scene('E', seed=3, region=CLUSTER)
     cs = _cuda_settings(cam)
@@ -110,32 +119,77 @@ def test_dropin_clustered_lists_beyond_lds():
     assert (pk.tensors['point_list'].cpu().numpy()[:pk.num_rendered] == cr.point_list()).all()
     _check_images(col.cpu().numpy(), radii.cpu().numpy(), dep.cpu().numpy(), oc, orad, od)
     gc, gr, gd, gg = _dropin(cam, rv, gout)
-    for k, ok in GRAD_MAP:
-        assert_grad_close(gg[k].reshape(og[ok].shape), og[ok], what=f"clustered-E grad {k}")
+    og64 = _oracle(cam, rv, gout, "f64")[3]
+    _check_dropin_grads(gg, og, og64, "clustered-E", False)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # fused iteration vs the oracle's two renders + two backward passes
 # ---------------------------------------------------------------------------------------------------------------------
+# The comparison is staged, because get_loss is not smooth: |gt - render| has a kink wherever a pixel matches its target
+# to float32 rounding and the masks are step functions of the silhouette / depth, so two correct evaluations legitimately
+# disagree on the SIGN or the MASK of a few dozen of the ~2.4 M per-pixel loss terms of a full-size frame, and every such
+# pixel moves the gradient of the ~50 Gaussians under it by a few per cent.
+#   (A) the six rendered planes                       vs the oracle's two renders            1e-4
+#   (B) the loss value                                vs the oracle's get_loss               1e-4 relative
+#   (C) the per-pixel gradient planes dL/d(render)    vs autograd of the oracle's get_loss   equal except at kink pixels (counted)
+#   (D) every parameter / pose gradient               vs the oracle's two BACKWARD passes driven by the SAME gradient planes
+#       (float32 and float64 builds), i.e. the whole render-backward + glue adjoint with the kinks taken out: calibrated
+#       per-element check (tests/util.py: assert_grad_calibrated)
 
-def _oracle_get_loss(params_cpu, frame_cpu, variables_cpu, cfg, tracking, monkeypatch):
+class _Spy:
+    """Wraps c_ref.CRasterizer: keeps the rendered images (with retain_grad) of every call."""
+    renders = []
+
+    def __init__(self, raster_settings):
+        self.inner = c_ref.CRasterizer(raster_settings)
+
+    def __call__(self, **kw):
+        out = self.inner(**kw)
+        if out[0].requires_grad:
+            out[0].retain_grad()
+        _Spy.renders.append(out[0])
+        return out
+
+
+def _cpu_case(params, frame, cam_args, dtype):
+    from splatam_amd import slam
+    W, H, k = cam_args
+    pc = {k_: torch.nn.Parameter(v.detach().cpu().to(dtype).clone()) for k_, v in params.items()}
+    cam_c = slam.setup_camera(W, H, k, np.eye(4, dtype=np.float32), device="cpu")
+    frame_c = {'cam': cam_c, 'im': frame['im'].cpu().to(dtype), 'depth': frame['depth'].cpu().to(dtype), 'id': 1,
+               'w2c': torch.eye(4, dtype=dtype)}
+    return pc, frame_c
+
+
+def _oracle_get_loss(params, frame, variables, cam_args, cfg, tracking, monkeypatch):
     """splatam_amd.slam.get_loss (pinned to /root/reference/scripts/splatam.py:214-347 by tests/golden/) on CPU tensors with the
-    C oracle as its Renderer: the oracle's RGB render, depth/silhouette render and both backward passes."""
+    C oracle as its Renderer: returns (loss, [rgb render, depth/sil render], their autograd gradients)."""
+    from splatam_amd import slam
+    monkeypatch.setattr(slam, "Renderer", _Spy)
+    _Spy.renders = []
+    pc, frame_c = _cpu_case(params, frame, cam_args, torch.float32)
+    vc = {k_: v.cpu().clone() for k_, v in variables.items()}
+    loss, _, _ = slam.get_loss(pc, frame_c, vc, 1, cfg['loss_weights'], cfg['use_sil_for_loss'], cfg['sil_thres'], cfg['use_l1'],
+                               cfg['ignore_outlier_depth_loss'], tracking=tracking, mapping=not tracking)
+    loss.backward()
+    im, ds = _Spy.renders
+    zero = torch.zeros_like(ds)
+    return float(loss.detach()), [im.detach(), ds.detach()], [im.grad, ds.grad if ds.grad is not None else zero]
+
+
+def _oracle_backward_from_planes(params, frame, cam_args, planes, tracking, dtype, monkeypatch):
+    """The oracle's two renders + two backward passes for GIVEN gradient planes (dL/drgb [3], dL/ddepth [1]) through the
+    reference-shaped glue (transform_to_frame, render-variable assembly): gradients of every parameter."""
     from splatam_amd import slam
     monkeypatch.setattr(slam, "Renderer", c_ref.CRasterizer)
-    captured = {}
-    orig = c_ref.CRasterizer.forward
-
-    def spy(self, **kw):
-        out = orig(self, **kw)
-        captured.setdefault('renders', []).append(out[0].detach())
-        return out
-    monkeypatch.setattr(c_ref.CRasterizer, "forward", spy)
-    loss, variables, wl = slam.get_loss(params_cpu, frame_cpu, variables_cpu, 1, cfg['loss_weights'], cfg['use_sil_for_loss'],
-                                        cfg['sil_thres'], cfg['use_l1'], cfg['ignore_outlier_depth_loss'], tracking=tracking,
-                                        mapping=not tracking)
-    loss.backward()
-    return float(loss.detach()), captured['renders'], variables
+    pc, frame_c = _cpu_case(params, frame, cam_args, dtype)
+    tg = slam.transform_to_frame(pc, 1, gaussians_grad=not tracking, camera_grad=tracking)
+    im, _, _ = slam.Renderer(raster_settings=frame_c['cam'])(**slam.transformed_params2rendervar(pc, tg))
+    ds, _, _ = slam.Renderer(raster_settings=frame_c['cam'])(**slam.transformed_params2depthplussilhouette(pc, frame_c['w2c'], tg))
+    pl = planes.to(dtype)
+    ((im * pl[0:3]).sum() + (ds[0] * pl[3]).sum()).backward()
+    return {k_: (None if v.grad is None else v.grad.numpy()) for k_, v in pc.items()}
 
 
 def _fused_case(cfg_name, aniso, tracking, monkeypatch, seed=0, region=None):
@@ -162,54 +216,56 @@ def _fused_case(cfg_name, aniso, tracking, monkeypatch, seed=0, region=None):
     eng.loss_backward(frame, 1, cfg, tracking=tracking)
     torch.cuda.synchronize()
     assert not eng.check_overflow(grow=False)
-    # the same iteration on the oracle
-    pc = {k_: torch.nn.Parameter(v.detach().cpu().clone()) for k_, v in params.items()}
-    cam_c = slam.setup_camera(W, H, k, np.eye(4, dtype=np.float32), device="cpu")
-    frame_c = {'cam': cam_c, 'im': im.cpu(), 'depth': depth.cpu(), 'id': 1, 'w2c': torch.eye(4)}
-    vc = {k_: v.cpu().clone() for k_, v in variables.items()}
-    loss_ref, renders, _ = _oracle_get_loss(pc, frame_c, vc, cfg, tracking, monkeypatch)
-    return eng, pc, loss_ref, renders
-
-
-def _check_planes(eng, renders, what):
-    im, depth, sil, dsq = eng.rendered()
-    im_ref, ds_ref = renders[0].numpy(), renders[1].numpy()
-    assert_close_outliers(im.cpu().numpy(), im_ref, 1e-4, max_outlier_frac=1e-4, outlier_atol=0.03, what=f"{what} im")
-    got = torch.cat([depth, sil[None], dsq]).cpu().numpy()
-    assert_close_outliers(got, ds_ref, 1e-4, rtol=1e-4, max_outlier_frac=1e-4, outlier_atol=0.3, what=f"{what} depth/sil/depth^2")
+    what = f"fused {cfg_name}{'-aniso' if aniso else ''}{'-clustered' if region else ''} {'tracking' if tracking else 'mapping'}"
+    cam_args = (W, H, k)
+    loss_ref, renders, plane_grads = _oracle_get_loss(params, frame, variables, cam_args, cfg, tracking, monkeypatch)
+    # (A) rendered planes
+    imf, depthf, silf, dsqf = eng.rendered()
+    nflip = 2e-4            # the fused glue rounds differently from torch's: a few more alpha >= 1/255 decisions flip than on the drop-in path
+    assert_close_outliers(imf.cpu().numpy(), renders[0].numpy(), 1e-4, max_outlier_frac=nflip, outlier_atol=0.03, what=f"{what} im")
+    assert_close_outliers(torch.cat([depthf, silf[None], dsqf]).cpu().numpy(), renders[1].numpy(), 1e-4, rtol=1e-4,
+                          max_outlier_frac=nflip, outlier_atol=0.3, what=f"{what} depth/sil/depth^2")
+    # (B) loss
+    loss_f = eng.loss()
+    assert abs(loss_f - loss_ref) <= 1e-4 * abs(loss_ref), (what, loss_f, loss_ref)
+    # (C) gradient planes: equal except at the kinks of the L1 terms / mask edges
+    planes = eng.buf['dL_dout6'].detach().cpu()
+    ref_planes = torch.cat([plane_grads[0], plane_grads[1][0:1]])
+    pmax = float(ref_planes.abs().max())
+    assert_close_outliers(planes[0:4].numpy(), ref_planes.numpy(), 1e-4 * pmax, rtol=1e-3, max_outlier_frac=1e-3, outlier_atol=2.5 * pmax,
+                          what=f"{what} dL/d(render) planes")
+    assert float(planes[4:6].abs().max()) == 0.0 and float(plane_grads[1][1:3].abs().max()) == 0.0
+    # (D) parameter / pose gradients for the SAME gradient planes, float32 and float64 oracle
+    g32 = _oracle_backward_from_planes(params, frame, cam_args, planes, tracking, torch.float32, monkeypatch)
+    g64 = _oracle_backward_from_planes(params, frame, cam_args, planes, tracking, torch.float64, monkeypatch)
+    return eng, g32, g64, what
 
 
 @pytest.mark.parametrize("cfg_name,aniso", [('B', False), ('B', True), ('D', False), ('E', False)])
 def test_fused_mapping_vs_oracle(cfg_name, aniso, monkeypatch):
-    eng, pc, loss_ref, renders = _fused_case(cfg_name, aniso, False, monkeypatch)
-    _check_planes(eng, renders, f"fused {cfg_name}")
-    assert abs(eng.loss() - loss_ref) <= 1e-4 * abs(loss_ref), (eng.loss(), loss_ref)
+    eng, g32, g64, what = _fused_case(cfg_name, aniso, False, monkeypatch)
     keys = ["means3D", "rgb_colors", "logit_opacities", "log_scales"] + (["unnorm_rotations"] if aniso else [])
     for k in keys:
-        assert_grad_close(eng.grads[k].cpu().numpy(), pc[k].grad.numpy(), what=f"fused {cfg_name} mapping grad {k}")
+        assert_grad_calibrated(eng.grads[k].cpu().numpy(), g32[k], g64[k], what=f"{what} grad {k}")
     if not aniso:
         assert float(eng.grads["unnorm_rotations"].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("cfg_name,aniso", [('B', False), ('B', True), ('D', False)])
 def test_fused_tracking_vs_oracle(cfg_name, aniso, monkeypatch):
-    """Tracking at the shipped sil_thres = 0.99.  At full size a pixel whose silhouette sits within float32 noise of the threshold
-    moves the summed loss by ~2e-6 of its value (one of ~7e5 pixels), so no gap in the silhouette histogram is needed here."""
-    eng, pc, loss_ref, renders = _fused_case(cfg_name, aniso, True, monkeypatch)
-    _check_planes(eng, renders, f"fused {cfg_name}")
-    d = eng.buf['d_cam'].cpu().numpy()
-    assert abs(d[7] - loss_ref) <= 1e-4 * abs(loss_ref), (d[7], loss_ref)
-    gq = pc['cam_unnorm_rots'].grad[0, :, 1].numpy()
-    gt = pc['cam_trans'].grad[0, :, 1].numpy()
-    print("pose grad", d[0:7], gq, gt)
-    assert np.abs(d[0:4] - gq).max() <= 1e-3 * np.abs(gq).max(), (d[0:4], gq)
-    assert np.abs(d[4:7] - gt).max() <= 1e-3 * np.abs(gt).max(), (d[4:7], gt)
+    """Tracking at the SHIPPED sil_thres = 0.99 (round 1 compared at a threshold moved into a gap of the silhouette histogram)."""
+    eng, g32, g64, what = _fused_case(cfg_name, aniso, True, monkeypatch)
+    d = eng.buf['d_cam'].cpu().numpy().astype(np.float64)
+    gq32, gt32 = g32['cam_unnorm_rots'][0, :, 1], g32['cam_trans'][0, :, 1]
+    gq64, gt64 = g64['cam_unnorm_rots'][0, :, 1], g64['cam_trans'][0, :, 1]
+    print(what, "pose gradient", d[0:7], "oracle f32", gq32, gt32, "oracle f64", gq64, gt64)
+    for got, r32, r64 in ((d[0:4], gq32, gq64), (d[4:7], gt32, gt64)):
+        tol = max(1e-4 * np.abs(r64).max(), 2.0 * np.abs(r32 - r64).max())
+        assert np.abs(got - r64).max() <= tol, (what, got, r64, tol)
 
 
 def test_fused_clustered_vs_oracle(monkeypatch):
     """The clustered stress scene through the fused iteration (long lists: exact-list path, multi-workgroup sort)."""
-    eng, pc, loss_ref, renders = _fused_case('E', False, False, monkeypatch, seed=5, region=CLUSTER)
-    _check_planes(eng, renders, "fused clustered-E")
-    assert abs(eng.loss() - loss_ref) <= 1e-4 * abs(loss_ref), (eng.loss(), loss_ref)
+    eng, g32, g64, what = _fused_case('E', False, False, monkeypatch, seed=5, region=CLUSTER)
     for k in ("means3D", "rgb_colors", "logit_opacities", "log_scales"):
-        assert_grad_close(eng.grads[k].cpu().numpy(), pc[k].grad.numpy(), what=f"fused clustered-E grad {k}")
+        assert_grad_calibrated(eng.grads[k].cpu().numpy(), g32[k], g64[k], what=f"{what} grad {k}")

@@ -10,7 +10,7 @@ import torch
 
 from oracle import c_ref
 from oracle import raster_ref as R
-from tests.util import assert_close_outliers, grad_scale, scene, tilted_w2c
+from tests.util import assert_close_outliers, assert_grad_calibrated, grad_scale, scene, tilted_w2c
 
 pytestmark = pytest.mark.gpu
 
@@ -36,8 +36,8 @@ def _gpu_render(cam, rv, grad_out=None, keys=('means3D', 'means2D', 'opacities',
     return color.detach().cpu().numpy(), radii.cpu().numpy(), depth.detach().cpu().numpy(), grads
 
 
-def _c_oracle(cam, rv, grad_out=None):
-    cr = c_ref.CRef()
+def _c_oracle(cam, rv, grad_out=None, precision="f32"):
+    cr = c_ref.CRef(precision)
     W, H = cam.image_width, cam.image_height
     col, radii, dep = cr.forward(rv['means3D'].numpy(), rv['colors_precomp'].numpy(), rv['opacities'].numpy(),
                                  rv['scales'].numpy(), rv['rotations'].numpy(), cam.viewmatrix.numpy(),
@@ -63,13 +63,18 @@ GRAD_MAP = [('means3D', 'means3D'), ('means2D', 'means2D'), ('colors_precomp', '
             ('scales', 'scales'), ('rotations', 'rotations')]
 
 
-def _check_grads(gg, og):
+def _check_grads(gg, og, og64=None):
+    """North star: 1e-3 of the tensor's maximum (bounded fraction of float32 threshold flips).  With the float64 oracle's
+    gradients the check is also per element, calibrated against the float32 oracle's own rounding noise
+    (tests/util.py: assert_grad_calibrated)."""
     for k, ok in GRAD_MAP:
         ref = og[ok]
         got = gg[k].reshape(ref.shape)
         assert np.isfinite(got).all(), k
         assert_close_outliers(got, ref, 1e-3 * grad_scale(ref), max_outlier_frac=1e-4,
                               outlier_atol=0.05 * grad_scale(ref), what=f"grad {k}")
+        if og64 is not None and float(np.abs(og64[ok]).max()) > 1e-12 * max(1.0, float(np.abs(og64['means3D']).max())):
+            assert_grad_calibrated(got, ref, og64[ok], what=f"grad {k}")
 
 
 @pytest.mark.parametrize("n,W,H,aniso,view,bg", [
@@ -85,7 +90,7 @@ def test_forward_backward_parity(n, W, H, aniso, view, bg):
     gc, gr, gd, gg = _gpu_render(cam, rv, gout)
     oc, orad, od, og, _ = _c_oracle(cam, rv, gout)
     _check_forward(gc, gr, gd, oc, orad, od, W * H)
-    _check_grads(gg, og)
+    _check_grads(gg, og, _c_oracle(cam, rv, gout, "f64")[3])
 
 
 def test_against_autograd_oracle_small():
@@ -260,7 +265,7 @@ def test_full_size_replica_shape():
     gc, gr, gd, gg = _gpu_render(cam, rv, gout)
     oc, orad, od, og, cr = _c_oracle(cam, rv, gout)
     _check_forward(gc, gr, gd, oc, orad, od, W * H)
-    _check_grads(gg, og)
+    _check_grads(gg, og, _c_oracle(cam, rv, gout, "f64")[3])
     # size-independent properties: silhouette in [0,1]; rendering is linear in the colours
     rv2 = dict(rv)
     rv2['colors_precomp'] = 2.0 * rv['colors_precomp']

@@ -75,3 +75,38 @@ def assert_grad_close(got, ref, what="", rel=1e-3, floor=1e-3, max_outlier_frac=
     if err.size >= 10000:
         q = float(np.quantile(err, 1.0 - max_outlier_frac))
         assert q <= global_rel * scale, report + f"; quantile {q:.3e}"
+
+
+def assert_grad_calibrated(got, ref32, ref64, what="", factor=2.0, floor=1e-3, max_outlier_frac=1e-4, outlier_rel=0.05):
+    """Gradient parity judged against the float32 rounding noise of the algorithm itself.
+
+    Two CORRECT float32 evaluations of the rasterizer's backward differ per element by far more than 1e-3 of the element:
+    the projected centres (~1e3 px) carry ~1e-4 px of float32 rounding, and the chain to means3D / scales sums terms that
+    cancel.  The float64 build of the oracle (oracle/raster_ref.c, -DREF_DOUBLE) measures that noise: e32 = |ref32 - ref64|
+    is what the reference-arithmetic CPU implementation itself is off by.  Checked here:
+      (1) quantile by quantile (50 .. 99.99 %) the HIP result is no further from the float64 evaluation than `factor` x the
+          float32 oracle is (errors normalised per element by max(|ref64_i|, floor * max|ref64|));
+      (2) the fraction of elements off by more than 1e-3 of themselves is at most `factor` x the oracle's own fraction;
+      (3) the north star's bound: every element within 1e-3 of the tensor's maximum, except a bounded fraction of float32
+          threshold flips (alpha >= 1/255, T < 1e-4 decided differently for one (pixel, Gaussian) pair), each below
+          outlier_rel * max."""
+    got = np.asarray(got, dtype=np.float64)
+    ref32 = np.asarray(ref32, dtype=np.float64).reshape(got.shape)
+    ref64 = np.asarray(ref64, dtype=np.float64).reshape(got.shape)
+    assert np.isfinite(got).all(), f"{what}: non-finite gradient"
+    scale = float(np.abs(ref64).max()) + 1e-30
+    den = np.maximum(np.abs(ref64), floor * scale)
+    eg, e32 = np.abs(got - ref64) / den, np.abs(ref32 - ref64) / den
+    qs = tuple(q for q in (0.5, 0.9, 0.99, 0.999, 0.9999) if (1.0 - q) * eg.size >= 30) or (0.5,)      # quantiles the sample can resolve
+    qg, q32 = np.quantile(eg, qs), np.quantile(e32, qs)
+    fg, f32_ = float((eg > 1e-3).mean()), float((e32 > 1e-3).mean())
+    err = np.abs(got - ref32)
+    report = (f"{what}: scale {scale:.3e}; normalised error vs float64 at q={qs}: HIP {np.array2string(qg, precision=2)} "
+              f"float32 oracle {np.array2string(q32, precision=2)}; fraction > 1e-3: HIP {fg:.2e} oracle {f32_:.2e}; "
+              f"max |HIP - ref32| {err.max():.3e} = {err.max() / scale:.2e} of max")
+    print(report)
+    assert (qg <= factor * q32 + 2e-6).all(), report
+    assert fg <= factor * f32_ + 1e-4, report
+    nbad = int((err > 1e-3 * scale).sum())
+    assert nbad <= int(np.floor(max_outlier_frac * err.size)), report + f"; {nbad} elements beyond 1e-3 of max"
+    assert err.max() <= outlier_rel * scale, report
