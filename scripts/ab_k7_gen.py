@@ -32,7 +32,9 @@ for gen in (3, 5, 3, 5):
         print(f"  gen {gen} vs first: max |d means3D grad| {float((g - ref).abs().max()):.3e} of {float(ref.abs().max()):.3e}")
     ws = eng._workspace(False, False)
     ms = C.c_float(0)
+    ms0 = C.c_float(0)
     for iters in (5, 40):
+        _capi.check(L.splat_iter_time_kernel(0, iters, C.byref(eng._cam), N, C.byref(ws), torch.cuda.current_stream(dev).cuda_stream, C.byref(ms0)), "time")
         _capi.check(L.splat_iter_time_kernel(1, iters, C.byref(eng._cam), N, C.byref(ws), torch.cuda.current_stream(dev).cuda_stream, C.byref(ms)), "time")
     assert not eng.check_overflow()
 
@@ -47,4 +49,4 @@ for gen in (3, 5, 3, 5):
         return n / (time.perf_counter() - t0)
     tr = rate(lambda: eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING))
     mp = rate(lambda: eng.mapping_iteration(frames[2], 2, slam.REPLICA_MAPPING))
-    print(f"K7 generation {gen}: K7(map form) {ms.value * 1e3:.1f} us  tracking {tr:.0f} it/s  mapping {mp:.0f} it/s  loss {eng.loss():.6f}", flush=True)
+    print(f"K7 generation {gen}: K6(no sort) {ms0.value * 1e3:.1f} us  K7(map form) {ms.value * 1e3:.1f} us  tracking {tr:.0f} it/s  mapping {mp:.0f} it/s  loss {eng.loss():.6f}", flush=True)

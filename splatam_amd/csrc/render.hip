@@ -180,6 +180,16 @@ __device__ __forceinline__ void read_entry(const Batch<FP> &b, int e, Entry<FP> 
     o.mux = m.x; o.muy = m.y; o.id = __float_as_uint(m.z);
 }
 
+// One staged Gaussian as a compositing wave holds it: the whole LDS record, fetched ONE VISIT AHEAD (the wave's critical path
+// per visit is then instruction issue alone; with the record read inside the visit the dependent LDS round trips were
+// exposed and the SIMDs sat ~40 % idle at the 4-5 waves each that the register / LDS budget allows).
+template <int FP>
+struct Rec {
+    float4 a;               // A, B, Cq (conic * log2 e), opacity
+    float4 f[FP / 4];       // colours
+    float4 m;               // mu_x, mu_y, id (bits), -
+};
+
 // wave-uniform 64-bit word of this wave's quadrant mask
 template <int FP>
 __device__ __forceinline__ unsigned long long mask_word(const Batch<FP> &b, int quadrant, int w) {
@@ -299,34 +309,59 @@ __global__ __launch_bounds__(256) void render_forward_kernel(SplatCamera cam, co
                 gather<C, CS, WITH_DEPTH, FP>(pre, st, colors, lo + e, e < n, tile_x0, tile_y0, lk, e);
             }
             const unsigned base1 = (unsigned)(bi * kBatch + 1);
+            // one visit of this quadrant: `cur` was fetched from LDS during the previous visit (see Rec)
+            auto visit = [&](int e, const Rec<FP> &cur) {
+                const float dx = cur.m.x - fpx, dy = cur.m.y - fpy;
+                const float p2 = dx * (cur.a.x * dx + cur.a.y * dy) + cur.a.z * dy * dy;     // power * log2(e)
+                const float alpha = fminf(kAlphaMax, cur.a.w * fast_exp2(p2));
+                const unsigned long long live_m = __builtin_amdgcn_ballot_w64(p2 <= 0.f) & __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin) & ~done_m;
+                if (live_m == 0) return;
+                const float test_T = Tr * (1.f - alpha);
+                const unsigned long long stop_m = __builtin_amdgcn_ballot_w64(test_T < kTStop) & live_m;
+                const bool upd = lane_of(live_m & ~stop_m);
+                const float wgt = upd ? alpha * Tr : 0.f;
+#pragma unroll
+                for (int ch = 0; ch < F; ++ch) {
+                    const float4 &fv = cur.f[ch >> 2];
+                    const float c = (ch & 3) == 0 ? fv.x : ((ch & 3) == 1 ? fv.y : ((ch & 3) == 2 ? fv.z : fv.w));
+                    if (ch < C) Cc[ch] += c * wgt;
+                    else D += c * wgt;
+                }
+                Tr = upd ? test_T : Tr;
+                last = upd ? base1 + (unsigned)e : last;
+                done_m |= stop_m;
+                if (done_m == ~0ull) wdone = true;
+            };
+            auto load_rec = [&](int e, Rec<FP> &r) {
+                const float4 *p = B.rec + e * Batch<FP>::R4;
+                r.a = p[0];
+#pragma unroll
+                for (int v = 0; v < FP / 4; ++v) r.f[v] = p[1 + v];
+                r.m = p[Batch<FP>::R4 - 1];
+            };
+            // front to back over the set bits of this quadrant's mask; the NEXT record is in flight while the current one is
+            // composited (two register sets, ping-pong): the LDS round trip per visit is off the wave's critical path
 #pragma unroll 1
             for (int w = 0; w < 4 && !wdone; ++w) {
                 unsigned long long bits = mask_word(B, wave, w);
-                while (bits != 0) {
-                    const int e = w * 64 + __builtin_ctzll(bits);
+                if (bits == 0) continue;
+                Rec<FP> ra, rb;
+                int ja = __builtin_ctzll(bits);
+                bits &= bits - 1;
+                load_rec(w * 64 + ja, ra);
+                while (true) {
+                    const bool more_b = bits != 0;
+                    const int jb = more_b ? __builtin_ctzll(bits) : 0;
                     bits &= bits - 1;
-                    Entry<FP> cur;
-                    read_entry(B, e, cur);
-                    const float dx = cur.mux - fpx, dy = cur.muy - fpy;
-                    const float p2 = dx * (cur.ga.x * dx + cur.ga.y * dy) + cur.ga.z * dy * dy;     // power * log2(e)
-                    const float alpha = fminf(kAlphaMax, cur.ga.w * fast_exp2(p2));
-                    const unsigned long long live_m = __builtin_amdgcn_ballot_w64(p2 <= 0.f) & __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin) & ~done_m;
-                    if (live_m != 0) {
-                        const float test_T = Tr * (1.f - alpha);
-                        const unsigned long long stop_m = __builtin_amdgcn_ballot_w64(test_T < kTStop) & live_m;
-                        const bool upd = lane_of(live_m & ~stop_m);
-                        const float wgt = upd ? alpha * Tr : 0.f;
-#pragma unroll
-                        for (int ch = 0; ch < C; ++ch) Cc[ch] += cur.feat[ch] * wgt;
-                        if constexpr (WITH_DEPTH) D += cur.feat[C] * wgt;
-                        Tr = upd ? test_T : Tr;
-                        last = upd ? base1 + (unsigned)e : last;
-                        done_m |= stop_m;
-                        if (done_m == ~0ull) {
-                            wdone = true;
-                            bits = 0;
-                        }
-                    }
+                    load_rec(w * 64 + jb, rb);                  // unconditional: entry 0 of the word is a valid record
+                    visit(w * 64 + ja, ra);
+                    if (wdone || !more_b) break;
+                    const bool more_a = bits != 0;
+                    ja = more_a ? __builtin_ctzll(bits) : 0;
+                    bits &= bits - 1;
+                    load_rec(w * 64 + ja, ra);
+                    visit(w * 64 + jb, rb);
+                    if (wdone || !more_a) break;
                 }
             }
         }
@@ -384,6 +419,7 @@ __global__ __launch_bounds__(256) void render_forward_kernel(SplatCamera cam, co
 // SMASK: channels whose colour sums (dL/dcolour) the caller needs.  The reference API uses all C for both; the fused
 // iteration knows that the silhouette and depth^2 planes carry no gradient, and that tracking never reads dL/drgb.
 constexpr int popcount_c(unsigned m) { return m == 0 ? 0 : (int)(m & 1u) + popcount_c(m >> 1); }
+constexpr int highest_set_bit(unsigned m) { int h = -1; for (int i = 0; i < 32; ++i) if ((m >> i) & 1u) h = i; return h; }
 constexpr int nth_set_bit(unsigned m, int n) {      // index of the n-th (0-based) set bit
     int idx = 0;
     while (true) {
@@ -589,20 +625,18 @@ __global__ __launch_bounds__(256) void render_backward_kernel(SplatCamera cam, c
 // 0..7 sit in its own 8 lanes, values 8.. are rotated (DPP row_ror:8) into the lanes of its row partner, so that even visits
 // publish in one instruction and odd visits in the next (4 lines each).
 constexpr int kChunk = 8;               // visits per phase-2 pass (8 lanes each)
-constexpr int kPairRow = 72;            // float2 per visit slot: 64 pixels + 4 (rows 4..7 shifted) + 3 (slot & 3) + 1 spare
+constexpr int kPairRow = 73;            // float2 per visit slot: 64 pixels + 4 (rows 4..7 shifted), padded to an odd stride
 
 // (v, w) of (slot, pixel): conflict-free for the phase-1 ds_write_b64 (lane = pixel) and the phase-2 ds_read_b64
-// (lane = (slot, row), same column): 8-byte unit index mod 32 is a bijection of (slot & 3, row) for every column
-__device__ __forceinline__ int pair_index(int slot, int pixel) { return slot * kPairRow + pixel + 4 * (pixel >> 5) + (slot & 3); }
+// (lane = (slot, row), same column): with the odd row stride 73 = 9 (mod 32) the 8-byte unit index mod 32 is a bijection
+// of (slot & 3, row) for every column
+__device__ __forceinline__ int pair_index(int slot, int pixel) { return slot * kPairRow + pixel + 4 * (pixel >> 5); }
 
-template <int NX>
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 struct PairBuf {
-    float2 vw[4][kChunk * kPairRow];    // [wave][...]
-    float4 info[4][kChunk];             // [wave][slot]: mu_x - (quadrant x0 + 3.5), mu_y - quadrant y0, opacity, id (bits)
+    float2 vw[4][kChunk * kPairRow];    // [wave][slot][pixel] -> (v, w)
 };
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov_f32(float v) { return dpp_f32<CTRL>(v); }
 
 __device__ __forceinline__ float group8_allreduce_add(float v) {
     v += dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]
@@ -614,14 +648,17 @@ __device__ __forceinline__ float group8_allreduce_add(float v) {
 template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC = true, bool BG = true>
 __global__ __launch_bounds__(256) void render_backward_kernel5(SplatCamera cam, const float *colors, SplatState st,
                                                                const float *dL_dcolor, float *accum, int T, int per_xcd) {
-    constexpr int FP = (C + 3) / 4 * 4;
+    constexpr int CL = highest_set_bit(DMASK) + 1;        // colour channels staged per Gaussian: only those that carry gradient
+    static_assert(CL >= 1 && CL <= C, "DMASK names channels of the call");
+    constexpr int FP = (CL + 3) / 4 * 4;
+    constexpr int R4 = Batch<FP>::R4;
     constexpr int NS = popcount_c(SMASK);
     constexpr int NB = OPAC ? 6 : 5;          // published geometric sums: S1..S5 (+ S6)
     constexpr int NV = NB + NS;               // published values per visit
     static_assert(NV <= 16, "two publish instructions carry at most 16 values");
     constexpr int NX = NV > 8 ? NV - 8 : 0;   // values 8.. travel in the row partner's lanes
     __shared__ Batch<FP> B;
-    __shared__ PairBuf<NX> PB;
+    __shared__ PairBuf PB;
     __shared__ unsigned s_wmax[4];
     const int tile = block_tile(per_xcd, T);
     if (tile < 0) return;
@@ -650,18 +687,33 @@ __global__ __launch_bounds__(256) void render_backward_kernel5(SplatCamera cam, 
             if constexpr (BG) R += Tfin * cam.bg[ch] * dpix[ch];      // the background term of dL/dalpha: -T_final bg.dL/dC / (1 - alpha)
         }
     }
-    // ---- phase-2 constants of this lane: the incoming gradient of the 8 pixels of row s2 = lane & 7, channels in SMASK
+    // ---- phase-2 constants: the incoming gradient of the 8 pixels of row s2 = lane & 7 (channels in SMASK), from a per-wave
+    // LDS table [row][column] filled by the pixel lanes (row stride 8 records + 1: eight rows -> eight distinct bank groups).
+    // Few channels (tracking: the depth plane only): held in registers; more: one broadcast ds_read_b128 per pixel in phase 2.
     const int v2 = lane >> 3, s2 = lane & 7;
-    float drow[NS > 0 ? NS : 1][8];
+    constexpr int NS4 = NS > 0 ? (NS + 3) / 4 : 1;              // float4 per pixel in the table
+    constexpr bool kRowRegs = NS <= 2;
+    __shared__ float4 s_dtab[4][8 * (8 * NS4 + 1)];
     {
-        const int ry = qy0 + s2;
+        float t[NS4 * 4];
 #pragma unroll
-        for (int n = 0; n < NS; ++n)
+        for (int n = 0; n < NS4 * 4; ++n) t[n] = n < NS ? dpix[nth_set_bit(SMASK, n < NS ? n : 0)] : 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int rx = qx0 + k;
-                drow[n][k] = (rx < W && ry < H) ? dL_dcolor[(size_t)nth_set_bit(SMASK, n) * HW + (size_t)ry * W + rx] : 0.f;
-            }
+        for (int q = 0; q < NS4; ++q)
+            s_dtab[wave][(lane >> 3) * (8 * NS4 + 1) + (lane & 7) * NS4 + q] = make_float4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+    }
+    const float4 *const my_drow = s_dtab[wave] + s2 * (8 * NS4 + 1);
+    float drow[kRowRegs && NS > 0 ? NS : 1][8];
+    if constexpr (kRowRegs && NS > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 t = my_drow[k];
+            drow[0][k] = t.x;
+            if constexpr (NS > 1) drow[1][k] = t.y;
+        }
     }
     const unsigned wmax = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_max_u32(last));   // deepest contributor of this quadrant
     if (lane == 0) s_wmax[wave] = wmax;
@@ -681,32 +733,54 @@ __global__ __launch_bounds__(256) void render_backward_kernel5(SplatCamera cam, 
     for (int k = 0; k < NX; ++k)
         if (s2 == k) doff_x = slot_of(8 + k);
     float2 *const my_vw = PB.vw[wave];
-    float4 *const my_info = PB.info[wave];
-    const int wr_lane = lane + 4 * (lane >> 5);                          // pair_index(slot, lane) - slot * kPairRow - (slot & 3)
-    const int rd_base = v2 * kPairRow + s2 * 8 + 4 * (s2 >> 2) + (v2 & 3);   // pair_index(v2, s2 * 8 + k) - k
-    const float qcx = (float)qx0 + 3.5f, qcy = (float)qy0;
-    const float ay_off = (float)s2;
+    const int wr_lane = pair_index(0, lane);
+    // LDS byte address of column 0 of this lane's phase-2 row (generic shared pointer -> 32-bit LDS offset)
+    const unsigned rd_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float2 *)(my_vw + pair_index(v2, s2 * 8));
+    const float qcx = (float)qx0 + 3.5f, qcy = (float)(qy0 + s2);       // centre column of the quadrant, this lane's phase-2 row
+    unsigned long long epack = 0;       // byte n: batch entry (< 256) of the visit waiting in slot n (wave-uniform: scalar registers)
 
-    // ---- phase 2: nvis (wave-uniform) visits are waiting in the pair buffer
+    // ---- phase 2: nvis (wave-uniform) visits are waiting in the pair buffer; their records are still in B
     auto phase2 = [&](int nvis) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const float4 inf = my_info[v2];
+        const float4 *rp = B.rec + (int)((epack >> (8 * v2)) & 0xFFull) * R4;
+        const float op = rp[0].w;
+        const float4 mm = rp[R4 - 1];
         float R0 = 0.f, RX = 0.f, RXX = 0.f, Cs[NS > 0 ? NS : 1];
 #pragma unroll
         for (int n = 0; n < NS; ++n) Cs[n] = 0.f;
+        // the row's 8 (v, w) pairs as EIGHT ds_read_b64 (2 LDS cycles each, conflict-free in this layout); left to itself the
+        // compiler pairs them into ds_read2_b64, which the LDS serves in 16-lane groups at half the rate and with 2-way
+        // bank conflicts here (SQ_LDS_BANK_CONFLICT was 83 % of the LDS-active cycles)
+        v2f pr[8];
+        asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:8\n\tds_read_b64 %2, %8 offset:16\n\tds_read_b64 %3, %8 offset:24\n\t"
+                     "ds_read_b64 %4, %8 offset:32\n\tds_read_b64 %5, %8 offset:40\n\tds_read_b64 %6, %8 offset:48\n\tds_read_b64 %7, %8 offset:56\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(pr[0]), "=&v"(pr[1]), "=&v"(pr[2]), "=&v"(pr[3]), "=&v"(pr[4]), "=&v"(pr[5]), "=&v"(pr[6]), "=&v"(pr[7])
+                     : "v"(rd_addr)
+                     : "memory");
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float2 vw = my_vw[rd_base + k];
             const float kc = (float)k - 3.5f;
-            R0 += vw.x;
-            RX = fmaf(vw.x, kc, RX);
-            RXX = fmaf(vw.x, kc * kc, RXX);
+            R0 += pr[k].x;
+            RX = fmaf(pr[k].x, kc, RX);
+            RXX = fmaf(pr[k].x, kc * kc, RXX);
+            if constexpr (kRowRegs) {
 #pragma unroll
-            for (int n = 0; n < NS; ++n) Cs[n] = fmaf(vw.y, drow[n][k], Cs[n]);
+                for (int n = 0; n < NS; ++n) Cs[n] = fmaf(pr[k].y, drow[n][k], Cs[n]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < NS4; ++q) {
+                    const float4 t = my_drow[k * NS4 + q];
+                    if (4 * q < NS) Cs[4 * q] = fmaf(pr[k].y, t.x, Cs[4 * q]);
+                    if (4 * q + 1 < NS) Cs[4 * q + 1] = fmaf(pr[k].y, t.y, Cs[4 * q + 1]);
+                    if (4 * q + 2 < NS) Cs[4 * q + 2] = fmaf(pr[k].y, t.z, Cs[4 * q + 2]);
+                    if (4 * q + 3 < NS) Cs[4 * q + 3] = fmaf(pr[k].y, t.w, Cs[4 * q + 3]);
+                }
+            }
         }
-        const float ax = inf.x, ay = inf.y - ay_off;
+        const float ax = mm.x - qcx, ay = mm.y - qcy;
         const float Sdx = fmaf(ax, R0, -RX);                   // sum v dx      (this row)
         const float Sdxx = fmaf(ax, Sdx - RX, RXX);            // sum v dx^2
         float val[NV > 8 ? NV : 8];
@@ -720,13 +794,12 @@ __global__ __launch_bounds__(256) void render_backward_kernel5(SplatCamera cam, 
         for (int n = 0; n < NS; ++n) val[NB + n] = Cs[n];
 #pragma unroll
         for (int k = 0; k < NV; ++k) val[k] = group8_allreduce_add(val[k]);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) val[k] *= inf.z;           // q = opacity * dL/dalpha
-        const unsigned id = __float_as_uint(inf.w);
+        const unsigned id = __float_as_uint(mm.z);
         float pv = val[0];
 #pragma unroll
         for (int k = 1; k < 8; ++k)
             if (k < NV) pv = s2 == k ? val[k] : pv;
+        if (s2 < 5) pv *= op;                                  // S1..S5 carry q = opacity * dL/dalpha
         const bool valid = v2 < nvis;
         if constexpr (NX == 0) {
             if (valid && s2 < NV) atomicAdd(accum + (size_t)id * SPLAT_GRAD_STRIDE + doff_own, pv);
@@ -758,60 +831,98 @@ __global__ __launch_bounds__(256) void render_backward_kernel5(SplatCamera cam, 
     Staged<FP> pre;
     {
         const unsigned e = (unsigned)((nb - 1) * kBatch + tid);
-        gather<C, CS, false, FP>(pre, st, colors, lo + e, e < tmax, tile_x0, tile_y0);
+        gather<CL, CS, false, FP>(pre, st, colors, lo + e, e < tmax, tile_x0, tile_y0);
     }
     for (int bi = nb - 1; bi >= 0; --bi) {
         if (bi < nb - 1) __syncthreads();           // every wave has finished reading the previous batch
         commit(B, pre, tid, 0u);
         __syncthreads();
         const bool more = bi > 0;
-        if (more) gather<C, CS, false, FP>(pre, st, colors, lo + (unsigned)((bi - 1) * kBatch + tid), true, tile_x0, tile_y0);
+        if (more) gather<CL, CS, false, FP>(pre, st, colors, lo + (unsigned)((bi - 1) * kBatch + tid), true, tile_x0, tile_y0);
         const int base = bi * kBatch;
         const int lim = (int)wmax - base;                      // entries [0, lim) of this batch can matter to this wave
+
+        auto load_rec = [&](int e, Rec<FP> &r) {
+            const float4 *p = B.rec + e * R4;
+            r.a = p[0];
+#pragma unroll
+            for (int v = 0; v < FP / 4; ++v) r.f[v] = p[1 + v];
+            r.m = p[R4 - 1];
+        };
+        // one visit: `cur` was fetched during the previous visit; fetch `nxt` now
+        auto visit = [&](int e, const Rec<FP> &cur) {
+            const unsigned pos = (unsigned)(base + e + 1);
+            const float dx = cur.m.x - fpx, dy = cur.m.y - fpy;
+            const float p2 = dx * (cur.a.x * dx + cur.a.y * dy) + cur.a.z * dy * dy;
+            const float G = fast_exp2(p2);
+            const float alpha = fminf(kAlphaMax, cur.a.w * G);
+            const unsigned long long live_m = __builtin_amdgcn_ballot_w64(pos <= last) & __builtin_amdgcn_ballot_w64(p2 <= 0.f) &
+                                              __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin);
+            if (live_m == 0) return;
+            // lanes without a live pixel run the same arithmetic on G = alpha = 0 (two selects; 1 / (1 - 0) and T * 1 are exact,
+            // so their T and R do not move and their pair is (0, 0); a select, not a multiply by 0, so that no inf * 0 can appear)
+            const bool live = lane_of(live_m);
+            const float Gl = live ? G : 0.f;
+            const float al = live ? alpha : 0.f;
+            const float rcp = __builtin_amdgcn_rcpf(1.f - al);
+            const float Tn = Tr * rcp;                     // transmittance in front of this Gaussian
+            float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch)
+                if ((DMASK >> ch) & 1u) {
+                    const float4 &fv = cur.f[ch >> 2];
+                    const float c = (ch & 3) == 0 ? fv.x : ((ch & 3) == 1 ? fv.y : ((ch & 3) == 2 ? fv.z : fv.w));
+                    part[ch & 3] += c * dpix[ch];
+                }
+            const float cdot = (part[0] + part[2]) + (part[1] + part[3]);
+            const float dL_dalpha = fmaf(cdot, Tn, -(R * rcp));
+            const float vv = Gl * dL_dalpha;
+            const float ww = al * Tn;
+            R = fmaf(cdot, ww, R);
+            Tr = Tn;
+            my_vw[nslot * kPairRow + wr_lane] = make_float2(vv, ww);
+            epack |= (unsigned long long)(unsigned)e << (8 * nslot);
+            if (++nslot == kChunk) {
+                phase2(kChunk);
+                nslot = 0;
+                epack = 0;
+            }
+        };
+        // walk the set bits of this quadrant's mask back to front; the record of the NEXT visit is fetched before the current
+        // one is processed (two register sets, ping-pong); everything here is wave-uniform
 #pragma unroll 1
         for (int w = 3; w >= 0; --w) {
             const int kk = lim - 64 * w;
             if (kk <= 0) continue;
             unsigned long long bits = mask_word(B, wave, w);
             if (kk < 64) bits &= (1ull << kk) - 1ull;
-            while (bits != 0) {
-                const int j = 63 - __builtin_clzll(bits);
-                bits &= ~(1ull << j);
-                const int e = w * 64 + j;
-                Entry<FP> cur;
-                read_entry(B, e, cur);
-                const unsigned pos = (unsigned)(base + e + 1);
-                const float dx = cur.mux - fpx, dy = cur.muy - fpy;
-                const float p2 = dx * (cur.ga.x * dx + cur.ga.y * dy) + cur.ga.z * dy * dy;
-                const float G = fast_exp2(p2);
-                const float alpha = fminf(kAlphaMax, cur.ga.w * G);
-                const unsigned long long live_m = __builtin_amdgcn_ballot_w64(pos <= last) & __builtin_amdgcn_ballot_w64(p2 <= 0.f) &
-                                                  __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin);
-                if (live_m == 0) continue;
-                const bool live = lane_of(live_m);
-                const float rcp = __builtin_amdgcn_rcpf(1.f - alpha);
-                const float Tn = Tr * rcp;                     // transmittance in front of this Gaussian
-                float part[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ch = 0; ch < C; ++ch)
-                    if ((DMASK >> ch) & 1u) part[ch & 3] += cur.feat[ch] * dpix[ch];
-                const float cdot = (part[0] + part[2]) + (part[1] + part[3]);
-                const float dL_dalpha = fmaf(cdot, Tn, -(R * rcp));
-                // selects (not multiplies by 0) so that a non-live lane can never inject inf * 0
-                const float vv = live ? G * dL_dalpha : 0.f;
-                const float ww = live ? alpha * Tn : 0.f;
-                R = fmaf(cdot, ww, R);
-                Tr = live ? Tn : Tr;
-                my_vw[nslot * kPairRow + (nslot & 3) + wr_lane] = make_float2(vv, ww);
-                if (lane == 0) my_info[nslot] = make_float4(cur.mux - qcx, cur.muy - qcy, cur.ga.w, __uint_as_float(cur.id));
-                if (++nslot == kChunk) {
-                    phase2(kChunk);
-                    nslot = 0;
-                }
+            if (bits == 0) continue;
+            Rec<FP> ra, rb;
+            int ja = 63 - __builtin_clzll(bits);
+            bits &= ~(1ull << ja);
+            load_rec(w * 64 + ja, ra);
+            while (true) {
+                const bool more_b = bits != 0;
+                const int jb = more_b ? 63 - __builtin_clzll(bits) : 0;
+                bits &= ~(1ull << jb);                          // (bit 0 of an empty word: no effect)
+                load_rec(w * 64 + jb, rb);                      // unconditional: entry 0 of the word is always a valid record
+                visit(w * 64 + ja, ra);
+                if (!more_b) break;
+                const bool more_a = bits != 0;
+                ja = more_a ? 63 - __builtin_clzll(bits) : 0;
+                bits &= ~(1ull << ja);
+                load_rec(w * 64 + ja, ra);
+                visit(w * 64 + jb, rb);
+                if (!more_a) break;
             }
         }
+        // the records of the waiting visits live in this batch: publish them before it is replaced
+        if (nslot > 0) {
+            phase2(nslot);
+            nslot = 0;
+            epack = 0;
+        }
     }
-    if (nslot > 0) phase2(nslot);
 }
 
 // ---------------------------------------------------------------------------
