@@ -27,13 +27,14 @@ def avg(sub):
     return 0.0
 
 
-k7m, k7t = avg("render_backward_kernel<6, 8, 15u, 15u"), avg("render_backward_kernel<6, 8, 15u, 8u")
+k7m = avg("render_backward_kernel5<6, 8, 15u, 15u") or avg("render_backward_kernel<6, 8, 15u, 15u")
+k7t = avg("render_backward_kernel5<6, 8, 15u, 8u") or avg("render_backward_kernel<6, 8, 15u, 8u")
 k6s = avg("render_forward_kernel<6, 8, false, true, false>") or avg("render_forward_kernel<6, 8, false, true>")
 k6t = avg("render_forward_kernel<6, 8, false, true, true>")
 f1, f6, f4, f5 = avg("fused_preprocess"), avg("fused_backward_kernel"), avg("ssim_forward"), avg("map_loss_backward")
 f7, ap, am = avg("pose_finish"), avg("adam_pose"), avg("adam_map")
-out = [f"# Round 1, `{tag}`: generation-3 composite kernels, one-instruction publish, two entries per trip (mapping form), rank sort,",
-       "tracking loss in the composite's epilogue, map edits on the device\n",
+out = [f"# `{tag}`: generation-5 backward composite (two phases: pixel-lane recursion -> LDS pair buffer -> row-lane moment sums, no per-visit lane",
+       "reduction), record prefetch one visit ahead in K6 / K7, rank sort and tracking loss inside K6\n",
        "`rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-slam-loop` on MI355X (gfx950), workload B",
        "(300k Gaussians, 1200x680), engine = fused.  The run also times the drop-in path (reference-shaped PyTorch glue around the drop-in",
        f"rasterizer), hence the MIOpen / rocBLAS rows and the 3-channel kernels.  Full CSV: `{tag}_bench_kernel_stats.csv`; bench line of the",
@@ -48,8 +49,8 @@ for r in rows[:28]:
     out.append(f"| `{r['Name'][:92]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {r['Percentage']} |")
 ro = d["roofline"]
 out += ["",
-        f"Reading: the dominant kernel of the fused iteration is `render_backward_kernel<6,8,15,15,2>` (mapping form, two list entries per loop trip, {k7m:.1f} us;",
-        f"tracking form `<6,8,15,8,1>` {k7t:.1f} us); bench.py's live HIP-event figure for it is {ro['kernel_ms'] * 1e3:.1f} us (`roofline.kernel_ms`, {ro['achieved']} GB/s",
+        f"Reading: the dominant kernel of the fused iteration is `render_backward_kernel5<6,8,15,15>` (mapping form, {k7m:.1f} us;",
+        f"tracking form `<6,8,15,8,false>` {k7t:.1f} us); bench.py's live HIP-event figure for it is {ro['kernel_ms'] * 1e3:.1f} us (`roofline.kernel_ms`, {ro['achieved']} GB/s",
         f"algorithmic = {100 * ro['frac']:.2f} % of HBM peak; K6 {ro['other']['render_forward_ms'] * 1e3:.1f} us = {ro['other']['render_forward_GBps']} GB/s).",
         f"Per fused tracking iteration (us): fused_preprocess {f1:.1f} + render_forward<6,8,sort,+tracking loss> {k6t:.1f} + render_backward<6,8,15,8> {k7t:.1f} +",
         f"fused_backward {f6:.1f} + pose_finish {f7:.1f} + adam_pose {ap:.1f} = {f1 + k6t + k7t + f6 + f7 + ap:.0f} -> {d['tracking_iters_per_s']:.0f} iterations/s measured; mapping: {f1:.1f} +",
