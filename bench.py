@@ -42,7 +42,12 @@ WORKLOADS = {
     "B": (300_000, 1200, 680, 600.0, 600.0, 599.5, 339.5),       # /root/reference/configs/data/replica.yaml:3-8
     "D": (150_000, 640, 480, 517.3, 516.5, 318.6, 255.3),        # /root/reference/configs/data/TUM/freiburg1_desk.yaml:3-8
     "E": (1_000_000, 1752, 1168, 1200.0, 1200.0, 875.5, 583.5),  # /root/reference/datasets/gradslam_datasets/scannetpp.py:28-29
+    # SURVEY.md 8(d) stress variants of E: every Gaussian inside 5 % of the image -> per-tile lists of ~5 000 (1 M) / ~25 000 (5 M)
+    # entries, far beyond the 4 096 keys one workgroup sorts in LDS ("per-tile Gaussian list spilling HBM", BASELINE config 5)
+    "E-clustered": (1_000_000, 1752, 1168, 1200.0, 1200.0, 875.5, 583.5),
+    "E-clustered-5M": (5_000_000, 1752, 1168, 1200.0, 1200.0, 875.5, 583.5),
 }
+REGIONS = {"E-clustered": (0.40, 0.40, 0.6236, 0.6236), "E-clustered-5M": (0.40, 0.40, 0.6236, 0.6236)}
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -50,7 +55,8 @@ def build_scene(name, dev, n_views, seed=0):
     from splatam_amd import slam
     N, W, H, fx, fy, cx, cy = WORKLOADS[name]
     num_frames = 2 + n_views
-    params, variables = slam.synthetic_params(N, W, H, fx, fy, cx, cy, num_frames=num_frames, seed=seed, device=dev)
+    params, variables = slam.synthetic_params(N, W, H, fx, fy, cx, cy, num_frames=num_frames, seed=seed, device=dev,
+                                              region=REGIONS.get(name))
     k = [[fx, 0, cx], [0, fy, cy], [0, 0, 1]]
     first_w2c = torch.eye(4, device=dev)
     cam = slam.setup_camera(W, H, k, first_w2c.cpu().numpy(), device=dev)

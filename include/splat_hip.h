@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define SPLAT_ABI_VERSION 2        /* 2: map edits, splat_iter_render / _tracking_step, outlier scratch in SplatIterWorkspace */
+#define SPLAT_ABI_VERSION 3        /* 3: SplatState.keys_alt / long_base (multi-workgroup sort of lists beyond LDS); 2: map edits,
+                                      splat_iter_render / _tracking_step, outlier scratch in SplatIterWorkspace */
 #define SPLAT_TILE 16            /* tile edge in pixels (one 256-thread workgroup per tile, one wave64 per 8x8 quadrant) */
 #define SPLAT_MAX_CHANNELS 8     /* colour channels per call: 3 for the reference API, up to 8 for fused passes */
 #define SPLAT_GRAD_STRIDE 16     /* floats per Gaussian in the backward accumulator (one 64-byte line) */
@@ -95,6 +96,10 @@ typedef struct SplatState {
     uint64_t *keys;              /* [capacity] (float bits of depth << 32) | Gaussian id, bucketed by tile */
     uint32_t *point_list;        /* [capacity] Gaussian ids, each tile's slice sorted by key */
     int64_t capacity;
+    /* scratch of the multi-workgroup sort of per-tile lists longer than 4096 entries (NULL: such a list is sorted in place
+     * by one workgroup -- correct, but O(n log^2 n) barrier stages) */
+    uint64_t *keys_alt;          /* [capacity] ping-pong partner of `keys` for the merge passes */
+    uint32_t *long_base;         /* [T+1] first work item of every tile with a long list */
     int32_t max_list_hint;       /* longest tile list if the host knows it (status[2] of an earlier read), 0 = unknown */
     int32_t tile_stride;         /* 0: compact lists, tile t = [tile_base[t], tile_base[t+1]) (the exact path);
                                     > 0: BUCKETED lists (fused iteration only): tile t = [t*stride, t*stride + min(count, stride)),

@@ -16,7 +16,7 @@ SPLAT_TILE = 16
 SPLAT_MAX_CHANNELS = 8
 SPLAT_GRAD_STRIDE = 16
 SPLAT_COUNTER_STRIDE = 32
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -40,7 +40,8 @@ class SplatState(C.Structure):
     _fields_ = [("depth", _fp), ("xy", _fp), ("conic_opacity", _fp), ("rect", _fp), ("radii", _fp),
                 ("rgb", _fp), ("clamped", _fp),
                 ("tile_count", _fp), ("tile_base", _fp), ("tile_cursor", _fp),
-                ("keys", _fp), ("point_list", _fp), ("capacity", C.c_int64), ("max_list_hint", C.c_int32), ("tile_stride", C.c_int32),
+                ("keys", _fp), ("point_list", _fp), ("capacity", C.c_int64), ("keys_alt", _fp), ("long_base", _fp),
+                ("max_list_hint", C.c_int32), ("tile_stride", C.c_int32),
                 ("final_T", _fp), ("n_contrib", _fp), ("status", _fp)]
 
 

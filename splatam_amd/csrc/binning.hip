@@ -100,10 +100,136 @@ __global__ __launch_bounds__(kBlock) void tile_sort_block_kernel(SplatState st) 
         __syncthreads();
         bitonic_sort(s_keys, n, tid, kBlock);
         for (int i = tid; i < n; i += kBlock) st.point_list[lo + i] = (uint32_t)s_keys[i];
-    } else {
-        // spilled tile list: same network run in place on the HBM bucket (L2-resident)
+    } else if (!st.keys_alt || !st.long_base) {
+        // list beyond LDS and no scratch from the caller: the same network run in place on the HBM bucket by this ONE workgroup
+        // (correct, slow: O(n log^2 n) barrier-separated stages); with scratch the multi-workgroup kernels below take the tile
         bitonic_sort(gk, n, tid, kBlock);
         for (int i = tid; i < n; i += kBlock) st.point_list[lo + i] = (uint32_t)gk[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Lists beyond LDS (BASELINE config 5: "per-tile Gaussian list spilling HBM"): many workgroups per tile.
+//   L1 long_scan_kernel       item space: tile t owns ceil(n_t / 1024) items when n_t > 4096 (exclusive scan -> long_base)
+//   L2 long_run_sort_kernel   every 4th item of a tile: one 4096-key run sorted in LDS (bitonic), in place
+//   L3 long_merge_kernel      pass p merges neighbouring runs of 4096 * 2^p keys, keys <-> keys_alt ping-pong.  Keys are
+//                             unique, so an element's merged position is its index in its own run + the number of smaller
+//                             keys in the partner run (one binary search of an L2-resident run per element): every element
+//                             is independent, any number of workgroups per tile, one streaming read + write per pass
+//   L4 long_publish_kernel    ids of the sorted keys (from whichever buffer the tile's last pass wrote) -> point_list
+// A tile of n keys takes ceil(log2(n / 4096)) passes; tiles that are done sit out the later passes.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kRun = kSortLds;          // keys per LDS-sorted run
+constexpr int kItemKeys = 1024;         // keys per workgroup item in the merge / publish kernels (4 per thread)
+
+__host__ __device__ inline int long_passes(long long n) {      // merge passes a list of n keys needs
+    int p = 0;
+    while (((long long)kRun << p) < n) ++p;
+    return p;
+}
+
+__global__ __launch_bounds__(1024) void long_scan_kernel(SplatState st, int T) {
+    __shared__ unsigned wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool dead = st.tile_stride == 0 && (long long)st.status[0] > st.capacity;      // lists were published empty
+    const int per = (T + 1023) / 1024;
+    const int lo = tid * per, hi = min(T, lo + per);
+    auto items_of = [&](int t) -> unsigned {
+        unsigned l;
+        int n;
+        tile_range(st, t, l, n);
+        return (!dead && n > kRun) ? (unsigned)((n + kItemKeys - 1) / kItemKeys) : 0u;
+    };
+    unsigned sum = 0;
+    for (int t = lo; t < hi; ++t) sum += items_of(t);
+    unsigned incl = sum;
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = (unsigned)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned wave_off = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) wave_off += wave_tot[w];
+        total += wave_tot[w];
+    }
+    unsigned run = wave_off + incl - sum;
+    for (int t = lo; t < hi; ++t) {
+        st.long_base[t] = run;
+        run += items_of(t);
+    }
+    if (tid == 0) st.long_base[T] = total;
+}
+
+// item -> (tile, chunk): the last tile whose first item is <= item (tiles without items share their successor's base)
+__device__ __forceinline__ bool long_item(const SplatState &st, int T, unsigned item, int &tile, int &chunk, unsigned &lo, int &n) {
+    if (item >= st.long_base[T]) return false;
+    int a = 0, b = T;                   // invariant: long_base[a] <= item < long_base[b]
+    while (b - a > 1) {
+        const int m = (a + b) >> 1;
+        if (st.long_base[m] <= item) a = m; else b = m;
+    }
+    tile = a;
+    chunk = (int)(item - st.long_base[a]);
+    tile_range(st, tile, lo, n);
+    return true;
+}
+
+__global__ __launch_bounds__(kBlock) void long_run_sort_kernel(SplatState st, int T) {
+    __shared__ uint64_t s_keys[kRun];
+    int tile, chunk, n;
+    unsigned lo;
+    if (!long_item(st, T, blockIdx.x, tile, chunk, lo, n)) return;
+    if (chunk & 3) return;              // one workgroup per run of 4 items
+    const int tid = threadIdx.x;
+    const int off = (chunk >> 2) * kRun, m = min(kRun, n - off);
+    uint64_t *gk = st.keys + lo + off;
+    for (int i = tid; i < m; i += kBlock) s_keys[i] = gk[i];
+    __syncthreads();
+    bitonic_sort(s_keys, m, tid, kBlock);
+    for (int i = tid; i < m; i += kBlock) gk[i] = s_keys[i];
+}
+
+__global__ __launch_bounds__(kBlock) void long_merge_kernel(SplatState st, int T, int pass) {
+    const long long L = (long long)kRun << pass;               // run length going into this pass
+    if (L >= (long long)st.status[2]) return;                  // no list of this iteration is that long
+    int tile, chunk, n;
+    unsigned lo;
+    if (!long_item(st, T, blockIdx.x, tile, chunk, lo, n)) return;
+    if ((long long)n <= L) return;                             // this tile was finished by an earlier pass
+    const uint64_t *src = ((pass & 1) ? st.keys_alt : st.keys) + lo;
+    uint64_t *dst = ((pass & 1) ? st.keys : st.keys_alt) + lo;
+    const int Li = (int)L;
+#pragma unroll
+    for (int k = 0; k < kItemKeys / kBlock; ++k) {
+        const int j = chunk * kItemKeys + k * kBlock + threadIdx.x;
+        if (j >= n) continue;
+        const uint64_t key = src[j];
+        const int a = j / Li, a0 = a * Li, b0 = (a ^ 1) * Li;
+        int pos = j;
+        if (b0 < n) {
+            const uint64_t *B = src + b0;
+            int lo_ = 0, hi_ = min(Li, n - b0);                // number of partner keys smaller than `key`
+            while (lo_ < hi_) {
+                const int mid = (lo_ + hi_) >> 1;
+                if (B[mid] < key) lo_ = mid + 1; else hi_ = mid;
+            }
+            pos = min(a0, b0) + (j - a0) + lo_;
+        }
+        dst[pos] = key;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void long_publish_kernel(SplatState st, int T) {
+    int tile, chunk, n;
+    unsigned lo;
+    if (!long_item(st, T, blockIdx.x, tile, chunk, lo, n)) return;
+    const uint64_t *buf = ((long_passes(n) & 1) ? st.keys_alt : st.keys) + lo;
+#pragma unroll
+    for (int k = 0; k < kItemKeys / kBlock; ++k) {
+        const int j = chunk * kItemKeys + k * kBlock + threadIdx.x;
+        if (j < n) st.point_list[lo + j] = (uint32_t)buf[j];
     }
 }
 
@@ -114,9 +240,22 @@ hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, S
     if (g.P > 0 && st.tile_stride == 0) hipLaunchKernelGGL(scatter_kernel, dim3((g.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, g, st, gx);
     if (T > 0 && sort) {
         hipLaunchKernelGGL(tile_sort_wave_kernel, dim3(T), dim3(64), 0, s, st);
-        // the host may know the longest list (status[2]); only then can the long-list kernel be skipped
-        if (!long_sort_skipped(st.max_list_hint))
+        // the host may know the longest list (status[2]); only then can the long-list kernels be skipped
+        if (!long_sort_skipped(st.max_list_hint)) {
             hipLaunchKernelGGL(tile_sort_block_kernel, dim3(T), dim3(kBlock), 0, s, st);
+            const long long hint = st.max_list_hint > 0 ? (long long)st.max_list_hint + st.max_list_hint / 2 : (long long)1 << 40;
+            if (st.keys_alt && st.long_base && hint > kRun && st.capacity > kRun) {
+                const long long bound = st.capacity < hint ? st.capacity : hint;       // no list is longer than this
+                const long long items = st.capacity / kItemKeys + T + 1;               // sum of ceil(n_t / 1024) over the long tiles
+                if (items > 0x7fffffffLL) return hipErrorInvalidValue;
+                hipLaunchKernelGGL(long_scan_kernel, dim3(1), dim3(1024), 0, s, st, T);
+                hipLaunchKernelGGL(long_run_sort_kernel, dim3((unsigned)items), dim3(kBlock), 0, s, st, T);
+                const int passes = long_passes(bound);
+                for (int p = 0; p < passes; ++p)
+                    hipLaunchKernelGGL(long_merge_kernel, dim3((unsigned)items), dim3(kBlock), 0, s, st, T, p);
+                hipLaunchKernelGGL(long_publish_kernel, dim3((unsigned)items), dim3(kBlock), 0, s, st, T);
+            }
+        }
     }
     return hipGetLastError();
 }
@@ -125,6 +264,7 @@ hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, S
 // which = 0: wave_reduce4_packed on 4*64 floats per wave -> 64 floats per wave
 // which = 1: bitonic_sort of n uint64 keys in LDS (n <= kSortLds), one workgroup
 // which = 2: bitonic_sort of n uint64 keys in global memory, one workgroup
+// (the multi-workgroup long-list path is tested through splat_bin_forward: tests/test_gpu_primitives.py)
 __global__ __launch_bounds__(64) void selftest_reduce_kernel(const float *in, float *out) {
     const int l = threadIdx.x, w = blockIdx.x;
     const float *p = in + (size_t)w * 256;

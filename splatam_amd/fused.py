@@ -75,6 +75,7 @@ class FusedEngine:
         b['tile_count'] = torch.zeros(T * CS, dtype=i32, **z)
         b['tile_base'] = torch.empty(T + 1, dtype=i32, **z)
         b['tile_cursor'] = torch.empty(T * CS, dtype=i32, **z)
+        b['long_base'] = torch.zeros(T + 1, dtype=i32, **z)
         b['status'] = torch.zeros(4, dtype=i32, **z)
         b['final_T'] = torch.empty(H, W, dtype=f32, **z)
         b['n_contrib'] = torch.empty(H, W, dtype=i32, **z)
@@ -347,6 +348,7 @@ class FusedEngine:
     def _alloc_lists(self, capacity):
         self.capacity = int(capacity)
         self.buf['keys'] = torch.empty(self.capacity, dtype=torch.int64, device=self.dev)
+        self.buf['keys_alt'] = torch.empty(self.capacity, dtype=torch.int64, device=self.dev)     # merge passes of lists beyond LDS
         self.buf['point_list'] = torch.empty(self.capacity, dtype=torch.int32, device=self.dev)
 
     def _make_cam(self, settings):
@@ -405,6 +407,7 @@ class FusedEngine:
         st.radii = b['radii'].data_ptr()
         st.tile_count, st.tile_base, st.tile_cursor = b['tile_count'].data_ptr(), b['tile_base'].data_ptr(), b['tile_cursor'].data_ptr()
         st.keys, st.point_list, st.capacity = b['keys'].data_ptr(), b['point_list'].data_ptr(), self.capacity
+        st.keys_alt, st.long_base = b['keys_alt'].data_ptr(), b['long_base'].data_ptr()
         st.max_list_hint = self.max_list_hint
         st.tile_stride = self.tile_stride
         st.final_T, st.n_contrib, st.status = b['final_T'].data_ptr(), b['n_contrib'].data_ptr(), b['status'].data_ptr()

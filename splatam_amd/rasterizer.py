@@ -151,7 +151,7 @@ def _alloc_state(pk: _Pack, dev, P: int, H: int, W: int, use_sh: bool):
     T = ((W + 15) // 16) * ((H + 15) // 16)
     f32, i32 = torch.float32, torch.int32
     CS = _capi.SPLAT_COUNTER_STRIDE
-    geom = torch.empty(P * 9 + (2 * CS + 1) * T + 1 + 4 + 8, dtype=i32, device=dev)   # depth1 xy2 conic4 rect2 | tiles | status
+    geom = torch.empty(P * 9 + (2 * CS + 2) * T + 2 + 4 + 8, dtype=i32, device=dev)   # depth1 xy2 conic4 rect2 | tiles | long_base | status
     o = 0
 
     def take(n, align=4):
@@ -165,6 +165,7 @@ def _alloc_state(pk: _Pack, dev, P: int, H: int, W: int, use_sh: bool):
     rect = take(2 * P, 2)
     depth = take(P, 1)
     tile_count, tile_base, tile_cursor = take(T * CS, 1), take(T + 1, 1), take(T * CS, 1)
+    long_base = take(T + 1, 1)
     status = take(4, 1)
     radii = torch.empty(P, dtype=i32, device=dev)
     final_T = torch.empty(H, W, dtype=f32, device=dev)
@@ -173,7 +174,7 @@ def _alloc_state(pk: _Pack, dev, P: int, H: int, W: int, use_sh: bool):
     st.depth, st.xy, st.conic_opacity, st.rect = depth.data_ptr(), xy.data_ptr(), conic.data_ptr(), rect.data_ptr()
     st.radii = radii.data_ptr()
     st.tile_count, st.tile_base, st.tile_cursor = tile_count.data_ptr(), tile_base.data_ptr(), tile_cursor.data_ptr()
-    st.status = status.data_ptr()
+    st.status, st.long_base = status.data_ptr(), long_base.data_ptr()
     st.final_T, st.n_contrib = final_T.data_ptr(), n_contrib.data_ptr()
     rgb = clamped = None
     if use_sh:
@@ -186,12 +187,20 @@ def _alloc_state(pk: _Pack, dev, P: int, H: int, W: int, use_sh: bool):
     return radii, status
 
 
-def _alloc_lists(pk: _Pack, dev, capacity: int):
+LONG_LIST = 4096        # per-tile lists beyond this are sorted by the multi-workgroup kernels, which need a second key buffer
+
+
+def _alloc_lists(pk: _Pack, dev, capacity: int, longest=None):
+    """``longest``: the longest per-tile list if the host knows it (exact mode); None = unknown (lazy mode)."""
     capacity = max(int(capacity), 1)
     keys = torch.empty(capacity, dtype=torch.int64, device=dev)
     plist = torch.empty(capacity, dtype=torch.int32, device=dev)
     pk.st.keys, pk.st.point_list, pk.st.capacity = keys.data_ptr(), plist.data_ptr(), capacity
     pk.tensors.update(keys=keys, point_list=plist)
+    if longest is None or longest > LONG_LIST:
+        alt = torch.empty(capacity, dtype=torch.int64, device=dev)
+        pk.st.keys_alt = alt.data_ptr()
+        pk.tensors.update(keys_alt=alt)
 
 
 def _stream(dev) -> int:
@@ -245,7 +254,7 @@ def _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotati
             stat = status.tolist()
             num_rendered = int(stat[0])
             if _SYNC_MODE == "exact":
-                _alloc_lists(pk, dev, num_rendered)
+                _alloc_lists(pk, dev, num_rendered, longest=int(stat[2]))
                 pk.st.max_list_hint = int(stat[2])        # lets the library skip the long-list sort kernel
             else:                                         # lazy, first call for this shape: learn the size
                 _capacity_hint[hint_key] = int(num_rendered * 1.5) + 1024

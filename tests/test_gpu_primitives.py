@@ -51,3 +51,34 @@ def test_global_bitonic_sort(n):
     assert rc == 0
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), torch.sort(keys.cpu())[0])
+
+
+@pytest.mark.parametrize("n", [70_000, 250_000, 600_000])
+def test_lists_beyond_lds_multi_workgroup_sort(n):
+    """Per-tile lists of ~7 k / ~25 k / ~60 k entries (1, 3 and 4 merge passes of the multi-workgroup sort, binning.hip L1-L4):
+    tile ranges and sorted ids must be the C oracle's, bit for bit; the render still matches."""
+    import numpy as np
+    from oracle import c_ref
+    from splatam_amd import rasterizer as rz
+    from tests.util import scene
+    from diff_gaussian_rasterization import GaussianRasterizationSettings as Camera
+    W, H = 96, 64
+    cam, rv = scene(n, W, H, 90.0, seed=n)
+    cs = Camera(image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=cam.bg.cuda(), scale_modifier=1.0,
+                viewmatrix=cam.viewmatrix.cuda(), projmatrix=cam.projmatrix.cuda(), sh_degree=0, campos=cam.campos.cuda(), prefiltered=False)
+    empty = torch.empty(0, device="cuda")
+    col, radii, dep, pk = rz.rasterize_forward(cs, rv['means3D'].cuda(), rv['colors_precomp'].cuda(), rv['opacities'].cuda().reshape(-1),
+                                               rv['scales'].cuda(), rv['rotations'].cuda(), empty, empty)
+    torch.cuda.synchronize()
+    cr = c_ref.CRef()
+    oc, orad, od = cr.forward(rv['means3D'].numpy(), rv['colors_precomp'].numpy(), rv['opacities'].numpy(), rv['scales'].numpy(),
+                              rv['rotations'].numpy(), cam.viewmatrix.numpy(), cam.projmatrix.numpy(), cam.tanfovx, cam.tanfovy, W, H,
+                              cam.bg.numpy())
+    base = cr.ranges()
+    longest = int(np.diff(base).max())
+    assert longest > 4096 and 'keys_alt' in pk.tensors, longest
+    assert pk.num_rendered == cr.num_rendered()
+    assert (pk.tensors['tile_base'].cpu().numpy() == base).all()
+    got, ref = pk.tensors['point_list'].cpu().numpy()[:pk.num_rendered], cr.point_list()
+    assert (got == ref).all(), f"{int((got != ref).sum())} of {ref.size} list entries differ (longest list {longest})"
+    assert np.quantile(np.abs(col.cpu().numpy() - oc), 0.9999) < 1e-4
