@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -112,6 +113,18 @@ def run_steps_fused(eng, frames, rank, world, nsteps, start=0):
             eng.mapping_iteration(frames[view], view, slam.REPLICA_MAPPING, allreduce if world > 1 else None)
 
 
+def run_steps_views(eng, frames, rank, world, nsteps, batch_views=8):
+    """BASELINE config 3 ("mapping-only, 8 keyframe views sharded over the GPUs"): ONE step = one mapping step over a fixed batch
+    of `batch_views` keyframe views; rank r renders views r, r + world, ... of the batch and accumulates their gradients, one
+    all-reduce (sum) follows, every rank divides by the batch size and takes the identical Adam step.  Strong scaling: N = 1
+    accumulates all eight views, N = 8 renders one each."""
+    from splatam_amd import slam
+    from splatam_amd.dist import all_reduce_sum_flat
+    views = [(frames[2 + v], 2 + v) for v in range(rank, batch_views, world)]
+    for _ in range(nsteps):
+        eng.mapping_batch(views, slam.REPLICA_MAPPING, total_views=batch_views, allreduce_sum=all_reduce_sum_flat if world > 1 else None)
+
+
 def phase_rate(fn, n, dev):
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -175,7 +188,7 @@ def kernel_roofline(params, frames, shape, dev):
     return roof, pk
 
 
-def fused_roofline(eng, frames, shape, dev):
+def fused_roofline(eng, frames, shape, dev, workload="B"):
     """Live HIP-event timing of the two 6-channel composite kernels of the fused iteration on the stream they are
     launched on (splat_iter_time_kernel), after a tracking iteration has left a valid state in the workspace.
     Algorithmic bytes (DESIGN.md 5): per instance 4 (id) + 8 (xy) + 16 (conic, opacity) + 24 (six colours) = 52 B;
@@ -204,21 +217,61 @@ def fused_roofline(eng, frames, shape, dev):
     gbs_b = bytes_bwd / (out["render_backward"] * 1e-3) / 1e9
     dominant = "render_backward" if out["render_backward"] >= out["render_forward"] else "render_forward"
     ach = gbs_b if dominant == "render_backward" else gbs_f
+    # counters of the same kernels from the newest committed rocprofv3 --pmc passes (separate passes, corrected as
+    # /opt/skills/guides/MI355X_MICROARCH.md prescribes); the file names its git head
+    pmc = load_pmc(workload)
+    k7 = pmc_kernel(pmc, "render_backward_kernel", "<6, 8, 15u, 15u")
+    k6 = pmc_kernel(pmc, "render_forward_kernel", "<6, 8, false, false, false>") or pmc_kernel(pmc, "render_forward_kernel", "<6, 8")
+    dom = k7 if dominant == "render_backward" else k6
+    rows = {}
+    per_unit = {"fused_preprocess_kernel": N * (48 + 87), "ssim_forward_kernel": HW * (2 * 12 + 36 + 16), "map_loss_backward_kernel": HW * (36 + 24 + 16),
+                "fused_backward_kernel": N * (64 + 40 + 48), "adam_map_kernel": N * 12 * 4 * 6}
+    for kname, abytes in per_unit.items():
+        d = pmc_kernel(pmc, kname)
+        if d and d.get("avg_us"):
+            rows[kname] = {"avg_us": round(d["avg_us"], 1), "algorithmic_bytes": abytes, "GBps": round(abytes / d["avg_us"] / 1e3, 1),
+                           "frac_of_hbm_peak": round(abytes / d["avg_us"] / 1e3 / HBM_PEAK_GBS, 4), "traffic_bytes": d.get("traffic_bytes"),
+                           "valu_issue_frac": d.get("valu_issue_frac")}
+    other = {"render_forward_ms": round(out["render_forward"], 4), "render_forward_GBps": round(gbs_f, 2),
+             "render_backward_ms": round(out["render_backward"], 4), "render_backward_GBps": round(gbs_b, 2),
+             "num_rendered": R,
+             # secondary ceiling: live (pixel, Gaussian) pairs; filled from the oracle's count by the cpu_baseline leg
+             "pairs_per_launch": None, "pair_evals_per_s": None,
+             "valu_issue_frac": dom.get("valu_issue_frac") if dom else None,
+             "valu_insts_per_launch": dom.get("SQ_INSTS_VALU") if dom else None,
+             "pmc_source": (f"profiles/{pmc[0]} @ {pmc[1].get('git_head')}" if pmc else None),
+             "kernels": rows,
+             "note": "K6 / K7 times are live HIP-event measurements of this run; counters (traffic = 2 x FETCH_SIZE + WRITE_SIZE, VALU "
+                     "issue = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles)) and the per-kernel rows come from the committed "
+                     "rocprofv3 passes named in pmc_source.  The kernels are instruction-issue bound, not HBM bound (DESIGN.md 5)"}
     return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-            "traffic": PMC_TRAFFIC.get(dominant) if (N, W, H) == (300_000, 1200, 680) else None, "kernel": dominant + "_kernel<6,8> (fused iteration)", "kernel_ms": round(out[dominant], 4),
-            "algorithmic_bytes": bytes_bwd if dominant == "render_backward" else bytes_fwd,
-            "other": {"render_forward_ms": round(out["render_forward"], 4), "render_forward_GBps": round(gbs_f, 2),
-                      "render_backward_ms": round(out["render_backward"], 4), "render_backward_GBps": round(gbs_b, 2),
-                      "num_rendered": R, "note": "kernels are VALU-issue bound, not HBM bound (DESIGN.md 5); traffic = PMC "
-                      "FETCH_SIZE*2 + WRITE_SIZE per launch from the last profiled round (profiles/), null if not collected"}}
+            "traffic": dom.get("traffic_bytes") if dom else None, "kernel": dominant + "_kernel<6,8> (fused iteration)",
+            "kernel_ms": round(out[dominant], 4), "algorithmic_bytes": bytes_bwd if dominant == "render_backward" else bytes_fwd,
+            "other": other}
 
 
-# HBM bytes per launch of the dominant kernels from the most recent rocprofv3 --pmc passes (profiles/r01_*_pmc*.txt), corrected
-# as /opt/skills/guides/MI355X_MICROARCH.md prescribes (FETCH_SIZE in KiB reads 1/2 of wide streaming reads on gfx950 -> x2).
-PMC_TRAFFIC = {     # profiles/r01_v7_fused_pmc_kernels.txt: (2 * FETCH_SIZE + WRITE_SIZE) KiB * 1024, bytes per launch at workload B
-    "render_backward": int((2 * 66.60e3 + 63.41e3) * 1024),     # render_backward_kernel<6,8,15,15,2>
-    "render_forward": int((2 * 58.76e3 + 27.05e3) * 1024),      # render_forward_kernel<6,8,false,*,false>
-}
+def load_pmc(workload):
+    """The newest profiles/*_pmc.json (scripts/pmc.sh -> scripts/pmc_to_json.py: rocprofv3 --pmc passes of the fused iteration,
+    one file per profiled round, with the git head it was taken at) for `workload`, or None."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("workload") == workload:
+            best = (os.path.basename(path), d)
+    return best
+
+
+def pmc_kernel(pmc, *needles):
+    if pmc is None:
+        return None
+    for name, d in pmc[1]["kernels"].items():
+        if all(n in name for n in needles):
+            return dict(d, name=name)
+    return None
 
 
 def render_mpix(params, frames, shape, dev, reps=10):
@@ -259,6 +312,7 @@ def cpu_baseline(name, params, frames, budget_s=25.0):
                                          cam.projmatrix.numpy(), cam.tanfovx, cam.tanfovy, cam.image_width,
                                          cam.image_height, cam.bg.numpy())
             ctx.cr = cr
+            _CpuRaster.last = cr
             return torch.from_numpy(col), torch.from_numpy(radii), torch.from_numpy(dep)
 
         @staticmethod
@@ -302,7 +356,7 @@ def cpu_baseline(name, params, frames, budget_s=25.0):
     finally:
         slam.Renderer = saved
     med = float(np.median(times))
-    return {"value": round(1.0 / med, 4), "unit": "iters/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": round(1.0 / med, 4), "unit": "iters/s", "cores": os.cpu_count(), "kind": "port", "pairs_per_render": _CpuRaster.last.num_pairs(),
             "sample": f"{len(times)} tracking iterations (2 fwd + 2 bwd rasterizations + host glue + Adam) of workload {name} "
                       f"at full size; C oracle (OpenMP, {os.cpu_count()} threads) + PyTorch-CPU glue; median {med:.3f} s/iter"}
 
@@ -335,7 +389,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="B", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="B", choices=sorted(WORKLOADS) + ["C"],
+                    help="C = BASELINE config 3: workload B's map, mapping-only, a fixed batch of 8 keyframe views per step "
+                         "split over the ranks (strong scaling)")
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--sync-mode", default="exact", choices=["exact", "lazy"])
     ap.add_argument("--engine", default="fused", choices=["fused", "dropin"])
@@ -357,6 +413,12 @@ def main():
     torch.cuda.set_device(dev)
     rz.set_sync_mode(args.sync_mode)
 
+    mode_c = args.workload == "C"
+    if mode_c:
+        args.workload = "B"
+        args.views = max(args.views, 8)
+        if args.engine != "fused" or 8 % world != 0:
+            raise SystemExit("--workload C runs on the fused engine with 1, 2, 4 or 8 ranks")
     params, variables, frames, shape = build_scene(args.workload, dev, args.views)
     N, W, H = shape
     fused = args.engine == "fused"
@@ -380,7 +442,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         if fused:
             probe = FusedEngine({k: v.detach().clone() for k, v in params.items()}, frames[1]['cam'])
-            roof = fused_roofline(probe, frames, shape, dev)
+            roof = fused_roofline(probe, frames, shape, dev, args.workload)
             del probe
         else:
             roof, _ = kernel_roofline(params_d, frames, shape, dev)
@@ -390,16 +452,47 @@ def main():
         eparams = {k: v.detach().clone() for k, v in params.items()}
         eng = FusedEngine(eparams, frames[1]['cam'], track_max_radius=variables['max_2D_radius'])
         eng.begin_tracking(1)
-        run_steps_fused(eng, frames, rank, world, args.warmup, 0)
+
+        def steps(n, start):
+            if mode_c:
+                run_steps_views(eng, frames, rank, world, n)
+            else:
+                run_steps_fused(eng, frames, rank, world, n, start)
+        steps(args.warmup, 0)
         if eng.check_overflow():            # also learns the longest tile list (skips the long-list sort launch from here on)
             raise SystemExit("instance lists overflowed during warm-up")
         barrier()
         t0 = time.perf_counter()
-        run_steps_fused(eng, frames, rank, world, args.steps, args.warmup)
+        steps(args.steps, args.warmup)
         barrier()
         elapsed = time.perf_counter() - t0
         if eng.check_overflow(grow=False):
             raise SystemExit("instance lists overflowed during the timed region: the result would be invalid")
+        if world > 1:                       # every rank must agree on the length of the sustained region (it holds collectives)
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t[0])
+        # a sustained figure beside the K-step one: the same schedule for >= 1 s (multiples of the 5-step mix period)
+        n_sus = max(args.steps, int(math.ceil(1.2 * args.steps / max(elapsed, 1e-6) / 5.0)) * 5)
+        barrier()
+        t1 = time.perf_counter()
+        steps(n_sus, args.warmup + args.steps)
+        barrier()
+        sustained_s = time.perf_counter() - t1
+        sustained_ok = not eng.check_overflow(grow=False)      # (thousands of Adam steps on ONE synthetic view set can outgrow the list buckets)
+        # the exchange step alone (rank-local average over 20 collectives of the flat gradient bucket)
+        allreduce_ms = None
+        if world > 1:
+            from splatam_amd.dist import all_reduce_sum_flat
+            for _ in range(3):
+                all_reduce_sum_flat(eng.reduce_flat)
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(20):
+                all_reduce_sum_flat(eng.reduce_flat)
+            torch.cuda.synchronize(dev)
+            allreduce_ms = 1e3 * (time.perf_counter() - t2) / 20
+            eng.grad_flat.zero_()
     else:
         variables = run_steps(params_d, variables, frames, bucket, rank, world, args.warmup, opt_track, opt_map, tstate, 0)
         barrier()
@@ -407,10 +500,20 @@ def main():
         variables = run_steps(params_d, variables, frames, bucket, rank, world, args.steps, opt_track, opt_map, tstate, args.warmup)
         barrier()
         elapsed = time.perf_counter() - t0
+    if not fused:
+        n_sus, sustained_s, allreduce_ms, sustained_ok = args.steps, elapsed, None, True
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, sustained_s], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, sustained_s = float(t[0]), float(t[1])
+
+    def units(nsteps):
+        """Work units of `nsteps` steps over all ranks.  Mix: a mapping step renders one view PER RANK (world iterations' worth
+        of views), a tracking step is the same iteration on every rank (replicas: counted once).  Config C: 8 views per step."""
+        if mode_c:
+            return 8 * nsteps
+        n_track = sum(1 for i in range(nsteps) if i % 5 < 2)        # (the schedule's phase is a multiple of 5 at every region start
+        return n_track + (nsteps - n_track) * world                # when warmup and steps are; otherwise off by at most 2)
 
     # per-phase rates (rank-local, informational)
     n_phase = max(5, min(40, args.steps))
@@ -439,14 +542,21 @@ def main():
     if rank == 0:
         if mpix is None:
             mpix, ms_call = render_mpix(params_d, frames, shape, dev)
+        wl = (f"C: {N} Gaussians, {W}x{H}, mapping-only, a batch of 8 keyframe views per step sharded over the ranks, one gradient all-reduce"
+              if mode_c else f"{args.workload}: {N} Gaussians, {W}x{H}, SplaTAM tracking+mapping loop (2:3 mix), isotropic map")
         result = {
-            "metric": "track+map iters/sec @300k Gaussians (render+backward Mpix/s alongside)",
-            "value": round(args.steps * world / elapsed, 3), "unit": "iters/s", "n_gpus": world,
+            "metric": ("mapping view-iterations/sec @300k Gaussians, 8 keyframe views per step" if mode_c
+                       else "track+map iters/sec @300k Gaussians (render+backward Mpix/s alongside)"),
+            "value": round(units(args.steps) / elapsed, 3), "unit": "iters/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {N} Gaussians, {W}x{H}, SplaTAM tracking+mapping loop (2:3 mix), isotropic map",
+            "higher_is_better": True, "scaling": "strong" if mode_c else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl,
                        "gaussians": N, "width": W, "height": H, "views": args.views, "sync_mode": args.sync_mode, "engine": args.engine,
-                       "parallelism": "1 process/GPU; mapping views sharded, one gradient all-reduce; tracking replicas"},
+                       "parallelism": ("1 process/GPU; 8 views per step sharded over the ranks, gradients accumulated per rank, one all-reduce (sum), identical Adam step"
+                                       if mode_c else "1 process/GPU; mapping: one view per rank per step, one gradient all-reduce (mean); tracking: replicas, counted once")},
+            "sustained": ({"steps": n_sus, "seconds": round(sustained_s, 3), "iters_per_s": round(units(n_sus) / sustained_s, 3)} if sustained_ok
+                          else {"steps": n_sus, "invalid": "a per-tile list outgrew its bucket during the sustained region"}),
+            "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4),
             "tracking_iters_per_s": round(track_rate, 3), "mapping_iters_per_s": round(map_rate, 3),
             "dropin_iters_per_s": round(dropin_rate, 3), "dropin_tracking_iters_per_s": round(track_rate_d, 3),
             "dropin_mapping_iters_per_s": round(map_rate_d, 3),
@@ -459,6 +569,10 @@ def main():
             result["slam_loop"] = slam_loop_figure(args.workload, dev)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.workload, params_d, frames)
+            pairs = result["cpu_baseline"].get("pairs_per_render")
+            if roof is not None and pairs:
+                roof["other"]["pairs_per_launch"] = pairs
+                roof["other"]["pair_evals_per_s"] = round(pairs / (roof["other"]["render_backward_ms"] * 1e-3), 1)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -39,6 +39,8 @@ def lib(precision: str = "f32"):
         L.ref_destroy.argtypes = [C.c_void_p]
         L.ref_num_rendered.restype = C.c_int64
         L.ref_num_rendered.argtypes = [C.c_void_p]
+        L.ref_num_pairs.restype = C.c_int64
+        L.ref_num_pairs.argtypes = [C.c_void_p]
         for name, rt in (("ref_ranges", C.c_int), ("ref_list", C.c_int), ("ref_final_T", rt_real),
                          ("ref_n_contrib", C.c_int), ("ref_geom_xy", rt_real),
                          ("ref_geom_conic_op", rt_real), ("ref_geom_depth", rt_real)):
@@ -103,6 +105,10 @@ class CRef:
     # saved state accessors -------------------------------------------------
     def num_rendered(self):
         return int(self.L.ref_num_rendered(self.ctx))
+
+    def num_pairs(self):
+        """Live (pixel, Gaussian) pairs composited by the last forward (the secondary ceiling of SURVEY.md 8d)."""
+        return int(self.L.ref_num_pairs(self.ctx))
 
     def _arr(self, fn, n, dt):
         ptr = getattr(self.L, fn)(self.ctx)

@@ -57,6 +57,7 @@ typedef struct {
     int *radii, *rect;          /* rect: minx,miny,maxx,maxy (tiles) */
     /* binning */
     int64_t R;
+    int64_t pairs;              /* live (pixel, Gaussian) pairs composited by the last forward */
     int *range;                 /* [tiles+1] */
     int *list;                  /* [R] Gaussian ids, per tile sorted by (depth bits, id) */
     /* per-pixel */
@@ -74,6 +75,7 @@ static void ctx_release(ref_ctx *c) {
 }
 void ref_destroy(ref_ctx *c) { if (c) { ctx_release(c); free(c); } }
 int64_t ref_num_rendered(const ref_ctx *c) { return c->R; }
+int64_t ref_num_pairs(const ref_ctx *c) { return c->pairs; }
 const int *ref_ranges(const ref_ctx *c) { return c->range; }
 const int *ref_list(const ref_ctx *c) { return c->list; }
 const real *ref_final_T(const ref_ctx *c) { return c->final_T; }
@@ -204,7 +206,8 @@ int ref_forward(ref_ctx *c, int P, int C, int W, int H,
     free(kv); free(count);
 
     /* ---- composite (Appendix A "Forward composite (K6)") ---- */
-    #pragma omp parallel for schedule(dynamic, 4)
+    int64_t pairs = 0;
+    #pragma omp parallel for schedule(dynamic, 4) reduction(+ : pairs)
     for (int t = 0; t < tiles; t++) {
         int tx = t % gx, ty = t / gx, s = c->range[t], e = c->range[t + 1];
         for (int ly = 0; ly < TILE; ly++) for (int lx = 0; lx < TILE; lx++) {
@@ -224,7 +227,7 @@ int ref_forward(ref_ctx *c, int P, int C, int W, int H,
                 if (test_T < 0.0001f) break;
                 for (int ch = 0; ch < C; ch++) Cc[ch] += colors[(size_t)id * C + ch] * alpha * T;
                 D += c->depth[id] * alpha * T;
-                T = test_T; last = contributor;
+                T = test_T; last = contributor; pairs++;
             }
             size_t pix = (size_t)py * W + px;
             c->final_T[pix] = T; c->n_contrib[pix] = last;
@@ -232,6 +235,7 @@ int ref_forward(ref_ctx *c, int P, int C, int W, int H,
             out_depth[pix] = D;
         }
     }
+    c->pairs = pairs;
     return 0;
 }
 

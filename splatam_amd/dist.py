@@ -86,6 +86,45 @@ def all_reduce_mean_flat(flat: torch.Tensor, group=None) -> None:
         flat.div_(dist.get_world_size(group))
 
 
+def all_reduce_sum_flat(flat: torch.Tensor, group=None) -> None:
+    """In-place sum over ranks of one flat gradient buffer (the caller divides by the number of views of all ranks)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+
+
 def shard_views(num_views: int, rank: int, world: int):
     """Indices of the keyframe views rank ``rank`` renders (round-robin)."""
     return list(range(rank, num_views, world))
+
+
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
+def get_rank(group=None) -> int:
+    return dist.get_rank(group) if dist.is_initialized() else 0
+
+
+def broadcast_pose(params, time_idx: int, src: int = 0, group=None) -> None:
+    """Every rank tracks the same frame (replicas; the backward composite sums with float atomics, so the tracked poses
+    differ in the last bits from rank to rank).  The map edits that follow tracking (add_new_gaussians thresholds the render at
+    the tracked pose) must see ONE pose: rank ``src``'s 7 floats are broadcast into params['cam_unnorm_rots' / 'cam_trans'][..., t]."""
+    if world_size(group) == 1:
+        return
+    with torch.no_grad():
+        pose = torch.cat((params['cam_unnorm_rots'].detach()[0, :, time_idx], params['cam_trans'].detach()[0, :, time_idx])).contiguous()
+        dist.broadcast(pose, src=src, group=group)
+        params['cam_unnorm_rots'][0, :, time_idx] = pose[0:4]
+        params['cam_trans'][0, :, time_idx] = pose[4:7]
+
+
+def assert_replicated_count(n: int, what: str, device, group=None) -> None:
+    """The replicas of the map must hold the same number of rows after every edit (the gradient all-reduce of the next
+    mapping step would otherwise mix buffers of different length): all-reduce of (min, max) of the row count."""
+    if world_size(group) == 1:
+        return
+    t = torch.tensor([n, -n], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    lo, hi = int(t[0]), -int(t[1])
+    if lo != hi:
+        raise RuntimeError(f"map replicas diverged after {what}: row counts {lo} .. {hi} across ranks")

@@ -537,6 +537,33 @@ class FusedEngine:
             bucket_allreduce(self.reduce_flat)      # one collective: 8 (isotropic) or 14 floats per Gaussian
         self.adam_map(cfg['lrs'])
 
+    def mapping_batch(self, views, cfg, total_views=None, allreduce_sum=None):
+        """One mapping step over SEVERAL keyframe views (the view-sharded form of the loop body: BASELINE config 3): the
+        gradients of the map over ``views`` = [(iter_data, iter_time_idx), ...] are accumulated in the flat bucket, summed over
+        the ranks by ``allreduce_sum`` (one collective on ``reduce_flat``), divided by ``total_views`` (views of ALL ranks) and
+        applied by ONE Adam step -- what a single process gets by accumulating the same views."""
+        acc = self._acc_flat()
+        for i, (data, t) in enumerate(views):
+            self.loss_backward(data, t, cfg, tracking=False)
+            if i == 0:
+                acc.copy_(self.grad_flat)
+            else:
+                acc.add_(self.grad_flat)
+        red = acc[:self.reduce_flat.numel()]
+        if allreduce_sum is not None:
+            allreduce_sum(red)
+        n = float(total_views if total_views is not None else len(views))
+        if n != 1.0:
+            red.mul_(1.0 / n)
+        self.grad_flat.copy_(acc)
+        self.adam_map(cfg['lrs'])
+
+    def _acc_flat(self):
+        a = getattr(self, "_acc_store", None)
+        if a is None or a.numel() < self.grad_flat.numel():
+            a = self._acc_store = torch.zeros(self._grad_store.numel(), dtype=torch.float32, device=self.dev)
+        return a[:self.grad_flat.numel()]
+
     # ------------------------------------------------------------------ read-backs (host sync)
     def loss(self):
         return float(self.buf['d_cam'][7])

@@ -230,10 +230,22 @@ def initialize_first_timestep(dataset, num_frames, scene_radius_depth_ratio, mea
 
 def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacity=None, verbose=False):
     """Runs the SplaTAM frame loop over ``dataset``; returns ``(params, variables, stats)`` with
-    ``stats = {keyframe_time_indices, tracking_iters, mapping_iters, tracking_s, mapping_s, num_gaussians, redone_frames}``."""
+    ``stats = {keyframe_time_indices, tracking_iters, mapping_iters, tracking_s, mapping_s, num_gaussians, redone_frames}``.
+
+    With ``torch.distributed`` initialised (one process per GPU, splatam_amd.dist.init_from_env) the loop runs on every rank
+    over the REPLICATED map:
+      * tracking: replicas only -- every rank tracks the frame; rank 0's pose is then broadcast (7 floats), because the float
+        atomics of the backward composite leave the replicas' poses different in the last bits and the densification that follows
+        thresholds a render at that pose;
+      * mapping: every iteration draws ``world`` keyframe views instead of one (the same random stream on every rank, the
+        reference's one-random-keyframe-per-iteration rule /root/reference/scripts/splatam.py:831-845 applied ``world`` times),
+        rank r renders the r-th, ONE gradient all-reduce (mean) follows, and every rank takes the identical Adam step;
+      * after every edit of the map (densification, pruning) the row counts of the replicas are compared (all-reduce of min / max)."""
+    from . import dist as sdist
     if engine not in ("fused", "dropin"):
         raise ValueError(engine)
     fused = engine == "fused"
+    world, rank = sdist.world_size(), sdist.get_rank()
     num_frames = len(dataset) if num_frames is None else min(num_frames, len(dataset))
     tcfg, mcfg = config['tracking'], config['mapping']
     if mcfg.get('use_gaussian_splatting_densification'):
@@ -270,14 +282,16 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
         scene_radius = variables['scene_radius']
     else:
         params, variables, intrinsics, first_frame_w2c, cam = initialize_first_timestep(
-            dataset, num_frames, config['scene_radius_depth_ratio'], config['mean_sq_dist_method'], dist_kind)
+            dataset, num_frames, config['scene_radius_depth_ratio'], config['mean_sq_dist_method'], dist_kind,
+            device=dataset[0][1].device)
         dev = params['means3D'].device
         first_frame_w2c = first_frame_w2c.to(dev).float().contiguous()
     keyframe_list, keyframe_time_indices = [], []
     stats = dict(tracking_iters=0, mapping_iters=0, tracking_s=0.0, mapping_s=0.0, redone_frames=0, num_gaussians=[])
 
     def sync():
-        torch.cuda.synchronize(dev)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
 
     for time_idx in range(num_frames):
         color, depth, _, gt_pose = dataset[time_idx]
@@ -304,6 +318,7 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
                     params['cam_unnorm_rots'][..., time_idx] = pose0[0]
                     params['cam_trans'][..., time_idx] = pose0[1]
             stats['tracking_iters'] += n_track
+            sdist.broadcast_pose(params, time_idx)              # replicas: one pose for the map edits that follow
         elif time_idx > 0:
             with torch.no_grad():
                 rel = torch.linalg.inv(gt_pose).to(dev)
@@ -321,6 +336,7 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
                 else:
                     params, variables = slam.add_new_gaussians(params, variables, curr_data, mcfg['sil_thres'], time_idx,
                                                                config['mean_sq_dist_method'], dist_kind)
+                sdist.assert_replicated_count(int(params['means3D'].shape[0]), f"add_new_gaussians (frame {time_idx})", dev)
             with torch.no_grad():
                 curr_w2c = _est_w2c(params, time_idx)
                 selected = keyframe_selection_overlap(depth, curr_w2c, intrinsics.to(dev), keyframe_list[:-1],
@@ -406,15 +422,24 @@ def _last_depth_loss(params, curr_data, variables, time_idx, tcfg):
 
 
 def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, mcfg, eng, scene_radius):
-    """The mapping iterations of one frame over the selected keyframes + the current frame."""
+    """The mapping iterations of one frame over the selected keyframes + the current frame.  With ``world`` ranks every
+    iteration draws ``world`` views from the SAME random stream on every rank; this rank renders its own one, the gradients are
+    averaged by one all-reduce, every rank takes the same Adam step and the same pruning decisions."""
+    from . import dist as sdist
+    world, rank = sdist.world_size(), sdist.get_rank()
     cam, intrinsics, w2c0 = curr_data['cam'], curr_data['intrinsics'], curr_data['w2c']
     prune, pd = mcfg['prune_gaussians'], mcfg['pruning_dict']
+    dev = params['means3D'].device
+    bucket = None                   # drop-in path: flat gradient bucket, re-made when an edit changes the number of rows
     if eng is not None:
         eng.reset_map_optimizer()
     else:
         optimizer = slam.initialize_optimizer(params, mcfg['lrs'], tracking=False)
     for it in range(mcfg['num_iters']):
-        sel = selected[np.random.randint(0, len(selected))]
+        if world == 1:
+            sel = selected[np.random.randint(0, len(selected))]
+        else:
+            sel = selected[int(np.random.randint(0, len(selected), size=world)[rank])]
         if sel == -1:
             iter_time_idx, iter_color, iter_depth = time_idx, curr_data['im'], curr_data['depth']
         else:
@@ -426,8 +451,11 @@ def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, 
         on_schedule = prune and it <= pd['stop_after'] and it >= pd['start_after'] and it % pd['prune_every'] == 0
         if eng is not None:
             eng.loss_backward(iter_data, iter_time_idx, mcfg, tracking=False)
+            if world > 1 and not on_schedule:                   # (an iteration on the pruning schedule takes no Adam step)
+                sdist.all_reduce_mean_flat(eng.reduce_flat)
             if prune:
                 if eng.prune_gaussians(it, pd, scene_radius):
+                    sdist.assert_replicated_count(eng.P, f"prune_gaussians (frame {time_idx}, iteration {it})", dev)
                     eng.relearn_lists(curr_data, time_idx)
             if not on_schedule:
                 eng.adam_map(mcfg['lrs'])
@@ -435,9 +463,16 @@ def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, 
             loss, _, _ = slam.get_loss(params, iter_data, variables, iter_time_idx, mcfg['loss_weights'], mcfg['use_sil_for_loss'],
                                        mcfg['sil_thres'], mcfg['use_l1'], mcfg['ignore_outlier_depth_loss'], mapping=True)
             loss.backward()
+            if world > 1 and not on_schedule:
+                if bucket is None or bucket.sizes != [params[k].numel() for k in bucket.keys]:
+                    bucket = sdist.GradBucket(params)
+                bucket.all_reduce_mean(params)
             with torch.no_grad():
                 if prune:
+                    n_before = params['means3D'].shape[0]
                     slam.prune_gaussians(params, variables, optimizer, it, pd)
+                    if params['means3D'].shape[0] != n_before:
+                        sdist.assert_replicated_count(int(params['means3D'].shape[0]), f"prune_gaussians (frame {time_idx}, iteration {it})", dev)
                 optimizer.step()
                 optimizer.zero_grad(set_to_none=True)
 

@@ -408,3 +408,41 @@ def test_view_sharded_exchange_keeps_replicas_identical():
         assert torch.equal(p1[k].detach(), p2[k].detach()), k
     assert torch.equal(p1['unnorm_rotations'].detach(), params['unnorm_rotations'].detach())      # untouched
     assert not torch.equal(p1['means3D'].detach(), params['means3D'].detach())
+
+
+def test_mapping_batch_equals_gradient_accumulation():
+    """FusedEngine.mapping_batch (BASELINE config 3: several keyframe views per mapping step; the ranks' sums are exchanged by ONE
+    all-reduce) against its definition: the mean of the per-view gradients, one Adam step.  Two 'ranks' are emulated in one
+    process: each accumulates its own view, the exchange callback adds the other rank's sum."""
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    params, variables, frame, cam = _scene(8000, 208, 160, seed=29, num_frames=4)
+    views = [(frame, 1), (dict(frame, im=(frame['im'] * 0.9 + 0.03).contiguous()), 2), (dict(frame, im=(frame['im'] * 0.8 + 0.1).contiguous()), 3)]
+    cfg = slam.REPLICA_MAPPING
+    clone = lambda: {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}      # noqa: E731
+    # definition: per-view gradients averaged, one Adam step
+    p_ref = clone()
+    e_ref = FusedEngine(p_ref, cam)
+    acc = torch.zeros_like(e_ref.grad_flat)
+    for fr, t in views:
+        e_ref.loss_backward(fr, t, cfg, tracking=False)
+        acc += e_ref.grad_flat
+    e_ref.grad_flat.copy_(acc / len(views))
+    e_ref.adam_map(cfg['lrs'])
+    # one process, all three views in one batch
+    p_one = clone()
+    FusedEngine(p_one, cam).mapping_batch(views, cfg)
+    # two ranks: views {0, 2} and {1}; the "all-reduce" adds the other rank's accumulated sum
+    p_a, p_b = clone(), clone()
+    e_a, e_b = FusedEngine(p_a, cam), FusedEngine(p_b, cam)
+    other = {}
+    e_b.loss_backward(*views[1], cfg, tracking=False)
+    other['b'] = e_b.reduce_flat.clone()
+    e_a.mapping_batch([views[0], views[2]], cfg, total_views=3, allreduce_sum=lambda red: red.add_(other['b']))
+    torch.cuda.synchronize()
+    for k in ('means3D', 'rgb_colors', 'logit_opacities', 'log_scales'):
+        ref = p_ref[k].detach()
+        step = float((ref - params[k].detach()).abs().max())
+        assert step > 0
+        for got, name in ((p_one[k].detach(), "one process"), (p_a[k].detach(), "two ranks")):
+            assert float((got - ref).abs().max()) <= 2e-3 * step, (k, name, float((got - ref).abs().max()), step)
