@@ -1,0 +1,92 @@
+"""The unmodified caller's contract on the HIP path itself.
+
+tests/golden/caller_reference.npz (tests/golden/make_golden_caller.py) holds what the REFERENCE's own get_loss
+(/root/reference/scripts/splatam.py:214-347, exec'd from its source) does at the rasterizer boundary: the settings tuple, the
+exact kwargs of both ``Renderer(raster_settings=curr_data['cam'])(**rendervar)`` calls (:249, :253), the gradients autograd
+hands to the two renders, what each call's inputs receive, the retained non-leaf ``means2D`` (:248) and the ``radius`` bookkeeping
+(:341-345).  Here exactly those kwargs go through ``diff_gaussian_rasterization`` on the GPU -- two forwards, then the two
+backwards in autograd's order -- and every output the caller reads is compared with the recording (oracle renders)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import assert_close_outliers, grad_scale
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "caller_reference.npz"))
+IN_KEYS = ('means3D', 'colors_precomp', 'rotations', 'opacities', 'scales', 'means2D')
+
+
+def _camera():
+    from diff_gaussian_rasterization import GaussianRasterizationSettings as Camera
+    n, W, H = (int(x) for x in GOLD["meta"][:3])
+    t = lambda k: torch.tensor(GOLD[f"cam/{k}"]).cuda()      # noqa: E731
+    return Camera(image_height=H, image_width=W, tanfovx=float(GOLD["cam/tanfovx"]), tanfovy=float(GOLD["cam/tanfovy"]), bg=t("bg"),
+                  scale_modifier=float(GOLD["cam/scale_modifier"]), viewmatrix=t("viewmatrix"), projmatrix=t("projmatrix"),
+                  sh_degree=0, campos=t("campos"), prefiltered=False)
+
+
+@pytest.mark.parametrize("mode", ["tracking", "mapping"])
+def test_reference_call_sequence_replayed_on_hip(mode):
+    from diff_gaussian_rasterization import GaussianRasterizer as Renderer
+    cam = _camera()
+    calls = []
+    for ci in (0, 1):
+        kw = {}
+        for k in IN_KEYS:
+            src = GOLD[f"call{ci}/in/{k}"] if f"call{ci}/in/{k}" in GOLD.files else GOLD[f"call0/in/{k}"]
+            leaf = torch.tensor(src).cuda()
+            wants = f"{mode}/call{ci}/grad_in/{k}" in GOLD.files
+            if k == 'means2D':
+                # the caller's construction (/root/reference/utils/slam_helpers.py:137): a NON-LEAF zero tensor with retain_grad()
+                kw[k] = torch.zeros_like(leaf, requires_grad=True) + 0
+                kw[k].retain_grad()
+            else:
+                kw[k] = leaf.requires_grad_(wants)
+        calls.append(kw)
+    # forward: two fresh modules, keyword arguments, 3-tuples (the second forward precedes the first backward)
+    outs = []
+    for kw in calls:
+        res = Renderer(raster_settings=cam)(**kw)
+        assert isinstance(res, tuple) and len(res) == 3
+        outs.append(res)
+    for ci, (color, radii, depth) in enumerate(outs):
+        assert radii.dtype == torch.int32 and tuple(depth.shape) == (1,) + tuple(color.shape[1:])
+        assert (radii.cpu().numpy() != GOLD[f"call{ci}/out/radii"]).sum() <= 1
+        ref = GOLD[f"call{ci}/out/color"]
+        assert_close_outliers(color.detach().cpu().numpy(), ref, 1e-4, rtol=1e-4, max_outlier_frac=1e-4, outlier_atol=0.03 * max(1.0, np.abs(ref).max()),
+                              what=f"call {ci} color")
+        assert_close_outliers(depth.detach().cpu().numpy(), GOLD[f"call{ci}/out/depth"], 1e-4, rtol=1e-4, max_outlier_frac=1e-4, outlier_atol=0.1,
+                              what=f"call {ci} depth")
+    # backward: ONE backward over both renders with the gradients the reference's loss delivered (depth-silhouette pass first
+    # in autograd's reverse order, then RGB -- per-call state, no globals)
+    torch.autograd.backward([outs[0][0], outs[1][0]],
+                            [torch.tensor(GOLD[f"{mode}/call0/grad_out/color"]).cuda(), torch.tensor(GOLD[f"{mode}/call1/grad_out/color"]).cuda()])
+    torch.cuda.synchronize()
+    for ci, kw in enumerate(calls):
+        for k in IN_KEYS:
+            key = f"{mode}/call{ci}/grad_in/{k}"
+            if key not in GOLD.files:
+                assert kw[k].grad is None, (ci, k)
+                continue
+            ref = GOLD[key]
+            got = kw[k].grad
+            assert got is not None, (ci, k)
+            if float(np.abs(ref).max()) == 0.0:
+                assert float(got.abs().max()) == 0.0, (ci, k)
+                continue
+            assert_close_outliers(got.cpu().numpy().reshape(ref.shape), ref, 1e-3 * grad_scale(ref), max_outlier_frac=2e-4,
+                                  outlier_atol=0.05 * grad_scale(ref), what=f"{mode} call {ci} grad {k}")
+    # what the caller reads afterwards: variables['means2D'].grad (the colour pass') and the radius bookkeeping
+    m2 = calls[0]['means2D'].grad.cpu().numpy()
+    ref = GOLD[f"{mode}/means2D_grad"]
+    assert float(np.abs(m2[:, 2]).max()) == 0.0
+    assert_close_outliers(m2, ref, 1e-3 * grad_scale(ref), max_outlier_frac=2e-4, outlier_atol=0.05 * grad_scale(ref), what="means2D.grad")
+    radius = outs[0][1]
+    seen = radius > 0
+    max_r = torch.zeros(radius.shape[0], device="cuda")
+    max_r[seen] = torch.max(radius[seen], max_r[seen])          # /root/reference/scripts/splatam.py:341-343
+    assert (seen.cpu().numpy() != GOLD[f"{mode}/seen"]).sum() <= 1
+    assert (max_r.cpu().numpy() != GOLD[f"{mode}/max_2D_radius"]).sum() <= 1
