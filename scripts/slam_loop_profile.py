@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Where the frame loop's wall time goes: wraps the engine's entry points and the host-side steps of pipeline.rgbd_slam with
+synchronising timers.  usage: scripts/slam_loop_profile.py [workload] [frames].  Developer tool (run through gpurun)."""
+import collections
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from splatam_amd import fused, pipeline  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "B"
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+N, W, H, fx, fy, cx, cy = bench.WORKLOADS[name]
+dev = torch.device("cuda", 0)
+acc = collections.defaultdict(lambda: [0.0, 0])
+
+
+def timed(label, fn):
+    def wrapper(*a, **k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn(*a, **k)
+        torch.cuda.synchronize()
+        acc[label][0] += time.perf_counter() - t0
+        acc[label][1] += 1
+        return r
+    return wrapper
+
+
+E = fused.FusedEngine
+for meth in ("add_new_gaussians", "relearn_lists", "prune_gaussians", "check_overflow", "adam_map", "begin_tracking", "end_tracking",
+             "reset_map_optimizer", "add_valid_depth_points"):
+    setattr(E, meth, timed(meth, getattr(E, meth)))
+_lb = E.loss_backward
+E.loss_backward = lambda self, d, t, cfg, tracking, **kw: timed("loss_backward(tracking)" if tracking else "loss_backward(mapping)", _lb)(self, d, t, cfg, tracking, **kw)
+pipeline.keyframe_selection_overlap = timed("keyframe_selection_overlap", pipeline.keyframe_selection_overlap)
+pipeline.slam.initialize_camera_pose = timed("initialize_camera_pose", pipeline.slam.initialize_camera_pose)
+ds = pipeline.SyntheticRGBDSequence(N, W, H, fx, fy, cx, cy, num_frames=frames, seed=3, device=dev)
+cfg = pipeline.replica_config()
+torch.manual_seed(0)
+np.random.seed(0)
+t0 = time.perf_counter()
+params, _, st = pipeline.rgbd_slam(ds, cfg, engine="fused")
+torch.cuda.synchronize()
+wall = time.perf_counter() - t0
+print(f"wall {wall:.3f} s; tracking_s {st['tracking_s']:.3f} ({st['tracking_iters']} it), mapping_s {st['mapping_s']:.3f} ({st['mapping_iters']} it), map {st['num_gaussians']}")
+for k, (t, n) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
+    print(f"  {k:32s} {t * 1e3:9.1f} ms  {n:5d} calls  {t / max(n, 1) * 1e3:8.3f} ms/call")

@@ -58,13 +58,16 @@ def keyframe_selection_overlap(gt_depth, w2c, intrinsics, keyframe_list, k, pixe
     """Indices (into ``keyframe_list``) of up to ``k`` keyframes that see part of the current frame: 1600 valid-depth
     pixels are back-projected and re-projected into every keyframe (one batched product over all keyframes); keyframes with
     a non-zero share of points inside the image (20 px border) are kept, ordered by that share, then shuffled."""
+    # a few thousand points against a few dozen keyframes: host-side work (on the GPU the nonzero / unique(dim=0) / tolist chain
+    # of this function cost 86 ms per frame in synchronisations and tiny launches -- more than the 60 mapping iterations)
+    gt_depth, w2c, intrinsics = gt_depth.cpu(), w2c.cpu(), intrinsics.cpu()
     H, W = gt_depth.shape[1], gt_depth.shape[2]
     valid = torch.stack(torch.where(gt_depth[0] > 0), dim=1)
     sampled = valid[torch.randint(valid.shape[0], (pixels,))]
     pts = _sampled_cloud(gt_depth, intrinsics, w2c, sampled)
     if len(keyframe_list) == 0:
         return []
-    est = torch.stack([kf['est_w2c'] for kf in keyframe_list])                     # [K,4,4]
+    est = torch.stack([kf['est_w2c'] for kf in keyframe_list]).cpu()               # [K,4,4]
     cam = torch.einsum('kij,nj->kni', est[:, :3, :3], pts) + est[:, None, :3, 3]     # [K,N,3]
     proj = torch.einsum('ij,knj->kni', intrinsics.to(cam.dtype), cam)
     zc = proj[..., 2] + 1e-5
@@ -230,7 +233,9 @@ def initialize_first_timestep(dataset, num_frames, scene_radius_depth_ratio, mea
 
 def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacity=None, verbose=False):
     """Runs the SplaTAM frame loop over ``dataset``; returns ``(params, variables, stats)`` with
-    ``stats = {keyframe_time_indices, tracking_iters, mapping_iters, tracking_s, mapping_s, num_gaussians, redone_frames}``.
+    ``stats = {keyframe_time_indices, tracking_iters, mapping_iters, tracking_s, mapping_s, mapping_loop_s, num_gaussians,
+    redone_frames}`` (``mapping_loop_s``: the iterations alone, where the reference's own mapping timer runs, scripts/splatam.py:825-891;
+    ``mapping_s`` also holds densification, keyframe selection and list re-learning).
 
     With ``torch.distributed`` initialised (one process per GPU, splatam_amd.dist.init_from_env) the loop runs on every rank
     over the REPLICATED map:
@@ -287,7 +292,7 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
         dev = params['means3D'].device
         first_frame_w2c = first_frame_w2c.to(dev).float().contiguous()
     keyframe_list, keyframe_time_indices = [], []
-    stats = dict(tracking_iters=0, mapping_iters=0, tracking_s=0.0, mapping_s=0.0, redone_frames=0, num_gaussians=[])
+    stats = dict(tracking_iters=0, mapping_iters=0, tracking_s=0.0, mapping_s=0.0, mapping_loop_s=0.0, redone_frames=0, num_gaussians=[])
 
     def sync():
         if dev.type == "cuda":
@@ -349,6 +354,8 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
                 snap = {k: eng.store[k][:eng.P].clone() for k in slam.GAUSSIAN_KEYS}
                 snap_vars = {k: eng.store[k][:eng.P].clone() for k in ('max_2D_radius', 'means2D_gradient_accum', 'denom', 'timestep')}
                 rng_state = np.random.get_state()
+            sync()
+            t_loop = time.perf_counter()                        # the reference's mapping timer starts here (scripts/splatam.py:825)
             for attempt in range(3):
                 _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, mcfg, eng,
                            scene_radius if fused else None)
@@ -369,6 +376,7 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
             stats['mapping_iters'] += mcfg['num_iters']
             sync()
             stats['mapping_s'] += time.perf_counter() - t0
+            stats['mapping_loop_s'] += time.perf_counter() - t_loop
 
         # ---------------- keyframe list (scripts/splatam.py:893-905)
         if time_idx == 0 or (time_idx + 1) % config['keyframe_every'] == 0 or time_idx == num_frames - 2:
