@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define SPLAT_ABI_VERSION 3        /* 3: SplatState.keys_alt / long_base (multi-workgroup sort of lists beyond LDS); 2: map edits,
+#define SPLAT_ABI_VERSION 4        /* 4: densification (splat_iter_means2d_accumulate, splat_map_densify_select / _duplicate);
+                                      3: SplatState.keys_alt / long_base (multi-workgroup sort of lists beyond LDS); 2: map edits,
                                       splat_iter_render / _tracking_step, outlier scratch in SplatIterWorkspace */
 #define SPLAT_TILE 16            /* tile edge in pixels (one 256-thread workgroup per tile, one wave64 per 8x8 quadrant) */
 #define SPLAT_MAX_CHANNELS 8     /* colour channels per call: 3 for the reference API, up to 8 for fused passes */
@@ -388,6 +389,43 @@ int32_t splat_map_row_floats(const SplatMapStore *store);
 /* prune_gaussians' removal rule + remove_points (/root/reference/utils/slam_external.py:139-188): stable compaction of
  * the five parameter arrays, the Adam moments and the per-Gaussian variables.  counts[0], counts[1] are written. */
 int splat_map_prune(SplatMapStore *store, const SplatPruneArgs *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Gradient-based densification (/root/reference/utils/slam_external.py:100-104, 191-240; on in
+ * /root/reference/configs/replica/gaussian_splatting.py:82, off in the SLAM configs).
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* accumulate_mean2d_gradient for the iteration whose splat_iter_loss_backward has just run on `ws`: the COLOUR pass' own
+ * dL/dmeans2D (what variables['means2D'].grad holds in the reference: the r, g, b planes of the loss gradient only, not the
+ * depth render's) is formed by one more backward composite over the three colour planes, and for every Gaussian seen by the
+ * render (radius > 0):  means2D_gradient_accum += |dL/dmeans2D.xy|,  denom += 1.  means2D_grad ([P][2], may be NULL)
+ * receives the gradient itself.  Leaves ws->accum zeroed. */
+int splat_iter_means2d_accumulate(const SplatCamera *cam, const SplatMap *map, SplatIterWorkspace *ws,
+                                  float *means2D_gradient_accum, float *denom, float *means2D_grad, void *stream);
+
+enum { SPLAT_DENSIFY_CLONE = 0, SPLAT_DENSIFY_SPLIT = 1 };
+
+typedef struct SplatDensifyArgs {
+    int32_t mode;                /* CLONE: grads >= grad_thresh and max exp(log_scales) <= small_scale; SPLIT: ... > small_scale */
+    float grad_thresh;           /* densify_dict['grad_thresh'] */
+    float small_scale;           /* 0.01 * variables['scene_radius'] */
+    int32_t rows_with_grad;      /* rows [0, rows_with_grad) carry an accumulated gradient (store->means2D_gradient_accum / denom,
+                                    NaN -> 0); later rows -- the clones appended just before the split -- count as 0 (padded_grad) */
+    int32_t num_to_split_into;   /* n (SPLIT) */
+    const float *samples;        /* splat_map_duplicate, SPLIT: [S * n][3] draws of torch.normal(0, exp(log_scales)[to_split].repeat(n, 3)) */
+    uint8_t *flags;              /* [capacity] selection flags: written by _select, read by _duplicate */
+    uint32_t *scratch;           /* splat_map_scratch_words(capacity) words */
+} SplatDensifyArgs;
+
+/* Selection: flags + store->counts[1] = selected rows S, counts[0] = rows after appending S (CLONE) / S * n (SPLIT) rows,
+ * counts[2] = the append would not fit `capacity`. */
+int splat_map_densify_select(SplatMapStore *store, const SplatDensifyArgs *args, void *stream);
+
+/* Appends the selected rows (after a _select with the same args): CLONE: copies, in row order; SPLIT: n blocks of the selected
+ * rows (torch's v[mask].repeat(n, 1)) with means3D += build_rotation(unnorm_rotations) @ sample and
+ * log_scales = log(exp(log_scales) / (0.8 n)).  Adam moments and max_2D_radius / means2D_gradient_accum / denom of the new rows
+ * are zero.  The caller then sets map.P = counts[0]; the split originals are removed with splat_map_prune(to_remove = flags). */
+int splat_map_duplicate(SplatMapStore *store, const SplatDensifyArgs *args, void *stream);
 
 /* Developer switches used by scripts/ (never by the product path): key 0 = skip the per-tile
  * count atomics of K1 (timing experiment; results are then invalid); key 1 = generation of the composite kernels

@@ -16,7 +16,7 @@ SPLAT_TILE = 16
 SPLAT_MAX_CHANNELS = 8
 SPLAT_GRAD_STRIDE = 16
 SPLAT_COUNTER_STRIDE = 32
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -95,6 +95,11 @@ class SplatPruneArgs(C.Structure):
                 ("to_remove", _fp), ("flags", _fp), ("stage", _fp), ("scratch", _fp)]
 
 
+class SplatDensifyArgs(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("grad_thresh", C.c_float), ("small_scale", C.c_float), ("rows_with_grad", C.c_int32),
+                ("num_to_split_into", C.c_int32), ("samples", _fp), ("flags", _fp), ("scratch", _fp)]
+
+
 class SplatPoseAdam(C.Structure):
     _fields_ = [("state", _fp), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("bc2_sqrt", C.c_float),
                 ("step_size_rot", C.c_float), ("step_size_trans", C.c_float)]
@@ -102,6 +107,8 @@ class SplatPoseAdam(C.Structure):
 
 SPLAT_ADD_VALID_DEPTH = 0
 SPLAT_ADD_NON_PRESENCE = 1
+SPLAT_DENSIFY_CLONE = 0
+SPLAT_DENSIFY_SPLIT = 1
 SPLAT_ITER_SUMS = 32
 SPLAT_ITER_SUM_COPIES = 64
 SPLAT_POSE_STATE = 24
@@ -113,6 +120,7 @@ EXPORTS = (
     "splat_mark_visible", "splat_time_kernel", "splat_debug_option",
     "splat_iter_loss_backward", "splat_iter_adam_map", "splat_iter_adam_pose", "splat_iter_time_kernel",
     "splat_iter_tracking_step", "splat_iter_render", "splat_map_scratch_words", "splat_map_row_floats", "splat_map_add_new_gaussians", "splat_map_prune",
+    "splat_iter_means2d_accumulate", "splat_map_densify_select", "splat_map_duplicate",
 )
 
 _lib = None
@@ -176,6 +184,12 @@ def lib():
     L.splat_map_add_new_gaussians.argtypes = [C.POINTER(SplatMapStore), C.POINTER(SplatAddArgs), _fp]
     L.splat_map_prune.restype = C.c_int
     L.splat_map_prune.argtypes = [C.POINTER(SplatMapStore), C.POINTER(SplatPruneArgs), _fp]
+    L.splat_iter_means2d_accumulate.restype = C.c_int
+    L.splat_iter_means2d_accumulate.argtypes = [cam, C.POINTER(SplatMap), C.POINTER(SplatIterWorkspace), _fp, _fp, _fp, _fp]
+    for name in ("splat_map_densify_select", "splat_map_duplicate"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(SplatMapStore), C.POINTER(SplatDensifyArgs), _fp]
     L.splat_debug_option.restype = C.c_int
     L.splat_debug_option.argtypes = [C.c_int, C.c_int]
     if hasattr(L, "splat_selftest"):

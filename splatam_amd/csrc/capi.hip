@@ -264,6 +264,34 @@ int splat_map_prune(SplatMapStore *store, const SplatPruneArgs *a, void *stream)
     return check(launch_map_prune(*store, *a, (hipStream_t)stream));
 }
 
+int splat_iter_means2d_accumulate(const SplatCamera *cam, const SplatMap *map, SplatIterWorkspace *ws, float *gaccum, float *denom,
+                                  float *means2D_grad, void *stream) {
+    if (!cam || !map || !ws || map->P < 0 || cam->image_width <= 0 || cam->image_height <= 0) return SPLAT_E_INVALID;
+    if (map->P > 0 && (!gaccum || !denom || !ws->accum || !ws->feat8 || !ws->dL_dout6 || !ws->st.radii || !ws->st.conic_opacity)) return SPLAT_E_INVALID;
+    if (!ws->st.point_list || !ws->st.final_T || !ws->st.n_contrib || !ws->st.tile_base) return SPLAT_E_INVALID;
+    return check(launch_iter_means2d_accumulate(*cam, *map, *ws, gaccum, denom, means2D_grad, (hipStream_t)stream));
+}
+
+static bool valid_densify(const SplatMapStore *store, const SplatDensifyArgs *a) {
+    if (!valid_store(store) || !a || !a->flags || !a->scratch) return false;
+    if (a->mode != SPLAT_DENSIFY_CLONE && a->mode != SPLAT_DENSIFY_SPLIT) return false;
+    if (a->rows_with_grad < 0 || a->rows_with_grad > store->map.P) return false;
+    if (a->rows_with_grad > 0 && (!store->means2D_gradient_accum || !store->denom)) return false;
+    if (a->mode == SPLAT_DENSIFY_SPLIT && a->num_to_split_into < 1) return false;
+    return true;
+}
+
+int splat_map_densify_select(SplatMapStore *store, const SplatDensifyArgs *a, void *stream) {
+    if (!valid_densify(store, a)) return SPLAT_E_INVALID;
+    return check(launch_map_densify_select(*store, *a, (hipStream_t)stream));
+}
+
+int splat_map_duplicate(SplatMapStore *store, const SplatDensifyArgs *a, void *stream) {
+    if (!valid_densify(store, a)) return SPLAT_E_INVALID;
+    if (a->mode == SPLAT_DENSIFY_SPLIT && !a->samples) return SPLAT_E_INVALID;
+    return check(launch_map_duplicate(*store, *a, (hipStream_t)stream));
+}
+
 int splat_debug_option(int key, int value) {
     if (key == 0) { const int old = g_debug_skip_count; g_debug_skip_count = value; return old; }
     if (key == 1) {

@@ -710,6 +710,41 @@ hipError_t launch_iter_render(const SplatCamera &cam, const SplatMap &map, const
     return hipGetLastError();
 }
 
+namespace {
+// accumulate_mean2d_gradient (/root/reference/utils/slam_external.py:100-104) from the colour-only sums S1, S2 of a Gaussian:
+// dL/dmeans2D (NDC, as the rasterizer returns it) = -(conic . S) * 0.5 * (W, H)   (K8: splat_math.h / fused_backward_kernel)
+__global__ __launch_bounds__(kBlock) void means2d_accumulate_kernel(SplatIterWorkspace ws, int P, int W, int H, float *gaccum, float *denom, float *out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P) return;
+    float gx = 0.f, gy = 0.f;
+    const bool seen = ws.st.radii[i] > 0;
+    if (seen) {
+        float4 *a4 = reinterpret_cast<float4 *>(ws.accum + (size_t)i * SPLAT_GRAD_STRIDE);
+        const float4 s0 = a4[0], s1 = a4[1];
+        a4[0] = make_float4(0.f, 0.f, 0.f, 0.f);               // consumed (slots 0..4 were written)
+        a4[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        (void)s1;
+        const float4 co = reinterpret_cast<const float4 *>(ws.st.conic_opacity)[i];
+        gx = -(co.x * s0.x + co.y * s0.y) * 0.5f * (float)W;
+        gy = -(co.z * s0.y + co.y * s0.x) * 0.5f * (float)H;
+        gaccum[i] += sqrtf(gx * gx + gy * gy);
+        denom[i] += 1.0f;
+    }
+    if (out) { out[2 * (size_t)i] = gx; out[2 * (size_t)i + 1] = gy; }
+}
+}  // namespace
+
+hipError_t launch_iter_means2d_accumulate(const SplatCamera &cam, const SplatMap &map, SplatIterWorkspace &ws, float *gaccum, float *denom,
+                                          float *means2D_grad, hipStream_t s) {
+    const int P = map.P;
+    if (P <= 0) return hipSuccess;
+    hipError_t e = launch_render_backward_rgb_only(cam, ws.feat8, ws.st, ws.dL_dout6, ws.accum, P, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(means2d_accumulate_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, ws, P, cam.image_width, cam.image_height, gaccum,
+                       denom, means2D_grad);
+    return hipGetLastError();
+}
+
 hipError_t launch_iter_adam_map(const SplatMap &map, const SplatAdamMap &opt, hipStream_t s) {
     if (map.P <= 0) return hipSuccess;
     AdamArgs a{map, opt};

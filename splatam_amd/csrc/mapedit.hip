@@ -382,6 +382,132 @@ __global__ __launch_bounds__(kBlock) void copy_back_kernel(MapArrays arr, const 
     for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < n; e += (long long)gridDim.x * kBlock) dst[e] = src[e];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// densify (/root/reference/utils/slam_external.py:191-240): clone / split selection and the duplication of rows
+// ---------------------------------------------------------------------------------------------------------
+//   D1 densify_flag_kernel     flags[i] = grads[i] >= grad_thresh  &&  max exp(log_scales[i]) <= / > 0.01 scene_radius
+//                              with grads = means2D_gradient_accum / denom, NaN (0 / 0) -> 0 and rows >= rows_with_grad -> 0
+//                              (the reference's padded_grad), + per-block counts;  E5 scan (append form)
+//   D2 duplicate_rows_kernel   the selected rows, in order, `repeat` times block after block (torch's v[mask].repeat(n, 1)),
+//                              appended at the tail; split form: means3D += build_rotation(unnorm_rotations) @ sample,
+//                              log_scales = log(exp(log_scales) / (0.8 n)); Adam moments of the new rows zero
+// The normal samples of the split are drawn by torch (the reference's own generator stream) and handed in.
+__device__ __forceinline__ float row_max_scale(const SplatMap &m, int i) {
+    if (m.isotropic) return expf(m.log_scales[i]);
+    return fmaxf(expf(m.log_scales[3 * (size_t)i]), fmaxf(expf(m.log_scales[3 * (size_t)i + 1]), expf(m.log_scales[3 * (size_t)i + 2])));
+}
+
+__global__ __launch_bounds__(kBlock) void densify_flag_kernel(SplatMapStore st, SplatDensifyArgs a) {
+    __shared__ unsigned s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const int P = st.map.P;
+    unsigned c = 0;
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const int i = blockIdx.x * kPerBlock + r * kBlock + threadIdx.x;
+        if (i < P) {
+            float g = 0.f;
+            if (i < a.rows_with_grad) {
+                g = st.means2D_gradient_accum[i] / st.denom[i];
+                if (g != g) g = 0.f;                                   // grads[grads.isnan()] = 0.0
+            }
+            const float mx = row_max_scale(st.map, i);
+            const bool big = mx > a.small_scale;
+            const bool sel = g >= a.grad_thresh && (a.mode == SPLAT_DENSIFY_SPLIT ? big : !big);
+            a.flags[i] = sel ? 1 : 0;
+            c += sel ? 1u : 0u;
+        }
+    }
+    for (int m = 32; m >= 1; m >>= 1) c += (unsigned)__shfl_xor((int)c, m, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) a.scratch[kWBlocks + blockIdx.x] = s_cnt;
+}
+
+// one workgroup: scan of the per-block counts; counts[1] = selected rows S, counts[0] = rows after appending S * repeat,
+// counts[2] = does not fit
+__global__ __launch_bounds__(kBlock) void densify_scan_kernel(uint32_t *scratch, int nblocks, int rows0, int capacity, int repeat, int32_t *counts) {
+    __shared__ unsigned s_tmp[8];
+    unsigned carry = 0;
+    for (int base = 0; base < nblocks; base += kBlock) {
+        const int b = base + threadIdx.x;
+        const unsigned v = b < nblocks ? scratch[kWBlocks + b] : 0u;
+        unsigned total;
+        const unsigned ex = block_exclusive_scan(v, s_tmp, &total);
+        if (b < nblocks) scratch[kWBlocks + b] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        const long long after = (long long)rows0 + (long long)carry * repeat;
+        const bool fits = after <= (long long)capacity;
+        counts[0] = fits ? (int)after : rows0;
+        counts[1] = (int)carry;
+        counts[2] = fits ? 0 : 1;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void duplicate_rows_kernel(SplatMapStore st, SplatDensifyArgs a, const int32_t *counts) {
+    __shared__ unsigned s_wave[kBlock / 64];
+    if (counts[2] != 0) return;                                        // does not fit: nothing is written
+    const int P = st.map.P, S = counts[1], n = a.mode == SPLAT_DENSIFY_SPLIT ? a.num_to_split_into : 1;
+    const bool iso = st.map.isotropic != 0;
+    const bool split = a.mode == SPLAT_DENSIFY_SPLIT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int width[5] = {3, 3, 4, 1, iso ? 1 : 3};
+    float *params[5] = {st.map.means3D, st.map.rgb_colors, st.map.unnorm_rotations, st.map.logit_opacities, st.map.log_scales};
+    unsigned base = a.scratch[kWBlocks + blockIdx.x];
+#pragma unroll 1
+    for (int r = 0; r < kRounds; ++r) {
+        const int i = blockIdx.x * kPerBlock + r * kBlock + threadIdx.x;
+        const bool sel = i < P && a.flags[i] != 0;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(sel);
+        if (lane == 0) s_wave[wave] = (unsigned)__popcll(m);
+        __syncthreads();
+        unsigned off = 0, tot = 0;
+        for (int k = 0; k < kBlock / 64; ++k) {
+            if (k < wave) off += s_wave[k];
+            tot += s_wave[k];
+        }
+        __syncthreads();
+        if (sel) {
+            const unsigned q = base + off + (unsigned)__popcll(m & ((1ull << lane) - 1ull));      // rank among the selected rows
+            float R[9];
+            if (split) {
+                const float4 u = reinterpret_cast<const float4 *>(st.map.unnorm_rotations)[i];
+                // build_rotation normalises its argument (/root/reference/utils/slam_external.py:25-42)
+                const float inv = 1.0f / sqrtf(u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w);
+                const float qn[4] = {u.x * inv, u.y * inv, u.z * inv, u.w * inv};
+                quat_to_rot(qn, R);
+            }
+            for (int rep = 0; rep < n; ++rep) {
+                const size_t row = (size_t)P + (size_t)rep * S + q;
+                for (int g = 0; g < 5; ++g) {
+                    const int w = width[g];
+                    for (int c = 0; c < w; ++c) {
+                        float v = params[g][(size_t)i * w + c];
+                        if (split && g == 0) {
+                            const float *sm = a.samples + 3 * ((size_t)rep * S + q);
+                            v += R[3 * c] * sm[0] + R[3 * c + 1] * sm[1] + R[3 * c + 2] * sm[2];
+                        }
+                        if (split && g == 4) v = logf(expf(v) / (0.8f * (float)n));
+                        params[g][row * w + c] = v;
+                        if (st.exp_avg[g]) st.exp_avg[g][row * w + c] = 0.f;
+                        if (st.exp_avg_sq[g]) st.exp_avg_sq[g][row * w + c] = 0.f;
+                    }
+                }
+                // per-Gaussian variables of the new rows: the three the reference re-creates are zero; `timestep` is copied (the
+                // reference's densify does not extend it at all: /root/reference/utils/slam_external.py:206-227)
+                if (st.max_2D_radius) st.max_2D_radius[row] = 0.f;
+                if (st.means2D_gradient_accum) st.means2D_gradient_accum[row] = 0.f;
+                if (st.denom) st.denom[row] = 0.f;
+                if (st.timestep) st.timestep[row] = st.timestep[i];
+            }
+        }
+        base += tot;
+    }
+}
+
 // tile counters of the bucketed lists after a forward-only pass (the full iteration folds them in its last per-Gaussian kernel)
 __global__ __launch_bounds__(kBlock) void fold_tile_counters_kernel(SplatState st, int T) {
     unsigned sum = 0, mx = 0;
@@ -480,6 +606,22 @@ hipError_t launch_map_prune(const SplatMapStore &st, const SplatPruneArgs &a, hi
         const int cblocks = min((int)(((long long)P * 4 + kBlock - 1) / kBlock), 2048);
         hipLaunchKernelGGL(copy_back_kernel, dim3(cblocks, arr.n), dim3(kBlock), 0, s, arr, a.stage, st.counts);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_map_densify_select(const SplatMapStore &st, const SplatDensifyArgs &a, hipStream_t s) {
+    const int P = st.map.P;
+    const int nblocks = (P + kPerBlock - 1) / kPerBlock;
+    if (P > 0) hipLaunchKernelGGL(densify_flag_kernel, dim3(nblocks), dim3(kBlock), 0, s, st, a);
+    const int rep = a.mode == SPLAT_DENSIFY_SPLIT ? a.num_to_split_into : 1;
+    hipLaunchKernelGGL(densify_scan_kernel, dim3(1), dim3(kBlock), 0, s, a.scratch, nblocks, P, st.capacity, rep, st.counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_map_duplicate(const SplatMapStore &st, const SplatDensifyArgs &a, hipStream_t s) {
+    const int P = st.map.P;
+    const int nblocks = (P + kPerBlock - 1) / kPerBlock;
+    if (P > 0) hipLaunchKernelGGL(duplicate_rows_kernel, dim3(nblocks), dim3(kBlock), 0, s, st, a, st.counts);
     return hipGetLastError();
 }
 

@@ -697,7 +697,11 @@ __global__ __launch_bounds__(256) void render_backward_kernel5(SplatCamera cam, 
     {
         float t[NS4 * 4];
 #pragma unroll
-        for (int n = 0; n < NS4 * 4; ++n) t[n] = n < NS ? dpix[nth_set_bit(SMASK, n < NS ? n : 0)] : 0.f;
+        for (int n = 0; n < NS4 * 4; ++n) {
+            t[n] = 0.f;
+            if constexpr (NS > 0)
+                if (n < NS) t[n] = dpix[nth_set_bit(SMASK, n < NS ? n : 0)];
+        }
 #pragma unroll
         for (int q = 0; q < NS4; ++q)
             s_dtab[wave][(lane >> 3) * (8 * NS4 + 1) + (lane & 7) * NS4 + q] = make_float4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
@@ -1047,6 +1051,17 @@ hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *fea
     if (rgb_sums) launch_bwd<6, 8, 0xFu, 0xFu, true, false>(cam, feat8, st, dL_dout6, accum, T, s);
     else if (opacity_sum || g_debug_entries_per_trip == 3) launch_bwd<6, 8, 0xFu, 0x8u, true, false>(cam, feat8, st, dL_dout6, accum, T, s);
     else launch_bwd<6, 8, 0xFu, 0x8u, false, false>(cam, feat8, st, dL_dout6, accum, T, s);      // camera tracking: no dL/dopacity wanted
+    return hipGetLastError();
+}
+
+// The colour pass' own geometric sums S1..S5 (gradient planes r, g, b only; no colour sums, no opacity sum): the extra pass of
+// splat_iter_means2d_accumulate.  `accum` must be zero on entry (the fused iteration leaves it so).
+hipError_t launch_render_backward_rgb_only(const SplatCamera &cam, const float *feat8, const SplatState &st, const float *dL_dout6,
+                                           float *accum, int P, hipStream_t s) {
+    const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
+    if (T == 0 || P == 0) return hipSuccess;
+    const int per = (T + 7) / 8;
+    hipLaunchKernelGGL((render_backward_kernel5<6, 8, 0x7u, 0x0u, false, false>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, dL_dout6, accum, T, per);
     return hipGetLastError();
 }
 

@@ -51,6 +51,12 @@ hipError_t launch_iter_render(const SplatCamera &cam, const SplatMap &map, const
                               hipStream_t s);
 hipError_t launch_map_add(const SplatMapStore &st, const SplatAddArgs &a, hipStream_t s);
 hipError_t launch_map_prune(const SplatMapStore &st, const SplatPruneArgs &a, hipStream_t s);
+hipError_t launch_map_densify_select(const SplatMapStore &st, const SplatDensifyArgs &a, hipStream_t s);
+hipError_t launch_map_duplicate(const SplatMapStore &st, const SplatDensifyArgs &a, hipStream_t s);
+hipError_t launch_iter_means2d_accumulate(const SplatCamera &cam, const SplatMap &map, SplatIterWorkspace &ws, float *accum, float *denom,
+                                          float *means2D_grad, hipStream_t s);
+hipError_t launch_render_backward_rgb_only(const SplatCamera &cam, const float *feat8, const SplatState &st, const float *dL_dout6,
+                                           float *accum, int P, hipStream_t s);
 size_t map_scratch_words(long long n);
 int map_row_floats(const SplatMapStore &st);
 extern int g_debug_skip_count;

@@ -344,6 +344,100 @@ class FusedEngine:
                     self.exp_avg_sq['logit_opacities'].zero_()
         return removed
 
+    # ------------------------------------------------------------------ gradient-based densification
+    def accumulate_mean2d_gradient(self, want_grad=False):
+        """accumulate_mean2d_gradient (/root/reference/utils/slam_external.py:100-104) for the iteration whose ``loss_backward``
+        has just run: variables['means2D_gradient_accum'][seen] += |colour pass' dL/dmeans2D.xy|, variables['denom'][seen] += 1.
+        The fused backward sums the RGB and the depth render together, so the colour pass' own screen-space gradient takes one
+        more backward composite over the three colour planes (splat_iter_means2d_accumulate).  ``want_grad``: also return that
+        gradient ([P, 2], the first two columns of the reference's variables['means2D'].grad)."""
+        if not self.managed:
+            raise RuntimeError("this FusedEngine was built without gaussian_capacity / variables: there is nothing to accumulate into")
+        out = torch.empty(self.P, 2, dtype=torch.float32, device=self.dev) if want_grad else None
+        ws = self._workspace(False, with_ssim=False)
+        m = self._map_struct()
+        with torch.cuda.device(self.dev):
+            _capi.check(self.L.splat_iter_means2d_accumulate(C.byref(self._cam), C.byref(m), C.byref(ws),
+                                                             self.store['means2D_gradient_accum'].data_ptr(), self.store['denom'].data_ptr(),
+                                                             out.data_ptr() if out is not None and self.P else None, self._stream()),
+                        "splat_iter_means2d_accumulate")
+        return out
+
+    def _densify_args(self, mode, thr, small, rows_with_grad, n=1, samples=None):
+        b = self.buf
+        if 'flags' not in b or b['flags'].numel() < self.Pcap:
+            b['flags'] = torch.empty(self.Pcap, dtype=torch.uint8, device=self.dev)
+        a = _capi.SplatDensifyArgs()
+        a.mode, a.grad_thresh, a.small_scale = mode, float(thr), float(small)
+        a.rows_with_grad, a.num_to_split_into = int(rows_with_grad), int(n)
+        a.samples = samples.data_ptr() if samples is not None and samples.numel() else None
+        a.flags = b['flags'].data_ptr()
+        a.scratch = self._map_scratch(max(self.H * self.W, self.Pcap)).data_ptr()
+        return a
+
+    def _select_and_append(self, mode, thr, small, rows_with_grad, n=1):
+        """One clone / split step: select on the device, (split: draw the samples with torch's generator, as the reference does),
+        append.  Returns the number of selected rows."""
+        while True:
+            a = self._densify_args(mode, thr, small, rows_with_grad, n)
+            st = self._store_struct(with_moments=True)
+            with torch.cuda.device(self.dev):
+                _capi.check(self.L.splat_map_densify_select(C.byref(st), C.byref(a), self._stream()), "splat_map_densify_select")
+            counts = self.buf['counts'].tolist()            # host sync (the reference synchronises on its boolean indexing here)
+            if not counts[2]:
+                break
+            self._grow_rows(int((self.P + counts[1] * n) * 1.5) + 1024)
+        S = counts[1]
+        if S == 0:
+            return 0
+        samples = None
+        if mode == _capi.SPLAT_DENSIFY_SPLIT:
+            sel = self.buf['flags'][:self.P].bool()
+            ls = self.store['log_scales'][:self.P]
+            stds = torch.exp(ls)[sel].repeat(n, 3) if self.iso else torch.exp(ls)[sel].repeat(n, 1)
+            # (the reference's repeat(n, 3) of an [S, 3] anisotropic scale would be [S n, 9]: its densify only works for isotropic maps)
+            samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=self.dev), std=stds).contiguous()
+        a = self._densify_args(mode, thr, small, rows_with_grad, n, samples)
+        st = self._store_struct(with_moments=True)
+        with torch.cuda.device(self.dev):
+            _capi.check(self.L.splat_map_duplicate(C.byref(st), C.byref(a), self._stream()), "splat_map_duplicate")
+        self._set_rows(counts[0])
+        return S
+
+    def densify(self, iter, densify_dict, scene_radius):
+        """densify (/root/reference/utils/slam_external.py:191-240) on the device, in place, called where the reference calls it
+        (between backward() and optimizer.step()): accumulate the screen-space gradient; on the schedule clone the small /
+        split the large Gaussians whose mean gradient reaches ``grad_thresh``, reset the three per-Gaussian variables, remove
+        the split originals, prune by opacity / size; optional opacity reset.  Returns True when the number of rows changed."""
+        if iter > densify_dict['stop_after']:
+            return False
+        self.accumulate_mean2d_gradient()
+        changed = False
+        if iter >= densify_dict['start_after'] and iter % densify_dict['densify_every'] == 0:
+            thr, small = densify_dict['grad_thresh'], float(0.01 * scene_radius)
+            P0 = self.P
+            self._select_and_append(_capi.SPLAT_DENSIFY_CLONE, thr, small, P0)
+            n = int(densify_dict['num_to_split_into'])
+            P1 = self.P
+            S = self._select_and_append(_capi.SPLAT_DENSIFY_SPLIT, thr, small, P0, n)
+            for k in ('means2D_gradient_accum', 'denom', 'max_2D_radius'):
+                self.store[k][:self.P].zero_()
+            if S:
+                to_remove = torch.zeros(self.P, dtype=torch.uint8, device=self.dev)
+                to_remove[:P1] = self.buf['flags'][:P1]
+                self.remove_points(to_remove)
+            op_thr = densify_dict['final_removal_opacity_threshold'] if iter == densify_dict['stop_after'] \
+                else densify_dict['removal_opacity_threshold']
+            big = float(0.1 * scene_radius) if iter >= densify_dict['remove_big_after'] else None
+            self.remove_points(None, op_thr, big)
+            changed = True
+        if iter > 0 and iter % densify_dict['reset_opacities_every'] == 0 and densify_dict['reset_opacities']:
+            with torch.no_grad():
+                self.params['logit_opacities'].fill_(math.log(0.01 / (1 - 0.01)))
+                self.exp_avg['logit_opacities'].zero_()
+                self.exp_avg_sq['logit_opacities'].zero_()
+        return changed
+
     # ------------------------------------------------------------------ plumbing
     def _alloc_lists(self, capacity):
         self.capacity = int(capacity)

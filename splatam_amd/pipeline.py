@@ -253,8 +253,11 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
     world, rank = sdist.world_size(), sdist.get_rank()
     num_frames = len(dataset) if num_frames is None else min(num_frames, len(dataset))
     tcfg, mcfg = config['tracking'], config['mapping']
-    if mcfg.get('use_gaussian_splatting_densification'):
-        raise NotImplementedError("gradient-based densification (configs/*/gaussian_splatting.py) is outside this loop")
+    if mcfg.get('use_gaussian_splatting_densification') and not fused:
+        # the reference's own densify cannot run inside its SLAM loop either: it never extends variables['timestep'], and the
+        # remove_points that follows indexes it with the longer mask (utils/slam_external.py:206-227, 139-162).  The fused engine
+        # carries `timestep` along with the duplicated rows (FusedEngine.densify).
+        raise NotImplementedError("gradient-based densification inside the frame loop needs engine='fused'")
     dist_kind = config.get('gaussian_distribution', 'isotropic')
     eng = None
     if fused:
@@ -461,10 +464,17 @@ def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, 
             eng.loss_backward(iter_data, iter_time_idx, mcfg, tracking=False)
             if world > 1 and not on_schedule:                   # (an iteration on the pruning schedule takes no Adam step)
                 sdist.all_reduce_mean_flat(eng.reduce_flat)
+            edited = False
             if prune:
-                if eng.prune_gaussians(it, pd, scene_radius):
-                    sdist.assert_replicated_count(eng.P, f"prune_gaussians (frame {time_idx}, iteration {it})", dev)
-                    eng.relearn_lists(curr_data, time_idx)
+                edited = bool(eng.prune_gaussians(it, pd, scene_radius))
+            if mcfg.get('use_gaussian_splatting_densification'):        # scripts/splatam.py:864-867
+                dd = mcfg['densify_dict']
+                dens_sched = it <= dd['stop_after'] and it >= dd['start_after'] and it % dd['densify_every'] == 0
+                edited = bool(eng.densify(it, dd, scene_radius)) or edited
+                on_schedule = on_schedule or dens_sched                   # re-created parameters carry no gradient: no Adam step
+            if edited:
+                sdist.assert_replicated_count(eng.P, f"map edit (frame {time_idx}, iteration {it})", dev)
+                eng.relearn_lists(curr_data, time_idx)
             if not on_schedule:
                 eng.adam_map(mcfg['lrs'])
         else:

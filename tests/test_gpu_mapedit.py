@@ -169,3 +169,132 @@ def test_render_only_pass_matches_full_iteration_and_densification_full_size():
     eng.relearn_lists(frame, 1)
     eng.mapping_iteration(frame, 1, cfg)
     assert not eng.check_overflow() and np.isfinite(eng.loss())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# gradient-based densification on the device (FusedEngine.accumulate_mean2d_gradient / densify)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _densify_scene(n=6000, W=160, H=112):
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    f, cx, cy = 150.0, W / 2 - 0.5, H / 2 - 0.5
+    params, variables = slam.synthetic_params(n, W, H, f, f, cx, cy, num_frames=3, seed=4, device="cuda")
+    k = [[f, 0, cx], [0, f, cy], [0, 0, 1]]
+    w2c = torch.eye(4, device="cuda")
+    cam = slam.setup_camera(W, H, k, np.eye(4, dtype=np.float32), device="cuda")
+    im, depth = slam.synthetic_frame(params, cam, w2c, 1, rot_deg=0.4, trans_m=0.01)
+    g = torch.Generator().manual_seed(9)
+    im = (im + 0.05 * torch.randn(im.shape, generator=g).cuda()).clamp(0, 1).contiguous()
+    frame = {'cam': cam, 'im': im, 'depth': depth.contiguous(), 'id': 1, 'w2c': w2c}
+    mirror = {k_: torch.nn.Parameter(v.detach().clone()) for k_, v in params.items()}
+    eng = FusedEngine(params, cam, gaussian_capacity=4 * n, variables=variables)
+    return eng, params, variables, mirror, frame
+
+
+def test_colour_pass_means2d_gradient_and_its_accumulation():
+    """The colour pass' own dL/dmeans2D (what the reference reads from variables['means2D'].grad,
+    /root/reference/utils/slam_external.py:100-104) from the fused iteration's extra RGB-only backward composite, against
+    autograd through the drop-in rasterizer; and the accumulation into means2D_gradient_accum / denom for the seen Gaussians."""
+    from splatam_amd import slam
+    eng, params, variables, mirror, frame = _densify_scene()
+    cfg = slam.REPLICA_MAPPING
+    mv = {'max_2D_radius': torch.zeros(eng.P, device="cuda"), 'means2D_gradient_accum': torch.zeros(eng.P, device="cuda"),
+          'denom': torch.zeros(eng.P, device="cuda")}
+    for it in range(2):
+        loss, mv, _ = slam.get_loss(mirror, frame, mv, 1, cfg['loss_weights'], cfg['use_sil_for_loss'], cfg['sil_thres'], cfg['use_l1'],
+                                    cfg['ignore_outlier_depth_loss'], mapping=True)
+        loss.backward()
+        mv = slam.accumulate_mean2d_gradient(mv)
+        eng.loss_backward(frame, 1, cfg, tracking=False)
+        g = eng.accumulate_mean2d_gradient(want_grad=True)
+        torch.cuda.synchronize()
+        ref = mv['means2D'].grad[:, :2]
+        scale = float(ref.abs().max())
+        err = (g - ref).abs()
+        assert float(torch.quantile(err.reshape(-1), 0.9995)) <= 1e-3 * scale and float(err.max()) <= 0.05 * scale, (float(err.max()), scale)
+        for p in mirror.values():
+            p.grad = None
+    acc, ref_acc = variables['means2D_gradient_accum'], mv['means2D_gradient_accum']
+    assert torch.equal(variables['denom'], mv['denom']) and float(mv['denom'].max()) == 2.0
+    assert float((acc - ref_acc).abs().max()) <= 2e-3 * float(ref_acc.max())
+    assert float(eng.buf['accum'].abs().max()) == 0.0           # the workspace invariant survives the extra pass
+    g0 = eng.grads['means3D'].clone()
+    eng.loss_backward(frame, 1, cfg, tracking=False)
+    torch.cuda.synchronize()
+    assert torch.allclose(eng.grads['means3D'], g0, rtol=1e-4, atol=1e-7 * float(g0.abs().max()))
+
+
+def test_densify_on_the_device_matches_the_torch_formulation():
+    """FusedEngine.densify against splatam_amd.slam.densify (pinned to the reference's own densify on the CPU by
+    tests/test_mapedit_mirror.py) on the GPU under the same torch seed: clone + split (torch.normal draws in the reference's
+    order) + removal of the split originals + opacity / size pruning; parameters, Adam moments and per-Gaussian variables of
+    the surviving rows, in the same order."""
+    from splatam_amd import slam
+    eng, params, variables, mirror, frame = _densify_scene()
+    cfg = slam.REPLICA_MAPPING
+    n = eng.P
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    # an accumulated gradient history and non-zero Adam moments on both sides
+    hist = torch.rand(n, generator=gen, device="cuda") * 2e-3
+    den = torch.randint(1, 5, (n,), generator=gen, device="cuda").float()
+    den[::7] = 0.0
+    hist[::7] = 0.0                                             # 0 / 0 -> NaN -> 0 rows
+    opt = slam.initialize_optimizer(mirror, cfg['lrs'], tracking=False)
+    for p in mirror.values():
+        p.grad = torch.zeros_like(p)
+    opt.step()                                                  # creates the state (zero gradient: no parameter moves)
+    for key in slam.GAUSSIAN_KEYS:
+        m = torch.randn(mirror[key].shape, generator=gen, device="cuda")
+        v = torch.rand(mirror[key].shape, generator=gen, device="cuda")
+        opt.state[mirror[key]]['exp_avg'].copy_(m)
+        opt.state[mirror[key]]['exp_avg_sq'].copy_(v)
+        eng.exp_avg[key].copy_(m)
+        eng.exp_avg_sq[key].copy_(v)
+    # this iteration's colour-pass gradient: the mirror accumulates autograd's, the engine its own; start the mirror so that
+    # after ITS accumulation both hold the same sums
+    mv = {'max_2D_radius': torch.zeros(n, device="cuda"), 'means2D_gradient_accum': torch.zeros(n, device="cuda"), 'denom': torch.zeros(n, device="cuda")}
+    loss, mv, _ = slam.get_loss(mirror, frame, mv, 1, cfg['loss_weights'], cfg['use_sil_for_loss'], cfg['sil_thres'], cfg['use_l1'],
+                                cfg['ignore_outlier_depth_loss'], mapping=True)
+    loss.backward()
+    eng.loss_backward(frame, 1, cfg, tracking=False)
+    variables['means2D_gradient_accum'].copy_(hist)
+    variables['denom'].copy_(den)
+    eng.accumulate_mean2d_gradient()
+    seen = mv['seen']
+    own = torch.zeros(n, device="cuda")
+    own[seen] = torch.norm(mv['means2D'].grad[seen, :2], dim=-1)
+    mv['means2D_gradient_accum'] = variables['means2D_gradient_accum'].clone() - own
+    mv['denom'] = variables['denom'].clone() - seen.float()
+    scales = torch.exp(mirror['log_scales'].detach()).max(dim=1).values
+    scene_radius = float(torch.quantile(scales, 0.6)) / 0.01     # ~60 % "small" (clone), ~40 % "large" (split)
+    mv['scene_radius'] = torch.tensor(scene_radius, device="cuda")
+    # threshold in a gap of the mean-gradient distribution (the two accumulations agree to rounding, not bit for bit)
+    grads = variables['means2D_gradient_accum'] / variables['denom']
+    grads[grads.isnan()] = 0.0
+    sv = torch.sort(grads).values
+    lo, hi = int(0.55 * n), int(0.75 * n)
+    kgap = lo + int(torch.argmax(sv[lo + 1:hi] - sv[lo:hi - 1]))
+    thr = float(0.5 * (sv[kgap] + sv[kgap + 1]))
+    dd = dict(start_after=0, remove_big_after=0, stop_after=100, densify_every=1, grad_thresh=thr, num_to_split_into=2,
+              removal_opacity_threshold=0.3, final_removal_opacity_threshold=0.3, reset_opacities=False, reset_opacities_every=3000)
+    torch.manual_seed(17)
+    mirror, mv = slam.densify(mirror, mv, opt, 1, dd)
+    torch.manual_seed(17)
+    assert eng.densify(1, dd, scene_radius)
+    torch.cuda.synchronize()
+    n1 = mirror['means3D'].shape[0]
+    assert eng.P == n1 and n1 != n, (eng.P, n1, n)
+    for key in slam.GAUSSIAN_KEYS:
+        ref = mirror[key].detach()
+        assert float((params[key].detach() - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max())), key
+        st = opt.state[mirror[key]]
+        assert torch.equal(eng.exp_avg[key], st['exp_avg']) and torch.equal(eng.exp_avg_sq[key], st['exp_avg_sq']), key
+    for key in ('means2D_gradient_accum', 'denom', 'max_2D_radius'):
+        assert torch.equal(variables[key], mv[key]) and float(variables[key].abs().max()) == 0.0, key
+    # and the engine keeps running on the edited map
+    eng.relearn_lists(frame, 1)
+    eng.loss_backward(frame, 1, cfg, tracking=False)
+    eng.adam_map(cfg['lrs'])
+    torch.cuda.synchronize()
+    assert not eng.check_overflow() and np.isfinite(eng.loss())
