@@ -280,6 +280,8 @@ def test_densify_on_the_device_matches_the_torch_formulation():
               removal_opacity_threshold=0.3, final_removal_opacity_threshold=0.3, reset_opacities=False, reset_opacities_every=3000)
     torch.manual_seed(17)
     mirror, mv = slam.densify(mirror, mv, opt, 1, dd)
+    variables['means2D_gradient_accum'].copy_(hist)             # FusedEngine.densify accumulates this iteration's gradient itself
+    variables['denom'].copy_(den)
     torch.manual_seed(17)
     assert eng.densify(1, dd, scene_radius)
     torch.cuda.synchronize()
