@@ -102,6 +102,10 @@ typedef struct SplatState {
     uint64_t *keys_alt;          /* [capacity] ping-pong partner of `keys` for the merge passes */
     uint32_t *long_base;         /* [T+1] first work item of every tile with a long list */
     int32_t max_list_hint;       /* longest tile list if the host knows it (status[2] of an earlier read), 0 = unknown */
+    int32_t order_hint;          /* fused iteration, bucketed lists: non-zero = the map is (mostly) in creation order (neighbouring rows
+                                    are neighbouring pixels: SplaTAM appends one Gaussian per pixel in scan order), so a workgroup's
+                                    instances fall on a few tiles and the bucket slots are taken per (workgroup, tile) through LDS;
+                                    0 = unknown / random order: one returning atomic per instance.  Results do not depend on it */
     int32_t tile_stride;         /* 0: compact lists, tile t = [tile_base[t], tile_base[t+1]) (the exact path);
                                     > 0: BUCKETED lists (fused iteration only): tile t = [t*stride, t*stride + min(count, stride)),
                                     filled by the per-Gaussian kernel itself -- no scan, no scatter pass; a tile that

@@ -56,68 +56,126 @@ __device__ __forceinline__ void load_gaussian(const SplatMap &m, int i, float *p
 // ---------------------------------------------------------------------------------------------------------
 // F1: per Gaussian: pose transform, activations, projection (K1), tile counts, feature record
 // ---------------------------------------------------------------------------------------------------------
+// Bucket slots of a workgroup's (Gaussian, tile) instances.  AGG (maps in creation order, SplatState.order_hint): the 256
+// consecutive Gaussians of a workgroup lie along one image row and touch a few dozen tiles, ~13 lanes per tile counter; their
+// returning global atomics serialise on those few addresses (116 us for 830 k Gaussians in the frame loop).  The workgroup
+// counts per tile in an LDS table (open addressing on the tile id) and takes ONE returning global atomic per (workgroup, tile)
+// for the whole group; a lane's slot is the group's base + its LDS rank.  Instances that do not find a table slot (or a
+// Gaussian's tiles beyond the eighth) fall back to their own global atomic.
+constexpr int kAggSlots = 128;
+constexpr int kAggPerLane = 8;
+
+template <bool AGG>
 __global__ __launch_bounds__(kBlock) void fused_preprocess_kernel(FusedArgs a) {
+    __shared__ unsigned s_key[AGG ? kAggSlots : 1], s_cnt[AGG ? kAggSlots : 1], s_base[AGG ? kAggSlots : 1];
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= a.map.P) return;
+    const bool active = i < a.map.P;
+    if constexpr (!AGG)
+        if (!active) return;
+    if constexpr (AGG) {
+        if (threadIdx.x < kAggSlots) { s_key[threadIdx.x] = 0xFFFFFFFFu; s_cnt[threadIdx.x] = 0u; }
+        __syncthreads();
+    }
     if (i == 0 && a.ws.st.tile_stride > 0) {
         // bucketed lists have no scan kernel: the per-iteration status words are reset here and re-accumulated by the
         // kernel that consumes the tile counters (fused_backward_kernel); [1] (overflow) stays sticky for the host
         a.ws.st.status[0] = 0; a.ws.st.status[2] = 0; a.ws.st.status[3] = 0;
     }
+    SplatState &st = a.ws.st;
+    Projected o{};
+    bool vis = false;
     CamConst c;
     load_cam(c, a.cam);
-    Pose P;
-    load_pose(a.map, a.frame.time_idx, P);
-    float p[3], u[4], logit, ls[3];
-    load_gaussian(a.map, i, p, u, logit, ls);
-    Glue G;
-    glue_forward(P, a.frame.w2c + 8, p, u, logit, ls, a.map.isotropic != 0, G);
-    float S6[6];
-    cov3d_from_scale_rot(G.s, c.scale_modifier, G.rq, S6);
-    Projected o;
-    const bool vis = project_gaussian(c, G.Xc, S6, o);
-    SplatState &st = a.ws.st;
-    st.depth[i] = o.depth;
-    reinterpret_cast<float2 *>(st.xy)[i] = make_float2(o.px, o.py);
-    reinterpret_cast<float4 *>(st.conic_opacity)[i] = make_float4(o.conic[0], o.conic[1], o.conic[2], G.op);
-    reinterpret_cast<uint2 *>(st.rect)[i] = make_uint2((unsigned)o.x0 | ((unsigned)o.y0 << 16), (unsigned)o.x1 | ((unsigned)o.y1 << 16));
-    st.radii[i] = o.radius;
-    float4 *f = reinterpret_cast<float4 *>(a.ws.feat8) + 2 * (size_t)i;
-    f[0] = make_float4(a.map.rgb_colors[3 * i], a.map.rgb_colors[3 * i + 1], a.map.rgb_colors[3 * i + 2], G.z);
-    f[1] = make_float4(1.0f, G.z * G.z, 0.f, 0.f);
-    if (vis) {
-        if (a.ws.max_2D_radius) a.ws.max_2D_radius[i] = fmaxf(a.ws.max_2D_radius[i], (float)o.radius);
-        if (st.tile_stride == 0) {
-            // exact path: count now, scan + scatter later
+    if (active) {
+        Pose P;
+        load_pose(a.map, a.frame.time_idx, P);
+        float p[3], u[4], logit, ls[3];
+        load_gaussian(a.map, i, p, u, logit, ls);
+        Glue G;
+        glue_forward(P, a.frame.w2c + 8, p, u, logit, ls, a.map.isotropic != 0, G);
+        float S6[6];
+        cov3d_from_scale_rot(G.s, c.scale_modifier, G.rq, S6);
+        vis = project_gaussian(c, G.Xc, S6, o);
+        st.depth[i] = o.depth;
+        reinterpret_cast<float2 *>(st.xy)[i] = make_float2(o.px, o.py);
+        reinterpret_cast<float4 *>(st.conic_opacity)[i] = make_float4(o.conic[0], o.conic[1], o.conic[2], G.op);
+        reinterpret_cast<uint2 *>(st.rect)[i] = make_uint2((unsigned)o.x0 | ((unsigned)o.y0 << 16), (unsigned)o.x1 | ((unsigned)o.y1 << 16));
+        st.radii[i] = o.radius;
+        float4 *f = reinterpret_cast<float4 *>(a.ws.feat8) + 2 * (size_t)i;
+        f[0] = make_float4(a.map.rgb_colors[3 * i], a.map.rgb_colors[3 * i + 1], a.map.rgb_colors[3 * i + 2], G.z);
+        f[1] = make_float4(1.0f, G.z * G.z, 0.f, 0.f);
+        if (vis && a.ws.max_2D_radius) a.ws.max_2D_radius[i] = fmaxf(a.ws.max_2D_radius[i], (float)o.radius);
+    }
+    if (st.tile_stride == 0) {
+        // exact path: count now, scan + scatter later
+        if (vis)
             for (int y = o.y0; y < o.y1; ++y)
                 for (int x = o.x0; x < o.x1; ++x) atomicAdd(&st.tile_count[(size_t)(y * c.gx + x) * SPLAT_COUNTER_STRIDE], 1u);
-        } else {
-            // bucketed path: the returning atomic IS the slot; up to four in flight per lane
-            const unsigned stride = (unsigned)st.tile_stride;
-            const uint64_t key = ((uint64_t)__float_as_uint(o.depth) << 32) | (uint32_t)i;
-            const int w = o.x1 - o.x0, nt = w * (o.y1 - o.y0);
-            bool spilled = false;
-            for (int t0 = 0; t0 < nt; t0 += 4) {
-                unsigned slot[4], tix[4];
-#pragma unroll
-                for (int uu = 0; uu < 4; ++uu) {
-                    const int t = t0 + uu;
-                    if (t < nt) {
-                        const int yy = t / w, xx = t - yy * w;
-                        tix[uu] = (unsigned)((o.y0 + yy) * c.gx + o.x0 + xx);
-                        slot[uu] = atomicAdd(&st.tile_count[(size_t)tix[uu] * SPLAT_COUNTER_STRIDE], 1u);
-                    }
-                }
-#pragma unroll
-                for (int uu = 0; uu < 4; ++uu)
-                    if (t0 + uu < nt) {
-                        if (slot[uu] < stride) st.keys[(size_t)tix[uu] * stride + slot[uu]] = key;
-                        else spilled = true;
-                    }
-            }
-            if (spilled) st.status[1] = 1;
-        }
+        return;                                              // (uniform over the launch)
     }
+    // bucketed path: the returning atomic IS the slot
+    const unsigned stride = (unsigned)st.tile_stride;
+    const uint64_t key = ((uint64_t)__float_as_uint(o.depth) << 32) | (uint32_t)i;
+    const int w = o.x1 - o.x0, nt = vis ? w * (o.y1 - o.y0) : 0;
+    bool spilled = false;
+    int t_direct = 0;                                       // tiles [t_direct, nt) take their own global atomic
+    if constexpr (AGG) {
+        unsigned where[kAggPerLane];                        // slot << 24 | rank; 0xFFFFFFFF: own global atomic
+        const int na = min(nt, kAggPerLane);
+#pragma unroll
+        for (int t = 0; t < kAggPerLane; ++t) {
+            where[t] = 0xFFFFFFFFu;
+            if (t < na) {
+                const int yy = t / w, xx = t - yy * w;
+                const unsigned tix = (unsigned)((o.y0 + yy) * c.gx + o.x0 + xx);
+                unsigned h = (tix * 2654435761u) >> 25;
+                for (int probe = 0; probe < 4; ++probe) {
+                    const unsigned old = atomicCAS(&s_key[h], 0xFFFFFFFFu, tix);
+                    if (old == 0xFFFFFFFFu || old == tix) {
+                        where[t] = (h << 24) | atomicAdd(&s_cnt[h], 1u);
+                        break;
+                    }
+                    h = (h + 1) & (kAggSlots - 1);
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < kAggSlots && s_key[threadIdx.x] != 0xFFFFFFFFu)
+            s_base[threadIdx.x] = atomicAdd(&st.tile_count[(size_t)s_key[threadIdx.x] * SPLAT_COUNTER_STRIDE], s_cnt[threadIdx.x]);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < kAggPerLane; ++t)
+            if (t < na) {
+                const int yy = t / w, xx = t - yy * w;
+                const unsigned tix = (unsigned)((o.y0 + yy) * c.gx + o.x0 + xx);
+                unsigned slot;
+                if (where[t] != 0xFFFFFFFFu) slot = s_base[where[t] >> 24] + (where[t] & 0xFFFFFFu);
+                else slot = atomicAdd(&st.tile_count[(size_t)tix * SPLAT_COUNTER_STRIDE], 1u);
+                if (slot < stride) st.keys[(size_t)tix * stride + slot] = key;
+                else spilled = true;
+            }
+        t_direct = na;
+    }
+    // up to four returning atomics in flight per lane
+    for (int t0 = t_direct; t0 < nt; t0 += 4) {
+        unsigned slot[4], tix[4];
+#pragma unroll
+        for (int uu = 0; uu < 4; ++uu) {
+            const int t = t0 + uu;
+            if (t < nt) {
+                const int yy = t / w, xx = t - yy * w;
+                tix[uu] = (unsigned)((o.y0 + yy) * c.gx + o.x0 + xx);
+                slot[uu] = atomicAdd(&st.tile_count[(size_t)tix[uu] * SPLAT_COUNTER_STRIDE], 1u);
+            }
+        }
+#pragma unroll
+        for (int uu = 0; uu < 4; ++uu)
+            if (t0 + uu < nt) {
+                if (slot[uu] < stride) st.keys[(size_t)tix[uu] * stride + slot[uu]] = key;
+                else spilled = true;
+            }
+    }
+    if (spilled) st.status[1] = 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -631,7 +689,10 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
     // (pose_finish / tile_scan / fused_backward); the caller zero-initialises the workspace once
     hipError_t e = hipSuccess;
     const int gblocks = (P + kBlock - 1) / kBlock;
-    if (P > 0) hipLaunchKernelGGL(fused_preprocess_kernel, dim3(gblocks), dim3(kBlock), 0, s, a);
+    if (P > 0) {
+        if (ws.st.order_hint && ws.st.tile_stride > 0) hipLaunchKernelGGL(fused_preprocess_kernel<true>, dim3(gblocks), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL(fused_preprocess_kernel<false>, dim3(gblocks), dim3(kBlock), 0, s, a);
+    }
     if (ws.st.tile_stride == 0) {
         e = launch_tile_scan(ws.st, T, s);
         if (e != hipSuccess) return e;
@@ -693,7 +754,10 @@ hipError_t launch_iter_render(const SplatCamera &cam, const SplatMap &map, const
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
     const int P = map.P;
     hipError_t e = hipSuccess;
-    if (P > 0) hipLaunchKernelGGL(fused_preprocess_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    if (P > 0) {
+        if (ws.st.order_hint && ws.st.tile_stride > 0) hipLaunchKernelGGL(fused_preprocess_kernel<true>, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL(fused_preprocess_kernel<false>, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    }
     if (ws.st.tile_stride == 0) {
         e = launch_tile_scan(ws.st, T, s);
         if (e != hipSuccess) return e;

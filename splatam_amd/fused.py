@@ -102,6 +102,9 @@ class FusedEngine:
         self.tile_stride = 0            # > 0: bucketed lists (no scan / scatter pass), learnt by check_overflow()
         self.num_tiles = T
         self.allow_buckets = True
+        # rows in creation (pixel-scan) order: true for a map this engine grew itself (add_valid_depth_points / add_new_gaussians
+        # append per pixel in scan order); callers that hand over such a map may set it.  Only a speed hint (SplatState.order_hint)
+        self.creation_order = bool(self.managed and P == 0)
         self._alloc_lists(self.capacity)
         self._cam = self._make_cam(cam)
         self._cam_ok = {}
@@ -504,6 +507,7 @@ class FusedEngine:
         st.keys_alt, st.long_base = b['keys_alt'].data_ptr(), b['long_base'].data_ptr()
         st.max_list_hint = self.max_list_hint
         st.tile_stride = self.tile_stride
+        st.order_hint = int(self.creation_order)
         st.final_T, st.n_contrib, st.status = b['final_T'].data_ptr(), b['n_contrib'].data_ptr(), b['status'].data_ptr()
         ws.feat8, ws.out6, ws.dL_dout6, ws.accum = b['feat8'].data_ptr(), b['out6'].data_ptr(), b['dL_dout6'].data_ptr(), b['accum'].data_ptr()
         ws.ssim_maps = b['ssim_maps'].data_ptr() if with_ssim else None

@@ -446,3 +446,35 @@ def test_mapping_batch_equals_gradient_accumulation():
         assert step > 0
         for got, name in ((p_one[k].detach(), "one process"), (p_a[k].detach(), "two ranks")):
             assert float((got - ref).abs().max()) <= 2e-3 * step, (k, name, float((got - ref).abs().max()), step)
+
+
+@pytest.mark.parametrize("order", ["random", "scan"])
+def test_order_hint_changes_nothing_but_speed(order):
+    """SplatState.order_hint (bucket slots taken per (workgroup, tile) through an LDS table instead of one returning atomic per
+    instance): same lists after the in-kernel sort, hence bit-identical renders, for a map in random order (most instances
+    fall back to their own atomic) and for one in pixel-scan order (the case it is for)."""
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    params, variables, frame, cam = _scene(30000, 320, 240, seed=31)
+    if order == "scan":
+        with torch.no_grad():
+            z = params['means3D'][:, 2]
+            key = torch.round(params['means3D'][:, 1] / z * 160.0 + 120.0) * 4096 + params['means3D'][:, 0] / z * 160.0
+            perm = torch.argsort(key)
+            for k in ('means3D', 'rgb_colors', 'unnorm_rotations', 'logit_opacities', 'log_scales'):
+                params[k] = torch.nn.Parameter(params[k].detach()[perm].contiguous())
+    cfg = slam.REPLICA_MAPPING
+    outs = []
+    for hint in (False, True):
+        eng = FusedEngine({k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}, cam)
+        eng.creation_order = hint
+        eng.loss_backward(frame, 1, cfg, tracking=False)
+        assert not eng.check_overflow() and eng.tile_stride > 0           # learns the buckets
+        eng.loss_backward(frame, 1, cfg, tracking=False)                  # bucketed lists: the hinted path
+        torch.cuda.synchronize()
+        assert not eng.check_overflow(grow=False)
+        outs.append((eng.buf['out6'].clone(), eng.grads['means3D'].clone(), eng.loss()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert abs(outs[0][2] - outs[1][2]) <= 1e-6 * abs(outs[0][2])
+    g0, g1 = outs
+    assert float((g0[1] - g1[1]).abs().max()) <= 1e-5 * float(g0[1].abs().max())
