@@ -309,6 +309,7 @@ __global__ __launch_bounds__(256) void render_forward_kernel(SplatCamera cam, co
                 gather<C, CS, WITH_DEPTH, FP>(pre, st, colors, lo + e, e < n, tile_x0, tile_y0, lk, e);
             }
             const unsigned base1 = (unsigned)(bi * kBatch + 1);
+            unsigned long long bits = 0;        // set bits of the current mask word still to visit (cleared when the wave is done)
             // one visit of this quadrant: `cur` was fetched from LDS during the previous visit (see Rec)
             auto visit = [&](int e, const Rec<FP> &cur) {
                 const float dx = cur.m.x - fpx, dy = cur.m.y - fpy;
@@ -329,8 +330,10 @@ __global__ __launch_bounds__(256) void render_forward_kernel(SplatCamera cam, co
                 }
                 Tr = upd ? test_T : Tr;
                 last = upd ? base1 + (unsigned)e : last;
-                done_m |= stop_m;
-                if (done_m == ~0ull) wdone = true;
+                if (stop_m != 0) {                  // (rare: a pixel saturates)
+                    done_m |= stop_m;
+                    if (done_m == ~0ull) bits = 0;  // every pixel of the quadrant is done: nothing left to visit
+                }
             };
             auto load_rec = [&](int e, Rec<FP> &r) {
                 const float4 *p = B.rec + e * Batch<FP>::R4;
@@ -342,28 +345,28 @@ __global__ __launch_bounds__(256) void render_forward_kernel(SplatCamera cam, co
             // front to back over the set bits of this quadrant's mask; the NEXT record is in flight while the current one is
             // composited (two register sets, ping-pong): the LDS round trip per visit is off the wave's critical path
 #pragma unroll 1
-            for (int w = 0; w < 4 && !wdone; ++w) {
-                unsigned long long bits = mask_word(B, wave, w);
+            for (int w = 0; w < 4 && done_m != ~0ull; ++w) {
+                bits = mask_word(B, wave, w);
                 if (bits == 0) continue;
                 Rec<FP> ra, rb;
                 int ja = __builtin_ctzll(bits);
                 bits &= bits - 1;
                 load_rec(w * 64 + ja, ra);
                 while (true) {
-                    const bool more_b = bits != 0;
-                    const int jb = more_b ? __builtin_ctzll(bits) : 0;
-                    bits &= bits - 1;
-                    load_rec(w * 64 + jb, rb);                  // unconditional: entry 0 of the word is a valid record
+                    // the next set bit, or bit 63 of an exhausted word: always a valid record of the batch, fetched unconditionally
+                    const int jb = __builtin_ctzll(bits | (1ull << 63));
+                    load_rec(w * 64 + jb, rb);
                     visit(w * 64 + ja, ra);
-                    if (wdone || !more_b) break;
-                    const bool more_a = bits != 0;
-                    ja = more_a ? __builtin_ctzll(bits) : 0;
+                    if (bits == 0) break;
                     bits &= bits - 1;
+                    ja = __builtin_ctzll(bits | (1ull << 63));
                     load_rec(w * 64 + ja, ra);
                     visit(w * 64 + jb, rb);
-                    if (wdone || !more_a) break;
+                    if (bits == 0) break;
+                    bits &= bits - 1;
                 }
             }
+            wdone = done_m == ~0ull;
         }
     }
     float acc_depth = 0.f, acc_im = 0.f;
@@ -906,18 +909,17 @@ __global__ __launch_bounds__(256) void render_backward_kernel5(SplatCamera cam, 
             bits &= ~(1ull << ja);
             load_rec(w * 64 + ja, ra);
             while (true) {
-                const bool more_b = bits != 0;
-                const int jb = more_b ? 63 - __builtin_clzll(bits) : 0;
-                bits &= ~(1ull << jb);                          // (bit 0 of an empty word: no effect)
-                load_rec(w * 64 + jb, rb);                      // unconditional: entry 0 of the word is always a valid record
+                // the next set bit from the top, or bit 0 of an exhausted word: always a valid record, fetched unconditionally
+                const int jb = 63 - __builtin_clzll(bits | 1ull);
+                load_rec(w * 64 + jb, rb);
                 visit(w * 64 + ja, ra);
-                if (!more_b) break;
-                const bool more_a = bits != 0;
-                ja = more_a ? 63 - __builtin_clzll(bits) : 0;
-                bits &= ~(1ull << ja);
+                if (bits == 0) break;
+                bits &= ~(1ull << jb);
+                ja = 63 - __builtin_clzll(bits | 1ull);
                 load_rec(w * 64 + ja, ra);
                 visit(w * 64 + jb, rb);
-                if (!more_a) break;
+                if (bits == 0) break;
+                bits &= ~(1ull << ja);
             }
         }
         // the records of the waiting visits live in this batch: publish them before it is replaced
