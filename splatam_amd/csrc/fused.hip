@@ -294,9 +294,12 @@ __global__ __launch_bounds__(kBlock) void track_loss_kernel(FusedArgs a, int HW)
 // F4 / F5: SSIM (11x11, sigma 1.5, zero padding; /root/reference/utils/slam_external.py:54-97)
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kSsimR = 5;                   // window radius
-constexpr int kTW = 32, kTH = 16;           // output tile of one 256-thread workgroup (2 pixels per thread)
+constexpr int kTW = 32, kTH = 16;           // output tile of one 256-thread workgroup
+constexpr int kRPT = kTH * kTW / kBlock;    // output rows per thread in the vertical passes
 constexpr int kHW_ = kTW + 2 * kSsimR;      // halo width 42
-constexpr int kHH_ = kTH + 2 * kSsimR;      // halo height 26
+constexpr int kHH_ = kTH + 2 * kSsimR;      // halo height 42
+constexpr int kHItems = kHH_ * (kTW / 4);   // horizontal-pass work items: (halo row, group of 4 columns)
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 // exp(-(x-5)^2 / (2 * 1.5^2)) normalised in float32, as create_window builds it (/root/reference/utils/slam_external.py:54-56)
 void ssim_window_host(float *g) {
@@ -305,10 +308,28 @@ void ssim_window_host(float *g) {
     for (int k = 0; k < 11; ++k) g[k] /= s;
 }
 
-// F4: grid (tiles_x, tiles_y, 3 channels).  Also accumulates the L1 image sum; the z == 0 slice handles the depth plane.
+// ssim_pixel (fused_math.h) with hardware reciprocals (1 ulp) instead of four IEEE divisions
+__device__ __forceinline__ float ssim_pixel_dev(float mu1, float mu2, float e11, float e22, float e12, float *dmu1, float *de11, float *de12) {
+    const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+    const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+    const float A = 2.f * mu12 + kSsimC1, B = 2.f * s12 + kSsimC2;
+    const float Cd = mu1_sq + mu2_sq + kSsimC1, Dd = s1 + s2 + kSsimC2;
+    const float iC = __builtin_amdgcn_rcpf(Cd), iD = __builtin_amdgcn_rcpf(Dd);
+    const float iCD = iC * iD;
+    const float map = A * B * iCD;
+    *dmu1 = (2.f * mu2) * (B - A) * iCD + map * (2.f * mu1) * (iD - iC);
+    *de11 = -map * iD;
+    *de12 = 2.f * A * iCD;
+    return map;
+}
+
+// F4: grid (tiles_x, tiles_y, 3 channels).  The five window statistics travel as two float pairs + one float, so that the
+// 11-tap sums are v_pk_fma_f32 (two statistics per instruction).  Also accumulates the L1 image sum; the z == 0 slice handles
+// the depth plane.
 __global__ __launch_bounds__(kBlock) void ssim_forward_kernel(FusedArgs a, int W, int H) {
     __shared__ float sx[kHH_][kHW_ + 1], sy[kHH_][kHW_ + 1];
-    __shared__ float sh[5][kHH_][kTW + 1];
+    __shared__ f2 shA[kHH_][kTW + 1], shB[kHH_][kTW + 1];      // horizontal sums of (x, y) and (x x, y y)
+    __shared__ float shC[kHH_][kTW + 1];                       // ... of x y
     __shared__ double s_part[4 * (kBlock / 64)];
     float g[11];
 #pragma unroll
@@ -325,59 +346,65 @@ __global__ __launch_bounds__(kBlock) void ssim_forward_kernel(FusedArgs a, int W
         sy[r][c] = in ? Y[(size_t)yy * W + xx] : 0.f;
     }
     __syncthreads();
-    // horizontal pass: one thread per (halo row, group of 4 columns): 14 + 14 LDS reads feed 4 outputs x 5 statistics
-    if (tid < kHH_ * (kTW / 4)) {
-        const int r = tid / (kTW / 4), c0 = (tid - r * (kTW / 4)) * 4;
-        float xv[14], yv[14];
+    // horizontal pass: one work item per (halo row, group of 4 columns): 14 + 14 LDS reads feed 4 outputs x 5 statistics
+    for (int item = tid; item < kHItems; item += kBlock) {
+        const int r = item / (kTW / 4), c0 = (item - r * (kTW / 4)) * 4;
+        f2 oA[4], oB[4];
+        float oC[4];
 #pragma unroll
-        for (int t = 0; t < 14; ++t) { xv[t] = sx[r][c0 + t]; yv[t] = sy[r][c0 + t]; }
-        float o[5][4];
-#pragma unroll
-        for (int q = 0; q < 5; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[q][j] = 0.f;
+        for (int j = 0; j < 4; ++j) { oA[j] = (f2)(0.f); oB[j] = (f2)(0.f); oC[j] = 0.f; }
 #pragma unroll
         for (int t = 0; t < 14; ++t) {
-            const float xx = xv[t] * xv[t], yy = yv[t] * yv[t], xy = xv[t] * yv[t];
+            const f2 p = {sx[r][c0 + t], sy[r][c0 + t]};
+            const f2 q = p * p;
+            const float xy = p.x * p.y;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int tap = t - j;
                 if (tap >= 0 && tap < 11) {
-                    const float w = g[tap];
-                    o[0][j] += w * xv[t]; o[1][j] += w * yv[t]; o[2][j] += w * xx; o[3][j] += w * yy; o[4][j] += w * xy;
+                    const f2 w = (f2)(g[tap]);
+                    oA[j] = __builtin_elementwise_fma(w, p, oA[j]);
+                    oB[j] = __builtin_elementwise_fma(w, q, oB[j]);
+                    oC[j] = fmaf(g[tap], xy, oC[j]);
                 }
             }
         }
 #pragma unroll
-        for (int q = 0; q < 5; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sh[q][r][c0 + j] = o[q][j];
+        for (int j = 0; j < 4; ++j) { shA[r][c0 + j] = oA[j]; shB[r][c0 + j] = oB[j]; shC[r][c0 + j] = oC[j]; }
     }
     __syncthreads();
     const float median = a.cfg.ignore_outlier_depth_loss ? a.ws.d_cam[13] : 0.f;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};        // depth L1 (masked), image L1, mask count, SSIM map sum
     float *M = a.ws.ssim_maps + (size_t)(3 * ch) * HW;
-    // vertical pass: one thread per (column, pair of rows): 12 LDS reads per statistic feed 2 outputs
+    // vertical pass: one thread per (column, group of kRPT rows): kRPT + 10 rows of sums feed kRPT outputs
     {
-        const int c = tid & (kTW - 1), r0 = (tid / kTW) * 2;
-        float v[2][5];
+        const int c = tid & (kTW - 1), r0 = (tid / kTW) * kRPT;
+        f2 vA[kRPT], vB[kRPT];
+        float vC[kRPT];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) { v[0][q] = 0.f; v[1][q] = 0.f; }
+        for (int j = 0; j < kRPT; ++j) { vA[j] = (f2)(0.f); vB[j] = (f2)(0.f); vC[j] = 0.f; }
 #pragma unroll
-        for (int t = 0; t < 12; ++t)
+        for (int t = 0; t < kRPT + 10; ++t) {
+            const f2 pa = shA[r0 + t][c], pb = shB[r0 + t][c];
+            const float pc = shC[r0 + t][c];
 #pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const float val = sh[q][r0 + t][c];
-                if (t < 11) v[0][q] += g[t] * val;
-                if (t >= 1) v[1][q] += g[t - 1] * val;
+            for (int j = 0; j < kRPT; ++j) {
+                const int tap = t - j;
+                if (tap >= 0 && tap < 11) {
+                    const f2 w = (f2)(g[tap]);
+                    vA[j] = __builtin_elementwise_fma(w, pa, vA[j]);
+                    vB[j] = __builtin_elementwise_fma(w, pb, vB[j]);
+                    vC[j] = fmaf(g[tap], pc, vC[j]);
+                }
             }
+        }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < kRPT; ++j) {
             const int r = r0 + j;
             const int yy = y0 + r, xx = x0 + c;
             if (yy < H && xx < W) {
                 float dmu1, de11, de12;
-                acc[3] += ssim_pixel(v[j][0], v[j][1], v[j][2], v[j][3], v[j][4], &dmu1, &de11, &de12);
+                acc[3] += ssim_pixel_dev(vA[j].x, vA[j].y, vB[j].x, vB[j].y, vC[j], &dmu1, &de11, &de12);
                 const size_t pix = (size_t)yy * W + xx;
                 M[pix] = dmu1; M[HW + pix] = de11; M[2 * HW + pix] = de12;
                 acc[1] += fabsf(sx[r + kSsimR][c + kSsimR] - sy[r + kSsimR][c + kSsimR]);
@@ -396,8 +423,10 @@ __global__ __launch_bounds__(kBlock) void ssim_forward_kernel(FusedArgs a, int W
 // F5: dL/d(rgb) = w_im * (0.8 sign(x - y) / (3HW) - 0.2 / (3HW) * [blur(dmu1) + 2 x blur(de11) + y blur(de12)]),
 //     depth plane: w_depth * mask * sign(d - gt) / count.
 __global__ __launch_bounds__(kBlock) void map_loss_backward_kernel(FusedArgs a, int W, int H) {
-    __shared__ float sm[3][kHH_][kHW_ + 1];
-    __shared__ float sh[3][kHH_][kTW + 1];
+    __shared__ f2 smA[kHH_][kHW_ + 1];          // (d/dmu1, d/dE11) maps with halo
+    __shared__ float smC[kHH_][kHW_ + 1];       // d/dE12
+    __shared__ f2 shA[kHH_][kTW + 1];
+    __shared__ float shC[kHH_][kTW + 1];
     __shared__ float s_count;
     float g[11];
 #pragma unroll
@@ -415,30 +444,31 @@ __global__ __launch_bounds__(kBlock) void map_loss_backward_kernel(FusedArgs a, 
         const int yy = y0 + r - kSsimR, xx = x0 + c - kSsimR;
         const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
         const size_t pix = (size_t)yy * W + xx;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) sm[q][r][c] = in ? M[q * HW + pix] : 0.f;
+        smA[r][c] = in ? (f2){M[pix], M[HW + pix]} : (f2)(0.f);
+        smC[r][c] = in ? M[2 * HW + pix] : 0.f;
     }
     __syncthreads();
-    if (tid < kHH_ * (kTW / 4)) {            // horizontal pass: (halo row, group of 4 columns) per thread
-        const int r = tid / (kTW / 4), c0 = (tid - r * (kTW / 4)) * 4;
-        float o[3][4];
+    for (int item = tid; item < kHItems; item += kBlock) {       // horizontal pass: (halo row, group of 4 columns)
+        const int r = item / (kTW / 4), c0 = (item - r * (kTW / 4)) * 4;
+        f2 oA[4];
+        float oC[4];
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[q][j] = 0.f;
+        for (int j = 0; j < 4; ++j) { oA[j] = (f2)(0.f); oC[j] = 0.f; }
 #pragma unroll
         for (int t = 0; t < 14; ++t) {
-            const float m0 = sm[0][r][c0 + t], m1 = sm[1][r][c0 + t], m2 = sm[2][r][c0 + t];
+            const f2 p = smA[r][c0 + t];
+            const float q = smC[r][c0 + t];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int tap = t - j;
-                if (tap >= 0 && tap < 11) { o[0][j] += g[tap] * m0; o[1][j] += g[tap] * m1; o[2][j] += g[tap] * m2; }
+                if (tap >= 0 && tap < 11) {
+                    oA[j] = __builtin_elementwise_fma((f2)(g[tap]), p, oA[j]);
+                    oC[j] = fmaf(g[tap], q, oC[j]);
+                }
             }
         }
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sh[q][r][c0 + j] = o[q][j];
+        for (int j = 0; j < 4; ++j) { shA[r][c0 + j] = oA[j]; shC[r][c0 + j] = oC[j]; }
     }
     __syncthreads();
     const float inv_n = 1.0f / (3.0f * (float)HW);
@@ -446,26 +476,32 @@ __global__ __launch_bounds__(kBlock) void map_loss_backward_kernel(FusedArgs a, 
     const float count = s_count;            // written before the first __syncthreads above
     const float *X = a.ws.out6 + ch * HW, *Y = a.frame.im + ch * HW;
     float *Gout = a.ws.dL_dout6;
-    {                                        // vertical pass: (column, pair of rows) per thread
-        const int c = tid & (kTW - 1), r0 = (tid / kTW) * 2;
-        float v[2][3];
+    {                                        // vertical pass: (column, group of kRPT rows) per thread
+        const int c = tid & (kTW - 1), r0 = (tid / kTW) * kRPT;
+        f2 vA[kRPT];
+        float vC[kRPT];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { v[0][q] = 0.f; v[1][q] = 0.f; }
+        for (int j = 0; j < kRPT; ++j) { vA[j] = (f2)(0.f); vC[j] = 0.f; }
 #pragma unroll
-        for (int t = 0; t < 12; ++t)
+        for (int t = 0; t < kRPT + 10; ++t) {
+            const f2 pa = shA[r0 + t][c];
+            const float pc = shC[r0 + t][c];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const float val = sh[q][r0 + t][c];
-                if (t < 11) v[0][q] += g[t] * val;
-                if (t >= 1) v[1][q] += g[t - 1] * val;
+            for (int j = 0; j < kRPT; ++j) {
+                const int tap = t - j;
+                if (tap >= 0 && tap < 11) {
+                    vA[j] = __builtin_elementwise_fma((f2)(g[tap]), pa, vA[j]);
+                    vC[j] = fmaf(g[tap], pc, vC[j]);
+                }
             }
+        }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < kRPT; ++j) {
             const int yy = y0 + r0 + j, xx = x0 + c;
             if (yy < H && xx < W) {
                 const size_t pix = (size_t)yy * W + xx;
                 const float xv = X[pix], yv = Y[pix];
-                const float dssim = v[j][0] + 2.f * xv * v[j][1] + yv * v[j][2];
+                const float dssim = vA[j].x + 2.f * xv * vA[j].y + yv * vC[j];
                 Gout[ch * HW + pix] = a.cfg.w_im * (0.8f * sgn(xv - yv) * inv_n - 0.2f * inv_n * dssim);
                 if (ch == 0) {
                     const float *o = a.ws.out6;
