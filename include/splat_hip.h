@@ -90,9 +90,10 @@ typedef struct SplatState {
     float *rgb;                  /* [P][3]  colours evaluated from SH (NULL unless shs is used) */
     uint8_t *clamped;            /* [P][3]  SH clamp flags (NULL unless shs is used) */
     /* per-tile */
-    uint32_t *tile_count;        /* [T * SPLAT_COUNTER_STRIDE] instances per tile, counter t at t * SPLAT_COUNTER_STRIDE */
+    uint32_t *tile_count;        /* [T * max(sub_bins, 1) * SPLAT_COUNTER_STRIDE] instances per tile, counter t at t * SPLAT_COUNTER_STRIDE */
     uint32_t *tile_base;         /* [T+1]   exclusive prefix sum of tile_count */
-    uint32_t *tile_cursor;       /* [T * SPLAT_COUNTER_STRIDE] scatter cursors, same spacing */
+    uint32_t *tile_cursor;       /* [T * max(sub_bins, 1) * SPLAT_COUNTER_STRIDE] scatter cursors, same spacing (spare words of the
+                                    lines hold the partial records of the tile scan) */
     /* per-instance ((Gaussian, tile) pairs) */
     uint64_t *keys;              /* [capacity] (float bits of depth << 32) | Gaussian id, bucketed by tile */
     uint32_t *point_list;        /* [capacity] Gaussian ids, each tile's slice sorted by key */
@@ -106,6 +107,10 @@ typedef struct SplatState {
                                     are neighbouring pixels: SplaTAM appends one Gaussian per pixel in scan order), so a workgroup's
                                     instances fall on a few tiles and the bucket slots are taken per (workgroup, tile) through LDS;
                                     0 = unknown / random order: one returning atomic per instance.  Results do not depend on it */
+    int32_t sub_bins;            /* exact path: counters per tile (a power of two; 0 / 1 = one).  tile_count / tile_cursor then hold
+                                    T * sub_bins counters ((tile * sub_bins + (Gaussian index & (sub_bins - 1))) * SPLAT_COUNTER_STRIDE):
+                                    spreads the count / scatter atomics of very long lists over several addresses.  The
+                                    lists themselves are unchanged.  Must be 0 / 1 with bucketed lists */
     int32_t tile_stride;         /* 0: compact lists, tile t = [tile_base[t], tile_base[t+1]) (the exact path);
                                     > 0: BUCKETED lists (fused iteration only): tile t = [t*stride, t*stride + min(count, stride)),
                                     filled by the per-Gaussian kernel itself -- no scan, no scatter pass; a tile that

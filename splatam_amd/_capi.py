@@ -41,7 +41,7 @@ class SplatState(C.Structure):
                 ("rgb", _fp), ("clamped", _fp),
                 ("tile_count", _fp), ("tile_base", _fp), ("tile_cursor", _fp),
                 ("keys", _fp), ("point_list", _fp), ("capacity", C.c_int64), ("keys_alt", _fp), ("long_base", _fp),
-                ("max_list_hint", C.c_int32), ("order_hint", C.c_int32), ("tile_stride", C.c_int32),
+                ("max_list_hint", C.c_int32), ("order_hint", C.c_int32), ("sub_bins", C.c_int32), ("tile_stride", C.c_int32),
                 ("final_T", _fp), ("n_contrib", _fp), ("status", _fp)]
 
 

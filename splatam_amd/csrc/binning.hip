@@ -34,7 +34,7 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(SplatGaussians g, Splat
             const int t = t0 + u;
             if (t < nt) {
                 const int yy = t / w, xx = t - yy * w;
-                slot[u] = atomicAdd(&st.tile_cursor[(size_t)((y0 + yy) * gx + x0 + xx) * SPLAT_COUNTER_STRIDE], 1u);
+                slot[u] = atomicAdd(&st.tile_cursor[sub_counter(st, (y0 + yy) * gx + x0 + xx, i)], 1u);
             }
         }
 #pragma unroll

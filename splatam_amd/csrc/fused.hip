@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void fused_preprocess_kernel(FusedArgs a) {
         // exact path: count now, scan + scatter later
         if (vis)
             for (int y = o.y0; y < o.y1; ++y)
-                for (int x = o.x0; x < o.x1; ++x) atomicAdd(&st.tile_count[(size_t)(y * c.gx + x) * SPLAT_COUNTER_STRIDE], 1u);
+                for (int x = o.x0; x < o.x1; ++x) atomicAdd(&st.tile_count[sub_counter(st, y * c.gx + x, i)], 1u);
         return;                                              // (uniform over the launch)
     }
     // bucketed path: the returning atomic IS the slot

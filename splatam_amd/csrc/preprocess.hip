@@ -51,50 +51,107 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(SplatCamera 
     }
     if (vis && !skip_count) {
         for (int y = o.y0; y < o.y1; ++y)
-            for (int x = o.x0; x < o.x1; ++x) atomicAdd(&st.tile_count[(size_t)(y * c.gx + x) * SPLAT_COUNTER_STRIDE], 1u);
+            for (int x = o.x0; x < o.x1; ++x) atomicAdd(&st.tile_count[sub_counter(st, y * c.gx + x, i)], 1u);
     }
 }
 
-// K2: exclusive prefix sum of tile_count (T <= a few 10^4) by one 1024-thread
-// workgroup: serial chunk per thread, wave64 shuffle scan, LDS across waves.
-__global__ __launch_bounds__(1024) void tile_scan_kernel(SplatState st, int T) {
-    __shared__ unsigned wave_tot[16];
-    __shared__ unsigned wave_max[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (T + 1023) / 1024;
-    const int lo = tid * per, hi = min(T, lo + per);
-    unsigned sum = 0, mx = 0;
-    for (int t = lo; t < hi; ++t) { const unsigned v = st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE]; sum += v; mx = max(mx, v); }
-    unsigned incl = sum;
+// K2: exclusive prefix sum of the per-tile instance counts, two launches of ceil(T / 256) workgroups (one thread per tile):
+//   K2a tile_scan_partial_kernel   tile total = sum of its SUB-BIN counters, workgroup-local exclusive scan -> tile_base[t]
+//                                  (workgroup-relative), workgroup total / maximum -> spare words of the cursor lines
+//   K2b tile_scan_finish_kernel    workgroup offset = sum of the totals before it; tile_base[t] and the cursor of every sub-bin
+//                                  made absolute, counters reset (the next call's K1 starts from zero without a memset), status
+// Sub-bins (SplatState.sub_bins = S, a power of two): a tile's count / cursor atomics are spread over S counters, chosen by the
+// low bits of the Gaussian index -- in the clustered stress scene (BASELINE config 5) 26 000 instances per tile hit ONE counter and
+// the count and scatter passes were bound by same-address atomic serialisation (~34 ns each: 0.9 ms per pass at 11 M instances).
+// A tile's list is still one contiguous range [tile_base[t], tile_base[t+1]): its sub-bins are laid end to end.
+constexpr int kScanBlock = 256;
+__device__ __forceinline__ int sub_bins_of(const SplatState &st) { return st.sub_bins > 1 ? st.sub_bins : 1; }
+// spare words of workgroup b's first cursor line hold its total (word 1) and its longest list (word 2)
+__device__ __forceinline__ uint32_t *scan_spare(const SplatState &st, int b, int S) { return st.tile_cursor + (size_t)b * kScanBlock * S * SPLAT_COUNTER_STRIDE; }
+
+__device__ __forceinline__ unsigned block256_exclusive_scan(unsigned v, unsigned *s_tmp, unsigned *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned inc = v;
     for (int d = 1; d < 64; d <<= 1) {
-        const unsigned o = (unsigned)__shfl_up((int)incl, d, 64);
-        if (lane >= d) incl += o;
+        const unsigned o = (unsigned)__shfl_up((int)inc, d, 64);
+        if (lane >= d) inc += o;
     }
-    mx = wave_max_u32(mx);
-    if (lane == 63) wave_tot[wave] = incl;
-    if (lane == 0) wave_max[wave] = mx;
+    if (lane == 63) s_tmp[wave] = inc;
     __syncthreads();
-    unsigned wave_off = 0, total = 0, gmax = 0;
-    for (int w = 0; w < 16; ++w) {
-        if (w < wave) wave_off += wave_tot[w];
-        total += wave_tot[w];
-        gmax = max(gmax, wave_max[w]);
+    unsigned base = 0, tot = 0;
+    for (int w = 0; w < kScanBlock / 64; ++w) {
+        const unsigned c = s_tmp[w];
+        if (w < wave) base += c;
+        tot += c;
     }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(kScanBlock) void tile_scan_partial_kernel(SplatState st, int T) {
+    __shared__ unsigned s_tmp[8];
+    const int S = sub_bins_of(st);
+    const int t = blockIdx.x * kScanBlock + threadIdx.x;
+    unsigned n = 0;
+    if (t < T)
+        for (int k = 0; k < S; ++k) n += st.tile_count[((size_t)t * S + k) * SPLAT_COUNTER_STRIDE];
+    unsigned total;
+    const unsigned ex = block256_exclusive_scan(n, s_tmp, &total);
+    if (t < T) st.tile_base[t] = ex;
+    const unsigned mx = wave_max_u32(n);
+    if ((threadIdx.x & 63) == 0) s_tmp[4 + (threadIdx.x >> 6)] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t *sp = scan_spare(st, blockIdx.x, S);
+        sp[1] = total;
+        sp[2] = max(max(s_tmp[4], s_tmp[5]), max(s_tmp[6], s_tmp[7]));
+    }
+}
+
+__global__ __launch_bounds__(kScanBlock) void tile_scan_finish_kernel(SplatState st, int T) {
+    __shared__ unsigned s_red[3][kScanBlock / 64];
+    const int S = sub_bins_of(st);
+    const int nb = (T + kScanBlock - 1) / kScanBlock;
+    // offset of this workgroup, grand total and longest list: every workgroup reduces the (few dozen) partial records
+    unsigned before = 0, all = 0, mx = 0;
+    for (int b = threadIdx.x; b < nb; b += kScanBlock) {
+        const uint32_t *sp = scan_spare(st, b, S);
+        const unsigned v = sp[1];
+        all += v;
+        if (b < (int)blockIdx.x) before += v;
+        mx = max(mx, sp[2]);
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        before += (unsigned)__shfl_xor((int)before, m, 64);
+        all += (unsigned)__shfl_xor((int)all, m, 64);
+        mx = max(mx, (unsigned)__shfl_xor((int)mx, m, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = before; s_red[1][threadIdx.x >> 6] = all; s_red[2][threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    before = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    all = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+    mx = max(max(s_red[2][0], s_red[2][1]), max(s_red[2][2], s_red[2][3]));
     // lists that do not fit the caller's buffers are published as EMPTY (and flagged in status[1]): a composite
     // launched behind an overflowing binning must never index past keys / point_list
-    const bool overflow = (long long)total > st.capacity;
-    unsigned run = wave_off + incl - sum;
-    for (int t = lo; t < hi; ++t) {
+    const bool overflow = (long long)all > st.capacity;
+    const int t = blockIdx.x * kScanBlock + threadIdx.x;
+    if (t < T) {
+        unsigned run = before + st.tile_base[t];
         st.tile_base[t] = overflow ? 0u : run;
-        st.tile_cursor[(size_t)t * SPLAT_COUNTER_STRIDE] = run;
-        run += st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE];
-        st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE] = 0;     // consumed: the next call's K1 starts from zero without a memset
+        for (int k = 0; k < S; ++k) {
+            const size_t c = ((size_t)t * S + k) * SPLAT_COUNTER_STRIDE;
+            const unsigned n = st.tile_count[c];
+            st.tile_cursor[c] = run;
+            st.tile_count[c] = 0;            // consumed: the next call's K1 starts from zero without a memset
+            run += n;
+        }
     }
-    if (tid == 0) {
-        st.tile_base[T] = overflow ? 0u : total;
-        st.status[0] = (int)total;
-        st.status[1] = (long long)total > st.capacity ? 1 : 0;
-        st.status[2] = (int)gmax;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st.tile_base[T] = overflow ? 0u : all;
+        st.status[0] = (int)all;
+        st.status[1] = overflow ? 1 : 0;
+        st.status[2] = (int)mx;
         st.status[3] = 0;
     }
 }
@@ -198,11 +255,15 @@ __global__ __launch_bounds__(kBlock) void mark_visible_kernel(int P, const float
 }
 
 hipError_t launch_tile_count_reset(SplatState &st, int T, hipStream_t s) {
-    return hipMemsetAsync(st.tile_count, 0, sizeof(uint32_t) * (size_t)T * SPLAT_COUNTER_STRIDE, s);
+    const int S = st.sub_bins > 1 ? st.sub_bins : 1;
+    return hipMemsetAsync(st.tile_count, 0, sizeof(uint32_t) * (size_t)T * S * SPLAT_COUNTER_STRIDE, s);
 }
 
 hipError_t launch_tile_scan(SplatState &st, int T, hipStream_t s) {
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, st, T);
+    if (T <= 0) return hipSuccess;
+    const int nb = (T + kScanBlock - 1) / kScanBlock;
+    hipLaunchKernelGGL(tile_scan_partial_kernel, dim3(nb), dim3(kScanBlock), 0, s, st, T);
+    hipLaunchKernelGGL(tile_scan_finish_kernel, dim3(nb), dim3(kScanBlock), 0, s, st, T);
     return hipGetLastError();
 }
 

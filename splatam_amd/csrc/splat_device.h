@@ -75,6 +75,12 @@ __device__ __forceinline__ void load_cam(CamConst &c, const SplatCamera &cam) {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// counter of (tile, sub-bin of Gaussian i): SplatState.sub_bins counters per tile, one 128-byte line each
+__device__ __forceinline__ size_t sub_counter(const SplatState &st, int tile, int i) {
+    const int S = st.sub_bins > 1 ? st.sub_bins : 1;
+    return ((size_t)tile * S + (size_t)(i & (S - 1))) * SPLAT_COUNTER_STRIDE;
+}
+
 // [lo, lo + n) of tile `tile` in keys / point_list: compact (exact path) or bucketed (SplatState.tile_stride)
 __device__ __forceinline__ void tile_range(const SplatState &st, int tile, unsigned &lo, int &n) {
     if (st.tile_stride > 0) {

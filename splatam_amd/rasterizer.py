@@ -144,6 +144,10 @@ def _build_pack(settings, means3D, colors, opacities, scales, rotations, cov3D, 
     return pk
 
 
+SUB_BINS_LONG = 16       # counters per tile once per-tile lists get very long (SplatState.sub_bins)
+_longest_seen: dict = {}   # (device, P, H, W) -> longest per-tile list of the last call with that shape
+
+
 def _alloc_state(pk: _Pack, dev, P: int, H: int, W: int, use_sh: bool):
     """Per-call scratch (the reference's geomBuffer / imgBuffer): one int32 slab
     for the per-Gaussian + per-tile words, torch's caching allocator makes this a
@@ -151,7 +155,10 @@ def _alloc_state(pk: _Pack, dev, P: int, H: int, W: int, use_sh: bool):
     T = ((W + 15) // 16) * ((H + 15) // 16)
     f32, i32 = torch.float32, torch.int32
     CS = _capi.SPLAT_COUNTER_STRIDE
-    geom = torch.empty(P * 9 + (2 * CS + 2) * T + 2 + 4 + 8, dtype=i32, device=dev)   # depth1 xy2 conic4 rect2 | tiles | long_base | status
+    # very long per-tile lists (clustered scenes): spread each tile's count / scatter atomics over several counters
+    S = SUB_BINS_LONG if _longest_seen.get((dev.index, P, H, W), 0) > 2048 else 1
+    pk.st.sub_bins = S
+    geom = torch.empty(P * 9 + (2 * CS * S + 2) * T + 2 + 4 + 8, dtype=i32, device=dev)   # depth1 xy2 conic4 rect2 | tiles | long_base | status
     o = 0
 
     def take(n, align=4):
@@ -164,7 +171,7 @@ def _alloc_state(pk: _Pack, dev, P: int, H: int, W: int, use_sh: bool):
     xy = take(2 * P, 2)
     rect = take(2 * P, 2)
     depth = take(P, 1)
-    tile_count, tile_base, tile_cursor = take(T * CS, 1), take(T + 1, 1), take(T * CS, 1)
+    tile_count, tile_base, tile_cursor = take(T * CS * S, 1), take(T + 1, 1), take(T * CS * S, 1)
     long_base = take(T + 1, 1)
     status = take(4, 1)
     radii = torch.empty(P, dtype=i32, device=dev)
@@ -253,6 +260,7 @@ def _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotati
             _capi.check(L.splat_preprocess_forward(C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), stream), "splat_preprocess_forward")
             stat = status.tolist()
             num_rendered = int(stat[0])
+            _longest_seen[hint_key] = int(stat[2])
             if _SYNC_MODE == "exact":
                 _alloc_lists(pk, dev, num_rendered, longest=int(stat[2]))
                 pk.st.max_list_hint = int(stat[2])        # lets the library skip the long-list sort kernel

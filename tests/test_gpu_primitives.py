@@ -67,9 +67,14 @@ def test_lists_beyond_lds_multi_workgroup_sort(n):
     cs = Camera(image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=cam.bg.cuda(), scale_modifier=1.0,
                 viewmatrix=cam.viewmatrix.cuda(), projmatrix=cam.projmatrix.cuda(), sh_degree=0, campos=cam.campos.cuda(), prefiltered=False)
     empty = torch.empty(0, device="cuda")
-    col, radii, dep, pk = rz.rasterize_forward(cs, rv['means3D'].cuda(), rv['colors_precomp'].cuda(), rv['opacities'].cuda().reshape(-1),
-                                               rv['scales'].cuda(), rv['rotations'].cuda(), empty, empty)
+    rz._longest_seen.clear()
+    args = (cs, rv['means3D'].cuda(), rv['colors_precomp'].cuda(), rv['opacities'].cuda().reshape(-1), rv['scales'].cuda(), rv['rotations'].cuda(),
+            empty, empty)
+    col1, radii1, dep1, pk1 = rz.rasterize_forward(*args)           # one counter per tile (nothing known about this shape yet)
+    col, radii, dep, pk = rz.rasterize_forward(*args)               # the first call saw very long lists: 16 counters per tile now
     torch.cuda.synchronize()
+    assert pk1.st.sub_bins == 1 and pk.st.sub_bins == rz.SUB_BINS_LONG
+    assert torch.equal(pk1.tensors['point_list'][:pk1.num_rendered], pk.tensors['point_list'][:pk.num_rendered]) and torch.equal(col1, col)
     cr = c_ref.CRef()
     oc, orad, od = cr.forward(rv['means3D'].numpy(), rv['colors_precomp'].numpy(), rv['opacities'].numpy(), rv['scales'].numpy(),
                               rv['rotations'].numpy(), cam.viewmatrix.numpy(), cam.projmatrix.numpy(), cam.tanfovx, cam.tanfovy, W, H,
