@@ -176,60 +176,77 @@ __device__ __forceinline__ bool long_item(const SplatState &st, int T, unsigned 
     return true;
 }
 
+// (the long-list kernels walk the item space with a grid stride: the number of items is only known on the device, long_base[T])
 __global__ __launch_bounds__(kBlock) void long_run_sort_kernel(SplatState st, int T) {
     __shared__ uint64_t s_keys[kRun];
-    int tile, chunk, n;
-    unsigned lo;
-    if (!long_item(st, T, blockIdx.x, tile, chunk, lo, n)) return;
-    if (chunk & 3) return;              // one workgroup per run of 4 items
-    const int tid = threadIdx.x;
-    const int off = (chunk >> 2) * kRun, m = min(kRun, n - off);
-    uint64_t *gk = st.keys + lo + off;
-    for (int i = tid; i < m; i += kBlock) s_keys[i] = gk[i];
-    __syncthreads();
-    bitonic_sort(s_keys, m, tid, kBlock);
-    for (int i = tid; i < m; i += kBlock) gk[i] = s_keys[i];
+    const unsigned total = st.long_base[T];
+    for (unsigned item = blockIdx.x * 4u; item < total; item += gridDim.x * 4u) {      // one workgroup per run of 4 items
+        int tile, chunk, n;
+        unsigned lo;
+        // items of a tile come in groups of 4 only at its start: find the run through the tile of the group's first item
+        if (!long_item(st, T, item, tile, chunk, lo, n)) break;
+        const int tid = threadIdx.x;
+        // the 4 items starting at `item` may straddle two tiles (a tile's item count need not be a multiple of 4): handle
+        // every run that STARTS inside [item, item + 4)
+        for (unsigned it = item; it < item + 4u && it < total; ++it) {
+            if (!long_item(st, T, it, tile, chunk, lo, n)) break;
+            if (chunk & 3) continue;
+            const int off = (chunk >> 2) * kRun, m = min(kRun, n - off);
+            uint64_t *gk = st.keys + lo + off;
+            __syncthreads();
+            for (int i = tid; i < m; i += kBlock) s_keys[i] = gk[i];
+            __syncthreads();
+            bitonic_sort(s_keys, m, tid, kBlock);
+            for (int i = tid; i < m; i += kBlock) gk[i] = s_keys[i];
+        }
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void long_merge_kernel(SplatState st, int T, int pass) {
     const long long L = (long long)kRun << pass;               // run length going into this pass
-    if (L >= (long long)st.status[2]) return;                  // no list of this iteration is that long
-    int tile, chunk, n;
-    unsigned lo;
-    if (!long_item(st, T, blockIdx.x, tile, chunk, lo, n)) return;
-    if ((long long)n <= L) return;                             // this tile was finished by an earlier pass
-    const uint64_t *src = ((pass & 1) ? st.keys_alt : st.keys) + lo;
-    uint64_t *dst = ((pass & 1) ? st.keys : st.keys_alt) + lo;
+    if (st.tile_stride == 0 && L >= (long long)st.status[2]) return;      // (exact lists: the scan knows the longest list of this iteration)
+    const unsigned total = st.long_base[T];
     const int Li = (int)L;
+    for (unsigned item = blockIdx.x; item < total; item += gridDim.x) {
+        int tile, chunk, n;
+        unsigned lo;
+        if (!long_item(st, T, item, tile, chunk, lo, n)) break;
+        if ((long long)n <= L) continue;                           // this tile was finished by an earlier pass
+        const uint64_t *src = ((pass & 1) ? st.keys_alt : st.keys) + lo;
+        uint64_t *dst = ((pass & 1) ? st.keys : st.keys_alt) + lo;
 #pragma unroll
-    for (int k = 0; k < kItemKeys / kBlock; ++k) {
-        const int j = chunk * kItemKeys + k * kBlock + threadIdx.x;
-        if (j >= n) continue;
-        const uint64_t key = src[j];
-        const int a = j / Li, a0 = a * Li, b0 = (a ^ 1) * Li;
-        int pos = j;
-        if (b0 < n) {
-            const uint64_t *B = src + b0;
-            int lo_ = 0, hi_ = min(Li, n - b0);                // number of partner keys smaller than `key`
-            while (lo_ < hi_) {
-                const int mid = (lo_ + hi_) >> 1;
-                if (B[mid] < key) lo_ = mid + 1; else hi_ = mid;
+        for (int k = 0; k < kItemKeys / kBlock; ++k) {
+            const int j = chunk * kItemKeys + k * kBlock + threadIdx.x;
+            if (j >= n) continue;
+            const uint64_t key = src[j];
+            const int a = j / Li, a0 = a * Li, b0 = (a ^ 1) * Li;
+            int pos = j;
+            if (b0 < n) {
+                const uint64_t *B = src + b0;
+                int lo_ = 0, hi_ = min(Li, n - b0);                // number of partner keys smaller than `key`
+                while (lo_ < hi_) {
+                    const int mid = (lo_ + hi_) >> 1;
+                    if (B[mid] < key) lo_ = mid + 1; else hi_ = mid;
+                }
+                pos = min(a0, b0) + (j - a0) + lo_;
             }
-            pos = min(a0, b0) + (j - a0) + lo_;
+            dst[pos] = key;
         }
-        dst[pos] = key;
     }
 }
 
 __global__ __launch_bounds__(kBlock) void long_publish_kernel(SplatState st, int T) {
-    int tile, chunk, n;
-    unsigned lo;
-    if (!long_item(st, T, blockIdx.x, tile, chunk, lo, n)) return;
-    const uint64_t *buf = ((long_passes(n) & 1) ? st.keys_alt : st.keys) + lo;
+    const unsigned total = st.long_base[T];
+    for (unsigned item = blockIdx.x; item < total; item += gridDim.x) {
+        int tile, chunk, n;
+        unsigned lo;
+        if (!long_item(st, T, item, tile, chunk, lo, n)) break;
+        const uint64_t *buf = ((long_passes(n) & 1) ? st.keys_alt : st.keys) + lo;
 #pragma unroll
-    for (int k = 0; k < kItemKeys / kBlock; ++k) {
-        const int j = chunk * kItemKeys + k * kBlock + threadIdx.x;
-        if (j < n) st.point_list[lo + j] = (uint32_t)buf[j];
+        for (int k = 0; k < kItemKeys / kBlock; ++k) {
+            const int j = chunk * kItemKeys + k * kBlock + threadIdx.x;
+            if (j < n) st.point_list[lo + j] = (uint32_t)buf[j];
+        }
     }
 }
 
@@ -245,11 +262,14 @@ hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, S
             hipLaunchKernelGGL(tile_sort_block_kernel, dim3(T), dim3(kBlock), 0, s, st);
             const long long hint = st.max_list_hint > 0 ? (long long)st.max_list_hint + st.max_list_hint / 2 : (long long)1 << 40;
             if (st.keys_alt && st.long_base && hint > kRun && st.capacity > kRun) {
-                const long long bound = st.capacity < hint ? st.capacity : hint;       // no list is longer than this
-                const long long items = st.capacity / kItemKeys + T + 1;               // sum of ceil(n_t / 1024) over the long tiles
-                if (items > 0x7fffffffLL) return hipErrorInvalidValue;
+                // no list is longer than `bound`: the hint, the capacity, or -- bucketed lists -- the bucket
+                long long bound = st.capacity < hint ? st.capacity : hint;
+                if (st.tile_stride > 0 && st.tile_stride < bound) bound = st.tile_stride;
+                // the item count (sum of ceil(n_t / 1024) over the long tiles) lives on the device: fixed grids, grid-stride loops
+                long long items = st.capacity / kItemKeys + T + 1;
+                if (items > 16384) items = 16384;
                 hipLaunchKernelGGL(long_scan_kernel, dim3(1), dim3(1024), 0, s, st, T);
-                hipLaunchKernelGGL(long_run_sort_kernel, dim3((unsigned)items), dim3(kBlock), 0, s, st, T);
+                hipLaunchKernelGGL(long_run_sort_kernel, dim3((unsigned)((items + 3) / 4)), dim3(kBlock), 0, s, st, T);
                 const int passes = long_passes(bound);
                 for (int p = 0; p < passes; ++p)
                     hipLaunchKernelGGL(long_merge_kernel, dim3((unsigned)items), dim3(kBlock), 0, s, st, T, p);

@@ -695,7 +695,9 @@ class FusedEngine:
         self._set_sub_bins(16 if longest > 2048 else 1)
         if grow and self.allow_buckets and longest > 0:
             stride = max(256, (int(longest * 1.5) + 63) // 64 * 64)
-            if stride != self.tile_stride and stride * self.num_tiles <= 64 * 1024 * 1024:
+            # buckets cost 20 bytes per slot (keys, their merge partner, sorted ids): up to ~15 GB of the 288 GB for the clustered
+            # stress scenes (337 M slots at 5 M Gaussians) -- one returning atomic per instance instead of count + scan + scatter
+            if stride != self.tile_stride and stride * self.num_tiles <= 768 * 1024 * 1024:
                 if stride * self.num_tiles > self.capacity:
                     self._alloc_lists(stride * self.num_tiles)
                 self.tile_stride = stride
