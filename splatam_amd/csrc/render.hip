@@ -214,7 +214,74 @@ __device__ __forceinline__ bool lane_of(unsigned long long m) { return __builtin
 // K6 forward composite
 // ---------------------------------------------------------------------------
 constexpr int kFusedSortMax = 1024;     // longest list the composite sorts itself (8 KiB of LDS)
-constexpr int kRankSortMax = 512;       // lists up to this length are rank sorted (into the upper half of those 8 KiB)
+
+// Two-level sort of n <= kFusedSortMax UNIQUE keys by one 256-thread workgroup: A holds the keys (in: any order, A[n] = ~0 when n
+// is odd; out: ascending), S is scratch for n keys (the batch buffer, idle before compositing starts).
+//   level 1: the list is cut into C = 4 (n <= 512) or 8 chunks of <= 128 keys; wave w RANK-sorts chunk w (and w + 4): keys are
+//            unique, so a key's position in its sorted chunk is the number of smaller keys in the chunk, counted against broadcast
+//            ds_read_b128 of the chunk -- no barrier inside;
+//   level 2: a key's final position is the sum over ALL chunks of the number of smaller keys there (its own chunk yields its
+//            local rank): C independent 8-step binary searches per key, interleaved.
+// ~250 instructions per wave at the ~220 entries of workload B (a full rank sort of the list: ~770; the bitonic network: ~36
+// barrier-separated stages), two barriers.
+__device__ __forceinline__ void sort_keys_two_level(uint64_t *A, uint64_t *S, const int n, const int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int C = n <= 512 ? 4 : 8;
+    const int cs = (((n + C - 1) / C) + 1) & ~1;            // chunk size: even (16-byte aligned pair reads), <= 128
+    // ---- level 1
+    for (int c = wave; c < C; c += 4) {
+        const int start = c * cs, len = min(n, start + cs) - start;
+        if (len <= 0) break;
+        const uint64_t k0 = lane < len ? A[start + lane] : ~0ull;
+        const uint64_t k1 = lane + 64 < len ? A[start + lane + 64] : ~0ull;
+        unsigned r0 = 0, r1 = 0;
+        const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(A + start);
+        const int np = (len + 1) >> 1;
+        if (len <= 64) {
+            for (int j = 0; j < np; ++j) {
+                const ulonglong2 ab = pairs[j];
+                r0 += (ab.x < k0 ? 1u : 0u) + (ab.y < k0 ? 1u : 0u);
+            }
+        } else {
+            for (int j = 0; j < np; ++j) {
+                const ulonglong2 ab = pairs[j];
+                r0 += (ab.x < k0 ? 1u : 0u) + (ab.y < k0 ? 1u : 0u);
+                r1 += (ab.x < k1 ? 1u : 0u) + (ab.y < k1 ? 1u : 0u);
+            }
+        }
+        // (a pair read of an odd-length chunk sees one key of the NEXT chunk or the ~0 pad: a key of the next chunk may be
+        //  smaller than an own key, so the partner of the last pair is masked below)
+        if (len & 1) {
+            const uint64_t extra = A[start + len];
+            r0 -= (lane < len && extra < k0) ? 1u : 0u;
+            r1 -= (lane + 64 < len && extra < k1) ? 1u : 0u;
+        }
+        if (lane < len) S[start + r0] = k0;
+        if (lane + 64 < len) S[start + r1] = k1;
+    }
+    __syncthreads();
+    // ---- level 2
+    for (int i = tid; i < n; i += 256) {
+        const uint64_t key = S[i];
+        unsigned pos[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) pos[c] = 0;
+#pragma unroll
+        for (int step = 128; step >= 1; step >>= 1) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int start = c * cs, len = min(n, start + cs) - start;       // <= 0 for chunks beyond the list (and c >= C)
+                const unsigned probe = pos[c] + (unsigned)step;
+                if ((int)probe <= len && S[start + probe - 1] < key) pos[c] = probe;
+            }
+        }
+        unsigned r = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) r += pos[c];
+        A[r] = key;
+    }
+    __syncthreads();
+}
 
 // SORT: the workgroup first sorts its tile's (depth, id) keys in LDS (256-thread bitonic network, a few microseconds
 // next to ~35 us of compositing) and publishes the ids for the backward pass: no separate sort launch, and the
@@ -227,7 +294,7 @@ __global__ __launch_bounds__(256) void render_forward_kernel(SplatCamera cam, co
     constexpr int F = C + (WITH_DEPTH ? 1 : 0);
     constexpr int FP = (F + 3) / 4 * 4;
     __shared__ Batch<FP> B;
-    __shared__ uint64_t s_keys[SORT ? kFusedSortMax : 1];
+    __shared__ __attribute__((aligned(16))) uint64_t s_keys[SORT ? kFusedSortMax + 2 : 2];
     const int tile = block_tile(per_xcd, T);
     if (tile < 0) return;
     const int W = cam.image_width, H = cam.image_height;
@@ -255,38 +322,9 @@ __global__ __launch_bounds__(256) void render_forward_kernel(SplatCamera cam, co
             n = kFusedSortMax;
         }
         for (int i = tid; i < n; i += 256) s_keys[i] = st.keys[lo + i];
-        if (n <= kRankSortMax) {
-            // Short list (the normal case: ~220 entries at workload B): RANK sort.  Keys are unique, so the rank of a key
-            // -- the number of smaller keys -- is its sorted position: every thread counts it for its (at most two) keys
-            // against broadcast reads of the whole list, one barrier instead of the ~36 barrier-separated
-            // compare-exchange stages of the bitonic network.  Sorted keys go to the upper half of s_keys.
-            if (tid == 0 && (n & 1)) s_keys[n] = ~0ull;                  // pad to an even count
-            __syncthreads();
-            const uint64_t k0 = tid < n ? s_keys[tid] : ~0ull;
-            const uint64_t k1 = tid + 256 < n ? s_keys[tid + 256] : ~0ull;
-            unsigned r0 = 0, r1 = 0;
-            const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(s_keys);
-            const int np = (n + 1) >> 1;
-            if (n <= 256) {
-                for (int j = 0; j < np; ++j) {
-                    const ulonglong2 ab = pairs[j];
-                    r0 += (ab.x < k0 ? 1u : 0u) + (ab.y < k0 ? 1u : 0u);
-                }
-            } else {
-                for (int j = 0; j < np; ++j) {
-                    const ulonglong2 ab = pairs[j];
-                    r0 += (ab.x < k0 ? 1u : 0u) + (ab.y < k0 ? 1u : 0u);
-                    r1 += (ab.x < k1 ? 1u : 0u) + (ab.y < k1 ? 1u : 0u);
-                }
-            }
-            if (tid < n) s_keys[kRankSortMax + r0] = k0;
-            if (tid + 256 < n) s_keys[kRankSortMax + r1] = k1;
-            __syncthreads();
-            lk = s_keys + kRankSortMax;
-        } else {
-            __syncthreads();
-            bitonic_sort(s_keys, n, tid, 256);
-        }
+        if (tid == 0 && (n & 1)) s_keys[n] = ~0ull;                  // pad to an even count (pair reads)
+        __syncthreads();
+        sort_keys_two_level(s_keys, reinterpret_cast<uint64_t *>(B.rec), n, tid);
         for (int i = tid; i < n; i += 256) st.point_list[lo + i] = (uint32_t)lk[i];
     }
     const int nb = (n + kBatch - 1) / kBatch;
