@@ -287,7 +287,7 @@ __device__ __forceinline__ void sort_keys_two_level(uint64_t *A, uint64_t *S, co
 // next to ~35 us of compositing) and publishes the ids for the backward pass: no separate sort launch, and the
 // gathers take their ids from LDS instead of a dependent global load.
 template <int C, int CS, bool WITH_DEPTH, bool SORT, bool TRACK = false>
-__global__ __launch_bounds__(256) void render_forward_kernel(SplatCamera cam, const float *colors, SplatState st,
+__global__ __launch_bounds__(256, 6) void render_forward_kernel(SplatCamera cam, const float *colors, SplatState st,
                                                              float *out_color, float *out_depth, int T, int per_xcd,
                                                              TrackLossEpilogue ep = TrackLossEpilogue{}) {
     static_assert(!TRACK || (C == 6 && !WITH_DEPTH), "the tracking-loss epilogue reads the six fused channels");
