@@ -439,8 +439,10 @@ int splat_map_duplicate(SplatMapStore *store, const SplatDensifyArgs *args, void
 /* Developer switches used by scripts/ (never by the product path): key 0 = skip the per-tile
  * count atomics of K1 (timing experiment; results are then invalid); key 1 = generation of the composite kernels
  * (3 = current; 2 = previous, 3-channel calls only, and 4 = rejected experiment exist only in a library built with
- * `make EXPERIMENTS=1`: the product library answers -1 for them); key 2 = list entries per loop trip of the
- * backward composite (2 = current, 1 = previous).  Returns the previous value, -1 for an unknown key / unavailable value. */
+ * `make EXPERIMENTS=1`: the product library answers -1 for them); key 3 = generation of the backward composite
+ * (5 = the product's two-phase kernel; 3 = round 1's per-visit-reduction kernel, EXPERIMENTS builds only); key 2 = list
+ * entries per loop trip of backward generation 3 (EXPERIMENTS builds only).  Returns the previous value, -1 for an
+ * unknown key / unavailable value. */
 int splat_debug_option(int key, int value);
 
 #ifdef __cplusplus

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the backward composite generations (splat_debug_option(3, 3 | 5)): K7 kernel time (mapping form) through
+"""A/B of the backward composite generations (splat_debug_option(3, 3 | 5), library built with EXPERIMENTS=1): K7 kernel time (mapping form) through
 splat_iter_time_kernel + fused iteration rates at a workload.  Developer tool (run through gpurun)."""
 import ctypes as C
 import os
@@ -18,6 +18,8 @@ dev = torch.device("cuda", 0)
 params, variables, frames, shape = bench.build_scene(wl, dev, 3)
 N, W, H = shape
 L = _capi.lib()
+if L.splat_debug_option(3, 3) < 0:
+    sys.exit("generation 3 is not in this library: rebuild with `make -C splatam_amd/csrc EXPERIMENTS=1`")
 ref = None
 for gen in (3, 5, 3, 5):
     L.splat_debug_option(3, gen)

@@ -301,8 +301,20 @@ int splat_debug_option(int key, int value) {
         return value == 3 ? 3 : -1;     // the product library holds generation 3 only
 #endif
     }
-    if (key == 2) { const int old = g_debug_entries_per_trip; g_debug_entries_per_trip = (value == 1 || value == 3) ? value : 2; return old; }
-    if (key == 3) { const int old = g_debug_k7_generation; if (value == 3 || value == 5) g_debug_k7_generation = value; return old; }
+    if (key == 2) {
+#if defined(SPLAT_EXPERIMENTS)
+        const int old = g_debug_entries_per_trip; g_debug_entries_per_trip = (value == 1 || value == 3) ? value : 2; return old;
+#else
+        return -1;
+#endif
+    }
+    if (key == 3) {
+#if defined(SPLAT_EXPERIMENTS)
+        const int old = g_debug_k7_generation; if (value == 3 || value == 5) g_debug_k7_generation = value; return old;
+#else
+        return value == 5 ? 5 : -1;     // the product library holds generation 5 only
+#endif
+    }
     return -1;
 }
 
