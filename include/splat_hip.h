@@ -30,12 +30,13 @@
 extern "C" {
 #endif
 
-#define SPLAT_ABI_VERSION 4        /* 4: densification (splat_iter_means2d_accumulate, splat_map_densify_select / _duplicate);
+#define SPLAT_ABI_VERSION 5        /* 5: SplatState.group_count / group_recs / group_stride (group binning), splat_iter_mapping_step; 4: densification (splat_iter_means2d_accumulate, splat_map_densify_select / _duplicate);
                                       3: SplatState.keys_alt / long_base (multi-workgroup sort of lists beyond LDS); 2: map edits,
                                       splat_iter_render / _tracking_step, outlier scratch in SplatIterWorkspace */
 #define SPLAT_TILE 16            /* tile edge in pixels (one 256-thread workgroup per tile, one wave64 per 8x8 quadrant) */
 #define SPLAT_MAX_CHANNELS 8     /* colour channels per call: 3 for the reference API, up to 8 for fused passes */
 #define SPLAT_GRAD_STRIDE 16     /* floats per Gaussian in the backward accumulator (one 64-byte line) */
+#define SPLAT_GROUP_TILES 2      /* group binning: a group is 2 x 2 tiles (SplatState.group_count) */
 #define SPLAT_COUNTER_STRIDE 32  /* uint32 words between two tile counters: one 128-byte line per counter, so that
                                     the ~200 atomics a tile receives do not serialise with its neighbours' */
 
@@ -102,6 +103,14 @@ typedef struct SplatState {
      * by one workgroup -- correct, but O(n log^2 n) barrier stages) */
     uint64_t *keys_alt;          /* [capacity] ping-pong partner of `keys` for the merge passes */
     uint32_t *long_base;         /* [T+1] first work item of every tile with a long list */
+    /* group binning (fused iteration, bucketed lists short enough for the composite's own sort): the per-Gaussian kernel
+     * files ONE record per touched GROUP of SPLAT_GROUP_TILES x SPLAT_GROUP_TILES tiles (slots taken per (workgroup, group)
+     * through an LDS histogram: ~1 global atomic per Gaussian in random row order, far fewer in creation order, instead of one
+     * per (Gaussian, tile) instance); the forward
+     * composite of a tile filters its group's records by their tile rectangle, sorts, and publishes point_list / tile_count
+     * exactly as the per-tile buckets would have held them.  NULL / group_stride 0: per-tile buckets */
+    uint32_t *group_count;       /* [G * SPLAT_COUNTER_STRIDE] records per group, G = ceil(tiles_x / 2) * ceil(tiles_y / 2); zero between iterations */
+    uint32_t *group_recs;        /* [G * group_stride][4] (Gaussian id, float bits of depth, rect word 0, rect word 1) */
     int32_t max_list_hint;       /* longest tile list if the host knows it (status[2] of an earlier read), 0 = unknown */
     int32_t order_hint;          /* fused iteration, bucketed lists: non-zero = the map is (mostly) in creation order (neighbouring rows
                                     are neighbouring pixels: SplaTAM appends one Gaussian per pixel in scan order), so a workgroup's
@@ -115,6 +124,8 @@ typedef struct SplatState {
                                     > 0: BUCKETED lists (fused iteration only): tile t = [t*stride, t*stride + min(count, stride)),
                                     filled by the per-Gaussian kernel itself -- no scan, no scatter pass; a tile that
                                     receives more than `stride` instances sets status[1] and is truncated */
+    int32_t group_stride;        /* > 0 (with group_count, group_recs, tile_stride > 0 and 0 < max_list_hint <= 819): group binning,
+                                    records per group bucket (>= SPLAT_GROUP_TILES^2 * tile_stride can never overflow first) */
     /* per-pixel */
     float *final_T;              /* [H][W] */
     int32_t *n_contrib;          /* [H][W] 1-based list position of the last contributor */
@@ -308,6 +319,14 @@ typedef struct SplatPoseAdam {
 } SplatPoseAdam;
 int splat_iter_tracking_step(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame,
                              const SplatLossConfig *cfg, SplatIterWorkspace *ws, const SplatPoseAdam *adam, void *stream);
+
+/* One whole single-view mapping iteration (/root/reference/scripts/splatam.py:846-863: get_loss, backward, optimizer.step) in
+ * one call: splat_iter_loss_backward with cfg->tracking clear, with splat_iter_adam_map folded into its last kernel (every
+ * Gaussian's parameters, gradients and moments are touched once).  adam->grad[k] must be the ws->d_* buffer of group k (the
+ * gradients are still written there) or NULL (group not stepped).  Not for the view-sharded batch: there the gradients are
+ * exchanged between splat_iter_loss_backward and splat_iter_adam_map. */
+int splat_iter_mapping_step(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame,
+                            const SplatLossConfig *cfg, SplatIterWorkspace *ws, const SplatAdamMap *adam, void *stream);
 
 /* Kernel-only timing helper for bench.py on the fused path: fn 0 = 6-channel composite forward, 1 = 6-channel composite
  * backward (the kernel alone: the launches accumulate on top of each other and the accumulator is zeroed again AFTER the

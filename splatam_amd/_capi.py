@@ -16,7 +16,8 @@ SPLAT_TILE = 16
 SPLAT_MAX_CHANNELS = 8
 SPLAT_GRAD_STRIDE = 16
 SPLAT_COUNTER_STRIDE = 32
-ABI_VERSION = 4
+SPLAT_GROUP_TILES = 2
+ABI_VERSION = 5
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -41,7 +42,9 @@ class SplatState(C.Structure):
                 ("rgb", _fp), ("clamped", _fp),
                 ("tile_count", _fp), ("tile_base", _fp), ("tile_cursor", _fp),
                 ("keys", _fp), ("point_list", _fp), ("capacity", C.c_int64), ("keys_alt", _fp), ("long_base", _fp),
+                ("group_count", _fp), ("group_recs", _fp),
                 ("max_list_hint", C.c_int32), ("order_hint", C.c_int32), ("sub_bins", C.c_int32), ("tile_stride", C.c_int32),
+                ("group_stride", C.c_int32),
                 ("final_T", _fp), ("n_contrib", _fp), ("status", _fp)]
 
 
@@ -119,7 +122,7 @@ EXPORTS = (
     "splat_render_backward", "splat_preprocess_backward", "splat_backward",
     "splat_mark_visible", "splat_time_kernel", "splat_debug_option",
     "splat_iter_loss_backward", "splat_iter_adam_map", "splat_iter_adam_pose", "splat_iter_time_kernel",
-    "splat_iter_tracking_step", "splat_iter_render", "splat_map_scratch_words", "splat_map_row_floats", "splat_map_add_new_gaussians", "splat_map_prune",
+    "splat_iter_tracking_step", "splat_iter_mapping_step", "splat_iter_render", "splat_map_scratch_words", "splat_map_row_floats", "splat_map_add_new_gaussians", "splat_map_prune",
     "splat_iter_means2d_accumulate", "splat_map_densify_select", "splat_map_duplicate",
 )
 
@@ -174,6 +177,9 @@ def lib():
     L.splat_iter_tracking_step.restype = C.c_int
     L.splat_iter_tracking_step.argtypes = [cam, C.POINTER(SplatMap), C.POINTER(SplatFrameData), C.POINTER(SplatLossConfig),
                                            C.POINTER(SplatIterWorkspace), C.POINTER(SplatPoseAdam), _fp]
+    L.splat_iter_mapping_step.restype = C.c_int
+    L.splat_iter_mapping_step.argtypes = [cam, C.POINTER(SplatMap), C.POINTER(SplatFrameData), C.POINTER(SplatLossConfig),
+                                          C.POINTER(SplatIterWorkspace), C.POINTER(SplatAdamMap), _fp]
     L.splat_iter_render.restype = C.c_int
     L.splat_iter_render.argtypes = [cam, C.POINTER(SplatMap), C.POINTER(SplatFrameData), C.POINTER(SplatIterWorkspace), _fp]
     L.splat_map_scratch_words.restype = C.c_size_t

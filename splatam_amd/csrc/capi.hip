@@ -138,7 +138,8 @@ int splat_time_kernel(int fn, int iters, const SplatCamera *cam, const SplatGaus
 }
 
 static int iter_loss_backward_impl(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame,
-                                   const SplatLossConfig *cfg, SplatIterWorkspace *ws, const SplatPoseAdam *adam, void *stream) {
+                                   const SplatLossConfig *cfg, SplatIterWorkspace *ws, const SplatPoseAdam *adam, void *stream,
+                                   const SplatAdamMap *map_adam = nullptr) {
     if (!cam || !map || !frame || !cfg || !ws) return SPLAT_E_INVALID;
     if (map->P < 0 || cam->image_width <= 0 || cam->image_height <= 0 || !cam->viewmatrix || !cam->projmatrix) return SPLAT_E_INVALID;
     if (map->num_frames <= 0 || frame->time_idx < 0 || frame->time_idx >= map->num_frames) return SPLAT_E_INVALID;
@@ -154,7 +155,7 @@ static int iter_loss_backward_impl(const SplatCamera *cam, const SplatMap *map, 
         return SPLAT_E_INVALID;
     if (!ws->out6 || !ws->dL_dout6 || !ws->sums || !ws->d_cam) return SPLAT_E_INVALID;
     if (!cfg->tracking && !ws->ssim_maps) return SPLAT_E_INVALID;
-    return check(launch_iter_loss_backward(*cam, *map, *frame, *cfg, *ws, (hipStream_t)stream, adam));
+    return check(launch_iter_loss_backward(*cam, *map, *frame, *cfg, *ws, (hipStream_t)stream, adam, map_adam));
 }
 
 int splat_iter_loss_backward(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame,
@@ -166,6 +167,16 @@ int splat_iter_tracking_step(const SplatCamera *cam, const SplatMap *map, const 
                              const SplatLossConfig *cfg, SplatIterWorkspace *ws, const SplatPoseAdam *adam, void *stream) {
     if (!cfg || !cfg->tracking || !cfg->camera_grad || !adam || !adam->state) return SPLAT_E_INVALID;
     return iter_loss_backward_impl(cam, map, frame, cfg, ws, adam, stream);
+}
+
+int splat_iter_mapping_step(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame,
+                            const SplatLossConfig *cfg, SplatIterWorkspace *ws, const SplatAdamMap *adam, void *stream) {
+    if (!cfg || cfg->tracking || !cfg->gaussians_grad || !adam || !ws) return SPLAT_E_INVALID;
+    // a stepped group takes the gradient this iteration forms: adam->grad[k] names the buffer it is ALSO written to
+    const float *const grads[5] = {ws->d_means3D, ws->d_rgb_colors, ws->d_unnorm_rotations, ws->d_logit_opacities, ws->d_log_scales};
+    for (int k = 0; k < 5; ++k)
+        if (adam->grad[k] && (adam->grad[k] != grads[k] || !adam->exp_avg[k] || !adam->exp_avg_sq[k])) return SPLAT_E_INVALID;
+    return iter_loss_backward_impl(cam, map, frame, cfg, ws, nullptr, stream, adam);
 }
 
 int splat_iter_adam_map(const SplatMap *map, const SplatAdamMap *opt, void *stream) {

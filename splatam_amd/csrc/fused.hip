@@ -36,6 +36,9 @@ struct FusedArgs {
 };
 
 __device__ __forceinline__ int c_num_tiles(int W, int H) { return ((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile); }
+__device__ __forceinline__ int c_num_groups(int W, int H) {
+    return (((W + kTile - 1) / kTile + SPLAT_GROUP_TILES - 1) / SPLAT_GROUP_TILES) * (((H + kTile - 1) / kTile + SPLAT_GROUP_TILES - 1) / SPLAT_GROUP_TILES);
+}
 
 __device__ __forceinline__ void load_pose(const SplatMap &m, int time_idx, Pose &P) {
     pose_from_params(m.cam_unnorm_rots + time_idx, m.cam_trans + time_idx, m.num_frames, P);
@@ -65,15 +68,35 @@ __device__ __forceinline__ void load_gaussian(const SplatMap &m, int i, float *p
 constexpr int kAggSlots = 128;
 constexpr int kAggPerLane = 8;
 
-template <bool AGG>
-__global__ __launch_bounds__(kBlock) void fused_preprocess_kernel(FusedArgs a) {
+// MODE 2, group binning (SplatState.group_count): the 512 Gaussians of a workgroup count their records per GROUP of 2 x 2 tiles in
+// an LDS histogram (one counter per group of the frame: dynamic LDS, 4 bytes x groups), the workgroup takes ONE returning global
+// atomic per non-empty group, and a record's slot is the group's base + its LDS rank: ~1.0 global atomics per Gaussian in ANY
+// row order (1.56 records per Gaussian over 836 groups at workload B) instead of 2.36, far fewer for a map in creation order.
+// Measured at B (iterations/s, tracking / mapping): per-tile buckets 3 700 / 2 945; groups with 256-Gaussian workgroups 3 900 / 3 025,
+// 512: 4 120 / 3 165, 1 024: 3 990 / 3 090 (fewer atomics, but one workgroup per CU leaves its phases unoverlapped).
+constexpr int kGroupBlock = 512;
+constexpr int kGroupPerLane = 4;            // groups a lane files through the histogram; a Gaussian's further groups take own atomics
+constexpr int kGT = SPLAT_GROUP_TILES;
+static_assert(kGT == 2, "the group index is tile >> 1");
+
+template <int MODE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fused_preprocess_kernel(FusedArgs a) {
+    constexpr bool AGG = MODE == 1;
+    constexpr bool GROUP = MODE == 2;
     __shared__ unsigned s_key[AGG ? kAggSlots : 1], s_cnt[AGG ? kAggSlots : 1], s_base[AGG ? kAggSlots : 1];
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+    extern __shared__ unsigned s_grp[];         // GROUP: records per group of this workgroup, then the group's base slot
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
     const bool active = i < a.map.P;
-    if constexpr (!AGG)
+    if constexpr (MODE == 0)
         if (!active) return;
     if constexpr (AGG) {
         if (threadIdx.x < kAggSlots) { s_key[threadIdx.x] = 0xFFFFFFFFu; s_cnt[threadIdx.x] = 0u; }
+        __syncthreads();
+    }
+    const int ggx = (((a.cam.image_width + kTile - 1) / kTile) + kGT - 1) / kGT;
+    const int num_groups = ggx * ((((a.cam.image_height + kTile - 1) / kTile) + kGT - 1) / kGT);
+    if constexpr (GROUP) {
+        for (int g = threadIdx.x; g < num_groups; g += BLOCK) s_grp[g] = 0u;
         __syncthreads();
     }
     if (i == 0 && a.ws.st.tile_stride > 0) {
@@ -112,6 +135,44 @@ __global__ __launch_bounds__(kBlock) void fused_preprocess_kernel(FusedArgs a) {
             for (int y = o.y0; y < o.y1; ++y)
                 for (int x = o.x0; x < o.x1; ++x) atomicAdd(&st.tile_count[sub_counter(st, y * c.gx + x, i)], 1u);
         return;                                              // (uniform over the launch)
+    }
+    if constexpr (GROUP) {
+        const unsigned gstride = (unsigned)st.group_stride;
+        const int gx0 = o.x0 >> 1, gy0 = o.y0 >> 1;
+        const int gw = vis ? ((o.x1 - 1) >> 1) - gx0 + 1 : 0, ng = vis ? gw * (((o.y1 - 1) >> 1) - gy0 + 1) : 0;
+        unsigned rank[kGroupPerLane];
+        const int nh = min(ng, kGroupPerLane);
+#pragma unroll
+        for (int t = 0; t < kGroupPerLane; ++t)
+            if (t < nh) {
+                const int yy = t / gw, xx = t - yy * gw;
+                rank[t] = atomicAdd(&s_grp[(gy0 + yy) * ggx + gx0 + xx], 1u);
+            }
+        __syncthreads();
+        for (int g = threadIdx.x; g < num_groups; g += BLOCK) {
+            const unsigned cnt = s_grp[g];
+            if (cnt) s_grp[g] = atomicAdd(&st.group_count[(size_t)g * SPLAT_COUNTER_STRIDE], cnt);
+        }
+        __syncthreads();
+        const uint4 rec = make_uint4((unsigned)i, __float_as_uint(o.depth), (unsigned)o.x0 | ((unsigned)o.y0 << 16), (unsigned)o.x1 | ((unsigned)o.y1 << 16));
+        uint4 *recs = reinterpret_cast<uint4 *>(st.group_recs);
+        bool spilled = false;
+        for (int t = 0; t < ng; ++t) {
+            const int yy = t / gw, xx = t - yy * gw;
+            const unsigned g = (unsigned)((gy0 + yy) * ggx + gx0 + xx);
+            unsigned slot;
+            if (t < kGroupPerLane) {
+                // (compile-time indices only: a dynamically indexed rank[] would live in scratch memory)
+                const unsigned r = t == 0 ? rank[0] : (t == 1 ? rank[1] : (t == 2 ? rank[2] : rank[3]));
+                slot = s_grp[g] + r;
+            } else {
+                slot = atomicAdd(&st.group_count[(size_t)g * SPLAT_COUNTER_STRIDE], 1u);
+            }
+            if (slot < gstride) recs[(size_t)g * gstride + slot] = rec;
+            else spilled = true;
+        }
+        if (spilled) st.status[1] = 1;
+        return;
     }
     // bucketed path: the returning atomic IS the slot
     const unsigned stride = (unsigned)st.tile_stride;
@@ -513,84 +574,6 @@ __global__ __launch_bounds__(kBlock) void map_loss_backward_kernel(FusedArgs a, 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// F6: per Gaussian adjoint: K8+K9, glue adjoint, pose partial sums
-// ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void fused_backward_kernel(FusedArgs a) {
-    __shared__ double s_part[kPoseSums * (kBlock / 64)];
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    float pose[kPoseSums];
-#pragma unroll
-    for (int k = 0; k < kPoseSums; ++k) pose[k] = 0.f;
-    const SplatIterWorkspace &ws = a.ws;
-    const bool iso = a.map.isotropic != 0;
-    if (i < a.map.P) {
-        const bool vis = ws.st.radii[i] > 0;
-        float dp[3] = {0.f, 0.f, 0.f}, du[4] = {0.f, 0.f, 0.f, 0.f}, dlogit = 0.f, dls[3] = {0.f, 0.f, 0.f};
-        float drgb[3] = {0.f, 0.f, 0.f};
-        if (vis) {
-            float acc[SPLAT_GRAD_STRIDE];
-            float4 *a4 = reinterpret_cast<float4 *>(ws.accum + (size_t)i * SPLAT_GRAD_STRIDE);
-#pragma unroll
-            for (int k = 0; k < SPLAT_GRAD_STRIDE / 4; ++k) {
-                const float4 v = a4[k];
-                acc[4 * k] = v.x; acc[4 * k + 1] = v.y; acc[4 * k + 2] = v.z; acc[4 * k + 3] = v.w;
-                a4[k] = make_float4(0.f, 0.f, 0.f, 0.f);      // consumed: the next iteration's K7 accumulates from zero without a memset
-            }
-            CamConst c;
-            load_cam(c, a.cam);
-            Pose P;
-            load_pose(a.map, a.frame.time_idx, P);
-            float p[3], u[4], logit, ls[3];
-            load_gaussian(a.map, i, p, u, logit, ls);
-            Glue G;
-            glue_forward(P, a.frame.w2c + 8, p, u, logit, ls, iso, G);
-            float S6[6];
-            cov3d_from_scale_rot(G.s, c.scale_modifier, G.rq, S6);
-            const float4 co = reinterpret_cast<const float4 *>(ws.st.conic_opacity)[i];
-            const float g_ndc[2] = {-(co.x * acc[0] + co.y * acc[1]) * 0.5f * c.W, -(co.z * acc[1] + co.y * acc[0]) * 0.5f * c.H};
-            const float g_conic[3] = {-0.5f * acc[2], -acc[3], -0.5f * acc[4]};
-            float dXc[3], dS6[6], ds[3], drq[4];
-            project_gaussian_backward(c, G.Xc, S6, g_ndc, g_conic, dXc, dS6);
-            cov3d_backward(G.s, c.scale_modifier, G.rq, dS6, ds, drq);
-            // colour channels: 6..8 rgb, 9 z, 10 silhouette (constant), 11 z^2
-            drgb[0] = acc[6]; drgb[1] = acc[7]; drgb[2] = acc[8];
-            const float dz = acc[9] + 2.f * G.z * acc[11];
-            glue_backward(P, a.frame.w2c + 8, p, iso, G, dXc, dz, acc[5], ds, drq, dp, du, &dlogit, dls, pose);
-        }
-        if (a.cfg.gaussians_grad) {
-            if (ws.d_means3D) { ws.d_means3D[3 * i] = dp[0]; ws.d_means3D[3 * i + 1] = dp[1]; ws.d_means3D[3 * i + 2] = dp[2]; }
-            // isotropic map: Sigma = s^2 I does not depend on the quaternion -- the derivative is exactly zero (what autograd
-            // leaves there is rounding noise); writing the exact zero lets the gradient exchange skip the four rotation floats
-            if (ws.d_unnorm_rotations)
-                reinterpret_cast<float4 *>(ws.d_unnorm_rotations)[i] = iso ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(du[0], du[1], du[2], du[3]);
-        }
-        if (ws.d_rgb_colors) { ws.d_rgb_colors[3 * i] = drgb[0]; ws.d_rgb_colors[3 * i + 1] = drgb[1]; ws.d_rgb_colors[3 * i + 2] = drgb[2]; }
-        if (ws.d_logit_opacities) ws.d_logit_opacities[i] = dlogit;
-        if (ws.d_log_scales) {
-            if (iso) ws.d_log_scales[i] = dls[0];
-            else { ws.d_log_scales[3 * i] = dls[0]; ws.d_log_scales[3 * i + 1] = dls[1]; ws.d_log_scales[3 * i + 2] = dls[2]; }
-        }
-    }
-    if (ws.st.tile_stride > 0) {
-        // bucketed lists: this is the last kernel that needs the tile counters -- fold them into the status words
-        // (num_rendered, longest list) and reset them for the next iteration's per-Gaussian kernel
-        const int T = c_num_tiles(a.cam.image_width, a.cam.image_height);
-        unsigned sum = 0, mx = 0;
-        for (int t = i; t < T; t += gridDim.x * kBlock) {
-            const unsigned cnt = ws.st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE];
-            ws.st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE] = 0;
-            sum += cnt;
-            mx = max(mx, cnt);
-        }
-        if (blockIdx.x * kBlock < T) {              // uniform per block; later blocks hold no tile
-            for (int m = 32; m >= 1; m >>= 1) { sum += (unsigned)__shfl_xor((int)sum, m, 64); mx = max(mx, (unsigned)__shfl_xor((int)mx, m, 64)); }
-            if ((threadIdx.x & 63) == 0 && sum) { atomicAdd((unsigned *)&ws.st.status[0], sum); atomicMax((unsigned *)&ws.st.status[2], mx); }
-        }
-    }
-    if (a.cfg.camera_grad) block_sum_to<kPoseSums>(sum_copy(ws.sums) + 8, pose, s_part);
-}
-
 // Adam step of the camera pose of one frame + the reference's best-candidate bookkeeping
 // (/root/reference/scripts/splatam.py:704-711); state: m_q[0..3] m_t[4..6] v_q[7..10] v_t[11..13] min_loss[14] cand_q[15..18] cand_t[19..21]
 struct PoseAdam {
@@ -670,6 +653,113 @@ __global__ __launch_bounds__(256) void pose_finish_kernel(FusedArgs a, int HW, P
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// F6: per Gaussian adjoint: K8+K9, glue adjoint, pose partial sums
+// ---------------------------------------------------------------------------------------------------------
+// ADAM (single-view mapping step, splat_iter_mapping_step): the Adam step of the five Gaussian groups on the gradients this
+// thread has just formed -- parameters, gradients and moments of a Gaussian are touched once instead of in a second kernel
+// (+1.3 % mapping iterations/s at B).  Folding F7 into the last workgroup to finish (a ticket) was measured too: no gain, the
+// tail is as long as the separate launch.
+template <bool ADAM>
+__global__ __launch_bounds__(kBlock) void fused_backward_kernel(FusedArgs a, SplatAdamMap opt) {
+    __shared__ double s_part[kPoseSums * (kBlock / 64)];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    float pose[kPoseSums];
+#pragma unroll
+    for (int k = 0; k < kPoseSums; ++k) pose[k] = 0.f;
+    const SplatIterWorkspace &ws = a.ws;
+    const bool iso = a.map.isotropic != 0;
+    if (i < a.map.P) {
+        const bool vis = ws.st.radii[i] > 0;
+        float dp[3] = {0.f, 0.f, 0.f}, du[4] = {0.f, 0.f, 0.f, 0.f}, dlogit = 0.f, dls[3] = {0.f, 0.f, 0.f};
+        float drgb[3] = {0.f, 0.f, 0.f};
+        if (vis) {
+            float acc[SPLAT_GRAD_STRIDE];
+            float4 *a4 = reinterpret_cast<float4 *>(ws.accum + (size_t)i * SPLAT_GRAD_STRIDE);
+#pragma unroll
+            for (int k = 0; k < SPLAT_GRAD_STRIDE / 4; ++k) {
+                const float4 v = a4[k];
+                acc[4 * k] = v.x; acc[4 * k + 1] = v.y; acc[4 * k + 2] = v.z; acc[4 * k + 3] = v.w;
+                a4[k] = make_float4(0.f, 0.f, 0.f, 0.f);      // consumed: the next iteration's K7 accumulates from zero without a memset
+            }
+            CamConst c;
+            load_cam(c, a.cam);
+            Pose P;
+            load_pose(a.map, a.frame.time_idx, P);
+            float p[3], u[4], logit, ls[3];
+            load_gaussian(a.map, i, p, u, logit, ls);
+            Glue G;
+            glue_forward(P, a.frame.w2c + 8, p, u, logit, ls, iso, G);
+            float S6[6];
+            cov3d_from_scale_rot(G.s, c.scale_modifier, G.rq, S6);
+            const float4 co = reinterpret_cast<const float4 *>(ws.st.conic_opacity)[i];
+            const float g_ndc[2] = {-(co.x * acc[0] + co.y * acc[1]) * 0.5f * c.W, -(co.z * acc[1] + co.y * acc[0]) * 0.5f * c.H};
+            const float g_conic[3] = {-0.5f * acc[2], -acc[3], -0.5f * acc[4]};
+            float dXc[3], dS6[6], ds[3], drq[4];
+            project_gaussian_backward(c, G.Xc, S6, g_ndc, g_conic, dXc, dS6);
+            cov3d_backward(G.s, c.scale_modifier, G.rq, dS6, ds, drq);
+            // colour channels: 6..8 rgb, 9 z, 10 silhouette (constant), 11 z^2
+            drgb[0] = acc[6]; drgb[1] = acc[7]; drgb[2] = acc[8];
+            const float dz = acc[9] + 2.f * G.z * acc[11];
+            glue_backward(P, a.frame.w2c + 8, p, iso, G, dXc, dz, acc[5], ds, drq, dp, du, &dlogit, dls, pose);
+        }
+        if (a.cfg.gaussians_grad) {
+            if (ws.d_means3D) { ws.d_means3D[3 * i] = dp[0]; ws.d_means3D[3 * i + 1] = dp[1]; ws.d_means3D[3 * i + 2] = dp[2]; }
+            // isotropic map: Sigma = s^2 I does not depend on the quaternion -- the derivative is exactly zero (what autograd
+            // leaves there is rounding noise); writing the exact zero lets the gradient exchange skip the four rotation floats
+            if (ws.d_unnorm_rotations)
+                reinterpret_cast<float4 *>(ws.d_unnorm_rotations)[i] = iso ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(du[0], du[1], du[2], du[3]);
+        }
+        if (ws.d_rgb_colors) { ws.d_rgb_colors[3 * i] = drgb[0]; ws.d_rgb_colors[3 * i + 1] = drgb[1]; ws.d_rgb_colors[3 * i + 2] = drgb[2]; }
+        if (ws.d_logit_opacities) ws.d_logit_opacities[i] = dlogit;
+        if (ws.d_log_scales) {
+            if (iso) ws.d_log_scales[i] = dls[0];
+            else { ws.d_log_scales[3 * i] = dls[0]; ws.d_log_scales[3 * i + 1] = dls[1]; ws.d_log_scales[3 * i + 2] = dls[2]; }
+        }
+        if constexpr (ADAM) {
+            // torch.optim.Adam over every row (a Gaussian outside the view has a zero gradient, but its moments still move it)
+            auto step = [&](int gidx, float *param, int width, const float *g) {
+                if (!opt.grad[gidx]) return;                    // torch skips parameters without a gradient
+                float *m = opt.exp_avg[gidx] + (size_t)i * width, *v = opt.exp_avg_sq[gidx] + (size_t)i * width;
+                float *p = param + (size_t)i * width;
+                for (int k = 0; k < width; ++k) {
+                    float mm = m[k], vv = v[k];
+                    if (g[k] == 0.f && mm == 0.f && vv == 0.f) continue;       // (see adam_map_kernel)
+                    p[k] = adam_update(p[k], g[k], mm, vv, opt.beta1, opt.beta2, opt.step_size[gidx], opt.bc2_sqrt, opt.eps);
+                    m[k] = mm;
+                    v[k] = vv;
+                }
+            };
+            const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
+            step(0, a.map.means3D, 3, dp);
+            step(1, a.map.rgb_colors, 3, drgb);
+            step(2, a.map.unnorm_rotations, 4, iso ? zero4 : du);
+            step(3, a.map.logit_opacities, 1, &dlogit);
+            step(4, a.map.log_scales, iso ? 1 : 3, dls);
+        }
+    }
+    if (ws.st.tile_stride > 0) {
+        // bucketed lists: this is the last kernel that needs the tile counters -- fold them into the status words
+        // (num_rendered, longest list) and reset them for the next iteration's per-Gaussian kernel
+        const int T = c_num_tiles(a.cam.image_width, a.cam.image_height);
+        unsigned sum = 0, mx = 0;
+        const int G = ws.st.group_count ? c_num_groups(a.cam.image_width, a.cam.image_height) : 0;      // G <= T
+        for (int t = i; t < T; t += gridDim.x * kBlock) {
+            const unsigned cnt = ws.st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE];
+            ws.st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE] = 0;
+            ws.st.tile_cursor[(size_t)t * SPLAT_COUNTER_STRIDE] = cnt;       // kept for a later pass over the same lists (splat_iter_means2d_accumulate)
+            if (t < G) ws.st.group_count[(size_t)t * SPLAT_COUNTER_STRIDE] = 0;
+            sum += cnt;
+            mx = max(mx, cnt);
+        }
+        if (blockIdx.x * kBlock < T) {              // uniform per block; later blocks hold no tile
+            for (int m = 32; m >= 1; m >>= 1) { sum += (unsigned)__shfl_xor((int)sum, m, 64); mx = max(mx, (unsigned)__shfl_xor((int)mx, m, 64)); }
+            if ((threadIdx.x & 63) == 0 && sum) { atomicAdd((unsigned *)&ws.st.status[0], sum); atomicMax((unsigned *)&ws.st.status[2], mx); }
+        }
+    }
+    if (a.cfg.camera_grad) block_sum_to<kPoseSums>(sum_copy(ws.sums) + 8, pose, s_part);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // F8: Adam
 // ---------------------------------------------------------------------------------------------------------
 struct AdamArgs {
@@ -692,8 +782,12 @@ __global__ __launch_bounds__(kBlock) void adam_map_kernel(AdamArgs a, long long 
             if (grad) {                                         // torch skips parameters without a gradient
                 const long long j = e - off;
                 float mm = a.opt.exp_avg[gidx][j], vv = a.opt.exp_avg_sq[gidx][j];
+                const float gg = grad[j];
+                // zero gradient on zero moments (Gaussians never seen since the optimizer was created; the rotations of an
+                // isotropic map): the step leaves parameter and moments as they are -- nothing to write
+                if (gg == 0.f && mm == 0.f && vv == 0.f) return;
                 float *p = params[gidx];
-                p[j] = adam_update(p[j], grad[j], mm, vv, a.opt.beta1, a.opt.beta2, a.opt.step_size[gidx], a.opt.bc2_sqrt, a.opt.eps);
+                p[j] = adam_update(p[j], gg, mm, vv, a.opt.beta1, a.opt.beta2, a.opt.step_size[gidx], a.opt.bc2_sqrt, a.opt.eps);
                 a.opt.exp_avg[gidx][j] = mm;
                 a.opt.exp_avg_sq[gidx][j] = vv;
             }
@@ -714,8 +808,39 @@ __global__ void adam_pose_kernel(SplatMap map, int time_idx, const float *d_cam,
 hipError_t launch_depth_error_median(const float *out6, const float *depth, float *err, uint32_t *scratch, int HW, int32_t *counts,
                                      hipStream_t s);
 
+// lists known (host hint, possibly stale: then flagged) to be short are sorted by the composite kernel itself
+static bool lists_sorted_by_composite(const SplatState &st) { return st.max_list_hint > 0 && st.max_list_hint + st.max_list_hint / 4 <= 1024; }
+
+static int num_tile_groups(const SplatCamera &cam) {
+    const int gx = (cam.image_width + kTile - 1) / kTile, gy = (cam.image_height + kTile - 1) / kTile;
+    return ((gx + kGT - 1) / kGT) * ((gy + kGT - 1) / kGT);
+}
+
+// group binning (SplatState.group_count) needs bucketed lists that the composite sorts itself, and one LDS counter per group
+static bool group_binning(const SplatState &st, const SplatCamera &cam) {
+    return st.group_stride > 0 && st.group_count && st.group_recs && st.tile_stride > 0 && lists_sorted_by_composite(st) &&
+           num_tile_groups(cam) <= 8192;
+}
+
+// F1 in the mode the state asks for
+static void launch_fused_preprocess(const FusedArgs &a, hipStream_t s) {
+    const int P = a.map.P;
+    if (P <= 0) return;
+    const SplatState &st = a.ws.st;
+    if (st.group_stride > 0)
+        hipLaunchKernelGGL((fused_preprocess_kernel<2, kGroupBlock>), dim3((P + kGroupBlock - 1) / kGroupBlock), dim3(kGroupBlock),
+                           sizeof(unsigned) * (size_t)num_tile_groups(a.cam), s, a);
+    else if (st.order_hint && st.tile_stride > 0)
+        hipLaunchKernelGGL((fused_preprocess_kernel<1, kBlock>), dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL((fused_preprocess_kernel<0, kBlock>), dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+}
+
 hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame,
-                                     const SplatLossConfig &cfg, SplatIterWorkspace &ws, hipStream_t s, const SplatPoseAdam *pose_adam) {
+                                     const SplatLossConfig &cfg, SplatIterWorkspace &ws_in, hipStream_t s, const SplatPoseAdam *pose_adam,
+                                     const SplatAdamMap *map_adam) {
+    SplatIterWorkspace ws = ws_in;          // (copy: the binning mode is decided per call)
+    if (!group_binning(ws.st, cam)) ws.st.group_stride = 0;
     FusedArgs a{cam, map, frame, cfg, ws, {}};
     ssim_window_host(a.win);
     const int W = cam.image_width, H = cam.image_height, HW = W * H;
@@ -725,10 +850,7 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
     // (pose_finish / tile_scan / fused_backward); the caller zero-initialises the workspace once
     hipError_t e = hipSuccess;
     const int gblocks = (P + kBlock - 1) / kBlock;
-    if (P > 0) {
-        if (ws.st.order_hint && ws.st.tile_stride > 0) hipLaunchKernelGGL(fused_preprocess_kernel<true>, dim3(gblocks), dim3(kBlock), 0, s, a);
-        else hipLaunchKernelGGL(fused_preprocess_kernel<false>, dim3(gblocks), dim3(kBlock), 0, s, a);
-    }
+    launch_fused_preprocess(a, s);
     if (ws.st.tile_stride == 0) {
         e = launch_tile_scan(ws.st, T, s);
         if (e != hipSuccess) return e;
@@ -736,8 +858,7 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
     SplatGaussians g{};
     g.P = P;
     g.channels = 6;
-    // lists known (host hint, possibly stale: then flagged) to be short are sorted by the composite kernel itself
-    const bool sort_in_k6 = ws.st.max_list_hint > 0 && ws.st.max_list_hint + ws.st.max_list_hint / 4 <= 1024;
+    const bool sort_in_k6 = lists_sorted_by_composite(ws.st);
     e = launch_bin_forward(cam, g, ws.st, s, !sort_in_k6);
     if (e != hipSuccess) return e;
     // tracking without outlier rejection: the loss and its gradient planes are formed in the composite's epilogue
@@ -770,30 +891,30 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
     e = launch_render_backward_feat8(cam, ws.feat8, ws.st, ws.dL_dout6, ws.accum, P, false, ws.d_rgb_colors != nullptr, s,
                                      ws.d_logit_opacities != nullptr);
     if (e != hipSuccess) return e;
-    if (P > 0) hipLaunchKernelGGL(fused_backward_kernel, dim3(gblocks), dim3(kBlock), 0, s, a);
     PoseAdam pa{};
     if (pose_adam)
         pa = PoseAdam{pose_adam->state, pose_adam->beta1, pose_adam->beta2, pose_adam->eps, pose_adam->bc2_sqrt, pose_adam->step_size_rot,
                       pose_adam->step_size_trans};
+    if (P > 0 && map_adam) hipLaunchKernelGGL(fused_backward_kernel<true>, dim3(gblocks), dim3(kBlock), 0, s, a, *map_adam);
+    else if (P > 0) hipLaunchKernelGGL(fused_backward_kernel<false>, dim3(gblocks), dim3(kBlock), 0, s, a, SplatAdamMap{});
     hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(256), 0, s, a, HW, pa);
     return hipGetLastError();
 }
 
 // Forward half only (F1, lists, K6): the render of add_new_gaussians / evaluation.  Leaves every per-iteration
 // scratch word the way a full iteration leaves it (tile counters zero, nothing accumulated).
-hipError_t launch_fold_tile_counters(SplatState &st, int T, hipStream_t s);
+hipError_t launch_fold_tile_counters(SplatState &st, int T, int G, hipStream_t s);
 
-hipError_t launch_iter_render(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame, SplatIterWorkspace &ws,
+hipError_t launch_iter_render(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame, SplatIterWorkspace &ws_in,
                               hipStream_t s) {
+    SplatIterWorkspace ws = ws_in;
+    if (!group_binning(ws.st, cam)) ws.st.group_stride = 0;
     FusedArgs a{cam, map, frame, SplatLossConfig{}, ws, {}};
     a.ws.max_2D_radius = nullptr;           // only get_loss updates variables['max_2D_radius'] (/root/reference/scripts/splatam.py:342)
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
     const int P = map.P;
     hipError_t e = hipSuccess;
-    if (P > 0) {
-        if (ws.st.order_hint && ws.st.tile_stride > 0) hipLaunchKernelGGL(fused_preprocess_kernel<true>, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
-        else hipLaunchKernelGGL(fused_preprocess_kernel<false>, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
-    }
+    launch_fused_preprocess(a, s);
     if (ws.st.tile_stride == 0) {
         e = launch_tile_scan(ws.st, T, s);
         if (e != hipSuccess) return e;
@@ -801,12 +922,12 @@ hipError_t launch_iter_render(const SplatCamera &cam, const SplatMap &map, const
     SplatGaussians g{};
     g.P = P;
     g.channels = 6;
-    const bool sort_in_k6 = ws.st.max_list_hint > 0 && ws.st.max_list_hint + ws.st.max_list_hint / 4 <= 1024;
+    const bool sort_in_k6 = lists_sorted_by_composite(ws.st);
     e = launch_bin_forward(cam, g, ws.st, s, !sort_in_k6);
     if (e != hipSuccess) return e;
     e = launch_render_forward_feat8(cam, ws.feat8, ws.st, ws.out6, sort_in_k6, s);
     if (e != hipSuccess) return e;
-    if (ws.st.tile_stride > 0) return launch_fold_tile_counters(ws.st, T, s);
+    if (ws.st.tile_stride > 0) return launch_fold_tile_counters(ws.st, T, num_tile_groups(cam), s);
     return hipGetLastError();
 }
 
@@ -838,7 +959,10 @@ hipError_t launch_iter_means2d_accumulate(const SplatCamera &cam, const SplatMap
                                           float *means2D_grad, hipStream_t s) {
     const int P = map.P;
     if (P <= 0) return hipSuccess;
-    hipError_t e = launch_render_backward_rgb_only(cam, ws.feat8, ws.st, ws.dL_dout6, ws.accum, P, s);
+    // bucketed lists: the iteration's last kernel folded and reset the tile counters, and left the counts in the cursor words
+    SplatState st = ws.st;
+    if (st.tile_stride > 0) st.tile_count = st.tile_cursor;
+    hipError_t e = launch_render_backward_rgb_only(cam, ws.feat8, st, ws.dL_dout6, ws.accum, P, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(means2d_accumulate_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, ws, P, cam.image_width, cam.image_height, gaccum,
                        denom, means2D_grad);

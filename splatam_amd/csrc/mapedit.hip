@@ -509,11 +509,13 @@ __global__ __launch_bounds__(kBlock) void duplicate_rows_kernel(SplatMapStore st
 }
 
 // tile counters of the bucketed lists after a forward-only pass (the full iteration folds them in its last per-Gaussian kernel)
-__global__ __launch_bounds__(kBlock) void fold_tile_counters_kernel(SplatState st, int T) {
+__global__ __launch_bounds__(kBlock) void fold_tile_counters_kernel(SplatState st, int T, int G) {
     unsigned sum = 0, mx = 0;
     for (int t = blockIdx.x * kBlock + threadIdx.x; t < T; t += gridDim.x * kBlock) {
         const unsigned cnt = st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE];
         st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE] = 0;
+        st.tile_cursor[(size_t)t * SPLAT_COUNTER_STRIDE] = cnt;
+        if (st.group_count && t < G) st.group_count[(size_t)t * SPLAT_COUNTER_STRIDE] = 0;      // (G <= T)
         sum += cnt;
         mx = max(mx, cnt);
     }
@@ -625,8 +627,8 @@ hipError_t launch_map_duplicate(const SplatMapStore &st, const SplatDensifyArgs 
     return hipGetLastError();
 }
 
-hipError_t launch_fold_tile_counters(SplatState &st, int T, hipStream_t s) {
-    if (T > 0) hipLaunchKernelGGL(fold_tile_counters_kernel, dim3(min((T + kBlock - 1) / kBlock, 64)), dim3(kBlock), 0, s, st, T);
+hipError_t launch_fold_tile_counters(SplatState &st, int T, int G, hipStream_t s) {
+    if (T > 0) hipLaunchKernelGGL(fold_tile_counters_kernel, dim3(min((T + kBlock - 1) / kBlock, 64)), dim3(kBlock), 0, s, st, T, G);
     return hipGetLastError();
 }
 

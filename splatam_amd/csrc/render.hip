@@ -23,6 +23,8 @@
 // Arithmetic: SURVEY.md Appendix A "Forward composite (K6)" / "Backward composite (K7)" -- the callee of
 // /root/reference/scripts/splatam.py:249,253 and of the autograd backward reached from :702,854.
 // exp(power) is evaluated as v_exp_f32(power * log2 e) with log2 e folded into the staged conic.
+#include <type_traits>
+
 #include "splat_device.h"
 
 namespace splat {
@@ -260,24 +262,41 @@ __device__ __forceinline__ void sort_keys_two_level(uint64_t *A, uint64_t *S, co
         if (lane + 64 < len) S[start + r1] = k1;
     }
     __syncthreads();
-    // ---- level 2
+    // ---- level 2: a key's rank = its index in its own chunk + its insertion points in the OTHER chunks.  The probes of one
+    //      step are independent LDS reads (issued together, no branch around them: a probe past the chunk's end reads some
+    //      other word of S, inside the LDS allocation, and is discarded by `probe <= len`); the step count follows the chunk size
+    const int top = 1 << (31 - __builtin_clz((unsigned)cs));      // largest power of two <= cs (wave-uniform)
     for (int i = tid; i < n; i += 256) {
         const uint64_t key = S[i];
-        unsigned pos[8];
+        int oc = 0;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) pos[c] = 0;
+        for (int c = 1; c < 8; ++c) oc += (i >= c * cs) ? 1 : 0;
+        unsigned r = (unsigned)(i - oc * cs);
+        auto search = [&](auto CC) {
+            constexpr int NC = decltype(CC)::value;
+            unsigned pos[NC - 1];
+            int base[NC - 1], len[NC - 1];
 #pragma unroll
-        for (int step = 128; step >= 1; step >>= 1) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int start = c * cs, len = min(n, start + cs) - start;       // <= 0 for chunks beyond the list (and c >= C)
-                const unsigned probe = pos[c] + (unsigned)step;
-                if ((int)probe <= len && S[start + probe - 1] < key) pos[c] = probe;
+            for (int d = 1; d < NC; ++d) {
+                const int start = ((oc + d) & (NC - 1)) * cs;
+                pos[d - 1] = 0;
+                base[d - 1] = start - 1;
+                len[d - 1] = min(n, start + cs) - start;          // <= 0 for a chunk beyond the list
             }
-        }
-        unsigned r = 0;
+#pragma unroll 1
+            for (int step = top; step >= 1; step >>= 1) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) r += pos[c];
+                for (int d = 0; d < NC - 1; ++d) {
+                    const unsigned probe = pos[d] + (unsigned)step;
+                    const uint64_t other = S[base[d] + (int)probe];
+                    pos[d] = (((int)probe <= len[d]) & (other < key)) ? probe : pos[d];
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < NC - 1; ++d) r += pos[d];
+        };
+        if (C == 4) search(std::integral_constant<int, 4>{});
+        else search(std::integral_constant<int, 8>{});
         A[r] = key;
     }
     __syncthreads();
@@ -317,13 +336,47 @@ __global__ __launch_bounds__(256, 6) void render_forward_kernel(SplatCamera cam,
     tile_range(st, tile, lo, n);
     const uint64_t *lk = SORT ? s_keys : nullptr;
     if constexpr (SORT) {
+        if (st.group_stride > 0) {
+            // group binning (SplatState.group_count): the tile's instances are the records of its 2 x 2-tile group whose tile
+            // rectangle holds this tile; compacted into LDS in any order (the sort below fixes it), and the count is published
+            // where the per-tile buckets would have left it (the backward composite and the counter fold read it there)
+            __shared__ int s_n;
+            if (tid == 0) s_n = 0;
+            __syncthreads();
+            const int ggx = (gx + SPLAT_GROUP_TILES - 1) / SPLAT_GROUP_TILES;
+            const int grp = (ty / SPLAT_GROUP_TILES) * ggx + tx / SPLAT_GROUP_TILES;
+            const int cnt = min((int)st.group_count[(size_t)grp * SPLAT_COUNTER_STRIDE], st.group_stride);
+            const uint4 *recs = reinterpret_cast<const uint4 *>(st.group_recs) + (size_t)grp * st.group_stride;
+            for (int i0 = 0; i0 < cnt; i0 += 256) {
+                const int i = i0 + tid;
+                uint4 r = make_uint4(0u, 0u, 0u, 0u);
+                if (i < cnt) r = recs[i];
+                const unsigned utx = (unsigned)tx, uty = (unsigned)ty;
+                const bool hit = i < cnt && utx >= (r.z & 0xFFFFu) && utx < (r.w & 0xFFFFu) && uty >= (r.z >> 16) && uty < (r.w >> 16);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+                int base = 0;
+                if (lane == 0 && m) base = atomicAdd(&s_n, __builtin_popcountll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                if (hit && pos < kFusedSortMax) s_keys[pos] = ((uint64_t)r.y << 32) | r.x;
+            }
+            __syncthreads();
+            n = s_n;
+            if (tid == 0) {
+                st.tile_count[(size_t)tile * SPLAT_COUNTER_STRIDE] = (unsigned)n;
+                if (n > st.tile_stride) st.status[1] = 1;         // the published list would not fit its bucket
+            }
+            n = min(n, st.tile_stride);
+        }
         if (n > kFusedSortMax) {        // the host's list-length hint was stale: flag it (the host repeats the iteration)
             if (tid == 0) st.status[3] = 1;
             n = kFusedSortMax;
         }
-        for (int i = tid; i < n; i += 256) s_keys[i] = st.keys[lo + i];
+        if (st.group_stride == 0)
+            for (int i = tid; i < n; i += 256) s_keys[i] = st.keys[lo + i];
         if (tid == 0 && (n & 1)) s_keys[n] = ~0ull;                  // pad to an even count (pair reads)
         __syncthreads();
+        static_assert(sizeof(B.rec) >= (kFusedSortMax + 256) * sizeof(uint64_t), "level-2 probes of the sort may read up to 255 words past the last chunk");
         sort_keys_two_level(s_keys, reinterpret_cast<uint64_t *>(B.rec), n, tid);
         for (int i = tid; i < n; i += 256) st.point_list[lo + i] = (uint32_t)lk[i];
     }

@@ -76,6 +76,9 @@ class FusedEngine:
         b['tile_base'] = torch.empty(T + 1, dtype=i32, **z)
         b['tile_cursor'] = torch.empty(T * CS, dtype=i32, **z)
         b['long_base'] = torch.zeros(T + 1, dtype=i32, **z)
+        GT = _capi.SPLAT_GROUP_TILES
+        self.num_groups = (((W + 15) // 16 + GT - 1) // GT) * (((H + 15) // 16 + GT - 1) // GT)
+        b['group_count'] = torch.zeros(self.num_groups * CS, dtype=i32, **z)
         b['status'] = torch.zeros(4, dtype=i32, **z)
         b['final_T'] = torch.empty(H, W, dtype=f32, **z)
         b['n_contrib'] = torch.empty(H, W, dtype=i32, **z)
@@ -102,6 +105,10 @@ class FusedEngine:
         self.tile_stride = 0            # > 0: bucketed lists (no scan / scatter pass), learnt by check_overflow()
         self.num_tiles = T
         self.allow_buckets = True
+        # group binning (SplatState.group_count): with bucketed lists short enough for the composite's own sort, the per-Gaussian
+        # kernel files one record per 2 x 2-tile group (slots through an LDS histogram) and the composite filters its group's
+        # records: ~10x fewer global atomics in the per-Gaussian kernel.  Results do not depend on it
+        self.group_bins = True
         self.sub_bins = 1               # counters per tile on the exact-list path (16 once lists get very long: SplatState.sub_bins)
         # rows in creation (pixel-scan) order: true for a map this engine grew itself (add_valid_depth_points / add_new_gaussians
         # append per pixel in scan order); callers that hand over such a map may set it.  Only a speed hint (SplatState.order_hint)
@@ -508,6 +515,14 @@ class FusedEngine:
         st.keys_alt, st.long_base = b['keys_alt'].data_ptr(), b['long_base'].data_ptr()
         st.max_list_hint = self.max_list_hint
         st.tile_stride = self.tile_stride
+        st.group_count, st.group_recs, st.group_stride = b['group_count'].data_ptr(), None, 0
+        if self.group_bins and self.tile_stride > 0 and 0 < self.max_list_hint and self.max_list_hint * 5 // 4 <= 1024:
+            gs = _capi.SPLAT_GROUP_TILES ** 2 * self.tile_stride
+            need = self.num_groups * gs * 4
+            if need <= 1 << 30:                       # (int32 words; 4 GiB of records)
+                if b.get('group_recs') is None or b['group_recs'].numel() < need:
+                    b['group_recs'] = torch.empty(need, dtype=torch.int32, device=self.dev)
+                st.group_recs, st.group_stride = b['group_recs'].data_ptr(), gs
         st.order_hint = int(self.creation_order)
         st.sub_bins = self.sub_bins if self.tile_stride == 0 else 1
         st.final_T, st.n_contrib, st.status = b['final_T'].data_ptr(), b['n_contrib'].data_ptr(), b['status'].data_ptr()
@@ -540,10 +555,11 @@ class FusedEngine:
         return c
 
     # ------------------------------------------------------------------ one iteration
-    def loss_backward(self, curr_data, time_idx, cfg, tracking, map_grads=None, do_ba=False, pose_adam=None):
+    def loss_backward(self, curr_data, time_idx, cfg, tracking, map_grads=None, do_ba=False, pose_adam=None, map_adam=None):
         """get_loss + backward.  Afterwards (stream order): ``self.grads`` (mapping) and
         ``self.buf['d_cam']`` = [dL/dq_raw(4), dL/dt_raw(3), loss].  ``pose_adam`` (a SplatPoseAdam): the pose's Adam step
-        rides in the last kernel (splat_iter_tracking_step)."""
+        rides in the last kernel (splat_iter_tracking_step); ``map_adam`` (a SplatAdamMap): likewise the map's
+        (splat_iter_mapping_step)."""
         if map_grads is None:
             map_grads = not tracking
         self._check_cam(curr_data)
@@ -565,12 +581,15 @@ class FusedEngine:
             if pose_adam is not None:
                 _capi.check(self.L.splat_iter_tracking_step(C.byref(self._cam), C.byref(m), C.byref(fr), C.byref(lc), C.byref(ws),
                                                             C.byref(pose_adam), self._stream()), "splat_iter_tracking_step")
+            elif map_adam is not None:
+                _capi.check(self.L.splat_iter_mapping_step(C.byref(self._cam), C.byref(m), C.byref(fr), C.byref(lc), C.byref(ws),
+                                                           C.byref(map_adam), self._stream()), "splat_iter_mapping_step")
             else:
                 _capi.check(self.L.splat_iter_loss_backward(C.byref(self._cam), C.byref(m), C.byref(fr), C.byref(lc), C.byref(ws),
                                                             self._stream()), "splat_iter_loss_backward")
 
-    def adam_map(self, lrs, beta1=0.9, beta2=0.999, eps=1e-15):
-        """torch.optim.Adam(param_groups, lr=0.0, eps=1e-15).step() over the five Gaussian groups
+    def _adam_map_args(self, lrs, beta1=0.9, beta2=0.999, eps=1e-15):
+        """The next step of torch.optim.Adam(param_groups, lr=0.0, eps=1e-15) over the five Gaussian groups
         (/root/reference/scripts/splatam.py:160-166).  Bias corrections in double on the host, as torch forms them."""
         self.map_step += 1
         t = self.map_step
@@ -582,6 +601,11 @@ class FusedEngine:
             o.grad[k] = self.grads[name].data_ptr()
             o.exp_avg[k] = self.exp_avg[name].data_ptr()
             o.exp_avg_sq[k] = self.exp_avg_sq[name].data_ptr()
+        return o
+
+    def adam_map(self, lrs, beta1=0.9, beta2=0.999, eps=1e-15):
+        """optimizer.step() of the mapping optimizer on ``self.grads`` (see _adam_map_args)."""
+        o = self._adam_map_args(lrs, beta1, beta2, eps)
         m = self._map_struct()
         with torch.cuda.device(self.dev):
             _capi.check(self.L.splat_iter_adam_map(C.byref(m), C.byref(o), self._stream()), "splat_iter_adam_map")
@@ -631,10 +655,13 @@ class FusedEngine:
         self.loss_backward(curr_data, self.track_time_idx, cfg, tracking=True, pose_adam=pa)
 
     def mapping_iteration(self, iter_data, iter_time_idx, cfg, bucket_allreduce=None):
-        """Loop body of /root/reference/scripts/splatam.py:828-869 (without pruning / densification)."""
+        """Loop body of /root/reference/scripts/splatam.py:828-869 (without pruning / densification).  Without a gradient
+        exchange the whole iteration is one C call (the Adam step rides in the last kernel: splat_iter_mapping_step)."""
+        if bucket_allreduce is None:
+            self.loss_backward(iter_data, iter_time_idx, cfg, tracking=False, map_adam=self._adam_map_args(cfg['lrs']))
+            return
         self.loss_backward(iter_data, iter_time_idx, cfg, tracking=False)
-        if bucket_allreduce is not None:
-            bucket_allreduce(self.reduce_flat)      # one collective: 8 (isotropic) or 14 floats per Gaussian
+        bucket_allreduce(self.reduce_flat)          # one collective: 8 (isotropic) or 14 floats per Gaussian
         self.adam_map(cfg['lrs'])
 
     def mapping_batch(self, views, cfg, total_views=None, allreduce_sum=None):
@@ -681,6 +708,7 @@ class FusedEngine:
             self.buf['d_cam'][12] = 0.0
             self.buf['status'].zero_()
             self.buf['tile_count'].zero_()
+            self.buf['group_count'].zero_()
             self.buf['accum'].zero_()
             self.buf['sums'].zero_()
             self.max_list_hint = 0

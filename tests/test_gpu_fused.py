@@ -468,6 +468,7 @@ def test_order_hint_changes_nothing_but_speed(order):
     for hint in (False, True):
         eng = FusedEngine({k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}, cam)
         eng.creation_order = hint
+        eng.group_bins = False                                             # (group binning would take precedence over the hint)
         eng.loss_backward(frame, 1, cfg, tracking=False)
         assert not eng.check_overflow() and eng.tile_stride > 0           # learns the buckets
         eng.loss_backward(frame, 1, cfg, tracking=False)                  # bucketed lists: the hinted path
@@ -478,3 +479,87 @@ def test_order_hint_changes_nothing_but_speed(order):
     assert abs(outs[0][2] - outs[1][2]) <= 1e-6 * abs(outs[0][2])
     g0, g1 = outs
     assert float((g0[1] - g1[1]).abs().max()) <= 1e-5 * float(g0[1].abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["random", "large", "odd_grid", "tracking"])
+def test_group_binning_changes_nothing_but_speed(case):
+    """SplatState.group_count (one record per (Gaussian, 2 x 2-tile group), slots through an LDS histogram; the forward composite
+    filters its group's records by tile rectangle): the per-tile lists after the composite's sort -- and the counts it
+    publishes -- are exactly those of the per-tile buckets, hence bit-identical renders and list statistics.  "large": splats
+    wide enough to touch more than four groups (a lane's further records take their own atomics); "odd_grid": an odd number of
+    tile columns / rows (edge groups of one tile); "tracking": the composite with the loss epilogue, and the render-only call."""
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    W, H = (328, 232) if case == "odd_grid" else (320, 240)
+    params, variables, frame, cam = _scene(30000 if case != "large" else 6000, W, H, seed=37)
+    if case == "large":
+        with torch.no_grad():
+            params['log_scales'] += 1.5
+    tracking = case == "tracking"
+    cfg = slam.REPLICA_TRACKING if tracking else slam.REPLICA_MAPPING
+    outs = []
+    for groups in (False, True):
+        eng = FusedEngine({k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}, cam)
+        eng.group_bins = groups
+        for attempt in range(4):                                          # (the wide splats outgrow the default list capacity once)
+            eng.loss_backward(frame, 1, cfg, tracking=tracking)
+            if not eng.check_overflow():
+                break
+        assert eng.tile_stride > 0                                         # learnt the buckets (and, with them, the groups)
+        eng.loss_backward(frame, 1, cfg, tracking=tracking)
+        torch.cuda.synchronize()
+        stat = eng.buf['status'].tolist()
+        assert not eng.check_overflow(grow=False)
+        ws = eng._workspace(False, with_ssim=False)
+        assert (ws.st.group_stride > 0) == groups
+        grads = eng.grads['means3D'].clone() if not tracking else eng.buf['d_cam'][:7].clone()
+        out6, loss = eng.buf['out6'].clone(), eng.loss()
+        eng.render(frame, 1)                                               # forward half only: same lists, same planes
+        torch.cuda.synchronize()
+        assert torch.equal(eng.buf['out6'], out6)
+        assert float(eng.buf['tile_count'].abs().max()) == 0.0 and float(eng.buf['group_count'].abs().max()) == 0.0
+        outs.append((out6, grads, loss, stat[0], stat[2]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][3] == outs[1][3] and outs[0][4] == outs[1][4], (outs[0][3:], outs[1][3:])     # num_rendered, longest list
+    assert abs(outs[0][2] - outs[1][2]) <= 1e-6 * abs(outs[0][2])
+    assert float((outs[0][1] - outs[1][1]).abs().max()) <= 2e-5 * float(outs[0][1].abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aniso", [False, True])
+def test_mapping_step_in_one_call_equals_loss_backward_plus_adam(aniso):
+    """splat_iter_mapping_step (the Adam step of the map folded into the iteration's last kernel) against the two calls it replaces
+    (splat_iter_loss_backward, splat_iter_adam_map), three iterations: same parameters and moments up to the summation order of
+    the backward composite's float atomics (Adam with eps = 1e-15 turns a gradient that is rounding noise into a +-lr step, so
+    elements are compared where the gradient is significant), and the loss / pose outputs of the folded F7."""
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine, PARAM_ORDER
+    params, variables, frame, cam = _scene(8000, 208, 160, aniso=aniso, seed=11)
+    cfg = slam.REPLICA_MAPPING
+    e1 = FusedEngine({k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}, cam)
+    e2 = FusedEngine({k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}, cam)
+    g_first = None
+    for it in range(3):
+        e1.mapping_iteration(frame, 1, cfg)
+        e2.loss_backward(frame, 1, cfg, tracking=False)
+        if g_first is None:
+            g_first = {k: e2.grads[k].clone() for k in PARAM_ORDER}
+        e2.adam_map(cfg['lrs'])
+        torch.cuda.synchronize()
+        assert abs(e1.loss() - e2.loss()) <= 1e-6 * abs(e2.loss())
+    assert not e1.check_overflow() and not e2.check_overflow()
+    for k in PARAM_ORDER:
+        assert float((e1.grads[k] - e2.grads[k]).abs().max()) <= 1e-3 * float(e2.grads[k].abs().max()) + 1e-12, k   # still written
+        if k == 'unnorm_rotations' and not aniso:
+            assert torch.equal(e1.params[k].detach(), params[k].detach()) and float(e1.exp_avg[k].abs().max()) == 0.0
+            continue
+        lr = cfg['lrs'][k]
+        sig = g_first[k].abs() > 1e-4 * g_first[k].abs().max()
+        diff = (e1.params[k].detach() - e2.params[k].detach()).abs()[sig]
+        assert float((diff > 0.05 * lr).float().mean()) < 5e-3, (k, float(diff.max()), lr)
+        dm = (e1.exp_avg[k] - e2.exp_avg[k]).abs()
+        assert float(dm.max()) <= 1e-3 * float(e2.exp_avg[k].abs().max()), k
+        dv = (e1.exp_avg_sq[k] - e2.exp_avg_sq[k]).abs()
+        assert float(dv.max()) <= 2e-3 * float(e2.exp_avg_sq[k].abs().max()), k
+    assert torch.equal(e1.params['cam_trans'], e2.params['cam_trans'])

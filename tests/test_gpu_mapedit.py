@@ -192,7 +192,8 @@ def _densify_scene(n=6000, W=160, H=112):
     return eng, params, variables, mirror, frame
 
 
-def test_colour_pass_means2d_gradient_and_its_accumulation():
+@pytest.mark.parametrize("lists", ["exact", "buckets", "groups"])
+def test_colour_pass_means2d_gradient_and_its_accumulation(lists):
     """The colour pass' own dL/dmeans2D (what the reference reads from variables['means2D'].grad,
     /root/reference/utils/slam_external.py:100-104) from the fused iteration's extra RGB-only backward composite, against
     autograd through the drop-in rasterizer; and the accumulation into means2D_gradient_accum / denom for the seen Gaussians."""
@@ -201,6 +202,12 @@ def test_colour_pass_means2d_gradient_and_its_accumulation():
     cfg = slam.REPLICA_MAPPING
     mv = {'max_2D_radius': torch.zeros(eng.P, device="cuda"), 'means2D_gradient_accum': torch.zeros(eng.P, device="cuda"),
           'denom': torch.zeros(eng.P, device="cuda")}
+    eng.group_bins = lists == "groups"
+    if lists != "exact":
+        # bucketed lists (learnt from one iteration's statistics): their tile counters are consumed and reset by the iteration's
+        # last kernel, the extra backward composite reads the counts it left behind
+        eng.loss_backward(frame, 1, cfg, tracking=False)
+        assert not eng.check_overflow() and eng.tile_stride > 0
     for it in range(2):
         loss, mv, _ = slam.get_loss(mirror, frame, mv, 1, cfg['loss_weights'], cfg['use_sil_for_loss'], cfg['sil_thres'], cfg['use_l1'],
                                     cfg['ignore_outlier_depth_loss'], mapping=True)
