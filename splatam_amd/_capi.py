@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsplat_hip.so")
+# (SPLAT_HIP_LIB: developer override, A/B timing of two builds in one process launch each: scripts/ab_lib.sh)
+LIB_PATH = os.environ.get("SPLAT_HIP_LIB") or os.path.join(_HERE, "lib", "libsplat_hip.so")
 
 SPLAT_TILE = 16
 SPLAT_MAX_CHANNELS = 8

@@ -201,10 +201,13 @@ int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P,
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return SPLAT_E_LAUNCH;
     hipError_t err = hipSuccess;
+    // bucketed lists: the iteration's last kernel consumed and reset the tile counters and left the counts in the cursor words
+    SplatState st = ws->st;
+    if (st.tile_stride > 0) st.tile_count = st.tile_cursor;
     (void)hipEventRecord(e0, s);
     for (int i = 0; i < iters && err == hipSuccess; ++i)
-        err = fn == 0 ? launch_render_forward_feat8(*cam, ws->feat8, ws->st, ws->out6, false, s)
-                      : launch_render_backward_feat8(*cam, ws->feat8, ws->st, ws->dL_dout6, ws->accum, P, false, true, s);
+        err = fn == 0 ? launch_render_forward_feat8(*cam, ws->feat8, st, ws->out6, false, s)
+                      : launch_render_backward_feat8(*cam, ws->feat8, st, ws->dL_dout6, ws->accum, P, false, true, s);
     (void)hipEventRecord(e1, s);
     // the timed backward launches accumulated into ws->accum: restore the workspace invariant (every iteration leaves the
     // accumulator zeroed; fused_backward_kernel relies on it) outside the timed bracket
