@@ -35,6 +35,9 @@ for fn in (0, 1):
     out.append(ms.value * 1e3)
 
 
+host_us = []
+
+
 def rate(fn, n=120):
     for _ in range(10):
         fn()
@@ -42,11 +45,13 @@ def rate(fn, n=120):
     t0 = time.perf_counter()
     for _ in range(n):
         fn()
+    t1 = time.perf_counter()
     torch.cuda.synchronize()
+    host_us.append(1e6 * (t1 - t0) / n)         # time the host needs to enqueue one iteration
     return n / (time.perf_counter() - t0)
 
 
 tr = rate(lambda: eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING))
 mp = rate(lambda: eng.mapping_iteration(frames[2], 2, slam.REPLICA_MAPPING))
 assert not eng.check_overflow(grow=False)
-print(f"K6 (no sort) {out[0]:.1f} us   K7 (mapping form) {out[1]:.1f} us   tracking {tr:.0f} it/s   mapping {mp:.0f} it/s", flush=True)
+print(f"K6 (no sort) {out[0]:.1f} us   K7 (mapping form) {out[1]:.1f} us   tracking {tr:.0f} it/s   mapping {mp:.0f} it/s   host enqueue {host_us[0]:.0f} / {host_us[1]:.0f} us per iteration", flush=True)

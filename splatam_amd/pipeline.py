@@ -460,7 +460,12 @@ def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, 
         # the reference prunes between backward() and step(); remove_points re-creates the parameters without their
         # gradients, so an iteration on the pruning schedule takes no Adam step
         on_schedule = prune and it <= pd['stop_after'] and it >= pd['start_after'] and it % pd['prune_every'] == 0
-        if eng is not None:
+        # prune_gaussians also resets the opacities on its own schedule (utils/slam_external.py:186-190)
+        resets = prune and it <= pd['stop_after'] and it > 0 and it % pd['reset_opacities_every'] == 0 and pd['reset_opacities']
+        if eng is not None and world == 1 and not on_schedule and not resets and not mcfg.get('use_gaussian_splatting_densification'):
+            # nothing between backward() and step() in this iteration: one call, the Adam step rides in the last kernel
+            eng.mapping_iteration(iter_data, iter_time_idx, mcfg)
+        elif eng is not None:
             eng.loss_backward(iter_data, iter_time_idx, mcfg, tracking=False)
             if world > 1 and not on_schedule:                   # (an iteration on the pruning schedule takes no Adam step)
                 sdist.all_reduce_mean_flat(eng.reduce_flat)
