@@ -20,6 +20,12 @@ def main():
     params, variables, frames, shape = bench.build_scene(wl, dev, 2)
     eng = FusedEngine({k: v.detach().clone() for k, v in params.items()}, frames[1]['cam'])
     eng.begin_tracking(1)
+    # the steady state of the frame loop: list statistics learnt (bucketed lists, group records, lists sorted inside the composite)
+    for _ in range(2):
+        eng.loss_backward(frames[2], 2, slam.REPLICA_MAPPING, tracking=False)
+        torch.cuda.synchronize()
+        assert not eng.check_overflow()
+    assert eng.tile_stride > 0
     for _ in range(reps):
         eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING)
         eng.mapping_iteration(frames[2], 2, slam.REPLICA_MAPPING)

@@ -31,10 +31,12 @@ k7m = avg("render_backward_kernel5<6, 8, 15u, 15u") or avg("render_backward_kern
 k7t = avg("render_backward_kernel5<6, 8, 15u, 8u") or avg("render_backward_kernel<6, 8, 15u, 8u")
 k6s = avg("render_forward_kernel<6, 8, false, true, false>") or avg("render_forward_kernel<6, 8, false, true>")
 k6t = avg("render_forward_kernel<6, 8, false, true, true>")
-f1, f6, f4, f5 = avg("fused_preprocess"), avg("fused_backward_kernel"), avg("ssim_forward"), avg("map_loss_backward")
+f1, f4, f5 = avg("fused_preprocess_kernel<2") or avg("fused_preprocess"), avg("ssim_forward"), avg("map_loss_backward")
+f6 = avg("fused_backward_kernel<false>") or avg("fused_backward_kernel")          # tracking (and exchanged mapping) form
+f6m = avg("fused_backward_kernel<true>") or f6                                    # single-view mapping step: Adam inside
 f7, ap, am = avg("pose_finish"), avg("adam_pose"), avg("adam_map")
-out = [f"# `{tag}`: generation-5 backward composite (two phases: pixel-lane recursion -> LDS pair buffer -> row-lane moment sums, no per-visit lane",
-       "reduction), record prefetch one visit ahead in K6 / K7, rank sort and tracking loss inside K6\n",
+out = [f"# `{tag}`: group binning (one record per Gaussian and 2x2-tile group through an LDS histogram; the forward composite filters, sorts and",
+       "publishes its tile's list), generation-5 backward composite, Adam of the map inside F6 for the single-view mapping step\n",
        "`rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-slam-loop` on MI355X (gfx950), workload B",
        "(300k Gaussians, 1200x680), engine = fused.  The run also times the drop-in path (reference-shaped PyTorch glue around the drop-in",
        f"rasterizer), hence the MIOpen / rocBLAS rows and the 3-channel kernels.  Full CSV: `{tag}_bench_kernel_stats.csv`; bench line of the",
@@ -54,8 +56,8 @@ out += ["",
         f"algorithmic = {100 * ro['frac']:.2f} % of HBM peak; K6 {ro['other']['render_forward_ms'] * 1e3:.1f} us = {ro['other']['render_forward_GBps']} GB/s).",
         f"Per fused tracking iteration (us): fused_preprocess {f1:.1f} + render_forward<6,8,sort,+tracking loss> {k6t:.1f} + render_backward<6,8,15,8> {k7t:.1f} +",
         f"fused_backward {f6:.1f} + pose_finish {f7:.1f} + adam_pose {ap:.1f} = {f1 + k6t + k7t + f6 + f7 + ap:.0f} -> {d['tracking_iters_per_s']:.0f} iterations/s measured; mapping: {f1:.1f} +",
-        f"render_forward<6,8,sort> {k6s:.1f} + ssim {f4:.1f} + map_loss_backward {f5:.1f} + render_backward {k7m:.1f} + {f6:.1f} + {f7:.1f} + adam_map {am:.1f} = "
-        f"{f1 + k6s + f4 + f5 + k7m + f6 + f7 + am:.0f} -> {d['mapping_iters_per_s']:.0f} iterations/s.",
+        f"render_forward<6,8,sort> {k6s:.1f} + ssim {f4:.1f} + map_loss_backward {f5:.1f} + render_backward {k7m:.1f} + fused_backward<Adam> {f6m:.1f} + {f7:.1f} = "
+        f"{f1 + k6s + f4 + f5 + k7m + f6m + f7:.0f} -> {d['mapping_iters_per_s']:.0f} iterations/s (adam_map as a kernel of its own, {am:.1f} us, only in the exchanged / batched step).",
         "GPU-bound, no host gaps, no memset launches.\n"]
 sl = d.get("slam_loop")
 if sl:
