@@ -45,6 +45,9 @@ WORKLOADS = {
     "E": (1_000_000, 1752, 1168, 1200.0, 1200.0, 875.5, 583.5),  # /root/reference/datasets/gradslam_datasets/scannetpp.py:28-29
     # SURVEY.md 8(d) stress variants of E: every Gaussian inside 5 % of the image -> per-tile lists of ~5 000 (1 M) / ~25 000 (5 M)
     # entries, far beyond the 4 096 keys one workgroup sorts in LDS ("per-tile Gaussian list spilling HBM", BASELINE config 5)
+    # B at four times the frame and the Gaussians (same density: the same per-tile work over 4x the tiles): what launch ramp /
+    # tail effects cost the composites at B (profiles/r02_experiments.md)
+    "B-4x": (1_200_000, 2400, 1360, 600.0, 600.0, 1199.5, 679.5),
     "E-clustered": (1_000_000, 1752, 1168, 1200.0, 1200.0, 875.5, 583.5),
     "E-clustered-5M": (5_000_000, 1752, 1168, 1200.0, 1200.0, 875.5, 583.5),
 }

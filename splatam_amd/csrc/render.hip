@@ -363,13 +363,17 @@ __global__ __launch_bounds__(256, 6) void render_forward_kernel(SplatCamera cam,
             __syncthreads();
             n = s_n;
             if (tid == 0) {
-                st.tile_count[(size_t)tile * SPLAT_COUNTER_STRIDE] = (unsigned)n;
+                // (a count that is flagged below is published CLAMPED: the backward composite must not walk past the published ids)
+                st.tile_count[(size_t)tile * SPLAT_COUNTER_STRIDE] = (unsigned)min(n, min(st.tile_stride, kFusedSortMax));
                 if (n > st.tile_stride) st.status[1] = 1;         // the published list would not fit its bucket
             }
             n = min(n, st.tile_stride);
         }
         if (n > kFusedSortMax) {        // the host's list-length hint was stale: flag it (the host repeats the iteration)
-            if (tid == 0) st.status[3] = 1;
+            if (tid == 0) {
+                st.status[3] = 1;
+                if (st.tile_stride > 0) st.tile_count[(size_t)tile * SPLAT_COUNTER_STRIDE] = (unsigned)kFusedSortMax;    // (see above)
+            }
             n = kFusedSortMax;
         }
         if (st.group_stride == 0)

@@ -563,3 +563,40 @@ def test_mapping_step_in_one_call_equals_loss_backward_plus_adam(aniso):
         dv = (e1.exp_avg_sq[k] - e2.exp_avg_sq[k]).abs()
         assert float(dv.max()) <= 2e-3 * float(e2.exp_avg_sq[k].abs().max()), k
     assert torch.equal(e1.params['cam_trans'], e2.params['cam_trans'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("groups", [False, True])
+def test_stale_hint_with_bucketed_lists_is_flagged_and_memory_safe(groups):
+    """Bucketed lists (and group records) whose host statistics have gone stale: tiles with more instances than the composite can
+    sort itself (1 024) while the hint still says "short".  The composite truncates, flags the iteration for a re-run, and publishes
+    the CLAMPED count -- the backward composite must never walk into list slots nobody wrote (poisoned here, as re-used allocator
+    memory would be)."""
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    params, variables, frame, cam = _scene(60000, 96, 64, seed=11)       # dense: several thousand instances per tile
+    eng = FusedEngine(params, cam)
+    eng.group_bins = groups
+    cfg = slam.REPLICA_MAPPING
+    eng.loss_backward(frame, 1, cfg, tracking=False)
+    torch.cuda.synchronize()
+    assert not eng.check_overflow()
+    assert eng.max_list_hint > 1024
+    good, good_loss = eng.grads['means3D'].clone(), eng.loss()
+    # stale statistics: "no list is longer than 100", buckets of 1 536 slots
+    eng.max_list_hint, eng.tile_stride = 100, 1536
+    if eng.tile_stride * eng.num_tiles > eng.capacity:
+        eng._alloc_lists(eng.tile_stride * eng.num_tiles)
+    eng.buf['point_list'].fill_(0x7f7f7f7f)
+    eng.buf['keys'].fill_(0x7f7f7f7f7f7f7f7f)
+    eng.loss_backward(frame, 1, cfg, tracking=False)
+    torch.cuda.synchronize()                                            # no memory fault
+    ws = eng._workspace(False, with_ssim=False)
+    assert (ws.st.group_stride > 0) == groups
+    assert eng.check_overflow()                                          # ... and the iteration is reported as invalid
+    for _ in range(2):
+        eng.loss_backward(frame, 1, cfg, tracking=False)                 # statistics reset by check_overflow: exact lists again
+        torch.cuda.synchronize()
+        assert not eng.check_overflow()
+    assert abs(eng.loss() - good_loss) <= 1e-5 * abs(good_loss)
+    _cmp(eng.grads['means3D'], good, "dL/dmeans3D after recovery", tol=1e-4)
