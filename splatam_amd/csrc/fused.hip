@@ -659,15 +659,18 @@ __global__ __launch_bounds__(256) void pose_finish_kernel(FusedArgs a, int HW, P
 // thread has just formed -- parameters, gradients and moments of a Gaussian are touched once instead of in a second kernel
 // (+1.3 % mapping iterations/s at B).  Folding F7 into the last workgroup to finish (a ticket) was measured too: no gain, the
 // tail is as long as the separate launch.
-template <bool ADAM>
+// MAPGRADS = false (tracking: no per-Gaussian gradient is stored): only the camera partial sums are wanted, and with ISO (Sigma =
+// s^2 I in any camera frame) they depend on dL/dX_c alone -- the covariance adjoints fall away at compile time.
+template <bool ADAM, bool MAPGRADS, bool ISO>
 __global__ __launch_bounds__(kBlock) void fused_backward_kernel(FusedArgs a, SplatAdamMap opt) {
+    static_assert(MAPGRADS || !ADAM, "the Adam step consumes the map gradients");
     __shared__ double s_part[kPoseSums * (kBlock / 64)];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     float pose[kPoseSums];
 #pragma unroll
     for (int k = 0; k < kPoseSums; ++k) pose[k] = 0.f;
     const SplatIterWorkspace &ws = a.ws;
-    const bool iso = a.map.isotropic != 0;
+    constexpr bool iso = ISO;
     if (i < a.map.P) {
         const bool vis = ws.st.radii[i] > 0;
         float dp[3] = {0.f, 0.f, 0.f}, du[4] = {0.f, 0.f, 0.f, 0.f}, dlogit = 0.f, dls[3] = {0.f, 0.f, 0.f};
@@ -694,14 +697,15 @@ __global__ __launch_bounds__(kBlock) void fused_backward_kernel(FusedArgs a, Spl
             const float4 co = reinterpret_cast<const float4 *>(ws.st.conic_opacity)[i];
             const float g_ndc[2] = {-(co.x * acc[0] + co.y * acc[1]) * 0.5f * c.W, -(co.z * acc[1] + co.y * acc[0]) * 0.5f * c.H};
             const float g_conic[3] = {-0.5f * acc[2], -acc[3], -0.5f * acc[4]};
-            float dXc[3], dS6[6], ds[3], drq[4];
+            float dXc[3], dS6[6], ds[3] = {0.f, 0.f, 0.f}, drq[4] = {0.f, 0.f, 0.f, 0.f};
             project_gaussian_backward(c, G.Xc, S6, g_ndc, g_conic, dXc, dS6);
-            cov3d_backward(G.s, c.scale_modifier, G.rq, dS6, ds, drq);
+            if constexpr (MAPGRADS || !ISO) cov3d_backward(G.s, c.scale_modifier, G.rq, dS6, ds, drq);
             // colour channels: 6..8 rgb, 9 z, 10 silhouette (constant), 11 z^2
             drgb[0] = acc[6]; drgb[1] = acc[7]; drgb[2] = acc[8];
             const float dz = acc[9] + 2.f * G.z * acc[11];
             glue_backward(P, a.frame.w2c + 8, p, iso, G, dXc, dz, acc[5], ds, drq, dp, du, &dlogit, dls, pose);
         }
+        if constexpr (MAPGRADS) {
         if (a.cfg.gaussians_grad) {
             if (ws.d_means3D) { ws.d_means3D[3 * i] = dp[0]; ws.d_means3D[3 * i + 1] = dp[1]; ws.d_means3D[3 * i + 2] = dp[2]; }
             // isotropic map: Sigma = s^2 I does not depend on the quaternion -- the derivative is exactly zero (what autograd
@@ -714,6 +718,7 @@ __global__ __launch_bounds__(kBlock) void fused_backward_kernel(FusedArgs a, Spl
         if (ws.d_log_scales) {
             if (iso) ws.d_log_scales[i] = dls[0];
             else { ws.d_log_scales[3 * i] = dls[0]; ws.d_log_scales[3 * i + 1] = dls[1]; ws.d_log_scales[3 * i + 2] = dls[2]; }
+        }
         }
         if constexpr (ADAM) {
             // torch.optim.Adam over every row (a Gaussian outside the view has a zero gradient, but its moments still move it)
@@ -895,8 +900,18 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
     if (pose_adam)
         pa = PoseAdam{pose_adam->state, pose_adam->beta1, pose_adam->beta2, pose_adam->eps, pose_adam->bc2_sqrt, pose_adam->step_size_rot,
                       pose_adam->step_size_trans};
-    if (P > 0 && map_adam) hipLaunchKernelGGL(fused_backward_kernel<true>, dim3(gblocks), dim3(kBlock), 0, s, a, *map_adam);
-    else if (P > 0) hipLaunchKernelGGL(fused_backward_kernel<false>, dim3(gblocks), dim3(kBlock), 0, s, a, SplatAdamMap{});
+    if (P > 0) {
+        const bool iso = map.isotropic != 0;
+        const bool mapgrads = ws.d_means3D || ws.d_rgb_colors || ws.d_unnorm_rotations || ws.d_logit_opacities || ws.d_log_scales;
+        const SplatAdamMap opt = map_adam ? *map_adam : SplatAdamMap{};
+        const dim3 grid(gblocks), block(kBlock);
+        if (map_adam && iso) hipLaunchKernelGGL((fused_backward_kernel<true, true, true>), grid, block, 0, s, a, opt);
+        else if (map_adam) hipLaunchKernelGGL((fused_backward_kernel<true, true, false>), grid, block, 0, s, a, opt);
+        else if (mapgrads && iso) hipLaunchKernelGGL((fused_backward_kernel<false, true, true>), grid, block, 0, s, a, opt);
+        else if (mapgrads) hipLaunchKernelGGL((fused_backward_kernel<false, true, false>), grid, block, 0, s, a, opt);
+        else if (iso) hipLaunchKernelGGL((fused_backward_kernel<false, false, true>), grid, block, 0, s, a, opt);
+        else hipLaunchKernelGGL((fused_backward_kernel<false, false, false>), grid, block, 0, s, a, opt);
+    }
     hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(256), 0, s, a, HW, pa);
     return hipGetLastError();
 }
