@@ -32,8 +32,8 @@ k7t = avg("render_backward_kernel5<6, 8, 15u, 8u") or avg("render_backward_kerne
 k6s = avg("render_forward_kernel<6, 8, false, true, false>") or avg("render_forward_kernel<6, 8, false, true>")
 k6t = avg("render_forward_kernel<6, 8, false, true, true>")
 f1, f4, f5 = avg("fused_preprocess_kernel<2") or avg("fused_preprocess"), avg("ssim_forward"), avg("map_loss_backward")
-f6 = avg("fused_backward_kernel<false>") or avg("fused_backward_kernel")          # tracking (and exchanged mapping) form
-f6m = avg("fused_backward_kernel<true>") or f6                                    # single-view mapping step: Adam inside
+f6 = avg("fused_backward_kernel<false, false") or avg("fused_backward_kernel<false>") or avg("fused_backward_kernel")   # tracking form
+f6m = avg("fused_backward_kernel<true") or f6                                     # single-view mapping step: Adam inside
 f7, ap, am = avg("pose_finish"), avg("adam_pose"), avg("adam_map")
 out = [f"# `{tag}`: group binning (one record per Gaussian and 2x2-tile group through an LDS histogram; the forward composite filters, sorts and",
        "publishes its tile's list), generation-5 backward composite, Adam of the map inside F6 for the single-view mapping step\n",
