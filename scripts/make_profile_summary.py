@@ -28,7 +28,7 @@ def avg(sub):
 
 
 k7m = avg("render_backward_kernel5<6, 8, 15u, 15u") or avg("render_backward_kernel<6, 8, 15u, 15u")
-k7t = avg("render_backward_kernel5<6, 8, 15u, 8u") or avg("render_backward_kernel<6, 8, 15u, 8u")
+k7t = avg("render_backward_kernel5_w5<6, 8, 15u, 8u") or avg("render_backward_kernel5<6, 8, 15u, 8u") or avg("render_backward_kernel<6, 8, 15u, 8u")
 k6s = avg("render_forward_kernel<6, 8, false, true, false>") or avg("render_forward_kernel<6, 8, false, true>")
 k6t = avg("render_forward_kernel<6, 8, false, true, true>")
 f1, f4, f5 = avg("fused_preprocess_kernel<2") or avg("fused_preprocess"), avg("ssim_forward"), avg("map_loss_backward")

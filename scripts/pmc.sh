@@ -22,7 +22,7 @@ for r in rows:
     k = r.get('Kernel_Name', '')
     if 'splat' not in k:
         continue
-    m = re.search(r'([A-Za-z_0-9]+_kernel[0-9]*(?:<[^>]*>)?)', k)
+    m = re.search(r'([A-Za-z_0-9]+_kernel[0-9]*(?:_w[0-9])?(?:<[^>]*>)?)', k)
     acc[m.group(1) if m else k[:56]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in acc.items():
     print(k, ' '.join(f"{c}={sum(v)/len(v):.4g}" for c, v in sorted(d.items())), f"(n={len(next(iter(d.values())))})")

@@ -27,7 +27,7 @@ for line in open(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}.txt")):
         d[k] = float(v)
 if stats:
     for r in csv.DictReader(open(stats)):
-        m = re.search(r"([A-Za-z_0-9]+_kernel[0-9]*(?:<[^>]*>)?)", r["Name"])
+        m = re.search(r"([A-Za-z_0-9]+_kernel[0-9]*(?:_w[0-9])?(?:<[^>]*>)?)", r["Name"])
         if m and m.group(1) in kern:
             kern[m.group(1)]["avg_us"] = float(r["AverageNs"]) / 1e3
             kern[m.group(1)]["calls"] = int(r["Calls"])

@@ -572,9 +572,9 @@ __device__ __forceinline__ float group8_allreduce_add(float v) {
     return v;
 }
 
-template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC = true, bool BG = true>
-__global__ __launch_bounds__(256) void render_backward_kernel5(SplatCamera cam, const float *colors, SplatState st,
-                                                               const float *dL_dcolor, float *accum, int T, int per_xcd) {
+template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC, bool BG>
+__device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, const float *colors, const SplatState &st,
+                                                      const float *dL_dcolor, float *accum, int T, int per_xcd) {
     constexpr int CL = highest_set_bit(DMASK) + 1;        // colour channels staged per Gaussian: only those that carry gradient
     static_assert(CL >= 1 && CL <= C, "DMASK names channels of the call");
     constexpr int FP = (CL + 3) / 4 * 4;
@@ -620,7 +620,12 @@ __global__ __launch_bounds__(256) void render_backward_kernel5(SplatCamera cam, 
     const int v2 = lane >> 3, s2 = lane & 7;
     constexpr int NS4 = NS > 0 ? (NS + 3) / 4 : 1;              // float4 per pixel in the table
     constexpr bool kRowRegs = NS <= 2;
-    __shared__ float4 s_dtab[4][8 * (8 * NS4 + 1)];
+    // (with the rows in registers the table is only a transposition buffer at start-up: it then borrows the pair buffer, which is
+    //  first written by the first visit -- 4.6 KB less LDS, a fifth workgroup per CU)
+    constexpr int kTabWave = 8 * (8 * NS4 + 1);
+    static_assert(!kRowRegs || sizeof(float4) * kTabWave <= sizeof(PB.vw[0]), "the start-up table fits one wave's pair buffer");
+    __shared__ float4 s_dtab[kRowRegs ? 1 : 4 * kTabWave];
+    float4 *const my_tab = kRowRegs ? reinterpret_cast<float4 *>(PB.vw[wave]) : s_dtab + wave * kTabWave;
     {
         float t[NS4 * 4];
 #pragma unroll
@@ -631,9 +636,9 @@ __global__ __launch_bounds__(256) void render_backward_kernel5(SplatCamera cam, 
         }
 #pragma unroll
         for (int q = 0; q < NS4; ++q)
-            s_dtab[wave][(lane >> 3) * (8 * NS4 + 1) + (lane & 7) * NS4 + q] = make_float4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+            my_tab[(lane >> 3) * (8 * NS4 + 1) + (lane & 7) * NS4 + q] = make_float4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
     }
-    const float4 *const my_drow = s_dtab[wave] + s2 * (8 * NS4 + 1);
+    const float4 *const my_drow = my_tab + s2 * (8 * NS4 + 1);
     float drow[kRowRegs && NS > 0 ? NS : 1][8];
     if constexpr (kRowRegs && NS > 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -855,6 +860,21 @@ __global__ __launch_bounds__(256) void render_backward_kernel5(SplatCamera cam, 
     }
 }
 
+// Two launch shapes of the same body.  With at most two colour sums (the tracking form) the phase-2 gradient rows live in registers: the
+// kernel fits 96 VGPRs and 31 KB of LDS -> FIVE workgroups per CU (tracking +2.3 % at B); the mapping form (120 VGPRs, 35.7 KB) stays
+// at four with the compiler's own register budget (an explicit minimum of four waves made it 2 % slower).
+template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC = true, bool BG = true>
+__global__ __launch_bounds__(256) void render_backward_kernel5(SplatCamera cam, const float *colors, SplatState st, const float *dL_dcolor,
+                                                               float *accum, int T, int per_xcd) {
+    render_backward_body5<C, CS, DMASK, SMASK, OPAC, BG>(cam, colors, st, dL_dcolor, accum, T, per_xcd);
+}
+template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC = true, bool BG = true>
+__global__ __launch_bounds__(256, 5) void render_backward_kernel5_w5(SplatCamera cam, const float *colors, SplatState st,
+                                                                     const float *dL_dcolor, float *accum, int T, int per_xcd) {
+    static_assert(popcount_c(SMASK) <= 2, "the five-wave shape is for the forms whose gradient rows live in registers");
+    render_backward_body5<C, CS, DMASK, SMASK, OPAC, BG>(cam, colors, st, dL_dcolor, accum, T, per_xcd);
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
@@ -882,7 +902,10 @@ static void launch_bwd(const SplatCamera &cam, const float *colors, const SplatS
         return;
     }
 #endif
-    hipLaunchKernelGGL((render_backward_kernel5<C, CS, DMASK, SMASK, OPAC, BG>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
+    if constexpr (popcount_c(SMASK) <= 2)
+        hipLaunchKernelGGL((render_backward_kernel5_w5<C, CS, DMASK, SMASK, OPAC, BG>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
+    else
+        hipLaunchKernelGGL((render_backward_kernel5<C, CS, DMASK, SMASK, OPAC, BG>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
 }
 
 static const float *colour_source(const SplatGaussians &g, const SplatState &st) {
@@ -989,7 +1012,7 @@ hipError_t launch_render_backward_rgb_only(const SplatCamera &cam, const float *
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
     if (T == 0 || P == 0) return hipSuccess;
     const int per = (T + 7) / 8;
-    hipLaunchKernelGGL((render_backward_kernel5<6, 8, 0x7u, 0x0u, false, false>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, dL_dout6, accum, T, per);
+    hipLaunchKernelGGL((render_backward_kernel5_w5<6, 8, 0x7u, 0x0u, false, false>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, dL_dout6, accum, T, per);
     return hipGetLastError();
 }
 
