@@ -108,9 +108,11 @@ def run_steps_fused(eng, frames, rank, world, nsteps, start=0):
     n_views = len(frames) - 1
 
     from splatam_amd.dist import all_reduce_mean_flat as allreduce
+    from splatam_amd.dist import all_reduce_sum_flat as allreduce_sums
     for i in range(start, start + nsteps):
         if i % 5 < 2:
-            eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING)
+            # several ranks: the frame's tile rows are sharded over them (one 16 KB all-reduce of the partial sums per iteration)
+            eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING, shard=(rank, world) if world > 1 else None, allreduce_sums=allreduce_sums)
         else:
             view = 2 + (rank + i * world) % n_views
             eng.mapping_iteration(frames[view], view, slam.REPLICA_MAPPING, allreduce if world > 1 else None)
@@ -466,6 +468,8 @@ def main():
         # sort launch), the last ones already run the learnt configuration -- whose buffers are allocated there, not in the timed region
         w0 = max(args.warmup - 3, 0)
         steps(w0, 0)
+        if world > 1 and not mode_c:        # (the list statistics are learnt from a whole-frame iteration; a sharded tracking step covers a band)
+            eng.loss_backward(frames[2], 2, slam.REPLICA_MAPPING, tracking=False)
         if eng.check_overflow():
             raise SystemExit("instance lists overflowed during warm-up")
         steps(args.warmup - w0, w0)
@@ -528,7 +532,8 @@ def main():
     # per-phase rates (rank-local, informational)
     n_phase = max(5, min(40, args.steps))
     if fused:
-        track_rate = phase_rate(lambda: eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING), n_phase, dev)
+        track_rate = phase_rate(lambda: eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING, shard=(rank, world) if world > 1 else None,
+                                                               allreduce_sums=sdist.all_reduce_sum_flat), n_phase, dev)
         map_rate = phase_rate(lambda: eng.mapping_iteration(frames[2], 2, slam.REPLICA_MAPPING), n_phase, dev)
     n_drop = max(5, min(15, args.steps))
     if fused:       # the drop-in path has not run yet: MIOpen / rocBLAS pick their kernels on the first calls
@@ -563,7 +568,8 @@ def main():
             "config": {"workload": wl,
                        "gaussians": N, "width": W, "height": H, "views": args.views, "sync_mode": args.sync_mode, "engine": args.engine,
                        "parallelism": ("1 process/GPU; 8 views per step sharded over the ranks, gradients accumulated per rank, one all-reduce (sum), identical Adam step"
-                                       if mode_c else "1 process/GPU; mapping: one view per rank per step, one gradient all-reduce (mean); tracking: replicas, counted once")},
+                                       if mode_c else ("1 process/GPU; mapping: one view per rank per step, one gradient all-reduce (mean); tracking: the frame's tile rows sharded over the "
+                                             "ranks, one all-reduce of the partial sums per iteration, counted once" if world > 1 else "1 process/GPU"))},
             "sustained": ({"steps": n_sus, "seconds": round(sustained_s, 3), "iters_per_s": round(units(n_sus) / sustained_s, 3)} if sustained_ok
                           else {"steps": n_sus, "invalid": "a per-tile list outgrew its bucket during the sustained region"}),
             "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4),

@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define SPLAT_ABI_VERSION 5        /* 5: SplatState.group_count / group_recs / group_stride (group binning), splat_iter_mapping_step; 4: densification (splat_iter_means2d_accumulate, splat_map_densify_select / _duplicate);
+#define SPLAT_ABI_VERSION 6        /* 6: SplatState.tile_row_begin / _end, SplatLossConfig.defer_finish, splat_iter_finish (tile-row-sharded tracking);
+                                      5: SplatState.group_count / group_recs / group_stride (group binning), splat_iter_mapping_step; 4: densification (splat_iter_means2d_accumulate, splat_map_densify_select / _duplicate);
                                       3: SplatState.keys_alt / long_base (multi-workgroup sort of lists beyond LDS); 2: map edits,
                                       splat_iter_render / _tracking_step, outlier scratch in SplatIterWorkspace */
 #define SPLAT_TILE 16            /* tile edge in pixels (one 256-thread workgroup per tile, one wave64 per 8x8 quadrant) */
@@ -126,6 +127,12 @@ typedef struct SplatState {
                                     receives more than `stride` instances sets status[1] and is truncated */
     int32_t group_stride;        /* > 0 (with group_count, group_recs, tile_stride > 0 and 0 < max_list_hint <= 819): group binning,
                                     records per group bucket (>= SPLAT_GROUP_TILES^2 * tile_stride can never overflow first) */
+    /* fused iteration only: composite just the tile ROWS [tile_row_begin, tile_row_end) of the frame (0, 0 = all).  The
+     * per-Gaussian kernels still run over the whole map; lists, planes, per-pixel state and loss sums are produced for those
+     * rows only, and the per-Gaussian partial sums (hence the pose sums) hold those rows' share.  This is how the tracking
+     * iteration shards over GPUs: every quantity the pose gradient needs is a SUM over pixels, so the ranks' copies of
+     * SplatIterWorkspace.sums add up to the whole frame's (one all-reduce of 16 KB per iteration; splat_iter_finish) */
+    int32_t tile_row_begin, tile_row_end;
     /* per-pixel */
     float *final_T;              /* [H][W] */
     int32_t *n_contrib;          /* [H][W] 1-based list position of the last contributor */
@@ -250,6 +257,8 @@ typedef struct SplatLossConfig {
     int32_t ignore_outlier_depth_loss;
     float w_im;                  /* loss_weights['im'] */
     float w_depth;               /* loss_weights['depth'] */
+    int32_t defer_finish;        /* 1: stop before the last kernel (pose gradient, loss value, pose Adam step): the caller completes the
+                                    partial sums (all-reduce over the ranks that composited other tile rows) and calls splat_iter_finish */
 } SplatLossConfig;
 
 #define SPLAT_ITER_SUMS 32       /* doubles per copy of the partial sums */
@@ -319,6 +328,13 @@ typedef struct SplatPoseAdam {
 } SplatPoseAdam;
 int splat_iter_tracking_step(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame,
                              const SplatLossConfig *cfg, SplatIterWorkspace *ws, const SplatPoseAdam *adam, void *stream);
+
+/* The last kernel of an iteration whose splat_iter_loss_backward / splat_iter_tracking_step ran with cfg->defer_finish: totals
+ * ws->sums into ws->d_cam (pose gradient, loss), resets them, and takes the pose's Adam step when `adam` is given (as
+ * splat_iter_tracking_step would have).  Tile-row-sharded tracking: all-reduce ws->sums (SPLAT_ITER_SUM_COPIES x SPLAT_ITER_SUMS
+ * doubles, sum) over the ranks between the two calls; every rank then holds the same sums and takes the same step. */
+int splat_iter_finish(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame, const SplatLossConfig *cfg,
+                      SplatIterWorkspace *ws, const SplatPoseAdam *adam, void *stream);
 
 /* One whole single-view mapping iteration (/root/reference/scripts/splatam.py:846-863: get_loss, backward, optimizer.step) in
  * one call: splat_iter_loss_backward with cfg->tracking clear, with splat_iter_adam_map folded into its last kernel (every

@@ -18,7 +18,7 @@ SPLAT_MAX_CHANNELS = 8
 SPLAT_GRAD_STRIDE = 16
 SPLAT_COUNTER_STRIDE = 32
 SPLAT_GROUP_TILES = 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -45,7 +45,7 @@ class SplatState(C.Structure):
                 ("keys", _fp), ("point_list", _fp), ("capacity", C.c_int64), ("keys_alt", _fp), ("long_base", _fp),
                 ("group_count", _fp), ("group_recs", _fp),
                 ("max_list_hint", C.c_int32), ("order_hint", C.c_int32), ("sub_bins", C.c_int32), ("tile_stride", C.c_int32),
-                ("group_stride", C.c_int32),
+                ("group_stride", C.c_int32), ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),
                 ("final_T", _fp), ("n_contrib", _fp), ("status", _fp)]
 
 
@@ -68,7 +68,8 @@ class SplatFrameData(C.Structure):
 class SplatLossConfig(C.Structure):
     _fields_ = [("tracking", C.c_int32), ("camera_grad", C.c_int32), ("gaussians_grad", C.c_int32),
                 ("use_sil_for_loss", C.c_int32), ("sil_thres", C.c_float), ("use_l1", C.c_int32),
-                ("ignore_outlier_depth_loss", C.c_int32), ("w_im", C.c_float), ("w_depth", C.c_float)]
+                ("ignore_outlier_depth_loss", C.c_int32), ("w_im", C.c_float), ("w_depth", C.c_float),
+                ("defer_finish", C.c_int32)]
 
 
 class SplatIterWorkspace(C.Structure):
@@ -123,7 +124,7 @@ EXPORTS = (
     "splat_render_backward", "splat_preprocess_backward", "splat_backward",
     "splat_mark_visible", "splat_time_kernel", "splat_debug_option",
     "splat_iter_loss_backward", "splat_iter_adam_map", "splat_iter_adam_pose", "splat_iter_time_kernel",
-    "splat_iter_tracking_step", "splat_iter_mapping_step", "splat_iter_render", "splat_map_scratch_words", "splat_map_row_floats", "splat_map_add_new_gaussians", "splat_map_prune",
+    "splat_iter_tracking_step", "splat_iter_mapping_step", "splat_iter_finish", "splat_iter_render", "splat_map_scratch_words", "splat_map_row_floats", "splat_map_add_new_gaussians", "splat_map_prune",
     "splat_iter_means2d_accumulate", "splat_map_densify_select", "splat_map_duplicate",
 )
 
@@ -181,6 +182,9 @@ def lib():
     L.splat_iter_mapping_step.restype = C.c_int
     L.splat_iter_mapping_step.argtypes = [cam, C.POINTER(SplatMap), C.POINTER(SplatFrameData), C.POINTER(SplatLossConfig),
                                           C.POINTER(SplatIterWorkspace), C.POINTER(SplatAdamMap), _fp]
+    L.splat_iter_finish.restype = C.c_int
+    L.splat_iter_finish.argtypes = [cam, C.POINTER(SplatMap), C.POINTER(SplatFrameData), C.POINTER(SplatLossConfig),
+                                    C.POINTER(SplatIterWorkspace), C.POINTER(SplatPoseAdam), _fp]
     L.splat_iter_render.restype = C.c_int
     L.splat_iter_render.argtypes = [cam, C.POINTER(SplatMap), C.POINTER(SplatFrameData), C.POINTER(SplatIterWorkspace), _fp]
     L.splat_map_scratch_words.restype = C.c_size_t

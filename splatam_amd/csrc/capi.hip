@@ -155,6 +155,10 @@ static int iter_loss_backward_impl(const SplatCamera *cam, const SplatMap *map, 
         return SPLAT_E_INVALID;
     if (!ws->out6 || !ws->dL_dout6 || !ws->sums || !ws->d_cam) return SPLAT_E_INVALID;
     if (!cfg->tracking && !ws->ssim_maps) return SPLAT_E_INVALID;
+    if (st.tile_row_begin < 0 || st.tile_row_end < 0 || (st.tile_row_end > 0 && st.tile_row_end <= st.tile_row_begin) ||
+        st.tile_row_end > (cam->image_height + SPLAT_TILE - 1) / SPLAT_TILE)
+        return SPLAT_E_INVALID;
+    if (st.tile_row_end > st.tile_row_begin && (!cfg->tracking || cfg->ignore_outlier_depth_loss || map_adam)) return SPLAT_E_INVALID;
     return check(launch_iter_loss_backward(*cam, *map, *frame, *cfg, *ws, (hipStream_t)stream, adam, map_adam));
 }
 
@@ -167,6 +171,15 @@ int splat_iter_tracking_step(const SplatCamera *cam, const SplatMap *map, const 
                              const SplatLossConfig *cfg, SplatIterWorkspace *ws, const SplatPoseAdam *adam, void *stream) {
     if (!cfg || !cfg->tracking || !cfg->camera_grad || !adam || !adam->state) return SPLAT_E_INVALID;
     return iter_loss_backward_impl(cam, map, frame, cfg, ws, adam, stream);
+}
+
+int splat_iter_finish(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame, const SplatLossConfig *cfg,
+                      SplatIterWorkspace *ws, const SplatPoseAdam *adam, void *stream) {
+    if (!cam || !map || !frame || !cfg || !ws || !ws->sums || !ws->d_cam || !ws->st.status) return SPLAT_E_INVALID;
+    if (!map->cam_unnorm_rots || !map->cam_trans || map->num_frames <= 0 || frame->time_idx < 0 || frame->time_idx >= map->num_frames)
+        return SPLAT_E_INVALID;
+    if (adam && !adam->state) return SPLAT_E_INVALID;
+    return check(launch_iter_finish(*cam, *map, *frame, *cfg, *ws, (hipStream_t)stream, adam));
 }
 
 int splat_iter_mapping_step(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame,

@@ -119,6 +119,10 @@ __global__ __launch_bounds__(BLOCK) void fused_preprocess_kernel(FusedArgs a) {
         float S6[6];
         cov3d_from_scale_rot(G.s, c.scale_modifier, G.rq, S6);
         vis = project_gaussian(c, G.Xc, S6, o);
+        if (st.tile_row_end > st.tile_row_begin) {      // a band of tile rows is composited: instances outside it are not filed
+            o.y0 = max(o.y0, st.tile_row_begin);
+            o.y1 = max(o.y0, min(o.y1, st.tile_row_end));
+        }
         st.depth[i] = o.depth;
         reinterpret_cast<float2 *>(st.xy)[i] = make_float2(o.px, o.py);
         reinterpret_cast<float4 *>(st.conic_opacity)[i] = make_float4(o.conic[0], o.conic[1], o.conic[2], G.op);
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(BLOCK) void fused_preprocess_kernel(FusedArgs a) {
     }
     if (st.tile_stride == 0) {
         // exact path: count now, scan + scatter later
-        if (vis)
+        if (vis && o.y1 > o.y0)
             for (int y = o.y0; y < o.y1; ++y)
                 for (int x = o.x0; x < o.x1; ++x) atomicAdd(&st.tile_count[sub_counter(st, y * c.gx + x, i)], 1u);
         return;                                              // (uniform over the launch)
@@ -139,7 +143,8 @@ __global__ __launch_bounds__(BLOCK) void fused_preprocess_kernel(FusedArgs a) {
     if constexpr (GROUP) {
         const unsigned gstride = (unsigned)st.group_stride;
         const int gx0 = o.x0 >> 1, gy0 = o.y0 >> 1;
-        const int gw = vis ? ((o.x1 - 1) >> 1) - gx0 + 1 : 0, ng = vis ? gw * (((o.y1 - 1) >> 1) - gy0 + 1) : 0;
+        const bool filed = vis && o.y1 > o.y0;
+        const int gw = filed ? ((o.x1 - 1) >> 1) - gx0 + 1 : 0, ng = filed ? gw * (((o.y1 - 1) >> 1) - gy0 + 1) : 0;
         unsigned rank[kGroupPerLane];
         const int nh = min(ng, kGroupPerLane);
 #pragma unroll
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(BLOCK) void fused_preprocess_kernel(FusedArgs a) {
     // bucketed path: the returning atomic IS the slot
     const unsigned stride = (unsigned)st.tile_stride;
     const uint64_t key = ((uint64_t)__float_as_uint(o.depth) << 32) | (uint32_t)i;
-    const int w = o.x1 - o.x0, nt = vis ? w * (o.y1 - o.y0) : 0;
+    const int w = o.x1 - o.x0, nt = (vis && o.y1 > o.y0) ? w * (o.y1 - o.y0) : 0;
     bool spilled = false;
     int t_direct = 0;                                       // tiles [t_direct, nt) take their own global atomic
     if constexpr (AGG) {
@@ -870,6 +875,8 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
     TrackLossEpilogue ep{frame.im, frame.depth, ws.dL_dout6, ws.sums, cfg.sil_thres, cfg.w_im, cfg.w_depth, cfg.use_sil_for_loss, cfg.use_l1};
     bool loss_done = false;
     const bool fuse_loss = cfg.tracking && !cfg.ignore_outlier_depth_loss;
+    // a band of tile rows (SplatState.tile_row_begin): only the loss that is formed per tile in the composite's epilogue is defined
+    if (ws.st.tile_row_end > ws.st.tile_row_begin && !fuse_loss) return hipErrorInvalidValue;
     e = launch_render_forward_feat8(cam, ws.feat8, ws.st, ws.out6, sort_in_k6, s, fuse_loss ? &ep : nullptr, fuse_loss ? &loss_done : nullptr);
     if (e != hipSuccess) return e;
     if (cfg.ignore_outlier_depth_loss) {
@@ -912,7 +919,19 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
         else if (iso) hipLaunchKernelGGL((fused_backward_kernel<false, false, true>), grid, block, 0, s, a, opt);
         else hipLaunchKernelGGL((fused_backward_kernel<false, false, false>), grid, block, 0, s, a, opt);
     }
-    hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(256), 0, s, a, HW, pa);
+    if (!cfg.defer_finish) hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(256), 0, s, a, HW, pa);
+    return hipGetLastError();
+}
+
+// F7 alone: the end of an iteration that ran with cfg.defer_finish (the caller has completed ws.sums in between)
+hipError_t launch_iter_finish(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame, const SplatLossConfig &cfg,
+                              SplatIterWorkspace &ws, hipStream_t s, const SplatPoseAdam *pose_adam) {
+    FusedArgs a{cam, map, frame, cfg, ws, {}};
+    PoseAdam pa{};
+    if (pose_adam)
+        pa = PoseAdam{pose_adam->state, pose_adam->beta1, pose_adam->beta2, pose_adam->eps, pose_adam->bc2_sqrt, pose_adam->step_size_rot,
+                      pose_adam->step_size_trans};
+    hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(256), 0, s, a, cam.image_width * cam.image_height, pa);
     return hipGetLastError();
 }
 

@@ -314,10 +314,11 @@ __global__ __launch_bounds__(256, 6) void render_forward_kernel(SplatCamera cam,
     constexpr int FP = (F + 3) / 4 * 4;
     __shared__ Batch<FP> B;
     __shared__ __attribute__((aligned(16))) uint64_t s_keys[SORT ? kFusedSortMax + 2 : 2];
-    const int tile = block_tile(per_xcd, T);
-    if (tile < 0) return;
+    const int tile_local = block_tile(per_xcd, T);              // T: tiles of this launch (SplatState.tile_row_begin: a band of tile rows)
+    if (tile_local < 0) return;
     const int W = cam.image_width, H = cam.image_height;
     const int gx = (W + kTile - 1) / kTile;
+    const int tile = tile_local + st.tile_row_begin * gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx = tile % gx, ty = tile / gx;
     const int px = tx * kTile + (wave & 1) * 8 + (lane & 7), py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
@@ -587,10 +588,11 @@ __device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, co
     __shared__ Batch<FP> B;
     __shared__ PairBuf PB;
     __shared__ unsigned s_wmax[4];
-    const int tile = block_tile(per_xcd, T);
-    if (tile < 0) return;
+    const int tile_local = block_tile(per_xcd, T);
+    if (tile_local < 0) return;
     const int W = cam.image_width, H = cam.image_height;
     const int gx = (W + kTile - 1) / kTile;
+    const int tile = tile_local + st.tile_row_begin * gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx = tile % gx, ty = tile / gx;
     const int qx0 = tx * kTile + (wave & 1) * 8, qy0 = ty * kTile + (wave >> 1) * 8;      // this wave's quadrant
@@ -961,9 +963,17 @@ hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &
 }
 
 // Fused-iteration path (fused.hip): 6 channels (r, g, b, z, 1, z^2) read from 8-float records, no separate depth plane.
+// tiles a fused composite launch covers: the whole frame, or the band of tile rows SplatState.tile_row_begin / _end name
+static int launch_tiles(const SplatCamera &cam, const SplatState &st) {
+    const int gx = (cam.image_width + kTile - 1) / kTile;
+    const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
+    if (st.tile_row_end > st.tile_row_begin) return min(T, st.tile_row_end * gx) - st.tile_row_begin * gx;
+    return T;
+}
+
 hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat8, SplatState &st, float *out6, bool sort_in_kernel,
                                        hipStream_t s, const TrackLossEpilogue *ep, bool *ep_done) {
-    const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
+    const int T = launch_tiles(cam, st);
     if (ep_done) *ep_done = false;
     if (T == 0) return hipSuccess;
 #if defined(SPLAT_EXPERIMENTS)
@@ -987,7 +997,7 @@ hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat
 
 hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *feat8, const SplatState &st, const float *dL_dout6,
                                         float *accum, int P, bool zero_accum, bool rgb_sums, hipStream_t s, bool opacity_sum) {
-    const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
+    const int T = launch_tiles(cam, st);
     if (zero_accum) {
         hipError_t e = hipMemsetAsync(accum, 0, sizeof(float) * SPLAT_GRAD_STRIDE * (size_t)P, s);
         if (e != hipSuccess) return e;
@@ -1009,7 +1019,7 @@ hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *fea
 // splat_iter_means2d_accumulate.  `accum` must be zero on entry (the fused iteration leaves it so).
 hipError_t launch_render_backward_rgb_only(const SplatCamera &cam, const float *feat8, const SplatState &st, const float *dL_dout6,
                                            float *accum, int P, hipStream_t s) {
-    const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
+    const int T = launch_tiles(cam, st);
     if (T == 0 || P == 0) return hipSuccess;
     const int per = (T + 7) / 8;
     hipLaunchKernelGGL((render_backward_kernel5_w5<6, 8, 0x7u, 0x0u, false, false>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, dL_dout6, accum, T, per);

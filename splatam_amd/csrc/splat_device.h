@@ -45,6 +45,8 @@ hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *fea
 hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame,
                                      const SplatLossConfig &cfg, SplatIterWorkspace &ws, hipStream_t s, const SplatPoseAdam *pose_adam = nullptr,
                                      const SplatAdamMap *map_adam = nullptr);
+hipError_t launch_iter_finish(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame, const SplatLossConfig &cfg,
+                              SplatIterWorkspace &ws, hipStream_t s, const SplatPoseAdam *pose_adam);
 hipError_t launch_iter_adam_map(const SplatMap &map, const SplatAdamMap &opt, hipStream_t s);
 hipError_t launch_iter_adam_pose(const SplatMap &map, int time_idx, const float *d_cam, float *state, float beta1, float beta2,
                                  float eps, float bc2_sqrt, float ss_rot, float ss_trans, hipStream_t s);

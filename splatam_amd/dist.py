@@ -92,6 +92,23 @@ def all_reduce_sum_flat(flat: torch.Tensor, group=None) -> None:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
 
 
+def any_rank(flag: bool, device=None, group=None) -> bool:
+    """True on every rank when ``flag`` is true on at least one (one tiny all-reduce; a no-op for a single process)."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(int(t[0]))
+
+
+def tile_row_band(tile_rows: int, rank: int, world: int):
+    """Rows [begin, end) of a ``tile_rows``-row tile grid that rank ``rank`` composites in tile-row-sharded tracking: contiguous,
+    disjoint, covering, sizes differing by at most one."""
+    if not 0 <= rank < world or world > tile_rows:
+        raise ValueError(f"cannot give each of {world} ranks a band of a {tile_rows}-row tile grid (rank {rank})")
+    return (rank * tile_rows) // world, ((rank + 1) * tile_rows) // world
+
+
 def shard_views(num_views: int, rank: int, world: int):
     """Indices of the keyframe views rank ``rank`` renders (round-robin)."""
     return list(range(rank, num_views, world))

@@ -109,6 +109,8 @@ class FusedEngine:
         # kernel files one record per 2 x 2-tile group (slots through an LDS histogram) and the composite filters its group's
         # records: ~10x fewer global atomics in the per-Gaussian kernel.  Results do not depend on it
         self.group_bins = True
+        self._tile_rows = None          # (begin, end): the band of tile rows the next iteration composites (tile-row-sharded tracking)
+        self._stats_partial = False     # the last iteration's list statistics cover a band only: check_overflow() does not learn from them
         self.sub_bins = 1               # counters per tile on the exact-list path (16 once lists get very long: SplatState.sub_bins)
         # rows in creation (pixel-scan) order: true for a map this engine grew itself (add_valid_depth_points / add_new_gaussians
         # append per pixel in scan order); callers that hand over such a map may set it.  Only a speed hint (SplatState.order_hint)
@@ -515,6 +517,7 @@ class FusedEngine:
         st.keys_alt, st.long_base = b['keys_alt'].data_ptr(), b['long_base'].data_ptr()
         st.max_list_hint = self.max_list_hint
         st.tile_stride = self.tile_stride
+        st.tile_row_begin, st.tile_row_end = self._tile_rows if self._tile_rows else (0, 0)
         st.group_count, st.group_recs, st.group_stride = b['group_count'].data_ptr(), None, 0
         if self.group_bins and self.tile_stride > 0 and 0 < self.max_list_hint and self.max_list_hint * 5 // 4 <= 1024:
             gs = _capi.SPLAT_GROUP_TILES ** 2 * self.tile_stride
@@ -544,8 +547,9 @@ class FusedEngine:
         return torch.cuda.current_stream(self.dev).cuda_stream
 
     @staticmethod
-    def loss_config(cfg, tracking, do_ba=False):
+    def loss_config(cfg, tracking, do_ba=False, defer_finish=False):
         c = _capi.SplatLossConfig()
+        c.defer_finish = int(defer_finish)
         c.tracking = int(tracking)
         c.camera_grad = int(tracking or do_ba)
         c.gaussians_grad = int(not tracking)
@@ -555,7 +559,8 @@ class FusedEngine:
         return c
 
     # ------------------------------------------------------------------ one iteration
-    def loss_backward(self, curr_data, time_idx, cfg, tracking, map_grads=None, do_ba=False, pose_adam=None, map_adam=None):
+    def loss_backward(self, curr_data, time_idx, cfg, tracking, map_grads=None, do_ba=False, pose_adam=None, map_adam=None,
+                      tile_rows=None):
         """get_loss + backward.  Afterwards (stream order): ``self.grads`` (mapping) and
         ``self.buf['d_cam']`` = [dL/dq_raw(4), dL/dt_raw(3), loss].  ``pose_adam`` (a SplatPoseAdam): the pose's Adam step
         rides in the last kernel (splat_iter_tracking_step); ``map_adam`` (a SplatAdamMap): likewise the map's
@@ -570,7 +575,10 @@ class FusedEngine:
             im, depth, w2c = im.contiguous(), depth.contiguous(), w2c.contiguous()
         fr.im, fr.depth, fr.w2c, fr.time_idx = im.data_ptr(), depth.data_ptr(), w2c.data_ptr(), int(time_idx)
         self._frame_keep = (im, depth, w2c)
-        lc = self.loss_config(cfg, tracking, do_ba)
+        lc = self.loss_config(cfg, tracking, do_ba, defer_finish=tile_rows is not None)
+        self._tile_rows = tile_rows         # a band: the iteration stops before its last kernel (finish_iteration completes it)
+        self._stats_partial = tile_rows is not None
+        self._lc_keep = lc
         if lc.ignore_outlier_depth_loss and 'outlier_err' not in self.buf:       # scratch of the median selection, on first use
             self.buf['outlier_err'] = torch.empty(self.H * self.W, dtype=torch.float32, device=self.dev)
             self.buf['outlier_scratch'] = torch.zeros(int(self.L.splat_map_scratch_words(self.H * self.W)), dtype=torch.int32,
@@ -587,6 +595,23 @@ class FusedEngine:
             else:
                 _capi.check(self.L.splat_iter_loss_backward(C.byref(self._cam), C.byref(m), C.byref(fr), C.byref(lc), C.byref(ws),
                                                             self._stream()), "splat_iter_loss_backward")
+        self._tile_rows = None
+        self._fr_keep = fr
+
+    def finish_iteration(self, pose_adam=None):
+        """The last kernel of an iteration that ran on a band of tile rows (``loss_backward(..., tile_rows=...)``), after the caller
+        has summed ``self.buf['sums']`` over the ranks: pose gradient, loss value and -- with ``pose_adam`` -- the pose's Adam step
+        and the best-candidate bookkeeping (splat_iter_finish)."""
+        ws = self._workspace(False, with_ssim=False)
+        m = self._map_struct()
+        with torch.cuda.device(self.dev):
+            _capi.check(self.L.splat_iter_finish(C.byref(self._cam), C.byref(m), C.byref(self._fr_keep), C.byref(self._lc_keep), C.byref(ws),
+                                                 C.byref(pose_adam) if pose_adam is not None else None, self._stream()), "splat_iter_finish")
+
+    def tile_row_band(self, rank, world):
+        """Rows [begin, end) of the 16-pixel tile grid that rank ``rank`` of ``world`` composites in tile-row-sharded tracking."""
+        from .dist import tile_row_band
+        return tile_row_band((self.H + 15) // 16, rank, world)
 
     def _adam_map_args(self, lrs, beta1=0.9, beta2=0.999, eps=1e-15):
         """The next step of torch.optim.Adam(param_groups, lr=0.0, eps=1e-15) over the five Gaussian groups
@@ -644,15 +669,32 @@ class FusedEngine:
             self.params['cam_unnorm_rots'][0, :, t] = st[15:19]
             self.params['cam_trans'][0, :, t] = st[19:22]
 
-    def tracking_iteration(self, curr_data, cfg):
-        """Loop body of /root/reference/scripts/splatam.py:690-711 for frame ``begin_tracking`` named."""
-        self.pose_step += 1                     # one C call: loss + backward + the pose's Adam step (default betas / eps of torch.optim.Adam)
+    def _pose_adam_args(self, cfg):
+        """The next step of the tracking optimizer (default betas / eps of torch.optim.Adam) as the C ABI takes it."""
+        self.pose_step += 1
         t, beta1, beta2 = self.pose_step, 0.9, 0.999
         bc1, bc2 = 1.0 - beta1 ** t, 1.0 - beta2 ** t
         pa = _capi.SplatPoseAdam()
         pa.state, pa.beta1, pa.beta2, pa.eps, pa.bc2_sqrt = self.buf['pose_state'].data_ptr(), beta1, beta2, 1e-8, math.sqrt(bc2)
         pa.step_size_rot, pa.step_size_trans = cfg['lrs']['cam_unnorm_rots'] / bc1, cfg['lrs']['cam_trans'] / bc1
-        self.loss_backward(curr_data, self.track_time_idx, cfg, tracking=True, pose_adam=pa)
+        return pa
+
+    def tracking_iteration(self, curr_data, cfg, shard=None, allreduce_sums=None):
+        """Loop body of /root/reference/scripts/splatam.py:690-711 for frame ``begin_tracking`` named.
+
+        ``shard = (rank, world)``: tile-row-sharded tracking over ``world`` processes holding the same map and pose -- this rank
+        composites its band of tile rows only (forward, loss, backward: every term of the loss and of the pose gradient is a sum
+        over pixels), ``allreduce_sums`` sums the 16 KB of partial sums over the ranks, and every rank takes the SAME Adam step on
+        the pose (no broadcast needed).  Not with ``ignore_outlier_depth_loss`` (its median sees the whole render)."""
+        pa = self._pose_adam_args(cfg)
+        if shard is None or shard[1] <= 1:
+            self.loss_backward(curr_data, self.track_time_idx, cfg, tracking=True, pose_adam=pa)
+            return
+        if cfg['ignore_outlier_depth_loss']:
+            raise RuntimeError("tile-row-sharded tracking needs a pixel-local loss: not with ignore_outlier_depth_loss")
+        self.loss_backward(curr_data, self.track_time_idx, cfg, tracking=True, tile_rows=self.tile_row_band(*shard))
+        allreduce_sums(self.buf['sums'])
+        self.finish_iteration(pa)
 
     def mapping_iteration(self, iter_data, iter_time_idx, cfg, bucket_allreduce=None):
         """Loop body of /root/reference/scripts/splatam.py:828-869 (without pruning / densification).  Without a gradient
@@ -718,6 +760,8 @@ class FusedEngine:
                 if stat[0] > self.capacity:
                     self._alloc_lists(int(stat[0] * 1.5) + 65536)
             return True
+        if self._stats_partial:                 # the last iteration composited a band of tile rows: its statistics are not the frame's
+            return False
         longest = int(stat[2])
         self.max_list_hint = longest            # short lists: sorted inside the composite, no sort launch
         self._set_sub_bins(16 if longest > 2048 else 1)

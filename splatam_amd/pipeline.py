@@ -316,7 +316,8 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
             pose0 = (params['cam_unnorm_rots'].detach()[..., time_idx].clone(), params['cam_trans'].detach()[..., time_idx].clone())
             for attempt in range(3):
                 n_track = _track_frame(params, variables, curr_data, time_idx, tcfg, eng)
-                if not fused or not eng.check_overflow():
+                # (sharded tracking: a rank's lists cover its band only -- the decision to redo the frame is taken together)
+                if not fused or not sdist.any_rank(eng.check_overflow(), dev):
                     break
                 if attempt == 2:
                     raise RuntimeError(f"frame {time_idx}: the per-tile lists overflowed three times in a row")
@@ -403,9 +404,14 @@ def _track_frame(params, variables, curr_data, time_idx, tcfg, eng):
     else:
         optimizer = slam.initialize_optimizer(params, tcfg['lrs'], tracking=True)
         state = slam.TrackingState(params, time_idx)
+    # several ranks (replicated map and pose): each composites its band of tile rows, the partial sums are all-reduced, every rank
+    # takes the same Adam step on the pose (FusedEngine.tracking_iteration); the outlier-rejecting loss needs the whole render
+    from . import dist as sdist
+    world, rank = sdist.world_size(), sdist.get_rank()
+    shard = (rank, world) if (eng is not None and world > 1 and not tcfg['ignore_outlier_depth_loss']) else None
     while True:
         if eng is not None:
-            eng.tracking_iteration(curr_data, tcfg)
+            eng.tracking_iteration(curr_data, tcfg, shard=shard, allreduce_sums=sdist.all_reduce_sum_flat)
         else:
             loss, _ = slam.tracking_iteration(params, curr_data, variables, time_idx, optimizer, state, tcfg)
         it += 1

@@ -99,3 +99,36 @@ def test_single_process_bucket_is_a_noop(monkeypatch):
     b.all_reduce_mean(params)
     assert all(torch.equal(params[k].grad, torch.ones_like(params[k])) for k in KEYS)
     assert sdist.shard_views(8, 3, 8) == [3] and sdist.shard_views(8, 1, 2) == [1, 3, 5, 7]
+
+
+@pytest.mark.parametrize("rows,world", [(43, 8), (43, 1), (16, 3), (73, 8), (5, 5)])
+def test_tile_row_bands_partition_the_grid(rows, world):
+    """The bands of tile-row-sharded tracking: contiguous, disjoint, covering, balanced to one row."""
+    bands = [sdist.tile_row_band(rows, r, world) for r in range(world)]
+    assert bands[0][0] == 0 and bands[-1][1] == rows
+    assert all(bands[r][1] == bands[r + 1][0] for r in range(world - 1))
+    sizes = [e - b for b, e in bands]
+    assert min(sizes) >= 1 and max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sdist.tile_row_band(rows, 0, rows + 1)
+
+
+def _any_rank_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sdist.init_from_env(backend="gloo")
+    got = [sdist.any_rank(rank == 1), sdist.any_rank(False), sdist.any_rank(True)]
+    sums = torch.full((4,), float(rank + 1), dtype=torch.float64)
+    sdist.all_reduce_sum_flat(sums)                              # the exchange of the tracking iteration's partial sums
+    np.save(os.path.join(out_dir, f"any{rank}.npy"), np.array(got + [float(sums[0])]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_any_rank_and_partial_sum_exchange(tmp_path):
+    assert sdist.any_rank(True) is True and sdist.any_rank(False) is False      # single process: no collective
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_any_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in (0, 1):
+        assert np.load(tmp_path / f"any{r}.npy").tolist() == [1.0, 0.0, 1.0, 3.0]

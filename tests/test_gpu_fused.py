@@ -601,3 +601,49 @@ def test_stale_hint_with_bucketed_lists_is_flagged_and_memory_safe(groups):
         assert not eng.check_overflow()
     assert abs(eng.loss() - good_loss) <= 1e-5 * abs(good_loss)
     _cmp(eng.grads['means3D'], good, "dL/dmeans3D after recovery", tol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lists", ["exact", "learnt"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_row_sharded_tracking_equals_whole_frame_tracking(lists, world):
+    """Tracking sharded over tile rows (SplatState.tile_row_begin / _end, splat_iter_finish): ``world`` engines holding the same map and
+    pose each composite their band of the frame; their partial sums, added (what the all-reduce does), give the whole frame's loss
+    and pose gradient; every rank then takes the same Adam step.  Against the whole-frame tracking loop over four iterations, with the
+    exact lists of a fresh engine and with learnt bucketed lists / group records."""
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    params, variables, frame, cam = _scene(20000, 328, 248, seed=53)        # 21 x 16 tiles: bands of 8 + 8 or 5 + 5 + 6 rows
+    cfg = slam.REPLICA_TRACKING
+
+    def engine():
+        e = FusedEngine({k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}, cam)
+        if lists == "learnt":
+            e.loss_backward(frame, 1, slam.REPLICA_MAPPING, tracking=False)
+            assert not e.check_overflow() and e.tile_stride > 0
+        e.begin_tracking(1)
+        return e
+    full = engine()
+    ranks = [engine() for _ in range(world)]
+    bands = [e.tile_row_band(r, world) for r, e in enumerate(ranks)]
+    assert bands[0][0] == 0 and bands[-1][1] == 16 and all(bands[r][1] == bands[r + 1][0] for r in range(world - 1))
+    for it in range(4):
+        full.tracking_iteration(frame, cfg)
+        for r, e in enumerate(ranks):
+            e.loss_backward(frame, e.track_time_idx, cfg, tracking=True, tile_rows=bands[r])
+        total = sum(e.buf['sums'] for e in ranks)                          # the all-reduce
+        for e in ranks:
+            e.buf['sums'].copy_(total)
+            e.finish_iteration(e._pose_adam_args(cfg))
+        torch.cuda.synchronize()
+        assert abs(ranks[0].loss() - full.loss()) <= 2e-6 * abs(full.loss()), (it, ranks[0].loss(), full.loss())
+        g_full, g_shard = full.buf['d_cam'][:7], ranks[0].buf['d_cam'][:7]
+        assert float((g_full - g_shard).abs().max()) <= 2e-5 * float(g_full.abs().max()), it
+        for e in ranks[1:]:                                                # same sums -> the same step, bit for bit
+            assert torch.equal(e.params['cam_unnorm_rots'], ranks[0].params['cam_unnorm_rots'])
+            assert torch.equal(e.params['cam_trans'], ranks[0].params['cam_trans'])
+        assert not full.check_overflow(grow=False) and all(not e.check_overflow(grow=False) for e in ranks)
+    # Adam normalises the gradient: rounding-level differences of the sums stay rounding-level in the pose
+    assert float((ranks[0].params["cam_trans"].detach() - full.params["cam_trans"].detach()).abs().max()) <= 2e-5
+    assert float((ranks[0].params["cam_unnorm_rots"].detach() - full.params["cam_unnorm_rots"].detach()).abs().max()) <= 2e-5
+    assert float(ranks[0].buf['tile_count'].abs().max()) == 0.0 and float(ranks[0].buf['accum'].abs().max()) == 0.0
