@@ -144,6 +144,9 @@ typedef struct SplatState {
 
 const char *splat_error_string(int code);
 int splat_abi_version(void);
+/* sizeof() of the struct named `name` ("SplatState", "SplatIterWorkspace", ...) as this library was compiled, 0 for an unknown
+ * name: a binding that mirrors the structs by hand (ctypes, cgo, JNA) checks its layout against it at load time. */
+size_t splat_sizeof(const char *name);
 
 /* Bytes of scratch each SplatState array needs; lets a host binding size its
  * buffers the way the reference's resize-callback does. */

@@ -110,6 +110,10 @@ class SplatPoseAdam(C.Structure):
                 ("step_size_rot", C.c_float), ("step_size_trans", C.c_float)]
 
 
+MIRRORED_STRUCTS = (SplatCamera, SplatGaussians, SplatState, SplatGrads, SplatMap, SplatFrameData, SplatLossConfig, SplatIterWorkspace,
+                    SplatAdamMap, SplatMapStore, SplatAddArgs, SplatPruneArgs, SplatDensifyArgs, SplatPoseAdam)
+
+
 SPLAT_ADD_VALID_DEPTH = 0
 SPLAT_ADD_NON_PRESENCE = 1
 SPLAT_DENSIFY_CLONE = 0
@@ -119,7 +123,7 @@ SPLAT_ITER_SUM_COPIES = 64
 SPLAT_POSE_STATE = 24
 
 EXPORTS = (
-    "splat_error_string", "splat_abi_version", "splat_num_tiles",
+    "splat_error_string", "splat_abi_version", "splat_sizeof", "splat_num_tiles",
     "splat_preprocess_forward", "splat_bin_forward", "splat_render_forward", "splat_forward",
     "splat_render_backward", "splat_preprocess_backward", "splat_backward",
     "splat_mark_visible", "splat_time_kernel", "splat_debug_option",
@@ -208,6 +212,12 @@ def lib():
         L.splat_selftest.argtypes = [C.c_int, _fp, _fp, C.c_int, _fp]
     if L.splat_abi_version() != ABI_VERSION:
         raise RuntimeError(f"ABI mismatch: library {L.splat_abi_version()} vs binding {ABI_VERSION}")
+    L.splat_sizeof.restype = C.c_size_t
+    L.splat_sizeof.argtypes = [C.c_char_p]
+    for cls in MIRRORED_STRUCTS:        # the hand-written mirrors against the compiled layout
+        if L.splat_sizeof(cls.__name__.encode()) != C.sizeof(cls):
+            raise RuntimeError(f"struct layout mismatch: {cls.__name__} is {L.splat_sizeof(cls.__name__.encode())} bytes in the library, "
+                               f"{C.sizeof(cls)} in the binding")
     _lib = L
     return L
 

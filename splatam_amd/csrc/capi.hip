@@ -1,4 +1,6 @@
 // capi.hip -- the extern "C" surface declared in include/splat_hip.h.
+#include <cstring>
+
 #include "splat_device.h"
 
 using namespace splat;
@@ -46,6 +48,17 @@ const char *splat_error_string(int code) {
 }
 
 int splat_abi_version(void) { return SPLAT_ABI_VERSION; }
+
+size_t splat_sizeof(const char *name) {
+    if (!name) return 0;
+#define SPLAT_SIZEOF_CASE(T) if (strcmp(name, #T) == 0) return sizeof(T)
+    SPLAT_SIZEOF_CASE(SplatCamera); SPLAT_SIZEOF_CASE(SplatGaussians); SPLAT_SIZEOF_CASE(SplatState); SPLAT_SIZEOF_CASE(SplatGrads);
+    SPLAT_SIZEOF_CASE(SplatMap); SPLAT_SIZEOF_CASE(SplatFrameData); SPLAT_SIZEOF_CASE(SplatLossConfig); SPLAT_SIZEOF_CASE(SplatIterWorkspace);
+    SPLAT_SIZEOF_CASE(SplatAdamMap); SPLAT_SIZEOF_CASE(SplatPoseAdam); SPLAT_SIZEOF_CASE(SplatMapStore); SPLAT_SIZEOF_CASE(SplatAddArgs);
+    SPLAT_SIZEOF_CASE(SplatPruneArgs); SPLAT_SIZEOF_CASE(SplatDensifyArgs);
+#undef SPLAT_SIZEOF_CASE
+    return 0;
+}
 
 size_t splat_num_tiles(int32_t width, int32_t height) {
     if (width <= 0 || height <= 0) return 0;

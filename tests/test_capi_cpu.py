@@ -43,10 +43,18 @@ def _struct_fields(name):
 
 @pytest.mark.parametrize("name", ["SplatCamera", "SplatGaussians", "SplatState", "SplatGrads", "SplatMap", "SplatFrameData",
                                   "SplatLossConfig", "SplatIterWorkspace", "SplatAdamMap", "SplatMapStore", "SplatAddArgs",
-                                  "SplatPruneArgs", "SplatPoseAdam"])
+                                  "SplatPruneArgs", "SplatPoseAdam", "SplatDensifyArgs"])
 def test_ctypes_structs_mirror_header(name):
     from splatam_amd import _capi
     assert [f[0] for f in getattr(_capi, name)._fields_] == _struct_fields(name)
+    # ... and the compiled layout (field types, padding): sizeof as the library sees it
+    assert _capi.lib().splat_sizeof(name.encode()) == C.sizeof(getattr(_capi, name)) > 0
+    assert getattr(_capi, name) in _capi.MIRRORED_STRUCTS
+
+
+def test_sizeof_of_an_unknown_struct_is_zero():
+    from splatam_amd import _capi
+    assert _capi.lib().splat_sizeof(b"NoSuchStruct") == 0 and _capi.lib().splat_sizeof(None) == 0
 
 
 def test_constants_match_header():
