@@ -227,6 +227,7 @@ class FusedEngine:
         w2c = curr_data['w2c'] if curr_data['w2c'].is_contiguous() else curr_data['w2c'].contiguous()
         fr.im, fr.depth, fr.w2c, fr.time_idx = None, None, w2c.data_ptr(), int(time_idx)
         self._frame_keep = (w2c,)
+        self._tile_rows, self._stats_partial = None, False         # a whole-frame render: its list statistics are the frame's
         ws = self._workspace(False, with_ssim=False)
         ws.max_2D_radius = None
         m = self._map_struct()

@@ -643,6 +643,12 @@ def test_tile_row_sharded_tracking_equals_whole_frame_tracking(lists, world):
             assert torch.equal(e.params['cam_unnorm_rots'], ranks[0].params['cam_unnorm_rots'])
             assert torch.equal(e.params['cam_trans'], ranks[0].params['cam_trans'])
         assert not full.check_overflow(grow=False) and all(not e.check_overflow(grow=False) for e in ranks)
+    # a band's list statistics are not the frame's: check_overflow() learns nothing from them, a whole-frame render re-arms it
+    e = ranks[0]
+    hint, stride = e.max_list_hint, e.tile_stride
+    assert e._stats_partial and not e.check_overflow() and (e.max_list_hint, e.tile_stride) == (hint, stride)
+    e.relearn_lists(frame, 1)
+    assert not e._stats_partial and e.tile_stride > 0 and e.max_list_hint > 0
     # Adam normalises the gradient: rounding-level differences of the sums stay rounding-level in the pose
     assert float((ranks[0].params["cam_trans"].detach() - full.params["cam_trans"].detach()).abs().max()) <= 2e-5
     assert float((ranks[0].params["cam_unnorm_rots"].detach() - full.params["cam_unnorm_rots"].detach()).abs().max()) <= 2e-5
