@@ -363,7 +363,8 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
             for attempt in range(3):
                 _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, mcfg, eng,
                            scene_radius if fused else None)
-                if not fused or not eng.check_overflow():
+                # (ranks render different views: whether the frame's mapping is repeated is decided together)
+                if not fused or not sdist.any_rank(eng.check_overflow(), dev):
                     break
                 if attempt == 2:
                     raise RuntimeError(f"frame {time_idx}: the per-tile lists overflowed three times in a row")
