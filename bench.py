@@ -103,6 +103,9 @@ def run_steps(params, variables, frames, bucket, rank, world, nsteps, opt_track,
     return variables
 
 
+SHARD_TRACKING = True       # --replicated-tracking clears it
+
+
 def run_steps_fused(eng, frames, rank, world, nsteps, start=0):
     from splatam_amd import slam
     n_views = len(frames) - 1
@@ -112,7 +115,8 @@ def run_steps_fused(eng, frames, rank, world, nsteps, start=0):
     for i in range(start, start + nsteps):
         if i % 5 < 2:
             # several ranks: the frame's tile rows are sharded over them (one 16 KB all-reduce of the partial sums per iteration)
-            eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING, shard=(rank, world) if world > 1 else None, allreduce_sums=allreduce_sums)
+            eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING, shard=(rank, world) if (world > 1 and SHARD_TRACKING) else None,
+                                   allreduce_sums=allreduce_sums)
         else:
             view = 2 + (rank + i * world) % n_views
             eng.mapping_iteration(frames[view], view, slam.REPLICA_MAPPING, allreduce if world > 1 else None)
@@ -404,7 +408,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-slam-loop", action="store_true", help="skip the informational end-to-end frame-loop figure")
+    ap.add_argument("--replicated-tracking", action="store_true",
+                    help="--gpus N > 1: every rank tracks the whole frame (no exchange) instead of sharding the frame's tile rows over the ranks")
     args = ap.parse_args()
+    global SHARD_TRACKING
+    SHARD_TRACKING = not args.replicated_tracking
 
     from splatam_amd import dist as sdist
     from splatam_amd import rasterizer as rz
@@ -532,7 +540,7 @@ def main():
     # per-phase rates (rank-local, informational)
     n_phase = max(5, min(40, args.steps))
     if fused:
-        track_rate = phase_rate(lambda: eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING, shard=(rank, world) if world > 1 else None,
+        track_rate = phase_rate(lambda: eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING, shard=(rank, world) if (world > 1 and SHARD_TRACKING) else None,
                                                                allreduce_sums=sdist.all_reduce_sum_flat), n_phase, dev)
         map_rate = phase_rate(lambda: eng.mapping_iteration(frames[2], 2, slam.REPLICA_MAPPING), n_phase, dev)
     n_drop = max(5, min(15, args.steps))
@@ -569,7 +577,9 @@ def main():
                        "gaussians": N, "width": W, "height": H, "views": args.views, "sync_mode": args.sync_mode, "engine": args.engine,
                        "parallelism": ("1 process/GPU; 8 views per step sharded over the ranks, gradients accumulated per rank, one all-reduce (sum), identical Adam step"
                                        if mode_c else ("1 process/GPU; mapping: one view per rank per step, one gradient all-reduce (mean); tracking: the frame's tile rows sharded over the "
-                                             "ranks, one all-reduce of the partial sums per iteration, counted once" if world > 1 else "1 process/GPU"))},
+                                             "ranks, one all-reduce of the partial sums per iteration, counted once" if (world > 1 and SHARD_TRACKING) else
+                                            ("1 process/GPU; mapping: one view per rank per step, one gradient all-reduce (mean); tracking: replicas, counted once"
+                                             if world > 1 else "1 process/GPU")))},
             "sustained": ({"steps": n_sus, "seconds": round(sustained_s, 3), "iters_per_s": round(units(n_sus) / sustained_s, 3)} if sustained_ok
                           else {"steps": n_sus, "invalid": "a per-tile list outgrew its bucket during the sustained region"}),
             "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4),
