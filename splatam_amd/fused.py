@@ -109,6 +109,10 @@ class FusedEngine:
         # kernel files one record per 2 x 2-tile group (slots through an LDS histogram) and the composite filters its group's
         # records: ~10x fewer global atomics in the per-Gaussian kernel.  Results do not depend on it
         self.group_bins = True
+        # the Adam step inside F6 touches moments and parameters row by row (12-byte rows: three strided accesses per line); it beats the
+        # separate, fully coalesced adam_map_kernel while the map's rows stay cache resident (F6 + Adam at 300 k rows: 29 us fused vs
+        # 19 + 16 us; at 830 k rows: 96 us fused vs 42 + 42 us, rocprofv3 of the frame loop) -- larger maps take the two-kernel form
+        self.fused_adam_max_rows = 500_000
         self._tile_rows = None          # (begin, end): the band of tile rows the next iteration composites (tile-row-sharded tracking)
         self._stats_partial = False     # the last iteration's list statistics cover a band only: check_overflow() does not learn from them
         self.sub_bins = 1               # counters per tile on the exact-list path (16 once lists get very long: SplatState.sub_bins)
@@ -700,11 +704,12 @@ class FusedEngine:
     def mapping_iteration(self, iter_data, iter_time_idx, cfg, bucket_allreduce=None):
         """Loop body of /root/reference/scripts/splatam.py:828-869 (without pruning / densification).  Without a gradient
         exchange the whole iteration is one C call (the Adam step rides in the last kernel: splat_iter_mapping_step)."""
-        if bucket_allreduce is None:
+        if bucket_allreduce is None and self.P <= self.fused_adam_max_rows:
             self.loss_backward(iter_data, iter_time_idx, cfg, tracking=False, map_adam=self._adam_map_args(cfg['lrs']))
             return
         self.loss_backward(iter_data, iter_time_idx, cfg, tracking=False)
-        bucket_allreduce(self.reduce_flat)          # one collective: 8 (isotropic) or 14 floats per Gaussian
+        if bucket_allreduce is not None:
+            bucket_allreduce(self.reduce_flat)      # one collective: 8 (isotropic) or 14 floats per Gaussian
         self.adam_map(cfg['lrs'])
 
     def mapping_batch(self, views, cfg, total_views=None, allreduce_sum=None):
