@@ -1,18 +1,23 @@
 // fused.hip -- the fused SplaTAM iteration (include/splat_hip.h, "Fused SplaTAM iteration"): the callers on
-// either side of the rasterizer boundary as kernels, so that one optimisation iteration is ~10 launches with no
-// host synchronisation instead of ~150 PyTorch launches + MIOpen convolutions + a GEMM/GEMV pair.
+// either side of the rasterizer boundary as kernels, so that one optimisation iteration is 5 (tracking) or 7 (mapping)
+// launches with no host synchronisation instead of ~150 PyTorch launches + MIOpen convolutions + a GEMM/GEMV pair.
 //
-//   F1 fused_preprocess_kernel   transform_to_frame + both render-variable dicts + K1 (one lane per Gaussian)
-//      K2..K4                    tile scan, scatter, per-tile sort (binning.hip, unchanged)
-//      K6<6 channels>            r, g, b, z, 1, z^2 over shared geometry (render.hip)
-//   F3 track_loss_kernel         tracking: masked L1 sums + dL/d(out6) in one pass over the pixels
+//   F1 fused_preprocess_kernel   transform_to_frame + both render-variable dicts + K1 (one lane per Gaussian); files the
+//                                instances: per-tile counts (exact lists), bucket slots, or one record per 2x2-tile group
+//      K2..K4                    tile scan, scatter, per-tile sort (binning.hip) -- only while the list statistics are unknown or
+//                                lists are too long for the composite's own sort
+//      K6<6 channels>            r, g, b, z, 1, z^2 over shared geometry (render.hip); builds and sorts its tile's list itself;
+//                                tracking: forms the masked L1 loss and its gradient planes in its epilogue
+//   F3 track_loss_kernel         tracking with outlier rejection only: masked L1 sums + dL/d(out6) in one pass over the pixels
 //   F4 ssim_forward_kernel       mapping: separable 11x11 SSIM statistics -> map sum + three partial-derivative maps,
 //                                image L1 sum, masked depth L1 sum and mask count
 //   F5 map_loss_backward_kernel  mapping: blur of the partial maps -> dL/d(rgb), depth gradient with the final count
 //      K7<6 channels>            (render.hip)
-//   F6 fused_backward_kernel     K8+K9 + adjoint of F1's glue + camera-pose partial sums (block reduce, f64 atomics)
-//   F7 pose_finish_kernel        pose partial sums -> dL/d(cam_unnorm_rots[..., t]), dL/d(cam_trans[..., t]), loss value
-//   F8 adam_map_kernel / adam_pose_kernel
+//   F6 fused_backward_kernel     K8+K9 + adjoint of F1's glue + camera-pose partial sums (block reduce, f64 atomics);
+//                                single-view mapping step: + the Adam step of the map
+//   F7 pose_finish_kernel        pose partial sums -> dL/d(cam_unnorm_rots[..., t]), dL/d(cam_trans[..., t]), loss value,
+//                                tracking: + the pose's Adam step and the best-candidate bookkeeping
+//   F8 adam_map_kernel / adam_pose_kernel   (the steps as launches of their own: exchanged / batched mapping, hand-wired loops)
 //
 // Arithmetic lives in fused_math.h / splat_math.h (host-testable); reference lines are cited there and in
 // include/splat_hip.h.

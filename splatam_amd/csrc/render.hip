@@ -1,6 +1,6 @@
 // render.hip -- tile-wise alpha compositing, forward (K6) and backward (K7).
 //
-// MI355X mapping (third generation; earlier / rejected ones live in experiments/, built only with EXPERIMENTS=1):
+// MI355X mapping (forward: third generation, backward: fifth; earlier / rejected ones live in experiments/, built only with EXPERIMENTS=1):
 //   * one 256-thread workgroup per 16x16 tile, ONE WAVE64 PER 8x8 QUADRANT, one pixel per lane.  A frame of
 //     config B is 3 225 tiles = 12 900 waves = 12.6 per SIMD, so every SIMD always has several waves to
 //     interleave (the one-wave-per-tile kernels were latency bound at ~3 waves per SIMD);
@@ -12,11 +12,15 @@
 //     rounding margin), the four 64-bit ballots per gathering wave go to LDS, and each compositing wave walks
 //     ONLY the set bits of its own quadrant's 256-bit mask (s_ff1 / s_flbit on SGPRs).  A Gaussian that cannot
 //     touch a quadrant costs that wave nothing; results are unchanged (a culled pixel fails the alpha test);
-//   * inner loop: uniform-address (broadcast) ds_read_b128/b64 of the live entry; the scalar search for the next
-//     set bit overlaps the LDS latency (an explicit one-entry-ahead register prefetch measured slower: +40 VGPRs);
-//   * backward: the 6+C partial sums of a Gaussian are reduced across the 64 lanes four at a time with
-//     v_permlane32_swap / v_permlane16_swap + 4 DPP adds and leave the wave as ONE float atomic per
-//     (Gaussian, quadrant, component);
+//   * inner loop: the record of the NEXT visit is fetched (uniform-address, broadcast ds_read_b128 / b64) while the current one is
+//     composited (two register sets, ping-pong), so that a visit's critical path is instruction issue alone; loop control and
+//     the per-lane predicates (done / live / stop) live in scalar registers as 64-bit masks;
+//   * backward (generation 5): no cross-lane reduction per visit -- phase 1 (lane = pixel) leaves two numbers per live pixel
+//     in a per-wave LDS pair buffer, phase 2 (every 8 visits; lane = (visit, pixel row)) turns them into the 6 + C sums with
+//     dense FMAs and three DPP adds, and every accumulator line of a visit leaves the wave in ONE float atomic instruction;
+//   * with SORT the forward kernel builds its tile's list itself: it filters its 2x2-tile group's records (or reads its bucket),
+//     sorts the <= 1 024 keys in LDS in two levels (rank sort of chunks, then interleaved binary searches) and publishes ids and
+//     count for the backward pass;
 //   * blockIdx -> tile map gives each XCD (block b runs on XCD b % 8) a contiguous band of tiles, so that the
 //     Gaussians shared by neighbouring tiles are served by one XCD's L2.
 //
@@ -302,9 +306,9 @@ __device__ __forceinline__ void sort_keys_two_level(uint64_t *A, uint64_t *S, co
     __syncthreads();
 }
 
-// SORT: the workgroup first sorts its tile's (depth, id) keys in LDS (256-thread bitonic network, a few microseconds
-// next to ~35 us of compositing) and publishes the ids for the backward pass: no separate sort launch, and the
-// gathers take their ids from LDS instead of a dependent global load.
+// SORT: the workgroup first collects its tile's (depth, id) keys in LDS (from its bucket, or by filtering its group's records:
+// SplatState.group_count), sorts them there (sort_keys_two_level) and publishes ids and count for the backward pass: no scan,
+// scatter or sort launch, and the gathers take their ids from LDS instead of a dependent global load.
 template <int C, int CS, bool WITH_DEPTH, bool SORT, bool TRACK = false>
 __global__ __launch_bounds__(256, 6) void render_forward_kernel(SplatCamera cam, const float *colors, SplatState st,
                                                              float *out_color, float *out_depth, int T, int per_xcd,
