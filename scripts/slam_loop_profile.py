@@ -33,6 +33,13 @@ def timed(label, fn):
 
 
 E = fused.FusedEngine
+if os.environ.get("SLAM_FORCE_FUSED_ADAM"):          # the one-call mapping step at any map size (A/B of FusedEngine.fused_adam_max_rows)
+    _init = E.__init__
+
+    def _patched(self, *a, **k):
+        _init(self, *a, **k)
+        self.fused_adam_max_rows = 1 << 40
+    E.__init__ = _patched
 for meth in ("add_new_gaussians", "relearn_lists", "prune_gaussians", "check_overflow", "adam_map", "begin_tracking", "end_tracking",
              "reset_map_optimizer", "add_valid_depth_points"):
     setattr(E, meth, timed(meth, getattr(E, meth)))
