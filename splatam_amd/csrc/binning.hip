@@ -86,7 +86,10 @@ __global__ __launch_bounds__(64) void tile_sort_wave_kernel(SplatState st) {
     for (int i = tid; i < n; i += 64) st.point_list[lo + i] = (uint32_t)s_keys[i];
 }
 
-__global__ __launch_bounds__(kBlock) void tile_sort_block_kernel(SplatState st) {
+// `long_launched`: the host launches the multi-workgroup kernels below in this call (it decides from its list-length hint, which may
+// be stale: a list beyond LDS that nobody is going to sort is flagged -- status[3], the host repeats the iteration -- and published
+// unsorted, so that the composites of the invalid iteration still read valid Gaussian indices).
+__global__ __launch_bounds__(kBlock) void tile_sort_block_kernel(SplatState st, bool long_launched) {
     __shared__ uint64_t s_keys[kSortLds];
     if (st.tile_stride == 0 && (long long)st.status[0] > st.capacity) return;
     const int tile = blockIdx.x, tid = threadIdx.x;
@@ -104,6 +107,9 @@ __global__ __launch_bounds__(kBlock) void tile_sort_block_kernel(SplatState st) 
         // list beyond LDS and no scratch from the caller: the same network run in place on the HBM bucket by this ONE workgroup
         // (correct, slow: O(n log^2 n) barrier-separated stages); with scratch the multi-workgroup kernels below take the tile
         bitonic_sort(gk, n, tid, kBlock);
+        for (int i = tid; i < n; i += kBlock) st.point_list[lo + i] = (uint32_t)gk[i];
+    } else if (!long_launched) {
+        if (tid == 0) atomicOr((unsigned *)&st.status[3], 1u);
         for (int i = tid; i < n; i += kBlock) st.point_list[lo + i] = (uint32_t)gk[i];
     }
 }
@@ -235,13 +241,20 @@ __global__ __launch_bounds__(kBlock) void long_merge_kernel(SplatState st, int T
     }
 }
 
-__global__ __launch_bounds__(kBlock) void long_publish_kernel(SplatState st, int T) {
+// `passes`: merge passes the host launched (from its bound on the list length).  A list that needed more (stale hint) is flagged
+// -- status[3], the host repeats the iteration -- and published from the buffer its LAST LAUNCHED pass wrote: half merged, but valid ids.
+__global__ __launch_bounds__(kBlock) void long_publish_kernel(SplatState st, int T, int passes) {
     const unsigned total = st.long_base[T];
     for (unsigned item = blockIdx.x; item < total; item += gridDim.x) {
         int tile, chunk, n;
         unsigned lo;
         if (!long_item(st, T, item, tile, chunk, lo, n)) break;
-        const uint64_t *buf = ((long_passes(n) & 1) ? st.keys_alt : st.keys) + lo;
+        int done = long_passes(n);
+        if (done > passes) {
+            done = passes;
+            if (chunk == 0 && threadIdx.x == 0) atomicOr((unsigned *)&st.status[3], 1u);
+        }
+        const uint64_t *buf = ((done & 1) ? st.keys_alt : st.keys) + lo;
 #pragma unroll
         for (int k = 0; k < kItemKeys / kBlock; ++k) {
             const int j = chunk * kItemKeys + k * kBlock + threadIdx.x;
@@ -259,9 +272,10 @@ hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, S
         hipLaunchKernelGGL(tile_sort_wave_kernel, dim3(T), dim3(64), 0, s, st);
         // the host may know the longest list (status[2]); only then can the long-list kernels be skipped
         if (!long_sort_skipped(st.max_list_hint)) {
-            hipLaunchKernelGGL(tile_sort_block_kernel, dim3(T), dim3(kBlock), 0, s, st);
             const long long hint = st.max_list_hint > 0 ? (long long)st.max_list_hint + st.max_list_hint / 2 : (long long)1 << 40;
-            if (st.keys_alt && st.long_base && hint > kRun && st.capacity > kRun) {
+            const bool long_path = st.keys_alt && st.long_base && hint > kRun && st.capacity > kRun;
+            hipLaunchKernelGGL(tile_sort_block_kernel, dim3(T), dim3(kBlock), 0, s, st, long_path);
+            if (long_path) {
                 // no list is longer than `bound`: the hint, the capacity, or -- bucketed lists -- the bucket
                 long long bound = st.capacity < hint ? st.capacity : hint;
                 if (st.tile_stride > 0 && st.tile_stride < bound) bound = st.tile_stride;
@@ -273,7 +287,7 @@ hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, S
                 const int passes = long_passes(bound);
                 for (int p = 0; p < passes; ++p)
                     hipLaunchKernelGGL(long_merge_kernel, dim3((unsigned)items), dim3(kBlock), 0, s, st, T, p);
-                hipLaunchKernelGGL(long_publish_kernel, dim3((unsigned)items), dim3(kBlock), 0, s, st, T);
+                hipLaunchKernelGGL(long_publish_kernel, dim3((unsigned)items), dim3(kBlock), 0, s, st, T, passes);
             }
         }
     }

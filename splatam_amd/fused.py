@@ -357,10 +357,18 @@ class FusedEngine:
                 removed = self.remove_points(None, thr, big)
             if iter > 0 and iter % prune_dict['reset_opacities_every'] == 0 and prune_dict['reset_opacities']:
                 with torch.no_grad():
-                    self.params['logit_opacities'].fill_(math.log(0.01 / (1 - 0.01)))
-                    self.exp_avg['logit_opacities'].zero_()
-                    self.exp_avg_sq['logit_opacities'].zero_()
+                    self._reset_opacities()
         return removed
+
+    def _reset_opacities(self):
+        """The reference's opacity reset re-creates the parameter through update_params_and_optimizer
+        (/root/reference/utils/slam_external.py:186-190, :236-240): value inverse_sigmoid(0.01), fresh Adam state and NO .grad, so
+        the optimizer.step() of that iteration leaves logit_opacities alone.  Same here: moments and this iteration's gradient are
+        zeroed (adam_map skips elements whose gradient and both moments are zero)."""
+        self.params['logit_opacities'].fill_(math.log(0.01 / (1 - 0.01)))
+        self.exp_avg['logit_opacities'].zero_()
+        self.exp_avg_sq['logit_opacities'].zero_()
+        self.grads['logit_opacities'].zero_()
 
     # ------------------------------------------------------------------ gradient-based densification
     def accumulate_mean2d_gradient(self, want_grad=False):
@@ -422,14 +430,18 @@ class FusedEngine:
         self._set_rows(counts[0])
         return S
 
-    def densify(self, iter, densify_dict, scene_radius):
+    def densify(self, iter, densify_dict, scene_radius, accumulate=True):
         """densify (/root/reference/utils/slam_external.py:191-240) on the device, in place, called where the reference calls it
         (between backward() and optimizer.step()): accumulate the screen-space gradient; on the schedule clone the small /
         split the large Gaussians whose mean gradient reaches ``grad_thresh``, reset the three per-Gaussian variables, remove
         the split originals, prune by opacity / size; optional opacity reset.  Returns True when the number of rows changed."""
         if iter > densify_dict['stop_after']:
             return False
-        self.accumulate_mean2d_gradient()
+        if accumulate:
+            # re-runs the RGB backward composite over THIS iteration's workspace (lists, radii, feat8 indexed by the rows the
+            # render saw): a caller that removes rows between loss_backward() and densify() must accumulate BEFORE it does
+            # (accumulate_mean2d_gradient(), then densify(..., accumulate=False)) -- pipeline._map_frame does
+            self.accumulate_mean2d_gradient()
         changed = False
         if iter >= densify_dict['start_after'] and iter % densify_dict['densify_every'] == 0:
             thr, small = densify_dict['grad_thresh'], float(0.01 * scene_radius)
@@ -451,9 +463,7 @@ class FusedEngine:
             changed = True
         if iter > 0 and iter % densify_dict['reset_opacities_every'] == 0 and densify_dict['reset_opacities']:
             with torch.no_grad():
-                self.params['logit_opacities'].fill_(math.log(0.01 / (1 - 0.01)))
-                self.exp_avg['logit_opacities'].zero_()
-                self.exp_avg_sq['logit_opacities'].zero_()
+                self._reset_opacities()
         return changed
 
     # ------------------------------------------------------------------ plumbing

@@ -448,6 +448,10 @@ def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, 
     cam, intrinsics, w2c0 = curr_data['cam'], curr_data['intrinsics'], curr_data['w2c']
     prune, pd = mcfg['prune_gaussians'], mcfg['pruning_dict']
     dev = params['means3D'].device
+    if world > 1 and mcfg.get('use_gaussian_splatting_densification'):
+        # every rank renders another view: means2D_gradient_accum / denom / max_2D_radius would differ between the replicas and
+        # so would the clone / split selection -- the replicated-map invariant of the multi-rank loop does not hold
+        raise NotImplementedError("gradient-based densification is not supported in the multi-rank frame loop")
     bucket = None                   # drop-in path: flat gradient bucket, re-made when an edit changes the number of rows
     if eng is not None:
         eng.reset_map_optimizer()
@@ -477,12 +481,17 @@ def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, 
             if world > 1 and not on_schedule:                   # (an iteration on the pruning schedule takes no Adam step)
                 sdist.all_reduce_mean_flat(eng.reduce_flat)
             edited = False
+            densifying = bool(mcfg.get('use_gaussian_splatting_densification'))
+            if densifying and it <= mcfg['densify_dict']['stop_after']:
+                # the colour pass' screen-space gradient is accumulated from THIS iteration's workspace (lists, radii, features
+                # indexed by the rows the render saw): before any row is removed
+                eng.accumulate_mean2d_gradient()
             if prune:
                 edited = bool(eng.prune_gaussians(it, pd, scene_radius))
-            if mcfg.get('use_gaussian_splatting_densification'):        # scripts/splatam.py:864-867
+            if densifying:                                               # scripts/splatam.py:864-867
                 dd = mcfg['densify_dict']
                 dens_sched = it <= dd['stop_after'] and it >= dd['start_after'] and it % dd['densify_every'] == 0
-                edited = bool(eng.densify(it, dd, scene_radius)) or edited
+                edited = bool(eng.densify(it, dd, scene_radius, accumulate=False)) or edited
                 on_schedule = on_schedule or dens_sched                   # re-created parameters carry no gradient: no Adam step
             if edited:
                 sdist.assert_replicated_count(eng.P, f"map edit (frame {time_idx}, iteration {it})", dev)

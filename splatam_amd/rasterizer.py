@@ -336,7 +336,11 @@ def rasterize_backward(pk: _Pack, grad_color, need_scale_rot: bool, need_cov3D: 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                grad_enabled=True):
+        # grad_enabled: torch.is_grad_enabled() as the CALLER saw it (inside Function.forward it is always False, and
+        # ctx.needs_input_grad reflects the inputs' requires_grad whatever the grad mode: nn.Parameters rendered under
+        # torch.no_grad -- evaluation, add_new_gaussians -- would otherwise count as "a backward will follow")
         dev = means3D.device
         means3D = _check_input("means3D", means3D, dev)
         P = means3D.shape[0]
@@ -356,7 +360,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if sh.numel() and (sh.dim() != 3 or sh.shape[0] != P or sh.shape[2] != 3):
             raise RuntimeError(f"shs must be [{P}, M, 3], got {tuple(sh.shape)}")
         color, radii, depth, pk = rasterize_forward(raster_settings, means3D, colors, opac, scales_c, rots_c, cov_c, sh,
-                                                    will_backward=any(ctx.needs_input_grad))
+                                                    will_backward=bool(grad_enabled) and any(ctx.needs_input_grad))
         ctx.pack = pk
         ctx.use_sh = sh.numel() > 0
         ctx.sh_shape = tuple(sh.shape)
@@ -370,16 +374,16 @@ class _RasterizeGaussians(torch.autograd.Function):
         # the rendered depth carries no gradient in the reference either
         pk = ctx.pack
         if grad_out_color is None:
-            return (None,) * 9
+            return (None,) * 10
         d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rots, d_cov = rasterize_backward(
             pk, grad_out_color, need_scale_rot=not ctx.use_cov, need_cov3D=ctx.use_cov,
             use_sh=ctx.use_sh, sh_shape=ctx.sh_shape)
-        return (d_means3D, d_means2D, d_sh, d_colors, d_opac.reshape(ctx.opac_shape), d_scales, d_rots, d_cov, None)
+        return (d_means3D, d_means2D, d_sh, d_colors, d_opac.reshape(ctx.opac_shape), d_scales, d_rots, d_cov, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, torch.is_grad_enabled())
 
 
 class GaussianRasterizer(nn.Module):

@@ -40,6 +40,14 @@ def test_lazy_mode_overflow_under_no_grad_rerenders():
         torch.cuda.synchronize()
         assert rz._capacity_hint != hint, "the overflow was not noticed"
         assert float((got - ref_big).abs().max()) < 1e-5
+        # the same with inputs that REQUIRE grad (the params dict holds nn.Parameters) rendered under no_grad: needs_input_grad
+        # is True there whatever the grad mode, so the wrapper passes the caller's grad mode along
+        rz._capacity_hint.clear()
+        with torch.no_grad():
+            Renderer(raster_settings=cs)(**small)
+            got_p = Renderer(raster_settings=cs)(**{k: torch.nn.Parameter(v.clone()) for k, v in big.items()})[0]
+        torch.cuda.synchronize()
+        assert float((got_p - ref_big).abs().max()) < 1e-5
         # with autograd the check happens in backward and raises (the forward that was handed out is invalid)
         rz._capacity_hint.clear()
         with torch.no_grad():
@@ -125,3 +133,38 @@ def test_time_kernel_leaves_the_accumulator_zeroed():
     eng.loss_backward(frame, 1, cfg, tracking=False)          # the next real iteration is not polluted
     torch.cuda.synchronize()
     assert torch.allclose(eng.grads['means3D'], g0, rtol=1e-4, atol=1e-7 * float(g0.abs().max()))
+
+
+# ---- round-2 advisor findings ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("stale_hint", [2000, 3000])
+def test_stale_hint_with_lists_beyond_lds_is_flagged_and_memory_safe(stale_hint):
+    """Exact-list path (tile_stride == 0) with the caller's scratch for the multi-workgroup sort: a stale list-length hint of
+    ~683..2730 launches the workgroup-per-tile sort but NOT the multi-workgroup kernels (hint 2000), or launches them with too
+    few merge passes (hint 3000 -> bound 4500 -> one pass for lists that need three).  Either way a list beyond 4 096 keys
+    used to be left unsorted / half merged WITHOUT a flag.  Now: flagged (the host repeats) and published with valid ids."""
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    from tests.test_gpu_fused import _scene, _cmp
+    params, variables, frame, cam = _scene(200000, 96, 64, seed=11)      # ~20 k instances per tile
+    eng = FusedEngine(params, cam)
+    eng.allow_buckets = False
+    cfg = slam.REPLICA_MAPPING
+    eng.loss_backward(frame, 1, cfg, tracking=False)
+    torch.cuda.synchronize()
+    assert not eng.check_overflow()
+    assert eng.max_list_hint > 3 * 4096, eng.max_list_hint
+    good = eng.grads['means3D'].clone()
+    good_loss = eng.loss()
+    eng.buf['point_list'].fill_(0x7f7f7f7f)
+    if 'keys_alt' in eng.buf:
+        eng.buf['keys_alt'].fill_(0x7f7f7f7f7f7f7f7f)
+    eng.max_list_hint = stale_hint
+    eng.loss_backward(frame, 1, cfg, tracking=False)
+    torch.cuda.synchronize()                                            # no memory fault
+    assert eng.check_overflow()                                          # the iteration is reported as invalid
+    eng.loss_backward(frame, 1, cfg, tracking=False)
+    torch.cuda.synchronize()
+    assert not eng.check_overflow()
+    assert abs(eng.loss() - good_loss) <= 1e-5 * abs(good_loss)
+    _cmp(eng.grads['means3D'], good, "dL/dmeans3D after recovery", tol=1e-4)

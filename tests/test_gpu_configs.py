@@ -241,7 +241,7 @@ def _fused_case(cfg_name, aniso, tracking, monkeypatch, seed=0, region=None):
     return eng, g32, g64, what
 
 
-@pytest.mark.parametrize("cfg_name,aniso", [('B', False), ('B', True), ('D', False), ('E', False)])
+@pytest.mark.parametrize("cfg_name,aniso", [('B', False), ('B', True), ('D', False), ('D', True), ('E', False), ('E', True)])
 def test_fused_mapping_vs_oracle(cfg_name, aniso, monkeypatch):
     eng, g32, g64, what = _fused_case(cfg_name, aniso, False, monkeypatch)
     keys = ["means3D", "rgb_colors", "logit_opacities", "log_scales"] + (["unnorm_rotations"] if aniso else [])
@@ -251,10 +251,7 @@ def test_fused_mapping_vs_oracle(cfg_name, aniso, monkeypatch):
         assert float(eng.grads["unnorm_rotations"].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("cfg_name,aniso", [('B', False), ('B', True), ('D', False)])
-def test_fused_tracking_vs_oracle(cfg_name, aniso, monkeypatch):
-    """Tracking at the SHIPPED sil_thres = 0.99 (round 1 compared at a threshold moved into a gap of the silhouette histogram)."""
-    eng, g32, g64, what = _fused_case(cfg_name, aniso, True, monkeypatch)
+def _check_pose_gradient(eng, g32, g64, what):
     d = eng.buf['d_cam'].cpu().numpy().astype(np.float64)
     gq32, gt32 = g32['cam_unnorm_rots'][0, :, 1], g32['cam_trans'][0, :, 1]
     gq64, gt64 = g64['cam_unnorm_rots'][0, :, 1], g64['cam_trans'][0, :, 1]
@@ -262,6 +259,22 @@ def test_fused_tracking_vs_oracle(cfg_name, aniso, monkeypatch):
     for got, r32, r64 in ((d[0:4], gq32, gq64), (d[4:7], gt32, gt64)):
         tol = max(1e-4 * np.abs(r64).max(), 2.0 * np.abs(r32 - r64).max())
         assert np.abs(got - r64).max() <= tol, (what, got, r64, tol)
+
+
+@pytest.mark.parametrize("cfg_name,aniso", [('B', False), ('B', True), ('D', False), ('D', True), ('E', False), ('E', True)])
+def test_fused_tracking_vs_oracle(cfg_name, aniso, monkeypatch):
+    """Tracking at the SHIPPED sil_thres = 0.99 (round 1 compared at a threshold moved into a gap of the silhouette histogram).
+    D and E are the configurations that run 200 tracking iterations per frame (/root/reference/configs/tum/splatam.py:14,
+    /root/reference/configs/scannetpp/splatam.py:30)."""
+    eng, g32, g64, what = _fused_case(cfg_name, aniso, True, monkeypatch)
+    _check_pose_gradient(eng, g32, g64, what)
+
+
+def test_fused_clustered_tracking_vs_oracle(monkeypatch):
+    """Tracking on the clustered stress scene: the exact-list + multi-workgroup-sort path feeding the tracking form of the
+    backward composite."""
+    eng, g32, g64, what = _fused_case('E', False, True, monkeypatch, seed=5, region=CLUSTER)
+    _check_pose_gradient(eng, g32, g64, what)
 
 
 def test_fused_clustered_vs_oracle(monkeypatch):

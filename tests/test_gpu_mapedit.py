@@ -307,3 +307,47 @@ def test_densify_on_the_device_matches_the_torch_formulation():
     eng.adam_map(cfg['lrs'])
     torch.cuda.synchronize()
     assert not eng.check_overflow() and np.isfinite(eng.loss())
+
+
+def test_accumulate_before_a_prune_then_densify_without_accumulating():
+    """with pruning AND densification in one iteration the screen-space gradient must be accumulated from the
+    iteration's own workspace BEFORE rows are removed (pipeline._map_frame: accumulate_mean2d_gradient(), prune_gaussians(),
+    densify(accumulate=False)); accumulating after the compaction would index the old lists with the new rows."""
+    from splatam_amd import slam
+    eng, params, variables, mirror, frame = _densify_scene()
+    cfg = slam.REPLICA_MAPPING
+    n = eng.P
+    eng.loss_backward(frame, 1, cfg, tracking=False)
+    eng.accumulate_mean2d_gradient()
+    acc_full, den_full = variables['means2D_gradient_accum'][:n].clone(), variables['denom'][:n].clone()
+    assert float(acc_full.max()) > 0 and float(den_full.max()) == 1.0
+    keep = torch.arange(n, device="cuda") % 3 != 0
+    assert eng.remove_points((~keep).to(torch.uint8)) == int((~keep).sum())
+    dd = dict(start_after=10 ** 9, remove_big_after=0, stop_after=10 ** 9, densify_every=1, grad_thresh=1.0, num_to_split_into=2,
+              removal_opacity_threshold=0.0, final_removal_opacity_threshold=0.0, reset_opacities=False, reset_opacities_every=3000)
+    assert not eng.densify(1, dd, 1.0, accumulate=False)        # off its schedule: nothing but the (skipped) accumulation would happen
+    torch.cuda.synchronize()
+    assert eng.P == int(keep.sum())
+    assert torch.equal(variables['means2D_gradient_accum'][:eng.P], acc_full[keep])
+    assert torch.equal(variables['denom'][:eng.P], den_full[keep])
+
+
+def test_opacity_reset_leaves_the_reset_value_through_the_adam_step():
+    """the reference's reset re-creates logit_opacities without a .grad (/root/reference/utils/slam_external.py:186-190),
+    so the optimizer.step() of that iteration does not move it; the other groups step as usual."""
+    import math
+    from splatam_amd import slam
+    eng, params, variables, mirror, frame = _densify_scene()
+    cfg = slam.REPLICA_MAPPING
+    eng.reset_map_optimizer()
+    eng.loss_backward(frame, 1, cfg, tracking=False)
+    assert float(eng.grads['logit_opacities'].abs().max()) > 0
+    before = params['means3D'].detach().clone()
+    pd = dict(start_after=10 ** 9, remove_big_after=0, stop_after=10 ** 9, prune_every=1, removal_opacity_threshold=0.0,
+              final_removal_opacity_threshold=0.0, reset_opacities=True, reset_opacities_every=1)
+    assert eng.prune_gaussians(1, pd, 1.0) == 0
+    eng.adam_map(cfg['lrs'])
+    torch.cuda.synchronize()
+    want = math.log(0.01 / (1 - 0.01))
+    assert float((params['logit_opacities'].detach() - want).abs().max()) <= 1e-6
+    assert float((params['means3D'].detach() - before).abs().max()) > 0

@@ -33,6 +33,9 @@ def assert_close_outliers(got, ref, atol, rtol=0.0, max_outlier_frac=0.0, outlie
     bad = err > (atol + rtol * np.abs(ref))
     nbad = int(bad.sum())
     allowed = int(np.floor(max_outlier_frac * err.size))
+    if what:
+        print(f"{what}: {nbad} of {err.size} elements beyond atol {atol:.3g} + rtol {rtol:.3g} ({nbad / max(err.size, 1):.2e}; allowed "
+              f"{max_outlier_frac:.2e}), max err {err.max() if err.size else 0.0:.3e}")
     assert nbad <= allowed, f"{what}: {nbad} elements out of tolerance (allowed {allowed}), max err {err.max():.3e}"
     if nbad and outlier_atol is not None:
         assert err.max() <= outlier_atol, f"{what}: outlier error {err.max():.3e} > {outlier_atol}"
@@ -77,7 +80,7 @@ def assert_grad_close(got, ref, what="", rel=1e-3, floor=1e-3, max_outlier_frac=
         assert q <= global_rel * scale, report + f"; quantile {q:.3e}"
 
 
-def assert_grad_calibrated(got, ref32, ref64, what="", factor=2.0, floor=1e-3, max_outlier_frac=1e-4, outlier_rel=0.05):
+def assert_grad_calibrated(got, ref32, ref64, what="", factor=1.3, floor=1e-3, max_outlier_frac=1e-4, outlier_rel=0.05):
     """Gradient parity judged against the float32 rounding noise of the algorithm itself.
 
     Two CORRECT float32 evaluations of the rasterizer's backward differ per element by far more than 1e-3 of the element:
@@ -85,7 +88,7 @@ def assert_grad_calibrated(got, ref32, ref64, what="", factor=2.0, floor=1e-3, m
     cancel.  The float64 build of the oracle (oracle/raster_ref.c, -DREF_DOUBLE) measures that noise: e32 = |ref32 - ref64|
     is what the reference-arithmetic CPU implementation itself is off by.  Checked here:
       (1) quantile by quantile (50 .. 99.99 %) the HIP result is no further from the float64 evaluation than `factor` x the
-          float32 oracle is (errors normalised per element by max(|ref64_i|, floor * max|ref64|));
+          float32 oracle is (factor 1.3 since round 3: the printed reports show the kernels AT the oracle's own error level) (errors normalised per element by max(|ref64_i|, floor * max|ref64|));
       (2) the fraction of elements off by more than 1e-3 of themselves is at most `factor` x the oracle's own fraction;
       (3) the north star's bound: every element within 1e-3 of the tensor's maximum, except a bounded fraction of float32
           threshold flips (alpha >= 1/255, T < 1e-4 decided differently for one (pixel, Gaussian) pair), each below
