@@ -33,7 +33,10 @@
 
 namespace splat {
 
-constexpr int kBatch = 256;     // list entries staged per LDS buffer
+constexpr int kBatch = 256;         // records per LDS buffer (one per thread)
+constexpr int kBatchEntries = 255;  // list entries staged per buffer: record 255 is the INERT record (zero opacity) that the padding of the
+                                    // visit lists points to
+constexpr int kSegBytes = 68;       // one visit list: <= 64 one-byte entries, padded with 0xFF to a multiple of 4, + the next group's look-ahead
 
 #if defined(SPLAT_EXPERIMENTS)
 // Superseded / rejected generations of these kernels (experiments/render_v2.hip, experiments/render_v4.hip), built only with
@@ -141,8 +144,21 @@ struct Batch {
     static constexpr int R4 = FP / 4 + 2;
     float4 rec[kBatch * R4];
     unsigned qmask[4][4][2];        // [quadrant][gathering wave][lo, hi]: ballot of "this Gaussian can touch the quadrant"
+    // VISIT LISTS [quadrant][gathering wave]: the set bits of qmask as one-byte batch entry indices, ascending, padded with 0xFF
+    // (the inert record) to a multiple of four.  The composites walk these four entries at a time (one ds_read_b32, v_bfe_u32 per
+    // entry, no per-visit scalar bookkeeping): the bit walk over qmask cost ~13 SALU instructions per visit, and on gfx950 every
+    // instruction of whatever type takes a 2-cycle issue slot of its SIMD, scalar ones at most every 4th cycle
+    // (profiles/r03_valu_issue_bench.txt) -- the composites are bound by the TOTAL instruction count.
+    // One word of slack on either side: the look-ahead of the first / last group reads it.
+    unsigned vlist[1 + 16 * (kSegBytes / 4) + 1];
+    unsigned char vcnt[4][4];       // entries per list
     unsigned flag[4];               // forward: wave w had no pixel left when this batch was committed
 };
+
+template <int FP>
+__device__ __forceinline__ const unsigned char *visit_list(const Batch<FP> &b, int quadrant, int gwave) {
+    return reinterpret_cast<const unsigned char *>(b.vlist + 1) + (quadrant * 4 + gwave) * kSegBytes;
+}
 
 template <int FP>
 __device__ __forceinline__ void commit(Batch<FP> &b, const Staged<FP> &s, int tid, unsigned flag) {
@@ -152,16 +168,23 @@ __device__ __forceinline__ void commit(Batch<FP> &b, const Staged<FP> &s, int ti
     for (int v = 0; v < FP / 4; ++v)
         b.rec[tid * R4 + 1 + v] = make_float4(s.feat[4 * v], s.feat[4 * v + 1], s.feat[4 * v + 2], s.feat[4 * v + 3]);
     b.rec[tid * R4 + R4 - 1] = make_float4(s.mu.x, s.mu.y, __uint_as_float(s.id), 0.f);
-    const int wave = tid >> 6;
+    const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64((s.mask >> q) & 1u);
-        if ((tid & 63) == 0) {
+        const bool hit = (s.mask >> q) & 1u;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        const int cnt = __builtin_popcountll(m);
+        unsigned char *seg = const_cast<unsigned char *>(visit_list(b, q, wave));
+        if (hit) seg[rank] = (unsigned char)tid;
+        if (lane < 4) seg[cnt + lane] = 0xFFu;                  // padding (cnt + 3 <= 67)
+        if (lane == 0) {
             b.qmask[q][wave][0] = (unsigned)m;
             b.qmask[q][wave][1] = (unsigned)(m >> 32);
+            b.vcnt[q][wave] = (unsigned char)cnt;
         }
     }
-    if ((tid & 63) == 0) b.flag[wave] = flag;
+    if (lane == 0) b.flag[wave] = flag;
 }
 
 template <int FP>
@@ -389,13 +412,13 @@ __global__ __launch_bounds__(256, 6) void render_forward_kernel(SplatCamera cam,
         sort_keys_two_level(s_keys, reinterpret_cast<uint64_t *>(B.rec), n, tid);
         for (int i = tid; i < n; i += 256) st.point_list[lo + i] = (uint32_t)lk[i];
     }
-    const int nb = (n + kBatch - 1) / kBatch;
+    const int nb = (n + kBatchEntries - 1) / kBatchEntries;
 
     if (nb > 0) {
         // One LDS buffer (a tile's list is usually ONE batch; a second buffer would halve the resident workgroups):
         // the next batch's gather is in flight in registers while this one is composited, then barrier - commit - barrier.
         Staged<FP> pre;
-        gather<C, CS, WITH_DEPTH, FP>(pre, st, colors, lo + tid, tid < n, tile_x0, tile_y0, lk, tid);
+        gather<C, CS, WITH_DEPTH, FP>(pre, st, colors, lo + tid, tid < kBatchEntries && tid < n, tile_x0, tile_y0, lk, tid);
         for (int bi = 0; bi < nb; ++bi) {
             if (bi > 0) __syncthreads();            // every wave has finished reading the previous batch
             commit(B, pre, tid, wdone ? 1u : 0u);
@@ -405,13 +428,16 @@ __global__ __launch_bounds__(256, 6) void render_forward_kernel(SplatCamera cam,
             if (__builtin_amdgcn_readfirstlane((int)alldone)) break;
             const bool more = bi + 1 < nb;
             if (more) {                         // next batch's gather stays in flight while this one is composited
-                const int e = (bi + 1) * kBatch + tid;
-                gather<C, CS, WITH_DEPTH, FP>(pre, st, colors, lo + e, e < n, tile_x0, tile_y0, lk, e);
+                const int e = (bi + 1) * kBatchEntries + tid;
+                gather<C, CS, WITH_DEPTH, FP>(pre, st, colors, lo + e, tid < kBatchEntries && e < n, tile_x0, tile_y0, lk, e);
             }
-            const unsigned base1 = (unsigned)(bi * kBatch + 1);
-            unsigned long long bits = 0;        // set bits of the current mask word still to visit (cleared when the wave is done)
+            const unsigned base1 = (unsigned)(bi * kBatchEntries + 1);
+            unsigned last_loc = ~0u;            // record (byte offset in B.rec) of the pixel's last contributor in this batch (none yet)
+            // a list entry -> its record's byte offset in B.rec: a wave-uniform value in a vector register (one byte-select shift per
+            // visit, no scalar bookkeeping); the visit identifies its entry by that offset
+            auto rec_of = [&](unsigned e) { return e * (unsigned)(Batch<FP>::R4 * sizeof(float4)); };
             // one visit of this quadrant: `cur` was fetched from LDS during the previous visit (see Rec)
-            auto visit = [&](int e, const Rec<FP> &cur) {
+            auto visit = [&](unsigned rec, const Rec<FP> &cur) {
                 const float dx = cur.m.x - fpx, dy = cur.m.y - fpy;
                 const float p2 = dx * (cur.a.x * dx + cur.a.y * dy) + cur.a.z * dy * dy;     // power * log2(e)
                 const float alpha = fminf(kAlphaMax, cur.a.w * fast_exp2(p2));
@@ -429,43 +455,49 @@ __global__ __launch_bounds__(256, 6) void render_forward_kernel(SplatCamera cam,
                     else D += c * wgt;
                 }
                 Tr = upd ? test_T : Tr;
-                last = upd ? base1 + (unsigned)e : last;
-                if (stop_m != 0) {                  // (rare: a pixel saturates)
-                    done_m |= stop_m;
-                    if (done_m == ~0ull) bits = 0;  // every pixel of the quadrant is done: nothing left to visit
-                }
+                last_loc = upd ? rec : last_loc;
+                done_m |= stop_m;                   // (rare: a pixel saturates)
             };
-            auto load_rec = [&](int e, Rec<FP> &r) {
-                const float4 *p = B.rec + e * Batch<FP>::R4;
+            auto load_rec = [&](unsigned rec, Rec<FP> &r) {
+                const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(B.rec) + rec);
                 r.a = p[0];
 #pragma unroll
                 for (int v = 0; v < FP / 4; ++v) r.f[v] = p[1 + v];
                 r.m = p[Batch<FP>::R4 - 1];
             };
-            // front to back over the set bits of this quadrant's mask; the NEXT record is in flight while the current one is
-            // composited (two register sets, ping-pong): the LDS round trip per visit is off the wave's critical path
+            // front to back over this quadrant's four visit lists (one per gathering wave), four entries per trip; the NEXT record is
+            // in flight while the current one is composited (two register sets, ping-pong).  A list's padding and the look-ahead past
+            // its end name the inert record or some other record of the batch: fetched, and -- the padding -- visited without effect
+            const unsigned cnts = (unsigned)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<const unsigned *>(B.vcnt[wave]));
 #pragma unroll 1
-            for (int w = 0; w < 4 && done_m != ~0ull; ++w) {
-                bits = mask_word(B, wave, w);
-                if (bits == 0) continue;
+            for (int g = 0; g < 4 && done_m != ~0ull; ++g) {
+                const int ng = (int)((cnts >> (8 * g)) & 0xFFu);
+                if (ng == 0) continue;
+                const unsigned char *seg = visit_list(B, wave, g);
+                unsigned cur4 = *reinterpret_cast<const unsigned *>(seg);
                 Rec<FP> ra, rb;
-                int ja = __builtin_ctzll(bits);
-                bits &= bits - 1;
-                load_rec(w * 64 + ja, ra);
-                while (true) {
-                    // the next set bit, or bit 63 of an exhausted word: always a valid record of the batch, fetched unconditionally
-                    const int jb = __builtin_ctzll(bits | (1ull << 63));
-                    load_rec(w * 64 + jb, rb);
-                    visit(w * 64 + ja, ra);
-                    if (bits == 0) break;
-                    bits &= bits - 1;
-                    ja = __builtin_ctzll(bits | (1ull << 63));
-                    load_rec(w * 64 + ja, ra);
-                    visit(w * 64 + jb, rb);
-                    if (bits == 0) break;
-                    bits &= bits - 1;
+                unsigned r0 = rec_of(cur4 & 0xFFu);
+                load_rec(r0, ra);
+#pragma unroll 1
+                for (int k = 0; k < ng; k += 4) {
+                    const unsigned nxt4 = *reinterpret_cast<const unsigned *>(seg + k + 4);
+                    const unsigned r1 = rec_of((cur4 >> 8) & 0xFFu);
+                    load_rec(r1, rb);
+                    visit(r0, ra);
+                    const unsigned r2 = rec_of((cur4 >> 16) & 0xFFu);
+                    load_rec(r2, ra);
+                    visit(r1, rb);
+                    const unsigned r3 = rec_of(cur4 >> 24);
+                    load_rec(r3, rb);
+                    visit(r2, ra);
+                    r0 = rec_of(nxt4 & 0xFFu);
+                    load_rec(r0, ra);
+                    visit(r3, rb);
+                    cur4 = nxt4;
+                    if (done_m == ~0ull) break;     // every pixel of the quadrant is done: nothing left to visit
                 }
             }
+            last = last_loc != ~0u ? base1 + last_loc / (unsigned)(Batch<FP>::R4 * sizeof(float4)) : last;
             wdone = done_m == ~0ull;
         }
     }
@@ -557,10 +589,10 @@ constexpr int nth_set_bit(unsigned m, int n) {      // index of the n-th (0-base
 // 0..7 sit in its own 8 lanes, values 8.. are rotated (DPP row_ror:8) into the lanes of its row partner, so that even visits
 // publish in one instruction and odd visits in the next (4 lines each).
 constexpr int kChunk = 8;               // visits per phase-2 pass (8 lanes each)
-constexpr int kPairRow = 73;            // float2 per visit slot: 64 pixels + 4 (rows 4..7 shifted), padded to an odd stride
+constexpr int kPairRow = 69;            // float2 per visit slot: 64 pixels + 4 (rows 4..7 shifted), padded to an odd stride
 
 // (v, w) of (slot, pixel): conflict-free for the phase-1 ds_write_b64 (lane = pixel) and the phase-2 ds_read_b64
-// (lane = (slot, row), same column): with the odd row stride 73 = 9 (mod 32) the 8-byte unit index mod 32 is a bijection
+// (lane = (slot, row), same column): with the odd row stride 69 = 5 (mod 32) the 8-byte unit index mod 32 is a bijection
 // of (slot & 3, row) for every column
 __device__ __forceinline__ int pair_index(int slot, int pixel) { return slot * kPairRow + pixel + 4 * (pixel >> 5); }
 
@@ -663,7 +695,7 @@ __device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, co
     const unsigned tmax = (unsigned)__builtin_amdgcn_readfirstlane((int)max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])));
     if (tmax == 0) return;                                     // uniform over the workgroup
     const unsigned lo = st.tile_stride > 0 ? (unsigned)tile * (unsigned)st.tile_stride : st.tile_base[tile];
-    const int nb = (int)((tmax + kBatch - 1) / kBatch);
+    const int nb = (int)((tmax + kBatchEntries - 1) / kBatchEntries);
 
     // accumulator slot of published value k: S1..S5 (S6) -> 0..5, colour sums -> 6 + channel
     auto slot_of = [](int k) { return k < NB ? k : 6 + nth_set_bit(SMASK, k - NB); };
@@ -679,14 +711,16 @@ __device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, co
     // LDS byte address of column 0 of this lane's phase-2 row (generic shared pointer -> 32-bit LDS offset)
     const unsigned rd_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float2 *)(my_vw + pair_index(v2, s2 * 8));
     const float qcx = (float)qx0 + 3.5f, qcy = (float)(qy0 + s2);       // centre column of the quadrant, this lane's phase-2 row
-    unsigned long long epack = 0;       // byte n: batch entry (< 256) of the visit waiting in slot n (wave-uniform: scalar registers)
+    unsigned slot_rec = 0;              // lanes 8 n .. 8 n + 7 (the phase-2 lanes of slot n): record (byte offset in B.rec) of the visit waiting in slot n
+    unsigned long long slot_m = 0xFFull;        // lanes of the slot the next live visit takes (wave-uniform)
+    float2 *wr_ptr = my_vw + wr_lane;   // where this lane's pixel writes the next visit's pair
 
     // ---- phase 2: nvis (wave-uniform) visits are waiting in the pair buffer; their records are still in B
     auto phase2 = [&](int nvis) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const float4 *rp = B.rec + (int)((epack >> (8 * v2)) & 0xFFull) * R4;
+        const float4 *rp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(B.rec) + slot_rec);
         const float op = rp[0].w;
         const float4 mm = rp[R4 - 1];
         float R0 = 0.f, RX = 0.f, RXX = 0.f, Cs[NS > 0 ? NS : 1];
@@ -772,33 +806,36 @@ __device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, co
     int nslot = 0;                                              // wave-uniform
     Staged<FP> pre;
     {
-        const unsigned e = (unsigned)((nb - 1) * kBatch + tid);
-        gather<CL, CS, false, FP>(pre, st, colors, lo + e, e < tmax, tile_x0, tile_y0);
+        const unsigned e = (unsigned)((nb - 1) * kBatchEntries + tid);
+        gather<CL, CS, false, FP>(pre, st, colors, lo + e, tid < kBatchEntries && e < tmax, tile_x0, tile_y0);
     }
     for (int bi = nb - 1; bi >= 0; --bi) {
         if (bi < nb - 1) __syncthreads();           // every wave has finished reading the previous batch
         commit(B, pre, tid, 0u);
         __syncthreads();
         const bool more = bi > 0;
-        if (more) gather<CL, CS, false, FP>(pre, st, colors, lo + (unsigned)((bi - 1) * kBatch + tid), true, tile_x0, tile_y0);
-        const int base = bi * kBatch;
+        if (more) gather<CL, CS, false, FP>(pre, st, colors, lo + (unsigned)((bi - 1) * kBatchEntries + tid), tid < kBatchEntries, tile_x0, tile_y0);
+        const int base = bi * kBatchEntries;
         const int lim = (int)wmax - base;                      // entries [0, lim) of this batch can matter to this wave
+        const int last_rec = ((int)last - base - 1) * (int)(R4 * sizeof(float4));      // this pixel blended the batch's records at byte offsets [0, last_rec]
 
-        auto load_rec = [&](int e, Rec<FP> &r) {
-            const float4 *p = B.rec + e * R4;
+        // a list entry -> its record's byte offset in B.rec: a wave-uniform value in a vector register (one v_mul_u32_u24 with a byte
+        // select per visit, no scalar bookkeeping); the visit identifies its entry by that offset
+        auto rec_of = [&](unsigned e) { return e * (unsigned)(R4 * sizeof(float4)); };
+        auto load_rec = [&](unsigned rec, Rec<FP> &r) {
+            const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(B.rec) + rec);
             r.a = p[0];
 #pragma unroll
             for (int v = 0; v < FP / 4; ++v) r.f[v] = p[1 + v];
             r.m = p[R4 - 1];
         };
-        // one visit: `cur` was fetched during the previous visit; fetch `nxt` now
-        auto visit = [&](int e, const Rec<FP> &cur) {
-            const unsigned pos = (unsigned)(base + e + 1);
+        // one visit: `cur` was fetched during the previous visit
+        auto visit = [&](unsigned rec, const Rec<FP> &cur) {
             const float dx = cur.m.x - fpx, dy = cur.m.y - fpy;
             const float p2 = dx * (cur.a.x * dx + cur.a.y * dy) + cur.a.z * dy * dy;
             const float G = fast_exp2(p2);
             const float alpha = fminf(kAlphaMax, cur.a.w * G);
-            const unsigned long long live_m = __builtin_amdgcn_ballot_w64(pos <= last) & __builtin_amdgcn_ballot_w64(p2 <= 0.f) &
+            const unsigned long long live_m = __builtin_amdgcn_ballot_w64((int)rec <= last_rec) & __builtin_amdgcn_ballot_w64(p2 <= 0.f) &
                                               __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin);
             if (live_m == 0) return;
             // lanes without a live pixel run the same arithmetic on G = alpha = 0 (two selects; 1 / (1 - 0) and T * 1 are exact,
@@ -808,60 +845,75 @@ __device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, co
             const float al = live ? alpha : 0.f;
             const float rcp = __builtin_amdgcn_rcpf(1.f - al);
             const float Tn = Tr * rcp;                     // transmittance in front of this Gaussian
-            float part[4] = {0.f, 0.f, 0.f, 0.f};
+            // c . dL/dC as ONE chain of fused multiply-adds (|DMASK| instructions; on gfx950 the composites are bound by the vector
+            // pipe -- plain operations 2 cycles, compares / selects / DPP 4, exp / rcp 8: profiles/r03_valu_issue_bench.txt)
+            float cdot = 0.f;
+            bool first = true;
 #pragma unroll
             for (int ch = 0; ch < C; ++ch)
                 if ((DMASK >> ch) & 1u) {
                     const float4 &fv = cur.f[ch >> 2];
                     const float c = (ch & 3) == 0 ? fv.x : ((ch & 3) == 1 ? fv.y : ((ch & 3) == 2 ? fv.z : fv.w));
-                    part[ch & 3] += c * dpix[ch];
+                    cdot = first ? c * dpix[ch] : fmaf(c, dpix[ch], cdot);
+                    first = false;
                 }
-            const float cdot = (part[0] + part[2]) + (part[1] + part[3]);
             const float dL_dalpha = fmaf(cdot, Tn, -(R * rcp));
             const float vv = Gl * dL_dalpha;
             const float ww = al * Tn;
             R = fmaf(cdot, ww, R);
             Tr = Tn;
-            my_vw[nslot * kPairRow + wr_lane] = make_float2(vv, ww);
-            epack |= (unsigned long long)(unsigned)e << (8 * nslot);
+            *wr_ptr = make_float2(vv, ww);
+            wr_ptr += kPairRow;
+            slot_rec = lane_of(slot_m) ? rec : slot_rec;
+            slot_m <<= 8;
             if (++nslot == kChunk) {
                 phase2(kChunk);
                 nslot = 0;
-                epack = 0;
+                slot_m = 0xFFull;
+                wr_ptr = my_vw + wr_lane;
             }
         };
-        // walk the set bits of this quadrant's mask back to front; the record of the NEXT visit is fetched before the current
-        // one is processed (two register sets, ping-pong); everything here is wave-uniform
+        // back to front over this quadrant's four visit lists (one per gathering wave), four entries per trip; the record of the NEXT
+        // visit is fetched before the current one is processed (two register sets, ping-pong).  Entries past lim (this wave's deepest
+        // contributor) are cut off through the quadrant masks; what the top group holds beyond them -- cut-off entries, the 0xFF
+        // padding (the inert record) -- is visited without effect, as is whatever the look-ahead below the list's start names
 #pragma unroll 1
-        for (int w = 3; w >= 0; --w) {
-            const int kk = lim - 64 * w;
+        for (int g = 3; g >= 0; --g) {
+            const int kk = lim - 64 * g;
             if (kk <= 0) continue;
-            unsigned long long bits = mask_word(B, wave, w);
+            unsigned long long bits = mask_word(B, wave, g);
             if (kk < 64) bits &= (1ull << kk) - 1ull;
             if (bits == 0) continue;
+            const unsigned char *seg = visit_list(B, wave, g);
+            int kb = (__builtin_popcountll(bits) - 1) & ~3;
+            unsigned cur4 = *reinterpret_cast<const unsigned *>(seg + kb);
             Rec<FP> ra, rb;
-            int ja = 63 - __builtin_clzll(bits);
-            bits &= ~(1ull << ja);
-            load_rec(w * 64 + ja, ra);
-            while (true) {
-                // the next set bit from the top, or bit 0 of an exhausted word: always a valid record, fetched unconditionally
-                const int jb = 63 - __builtin_clzll(bits | 1ull);
-                load_rec(w * 64 + jb, rb);
-                visit(w * 64 + ja, ra);
-                if (bits == 0) break;
-                bits &= ~(1ull << jb);
-                ja = 63 - __builtin_clzll(bits | 1ull);
-                load_rec(w * 64 + ja, ra);
-                visit(w * 64 + jb, rb);
-                if (bits == 0) break;
-                bits &= ~(1ull << ja);
+            unsigned r3 = rec_of(cur4 >> 24);
+            load_rec(r3, ra);
+#pragma unroll 1
+            for (; kb >= 0; kb -= 4) {
+                const unsigned nxt4 = *reinterpret_cast<const unsigned *>(seg + kb - 4);
+                const unsigned r2 = rec_of((cur4 >> 16) & 0xFFu);
+                load_rec(r2, rb);
+                visit(r3, ra);
+                const unsigned r1 = rec_of((cur4 >> 8) & 0xFFu);
+                load_rec(r1, ra);
+                visit(r2, rb);
+                const unsigned r0 = rec_of(cur4 & 0xFFu);
+                load_rec(r0, rb);
+                visit(r1, ra);
+                r3 = rec_of(nxt4 >> 24);
+                load_rec(r3, ra);
+                visit(r0, rb);
+                cur4 = nxt4;
             }
         }
         // the records of the waiting visits live in this batch: publish them before it is replaced
         if (nslot > 0) {
             phase2(nslot);
             nslot = 0;
-            epack = 0;
+            slot_m = 0xFFull;
+            wr_ptr = my_vw + wr_lane;
         }
     }
 }

@@ -12,7 +12,7 @@ two backward passes through the reference-shaped get_loss (splatam_amd.slam.get_
 oracle as its Renderer), not with the HIP drop-in path.
 
 Tolerances: 1e-4 colour / depth; lists / radii exact; gradients: the north star's 1e-3 of the tensor's maximum AND, per
-element, no further from the float64 evaluation of the oracle than 2x the float32 oracle itself is (tests/util.py:
+element, no further from the float64 evaluation of the oracle than 1.3x the float32 oracle itself is (tests/util.py:
 assert_grad_calibrated -- a flat per-element 1e-3 is not attainable by ANY float32 evaluation of this backward pass: the
 float32 and float64 builds of the oracle differ by more than that on 0.2-0.7 % of the elements)."""
 import numpy as np
@@ -192,6 +192,32 @@ def _oracle_backward_from_planes(params, frame, cam_args, planes, tracking, dtyp
     return {k_: (None if v.grad is None else v.grad.numpy()) for k_, v in pc.items()}
 
 
+def _assert_depth_ties_explain(big, params, c, what, time_idx=1, max_pixels=400):
+    """Every pixel of the boolean image `big` lies under two Gaussians whose float64 camera-space depths differ by less than
+    4 float32 ulps (a depth tie: their order is decided by rounding)."""
+    ys, xs = np.nonzero(big)
+    print(f"{what}: {ys.size} pixels beyond the one-decision bound")
+    if ys.size == 0:
+        return 0
+    assert ys.size <= max_pixels, (what, ys.size)
+    q = params['cam_unnorm_rots'][0, :, time_idx].detach().double().cpu().numpy()
+    t = params['cam_trans'][0, :, time_idx].detach().double().cpu().numpy()
+    q = q / np.linalg.norm(q)
+    w, x, y, z = q
+    Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                   [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                   [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    X = params['means3D'].detach().double().cpu().numpy() @ Rm.T + t
+    zc = X[:, 2]
+    u, v = c['fx'] * X[:, 0] / zc + c['cx'], c['fy'] * X[:, 1] / zc + c['cy']
+    for py, px in zip(ys, xs):
+        near = np.nonzero((np.abs(u - px) < 12) & (np.abs(v - py) < 12) & (zc > 0.2))[0]
+        zs = np.sort(zc[near])
+        gaps = (zs[1:] - zs[:-1]) / zs[1:]
+        assert gaps.size and gaps.min() < 4 * 2.0 ** -24, (what, "pixel", int(px), int(py), "smallest relative depth gap", gaps.min() if gaps.size else None)
+    return int(ys.size)
+
+
 def _fused_case(cfg_name, aniso, tracking, monkeypatch, seed=0, region=None):
     from splatam_amd import slam
     from splatam_amd.fused import FusedEngine
@@ -222,9 +248,14 @@ def _fused_case(cfg_name, aniso, tracking, monkeypatch, seed=0, region=None):
     # (A) rendered planes
     imf, depthf, silf, dsqf = eng.rendered()
     nflip = 2e-4            # the fused glue rounds differently from torch's: a few more alpha >= 1/255 decisions flip than on the drop-in path
-    assert_close_outliers(imf.cpu().numpy(), renders[0].numpy(), 1e-4, max_outlier_frac=nflip, outlier_atol=0.03, what=f"{what} im")
-    assert_close_outliers(torch.cat([depthf, silf[None], dsqf]).cpu().numpy(), renders[1].numpy(), 1e-4, rtol=1e-4,
-                          max_outlier_frac=nflip, outlier_atol=0.3, what=f"{what} depth/sil/depth^2")
+    got_im, got_ds = imf.cpu().numpy(), torch.cat([depthf, silf[None], dsqf]).cpu().numpy()
+    assert_close_outliers(got_im, renders[0].numpy(), 1e-4, max_outlier_frac=nflip, what=f"{what} im")
+    assert_close_outliers(got_ds, renders[1].numpy(), 1e-4, rtol=1e-4, max_outlier_frac=nflip, what=f"{what} depth/sil/depth^2")
+    # one alpha >= 1/255 decision moves a pixel by <= ~1/255 |c|; anything larger must be a DEPTH TIE: two overlapping Gaussians
+    # whose camera-space depths agree to float32 rounding are ordered by that rounding, and the in-kernel glue (FMA chain) rounds
+    # z = (R X + t).z differently from torch's matmul -- a legitimate swap of two list neighbours, verified per pixel
+    big = (np.abs(got_im - renders[0].numpy()).max(axis=0) > 0.03) | (np.abs(got_ds - renders[1].numpy()).max(axis=0) > 0.3)
+    eng.depth_tie_pixels = _assert_depth_ties_explain(big, params, c, what)
     # (B) loss
     loss_f = eng.loss()
     assert abs(loss_f - loss_ref) <= 1e-4 * abs(loss_ref), (what, loss_f, loss_ref)
@@ -232,7 +263,8 @@ def _fused_case(cfg_name, aniso, tracking, monkeypatch, seed=0, region=None):
     planes = eng.buf['dL_dout6'].detach().cpu()
     ref_planes = torch.cat([plane_grads[0], plane_grads[1][0:1]])
     pmax = float(ref_planes.abs().max())
-    assert_close_outliers(planes[0:4].numpy(), ref_planes.numpy(), 1e-4 * pmax, rtol=1e-3, max_outlier_frac=1e-3, outlier_atol=2.5 * pmax,
+    # (round 3: the printed reports show at most 1.0e-4 of the plane elements at a kink -- D mapping -- hence 1.5e-4, was 1e-3)
+    assert_close_outliers(planes[0:4].numpy(), ref_planes.numpy(), 1e-4 * pmax, rtol=1e-3, max_outlier_frac=1.5e-4, outlier_atol=2.5 * pmax,
                           what=f"{what} dL/d(render) planes")
     assert float(planes[4:6].abs().max()) == 0.0 and float(plane_grads[1][1:3].abs().max()) == 0.0
     # (D) parameter / pose gradients for the SAME gradient planes, float32 and float64 oracle
@@ -245,8 +277,11 @@ def _fused_case(cfg_name, aniso, tracking, monkeypatch, seed=0, region=None):
 def test_fused_mapping_vs_oracle(cfg_name, aniso, monkeypatch):
     eng, g32, g64, what = _fused_case(cfg_name, aniso, False, monkeypatch)
     keys = ["means3D", "rgb_colors", "logit_opacities", "log_scales"] + (["unnorm_rotations"] if aniso else [])
+    # a depth tie (two list neighbours swapped, verified above) moves the gradients of the Gaussians under it: the 99.99 % quantile
+    # of a 150 k-row tensor is 15 elements, so that one swap IS the tail there (D-anisotropic: log_scales 2.3x the oracle's own tail)
+    tail = 2.0 if eng.depth_tie_pixels == 0 else 4.0
     for k in keys:
-        assert_grad_calibrated(eng.grads[k].cpu().numpy(), g32[k], g64[k], what=f"{what} grad {k}")
+        assert_grad_calibrated(eng.grads[k].cpu().numpy(), g32[k], g64[k], what=f"{what} grad {k}", tail_factor=tail)
     if not aniso:
         assert float(eng.grads["unnorm_rotations"].abs().max()) == 0.0
 
