@@ -48,6 +48,9 @@ WORKLOADS = {
     # B at four times the frame and the Gaussians (same density: the same per-tile work over 4x the tiles): what launch ramp /
     # tail effects cost the composites at B (profiles/r02_experiments.md)
     "B-4x": (1_200_000, 2400, 1360, 600.0, 600.0, 1199.5, 679.5),
+    # the map SplaTAM really builds at B's frame size: one Gaussian per valid first-frame pixel, in pixel (creation) order, opacity 0.5,
+    # scale from the projective mean squared distance (initialize_first_timestep, /root/reference/scripts/splatam.py:169-211)
+    "B-loop": (816_000, 1200, 680, 600.0, 600.0, 599.5, 339.5),
     "E-clustered": (1_000_000, 1752, 1168, 1200.0, 1200.0, 875.5, 583.5),
     "E-clustered-5M": (5_000_000, 1752, 1168, 1200.0, 1200.0, 875.5, 583.5),
 }
@@ -55,8 +58,30 @@ REGIONS = {"E-clustered": (0.40, 0.40, 0.6236, 0.6236), "E-clustered-5M": (0.40,
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def build_scene_loop(name, dev, n_views, seed=3):
+    """Workload B-loop: the first frame of a synthetic RGB-D sequence (a smooth textured surface, splatam_amd.pipeline) turned into the
+    map exactly as the frame loop does it (initialize_first_timestep); frame 1 is tracked, frames 2.. are keyframes at their true poses."""
+    from splatam_amd import pipeline
+    N, W, H, fx, fy, cx, cy = WORKLOADS[name]
+    num_frames = 2 + n_views
+    ds = pipeline.SyntheticRGBDSequence(300_000, W, H, fx, fy, cx, cy, num_frames=num_frames, seed=seed, device=dev)
+    params, variables, intrinsics, w2c0, cam = pipeline.initialize_first_timestep(ds, num_frames, 3.0, "projective", "isotropic", device=dev)
+    frames = {}
+    for t in range(1, num_frames):
+        color, depth, _, pose = ds[t]
+        frames[t] = {'cam': cam, 'im': (color.permute(2, 0, 1) / 255).contiguous(), 'depth': depth.permute(2, 0, 1).contiguous(), 'id': t, 'w2c': w2c0}
+        if t > 1:
+            rel = torch.linalg.inv(pose)            # world (first camera) -> camera t
+            with torch.no_grad():
+                params['cam_unnorm_rots'][..., t] = pipeline._matrix_to_quaternion(rel[:3, :3]).to(dev)
+                params['cam_trans'][..., t] = rel[:3, 3].reshape(1, 3)
+    return params, variables, frames, (int(params['means3D'].shape[0]), W, H)
+
+
 def build_scene(name, dev, n_views, seed=0):
     from splatam_amd import slam
+    if name == "B-loop":
+        return build_scene_loop(name, dev, n_views)
     N, W, H, fx, fy, cx, cy = WORKLOADS[name]
     num_frames = 2 + n_views
     params, variables = slam.synthetic_params(N, W, H, fx, fy, cx, cy, num_frames=num_frames, seed=seed, device=dev,
@@ -219,6 +244,21 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
         for iters in (5, 30):     # warm-up, then measure
             _capi.check(L.splat_iter_time_kernel(fn, iters, C.byref(eng._cam), N, C.byref(ws), stream, C.byref(ms)), "splat_iter_time_kernel")
         out[name] = ms.value
+    # the forward composite as the iteration launches it once the list statistics are learnt (filters its group's records, sorts and
+    # publishes its tile's list itself): needs the learnt state -> two more iterations around check_overflow()
+    out["render_forward_sorting"] = None
+    eng.loss_backward(frames[1], 1, slam.REPLICA_TRACKING, tracking=True)
+    torch.cuda.synchronize(dev)
+    if not eng.check_overflow() and eng.tile_stride > 0:
+        eng.loss_backward(frames[1], 1, slam.REPLICA_TRACKING, tracking=True)
+        torch.cuda.synchronize(dev)
+        ws2 = eng._workspace(False, False)
+        ms = C.c_float(0)
+        rc = 0
+        for iters in (5, 30):
+            rc = L.splat_iter_time_kernel(2, iters, C.byref(eng._cam), N, C.byref(ws2), stream, C.byref(ms))
+        if rc == 0:
+            out["render_forward_sorting"] = ms.value
     HW = W * H
     bytes_fwd = R * 52 + HW * 32
     bytes_bwd = R * 52 + HW * 32 + N * 48
@@ -242,17 +282,24 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
                            "frac_of_hbm_peak": round(abytes / d["avg_us"] / 1e3 / HBM_PEAK_GBS, 4), "traffic_bytes": d.get("traffic_bytes"),
                            "valu_issue_frac": d.get("valu_issue_frac")}
     other = {"render_forward_ms": round(out["render_forward"], 4), "render_forward_GBps": round(gbs_f, 2),
+             "render_forward_sorting_ms": None if out["render_forward_sorting"] is None else round(out["render_forward_sorting"], 4),
              "render_backward_ms": round(out["render_backward"], 4), "render_backward_GBps": round(gbs_b, 2),
              "num_rendered": R,
              # secondary ceiling: live (pixel, Gaussian) pairs; filled from the oracle's count by the cpu_baseline leg
              "pairs_per_launch": None, "pair_evals_per_s": None,
-             "valu_issue_frac": dom.get("valu_issue_frac") if dom else None,
+             # filled with pairs_per_launch (cpu_baseline leg): vector lane-operations (64 x SQ_INSTS_VALU) per live pair, and the pair
+             # rate against SURVEY.md 8(d)'s secondary ceiling (4.9e12 pair evaluations / s)
+             "lane_ops_per_live_pair": None, "pair_evals_frac_of_survey_ceiling": None,
+             "valu_cycles_frac": dom.get("valu_cycles_frac") if dom else None,
              "valu_insts_per_launch": dom.get("SQ_INSTS_VALU") if dom else None,
              "pmc_source": (f"profiles/{pmc[0]} @ {pmc[1].get('git_head')}" if pmc else None),
              "kernels": rows,
-             "note": "K6 / K7 times are live HIP-event measurements of this run; counters (traffic = 2 x FETCH_SIZE + WRITE_SIZE, VALU "
-                     "issue = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles)) and the per-kernel rows come from the committed "
-                     "rocprofv3 passes named in pmc_source.  The kernels are instruction-issue bound, not HBM bound (DESIGN.md 5)"}
+             "note": "K6 / K7 times are live HIP-event measurements of this run; counters (traffic = 2 x FETCH_SIZE + WRITE_SIZE) and the "
+                     "per-kernel rows come from the committed rocprofv3 passes named in pmc_source.  valu_cycles_frac = vector-pipe cycles "
+                     "of the kernel's instruction mix / (1024 SIMDs x kernel cycles) with the MEASURED issue costs of gfx950 "
+                     "(profiles/r03_valu_issue_bench.txt, r03_visit_replay.txt: plain VALU 2 cycles per wave64 instruction, compares / "
+                     "selects / DPP 4, exp / rcp ~20 in the visit's mix; round 2 priced every instruction at 4).  The composites are "
+                     "bound by the vector pipe at ~21 % live lanes, not by HBM (DESIGN.md 5)"}
     return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
             "traffic": dom.get("traffic_bytes") if dom else None, "kernel": dominant + "_kernel<6,8> (fused iteration)",
             "kernel_ms": round(out[dominant], 4), "algorithmic_bytes": bytes_bwd if dominant == "render_backward" else bytes_fwd,
@@ -405,6 +452,7 @@ def main():
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--sync-mode", default="exact", choices=["exact", "lazy"])
     ap.add_argument("--engine", default="fused", choices=["fused", "dropin"])
+    ap.add_argument("--sustain-s", type=float, default=6.5, help="length of the sustained region in seconds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-slam-loop", action="store_true", help="skip the informational end-to-end frame-loop figure")
@@ -494,14 +542,27 @@ def main():
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t[0])
-        # a sustained figure beside the K-step one: the same schedule for >= 1 s (multiples of the 5-step mix period)
-        n_sus = max(args.steps, int(math.ceil(1.2 * args.steps / max(elapsed, 1e-6) / 5.0)) * 5)
+        # a sustained figure beside the K-step one: the same schedule for >= 6.5 s in ONE block (multiples of the 5-step mix period; the
+        # driver samples GPU utilisation every 5 s: at least one sample falls inside).  Tens of thousands of Adam steps on one synthetic
+        # view set would move the map until its lists outgrow the learnt buckets, so every 1 000 steps the map, the poses and the Adam
+        # state go back to their values at the start of the region (a 14 MB device copy: < 0.01 % of the block)
+        n_sus = max(args.steps, int(math.ceil(args.sustain_s * args.steps / max(elapsed, 1e-6) / 5.0)) * 5)
+        snapshot = {k: v.detach().clone() for k, v in eparams.items()}
         barrier()
         t1 = time.perf_counter()
-        steps(n_sus, args.warmup + args.steps)
+        done = 0
+        while done < n_sus:
+            nblk = min(1000, n_sus - done)
+            steps(nblk, args.warmup + args.steps + done)
+            done += nblk
+            with torch.no_grad():
+                for k, v in eparams.items():
+                    v.copy_(snapshot[k])
+            eng.reset_map_optimizer()
+            eng.begin_tracking(1)
         barrier()
         sustained_s = time.perf_counter() - t1
-        sustained_ok = not eng.check_overflow(grow=False)      # (thousands of Adam steps on ONE synthetic view set can outgrow the list buckets)
+        sustained_ok = not eng.check_overflow(grow=False)
         # the exchange step alone (rank-local average over 20 collectives of the flat gradient bucket)
         allreduce_ms = None
         if world > 1:
@@ -566,7 +627,9 @@ def main():
         if mpix is None:
             mpix, ms_call = render_mpix(params_d, frames, shape, dev)
         wl = (f"C: {N} Gaussians, {W}x{H}, mapping-only, a batch of 8 keyframe views per step sharded over the ranks, one gradient all-reduce"
-              if mode_c else f"{args.workload}: {N} Gaussians, {W}x{H}, SplaTAM tracking+mapping loop (2:3 mix), isotropic map")
+              if mode_c else f"{args.workload}: {N} Gaussians, {W}x{H}, SplaTAM tracking+mapping loop (2:3 mix), isotropic map"
+                   + ("; fused tracking iterations do not form dL/d(rgb, opacity, scale): the reference computes them, steps them with learning "
+                      "rate 0 and discards the optimizer after the frame (parameters after any number of iterations are identical)" if fused else ""))
         result = {
             "metric": ("mapping view-iterations/sec @300k Gaussians, 8 keyframe views per step" if mode_c
                        else "track+map iters/sec @300k Gaussians (render+backward Mpix/s alongside)"),
@@ -599,6 +662,9 @@ def main():
             if roof is not None and pairs:
                 roof["other"]["pairs_per_launch"] = pairs
                 roof["other"]["pair_evals_per_s"] = round(pairs / (roof["other"]["render_backward_ms"] * 1e-3), 1)
+                roof["other"]["pair_evals_frac_of_survey_ceiling"] = round(roof["other"]["pair_evals_per_s"] / 4.9e12, 4)
+                if roof["other"].get("valu_insts_per_launch"):
+                    roof["other"]["lane_ops_per_live_pair"] = round(64.0 * roof["other"]["valu_insts_per_launch"] / pairs, 1)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

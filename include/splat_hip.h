@@ -347,10 +347,12 @@ int splat_iter_finish(const SplatCamera *cam, const SplatMap *map, const SplatFr
 int splat_iter_mapping_step(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame,
                             const SplatLossConfig *cfg, SplatIterWorkspace *ws, const SplatAdamMap *adam, void *stream);
 
-/* Kernel-only timing helper for bench.py on the fused path: fn 0 = 6-channel composite forward, 1 = 6-channel composite
- * backward (the kernel alone: the launches accumulate on top of each other and the accumulator is zeroed again AFTER the
- * timed bracket, so the workspace stays usable), launched `iters` times on `stream` between two hipEvents; the workspace
- * must hold the state of a completed splat_iter_loss_backward. */
+/* Kernel-only timing helper for bench.py on the fused path: fn 0 = 6-channel composite forward reading published lists, 1 = 6-channel
+ * composite backward (the kernel alone: the launches accumulate on top of each other and the accumulator is zeroed again AFTER the
+ * timed bracket, so the workspace stays usable), 2 = the forward composite in the form the iteration launches on short lists
+ * (it filters its group's records / reads its bucket, sorts and publishes the tile's list itself; needs bucketed lists and a list
+ * length hint <= 819, SPLAT_E_INVALID otherwise), launched `iters` times on `stream` between two hipEvents; the workspace must hold
+ * the state of a completed splat_iter_loss_backward. */
 int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P, SplatIterWorkspace *ws, void *stream, float *ms);
 
 /* ------------------------------------------------------------------------------------------------------------

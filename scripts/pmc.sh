@@ -29,6 +29,7 @@ for k, d in acc.items():
 PY
 }
 pass inst SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM
+pass trans SQ_INSTS_VALU_TRANS_F32 SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU
 pass wait SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_INSTS_BRANCH
 pass fetch FETCH_SIZE GRBM_GUI_ACTIVE
 pass write WRITE_SIZE

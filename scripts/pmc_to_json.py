@@ -39,7 +39,12 @@ for k, d in kern.items():
     if "SQ_INSTS_VALU" in d and "GRBM_GUI_ACTIVE" in d:
         cycles = d["GRBM_GUI_ACTIVE"] / 8.0                     # GRBM_GUI_ACTIVE sums the 8 XCDs
         d["kernel_cycles"] = cycles
-        d["valu_issue_frac"] = round(d["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cycles), 4)      # 4 cycles per wave64 VALU instruction, 1024 SIMDs
+        # vector-pipe cycles of the kernel's instruction mix with the issue costs MEASURED on gfx950 (profiles/r03_valu_issue_bench.txt,
+        # r03_visit_replay.txt): a plain wave64 VALU instruction 2 cycles, compares / selects / DPP 4 -- 2.5 on average over the
+        # composites' non-transcendental mix (counted in their ISA) --, exp / rcp ~20 inside the visit's dependent mix (8 back to back).
+        # Round 2 priced every instruction at 4 cycles ("valu_issue_frac").
+        trans = d.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+        d["valu_cycles_frac"] = round(((d["SQ_INSTS_VALU"] - trans) * 2.5 + trans * 20.0) / (1024.0 * cycles), 4)
 head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, text=True).stdout.strip()
 out = {"source": f"scripts/pmc.sh {tag} {workload} fused (rocprofv3 --pmc, separate passes: inst / wait / fetch / write)", "workload": workload,
        "git_head": head, "kernels": kern}

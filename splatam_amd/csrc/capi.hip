@@ -221,7 +221,7 @@ int splat_iter_adam_pose(const SplatMap *map, int32_t time_idx, const float *d_c
 }
 
 int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P, SplatIterWorkspace *ws, void *stream, float *ms) {
-    if (!ms || iters <= 0 || !cam || !ws || (fn != 0 && fn != 1) || P < 0) return SPLAT_E_INVALID;
+    if (!ms || iters <= 0 || !cam || !ws || fn < 0 || fn > 2 || P < 0) return SPLAT_E_INVALID;
     if (!ws->feat8 || !ws->out6 || !ws->dL_dout6 || !ws->accum || !ws->st.tile_base || !ws->st.point_list) return SPLAT_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0, e1;
@@ -230,9 +230,21 @@ int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P,
     // bucketed lists: the iteration's last kernel consumed and reset the tile counters and left the counts in the cursor words
     SplatState st = ws->st;
     if (st.tile_stride > 0) st.tile_count = st.tile_cursor;
+    // fn 2: the forward composite in the form the iteration launches when the lists are short -- it filters its group's records (or
+    // reads its bucket), sorts and publishes the tile's list itself.  The iteration's last kernel left the groups' record counts in
+    // word 1 of their counter lines and the tiles' counts in the cursor words; the re-published lists and counts are the same values
+    bool sort_form = false;
+    if (fn == 2) {
+        if (st.tile_stride <= 0 || !(st.max_list_hint > 0 && st.max_list_hint + st.max_list_hint / 4 <= 1024)) return SPLAT_E_INVALID;
+        sort_form = true;
+        if (st.group_stride > 0 && st.group_count && st.group_recs) st.group_count = st.group_count + 1;
+        else st.group_stride = 0;
+    } else {
+        st.group_stride = 0;
+    }
     (void)hipEventRecord(e0, s);
     for (int i = 0; i < iters && err == hipSuccess; ++i)
-        err = fn == 0 ? launch_render_forward_feat8(*cam, ws->feat8, st, ws->out6, false, s)
+        err = fn != 1 ? launch_render_forward_feat8(*cam, ws->feat8, st, ws->out6, sort_form, s)
                       : launch_render_backward_feat8(*cam, ws->feat8, st, ws->dL_dout6, ws->accum, P, false, true, s);
     (void)hipEventRecord(e1, s);
     // the timed backward launches accumulated into ws->accum: restore the workspace invariant (every iteration leaves the

@@ -762,7 +762,12 @@ __global__ __launch_bounds__(kBlock) void fused_backward_kernel(FusedArgs a, Spl
             const unsigned cnt = ws.st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE];
             ws.st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE] = 0;
             ws.st.tile_cursor[(size_t)t * SPLAT_COUNTER_STRIDE] = cnt;       // kept for a later pass over the same lists (splat_iter_means2d_accumulate)
-            if (t < G) ws.st.group_count[(size_t)t * SPLAT_COUNTER_STRIDE] = 0;
+            if (t < G) {
+                // (the group's record count stays in word 1 of its counter line for a later pass over the same records:
+                //  splat_iter_time_kernel times the sorting form of the forward composite on it)
+                ws.st.group_count[(size_t)t * SPLAT_COUNTER_STRIDE + 1] = ws.st.group_count[(size_t)t * SPLAT_COUNTER_STRIDE];
+                ws.st.group_count[(size_t)t * SPLAT_COUNTER_STRIDE] = 0;
+            }
             sum += cnt;
             mx = max(mx, cnt);
         }

@@ -515,7 +515,10 @@ __global__ __launch_bounds__(kBlock) void fold_tile_counters_kernel(SplatState s
         const unsigned cnt = st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE];
         st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE] = 0;
         st.tile_cursor[(size_t)t * SPLAT_COUNTER_STRIDE] = cnt;
-        if (st.group_count && t < G) st.group_count[(size_t)t * SPLAT_COUNTER_STRIDE] = 0;      // (G <= T)
+        if (st.group_count && t < G) {                                                          // (G <= T)
+            st.group_count[(size_t)t * SPLAT_COUNTER_STRIDE + 1] = st.group_count[(size_t)t * SPLAT_COUNTER_STRIDE];    // kept, see fused_backward_kernel
+            st.group_count[(size_t)t * SPLAT_COUNTER_STRIDE] = 0;
+        }
         sum += cnt;
         mx = max(mx, cnt);
     }
