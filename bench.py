@@ -15,7 +15,9 @@ Two engines run the same iteration (same loss, same gradients, same Adam update:
     launches of libsplat_hip.so (shared geometry, ONE 6-channel composite for the RGB and depth/silhouette renders,
     fused loss / SSIM / pose-gradient / Adam kernels, no host synchronisation);
   * ``dropin``: the reference's own Python glue (splatam_amd.slam, PyTorch autograd + torch.optim.Adam) around the
-    drop-in ``GaussianRasterizer`` -- what an unmodified scripts/splatam.py gets; reported as ``dropin_iters_per_s``.
+    drop-in ``GaussianRasterizer`` -- what an unmodified scripts/splatam.py gets; reported as ``dropin_iters_per_s``;
+  * ``plugin_iters_per_s``: the same loop statements with ``splatam_amd.plugin.install()`` (get_loss / initialize_optimizer of the
+    caller's module replaced at run time by adapters over the fused engine).
 
 Prints ONE JSON line on rank 0.
 """
@@ -564,7 +566,7 @@ def main():
         sustained_s = time.perf_counter() - t1
         sustained_ok = not eng.check_overflow(grow=False)
         # the exchange step alone (rank-local average over 20 collectives of the flat gradient bucket)
-        allreduce_ms = None
+        allreduce_ms = allreduce_small_ms = None
         if world > 1:
             from splatam_amd.dist import all_reduce_sum_flat
             for _ in range(3):
@@ -576,6 +578,16 @@ def main():
             torch.cuda.synchronize(dev)
             allreduce_ms = 1e3 * (time.perf_counter() - t2) / 20
             eng.grad_flat.zero_()
+            # the small exchange of tile-row-sharded tracking (the 16 KB record of partial sums), likewise
+            for _ in range(3):
+                all_reduce_sum_flat(eng.buf['sums'])
+            barrier()
+            t3 = time.perf_counter()
+            for _ in range(20):
+                all_reduce_sum_flat(eng.buf['sums'])
+            torch.cuda.synchronize(dev)
+            allreduce_small_ms = 1e3 * (time.perf_counter() - t3) / 20
+            eng.buf['sums'].zero_()
     else:
         variables = run_steps(params_d, variables, frames, bucket, rank, world, args.warmup, opt_track, opt_map, tstate, 0)
         barrier()
@@ -584,7 +596,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
     if not fused:
-        n_sus, sustained_s, allreduce_ms, sustained_ok = args.steps, elapsed, None, True
+        n_sus, sustained_s, allreduce_ms, allreduce_small_ms, sustained_ok = args.steps, elapsed, None, None, True
     if world > 1:
         t = torch.tensor([elapsed, sustained_s], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -604,6 +616,13 @@ def main():
         track_rate = phase_rate(lambda: eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING, shard=(rank, world) if (world > 1 and SHARD_TRACKING) else None,
                                                                allreduce_sums=sdist.all_reduce_sum_flat), n_phase, dev)
         map_rate = phase_rate(lambda: eng.mapping_iteration(frames[2], 2, slam.REPLICA_MAPPING), n_phase, dev)
+        # several ranks: the same tracking iteration replicated (every rank composites the whole frame, no exchange), and the mapping
+        # iteration with its gradient exchange -- beside the sharded / local rates above, so that a reader of the N-GPU line sees what
+        # each phase gains
+        track_rate_repl = map_rate_exch = None
+        if world > 1:
+            track_rate_repl = phase_rate(lambda: eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING), n_phase, dev)
+            map_rate_exch = phase_rate(lambda: eng.mapping_iteration(frames[2], 2, slam.REPLICA_MAPPING, sdist.all_reduce_mean_flat), n_phase, dev)
     n_drop = max(5, min(15, args.steps))
     if fused:       # the drop-in path has not run yet: MIOpen / rocBLAS pick their kernels on the first calls
         for _ in range(3):
@@ -619,6 +638,22 @@ def main():
             opt_map.zero_grad(set_to_none=True)
     map_rate_d = phase_rate(map_once, n_drop, dev)
     dropin_rate = 5.0 / (2.0 / track_rate_d + 3.0 / map_rate_d)
+    # the SAME statements with splatam_amd.plugin installed (get_loss / initialize_optimizer of the module replaced at run time): what an
+    # unmodified scripts/splatam.py gets from the plug-in -- the fused iteration behind the reference's own loop statements
+    from splatam_amd import plugin
+    params_p = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    vars_p = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in variables.items()}
+    with plugin.install(slam):
+        opt_track_p = slam.initialize_optimizer(params_p, slam.REPLICA_TRACKING['lrs'], tracking=True)
+        tstate_p = slam.TrackingState(params_p, 1)
+        for _ in range(3):
+            slam.tracking_iteration(params_p, frames[1], vars_p, 1, opt_track_p, tstate_p)
+        track_rate_p = phase_rate(lambda: slam.tracking_iteration(params_p, frames[1], vars_p, 1, opt_track_p, tstate_p), n_phase, dev)
+        opt_map_p = slam.initialize_optimizer(params_p, slam.REPLICA_MAPPING['lrs'], tracking=False)
+        for _ in range(3):
+            slam.mapping_iteration(params_p, frames[2], vars_p, 2, opt_map_p)
+        map_rate_p = phase_rate(lambda: slam.mapping_iteration(params_p, frames[2], vars_p, 2, opt_map_p), n_phase, dev)
+    plugin_rate = 5.0 / (2.0 / track_rate_p + 3.0 / map_rate_p)
     if not fused:
         track_rate, map_rate = track_rate_d, map_rate_d
 
@@ -646,7 +681,12 @@ def main():
             "sustained": ({"steps": n_sus, "seconds": round(sustained_s, 3), "iters_per_s": round(units(n_sus) / sustained_s, 3)} if sustained_ok
                           else {"steps": n_sus, "invalid": "a per-tile list outgrew its bucket during the sustained region"}),
             "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4),
+            "allreduce_small_ms": None if allreduce_small_ms is None else round(allreduce_small_ms, 4),
+            "tracking_replicated_iters_per_s": None if not (fused and world > 1) else round(track_rate_repl, 3),
+            "mapping_with_exchange_iters_per_s": None if not (fused and world > 1) else round(map_rate_exch, 3),
             "tracking_iters_per_s": round(track_rate, 3), "mapping_iters_per_s": round(map_rate, 3),
+            "plugin_iters_per_s": round(plugin_rate, 3), "plugin_tracking_iters_per_s": round(track_rate_p, 3),
+            "plugin_mapping_iters_per_s": round(map_rate_p, 3),
             "dropin_iters_per_s": round(dropin_rate, 3), "dropin_tracking_iters_per_s": round(track_rate_d, 3),
             "dropin_mapping_iters_per_s": round(map_rate_d, 3),
             "render_fwd_bwd_mpix_per_s": round(mpix, 2), "render_fwd_bwd_ms": round(ms_call, 4),

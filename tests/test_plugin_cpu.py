@@ -1,0 +1,54 @@
+"""CPU side of splatam_amd.plugin: the adapters keep the reference's signatures, and the loop statements that
+tests/test_gpu_plugin.py restates appear in the reference's source in that order (checked when /root/reference is present: the GPU
+box has no copy of it)."""
+import inspect
+import os
+import re
+
+import pytest
+
+REF = "/root/reference/scripts/splatam.py"
+
+
+def test_adapter_signatures_match_the_reference_call_sites():
+    from splatam_amd import plugin
+    sig = inspect.signature(plugin.get_loss)
+    names = list(sig.parameters)
+    assert names[:9] == ['params', 'curr_data', 'variables', 'iter_time_idx', 'loss_weights', 'use_sil_for_loss', 'sil_thres', 'use_l1',
+                         'ignore_outlier_depth_loss']
+    for kw in ('tracking', 'mapping', 'do_ba', 'plot_dir', 'visualize_tracking_loss', 'tracking_iteration'):
+        assert kw in sig.parameters and sig.parameters[kw].default in (False, None)
+    assert list(inspect.signature(plugin.initialize_optimizer).parameters) == ['params', 'lrs_dict', 'tracking']
+
+
+def test_install_refuses_a_module_without_the_loop_names():
+    import types
+    from splatam_amd import plugin
+    with pytest.raises(RuntimeError, match="get_loss"):
+        plugin.install(types.ModuleType("empty"))
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference tree is not on this machine")
+def test_restated_loop_statements_follow_the_reference_source():
+    src = open(REF).read().splitlines()
+
+    def first(pattern, lo, hi):
+        for i in range(lo - 1, hi):
+            if re.search(pattern, src[i]):
+                return i + 1
+        raise AssertionError(f"{pattern!r} not found in lines {lo}-{hi}")
+    # the reference's signatures the adapters mirror
+    assert re.search(r"def get_loss\(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_for_loss,", src[213])
+    assert "def initialize_optimizer(params, lrs_dict, tracking):" in src[159]
+    # tracking loop: optimizer per frame, then get_loss -> backward -> step -> zero_grad -> best candidate
+    t_opt = first(r"optimizer = initialize_optimizer\(params, config\['tracking'\]\['lrs'\], tracking=True\)", 670, 690)
+    t = [first(p, t_opt, 745) for p in (r"loss, variables, losses = get_loss\(params, tracking_curr_data, variables, iter_time_idx",
+                                         r"loss\.backward\(\)", r"optimizer\.step\(\)", r"optimizer\.zero_grad\(set_to_none=True\)",
+                                         r"if loss < current_min_loss")]
+    assert t == sorted(t), t
+    # mapping loop: optimizer per frame, get_loss -> backward -> prune_gaussians -> step -> zero_grad
+    m_opt = first(r"optimizer = initialize_optimizer\(params, config\['mapping'\]\['lrs'\], tracking=False\)", 800, 830)
+    m = [first(p, m_opt, 895) for p in (r"loss, variables, losses = get_loss\(params, iter_data, variables, iter_time_idx",
+                                         r"loss\.backward\(\)", r"params, variables = prune_gaussians\(params, variables, optimizer, iter",
+                                         r"optimizer\.step\(\)", r"optimizer\.zero_grad\(set_to_none=True\)")]
+    assert m == sorted(m), m
