@@ -37,6 +37,7 @@ constexpr int kBatch = 256;         // records per LDS buffer (one per thread)
 constexpr int kBatchEntries = 255;  // list entries staged per buffer: record 255 is the INERT record (zero opacity) that the padding of the
                                     // visit lists points to
 constexpr int kSegBytes = 68;       // one visit list: <= 64 one-byte entries, padded with 0xFF to a multiple of 4, + the next group's look-ahead
+constexpr int kBlockListBytes = 264; // a block's visit list over a whole batch: <= 255 entries + padding + look-ahead
 
 #if defined(SPLAT_EXPERIMENTS)
 // Superseded / rejected generations of these kernels (experiments/render_v2.hip, experiments/render_v4.hip), built only with
@@ -87,7 +88,9 @@ __device__ __forceinline__ void load_colors(const float *colors, unsigned id, fl
     }
 }
 
-template <int C, int CS, bool WITH_DEPTH, int FP>
+// NL: visit lists per tile the staged mask addresses -- 4: one per 8x8 quadrant (bit q);  16: one per 4x4-PIXEL BLOCK, bit
+// 4 * quadrant + block-in-quadrant (block r of quadrant w: columns 4 (2 (w & 1) + (r & 1)) .., rows 4 (2 (w >> 1) + (r >> 1)) ..)
+template <int C, int CS, bool WITH_DEPTH, int FP, int NL = 4>
 __device__ __forceinline__ void gather(Staged<FP> &s, const SplatState &st, const float *colors, unsigned idx, bool valid,
                                        float tile_x0, float tile_y0, const uint64_t *lds_keys = nullptr, int lds_idx = 0) {
     s.ga = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -127,6 +130,26 @@ __device__ __forceinline__ void gather(Staged<FP> &s, const SplatState &st, cons
                 if (lam_min * (ddx * ddx + ddy * ddy) > tau2 * 1.001f + 1e-3f) mask &= ~(1u << q);
             }
             if (!(hx == hx) || !(hy == hy) || !(lam_min == lam_min)) mask = 15u;     // NaN geometry: no culling, let it propagate as the reference would
+            if constexpr (NL == 16) {
+                // per 4x4 block: the box test on the block's columns / rows, the radial test of the block's quadrant
+                const bool nan_geo = !(hx == hx) || !(hy == hy) || !(lam_min == lam_min);
+                unsigned xh = 0, yh = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    xh |= ((mu.x - hx <= tile_x0 + 4.f * b + 3.f) && (mu.x + hx >= tile_x0 + 4.f * b)) ? (1u << b) : 0u;
+                    yh |= ((mu.y - hy <= tile_y0 + 4.f * b + 3.f) && (mu.y + hy >= tile_y0 + 4.f * b)) ? (1u << b) : 0u;
+                }
+                // list L = 4 w + r: set when quadrant w passed the tests above and block r of it ((r & 1, r >> 1) within the quadrant)
+                // is hit in x and in y
+                unsigned m16 = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned xq = nan_geo ? 3u : (xh >> (2 * (w & 1))) & 3u, yq = nan_geo ? 3u : (yh >> (2 * (w >> 1))) & 3u;
+                    const unsigned sub = ((yq & 1u) ? xq : 0u) | ((yq & 2u) ? (xq << 2) : 0u);
+                    m16 |= (((mask >> w) & 1u) ? sub : 0u) << (4 * w);
+                }
+                mask = m16;
+            }
         }
         s.ga = make_float4(-0.5f * kLog2e * co.x, -kLog2e * co.y, -0.5f * kLog2e * co.z, co.w);
         s.mu = mu;
@@ -139,7 +162,7 @@ __device__ __forceinline__ void gather(Staged<FP> &s, const SplatState &st, cons
 //   [0] A, B, Cq, opacity   [1 .. FP/4] features   [FP/4 + 1] mu_x, mu_y, id (bits), 0
 // so that the compositing wave needs ONE address register and reads the record with FP/4 + 2 broadcast
 // ds_read_b128 (the 48 / 64-byte record stride keeps the staging ds_write_b128 conflict free).
-template <int FP>
+template <int FP, int NL = 4>
 struct Batch {
     static constexpr int R4 = FP / 4 + 2;
     float4 rec[kBatch * R4];
@@ -150,63 +173,95 @@ struct Batch {
     // instruction of whatever type takes a 2-cycle issue slot of its SIMD, scalar ones at most every 4th cycle
     // (profiles/r03_valu_issue_bench.txt) -- the composites are bound by the TOTAL instruction count.
     // One word of slack on either side: the look-ahead of the first / last group reads it.
-    unsigned vlist[1 + 16 * (kSegBytes / 4) + 1];
-    unsigned char vcnt[4][4];       // entries per list
+    // NL = 16 (forward composite): one list per 4x4-pixel block, see gather().  The four 16-lane rows of a compositing wave walk
+    // their blocks' lists IN STEP, so a trip count is the longest of four lists: those lists run over the whole batch (contiguous
+    // over the gathering waves, kBlockListBytes each) -- per gathering wave the maximum of four ~15-entry pieces sat 30 % above
+    // their mean.  The gathering waves exchange their per-list counts (vcnt, double buffered over the batches) one barrier
+    // before they write: commit_counts() / commit()
+    unsigned vlist[NL == 4 ? 1 + 16 * (kSegBytes / 4) + 1 : NL * (kBlockListBytes / 4)];
+    unsigned char vcnt[NL == 4 ? 1 : 2][NL][4];     // entries per list and gathering wave
+    unsigned char vtot[NL];         // NL == 16: entries per list
     unsigned flag[4];               // forward: wave w had no pixel left when this batch was committed
 };
 
-template <int FP>
-__device__ __forceinline__ const unsigned char *visit_list(const Batch<FP> &b, int quadrant, int gwave) {
-    return reinterpret_cast<const unsigned char *>(b.vlist + 1) + (quadrant * 4 + gwave) * kSegBytes;
+template <int FP, int NL>
+__device__ __forceinline__ const unsigned char *visit_list(const Batch<FP, NL> &b, int list, int gwave) {
+    return reinterpret_cast<const unsigned char *>(b.vlist + 1) + (list * 4 + gwave) * kSegBytes;
 }
 
 template <int FP>
-__device__ __forceinline__ void commit(Batch<FP> &b, const Staged<FP> &s, int tid, unsigned flag) {
-    constexpr int R4 = Batch<FP>::R4;
+__device__ __forceinline__ const unsigned char *block_list(const Batch<FP, 16> &b, int list) {
+    return reinterpret_cast<const unsigned char *>(b.vlist) + list * kBlockListBytes;
+}
+
+// NL == 16, step 1 (before the barrier that ends the previous batch): this gathering wave's entry count per block list
+template <int FP>
+__device__ __forceinline__ void commit_counts(Batch<FP, 16> &b, const Staged<FP> &s, int tid, int parity) {
+    const int wave = tid >> 6, lane = tid & 63;
+    unsigned mine = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int cnt = __builtin_popcountll(__builtin_amdgcn_ballot_w64((s.mask >> q) & 1u));
+        mine = lane == q ? (unsigned)cnt : mine;
+    }
+    if (lane < 16) b.vcnt[parity][lane][wave] = (unsigned char)mine;
+}
+
+template <int FP, int NL>
+__device__ __forceinline__ void commit(Batch<FP, NL> &b, const Staged<FP> &s, int tid, unsigned flag, int parity = 0) {
+    constexpr int R4 = Batch<FP, NL>::R4;
     b.rec[tid * R4] = s.ga;
 #pragma unroll
     for (int v = 0; v < FP / 4; ++v)
         b.rec[tid * R4 + 1 + v] = make_float4(s.feat[4 * v], s.feat[4 * v + 1], s.feat[4 * v + 2], s.feat[4 * v + 3]);
     b.rec[tid * R4 + R4 - 1] = make_float4(s.mu.x, s.mu.y, __uint_as_float(s.id), 0.f);
     const int wave = tid >> 6, lane = tid & 63;
+    if constexpr (NL == 16) {
+        // step 2 (after that barrier): entries at the offset the lower gathering waves leave; the lists of quadrant `wave` get
+        // their totals and their 0xFF padding (the inert record) up to the quadrant's longest list + the look-ahead from this wave
+        unsigned char *lists = reinterpret_cast<unsigned char *>(b.vlist);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const bool hit = (s.mask >> q) & 1u;
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        const int cnt = __builtin_popcountll(m);
-        unsigned char *seg = const_cast<unsigned char *>(visit_list(b, q, wave));
-        if (hit) seg[rank] = (unsigned char)tid;
-        if (lane < 4) seg[cnt + lane] = 0xFFu;                  // padding (cnt + 3 <= 67)
-        if (lane == 0) {
-            b.qmask[q][wave][0] = (unsigned)m;
-            b.qmask[q][wave][1] = (unsigned)(m >> 32);
-            b.vcnt[q][wave] = (unsigned char)cnt;
+        for (int q = 0; q < 16; ++q) {
+            const bool hit = (s.mask >> q) & 1u;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            const unsigned c4 = *reinterpret_cast<const unsigned *>(b.vcnt[parity][q]);           // counts of gathering waves 0..3
+            const unsigned below = c4 & ((1u << (8 * wave)) - 1u);                                 // (wave 0: none)
+            const int off = (int)((below & 0xFFu) + ((below >> 8) & 0xFFu) + ((below >> 16) & 0xFFu));
+            if (hit) lists[q * kBlockListBytes + off + rank] = (unsigned char)tid;
+        }
+        const unsigned *c4p = reinterpret_cast<const unsigned *>(b.vcnt[parity][wave * 4]);
+        int tot[4], tmax = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned c4 = c4p[r];
+            tot[r] = (int)((c4 & 0xFFu) + ((c4 >> 8) & 0xFFu) + ((c4 >> 16) & 0xFFu) + (c4 >> 24));
+            tmax = max(tmax, tot[r]);
+        }
+        const int pad_end = ((tmax + 3) & ~3) + 4;                  // the trips run to the longest list, the look-ahead 4 further
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            for (int j = tot[r] + lane; j < pad_end; j += 64) lists[(wave * 4 + r) * kBlockListBytes + j] = 0xFFu;
+            if (lane == 0) b.vtot[wave * 4 + r] = (unsigned char)tot[r];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const bool hit = (s.mask >> q) & 1u;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            const int cnt = __builtin_popcountll(m);
+            unsigned char *seg = const_cast<unsigned char *>(visit_list(b, q, wave));
+            if (hit) seg[rank] = (unsigned char)tid;
+            if (lane < 4) seg[cnt + lane] = 0xFFu;              // padding (cnt + 3 <= 67)
+            if (lane == 0) {
+                b.qmask[q][wave][0] = (unsigned)m;
+                b.qmask[q][wave][1] = (unsigned)(m >> 32);
+                b.vcnt[0][q][wave] = (unsigned char)cnt;
+            }
         }
     }
     if (lane == 0) b.flag[wave] = flag;
-}
-
-template <int FP>
-struct Entry {          // one staged Gaussian as the compositing wave holds it (wave-uniform values)
-    float4 ga;
-    float mux, muy;
-    unsigned id;
-    float feat[FP];
-};
-
-template <int FP>
-__device__ __forceinline__ void read_entry(const Batch<FP> &b, int e, Entry<FP> &o) {
-    constexpr int R4 = Batch<FP>::R4;
-    const float4 *r = b.rec + e * R4;
-    o.ga = r[0];
-#pragma unroll
-    for (int v = 0; v < FP / 4; ++v) {
-        const float4 t = r[1 + v];
-        o.feat[4 * v] = t.x; o.feat[4 * v + 1] = t.y; o.feat[4 * v + 2] = t.z; o.feat[4 * v + 3] = t.w;
-    }
-    const float4 m = r[R4 - 1];
-    o.mux = m.x; o.muy = m.y; o.id = __float_as_uint(m.z);
 }
 
 // One staged Gaussian as a compositing wave holds it: the whole LDS record, fetched ONE VISIT AHEAD (the wave's critical path
@@ -220,8 +275,8 @@ struct Rec {
 };
 
 // wave-uniform 64-bit word of this wave's quadrant mask
-template <int FP>
-__device__ __forceinline__ unsigned long long mask_word(const Batch<FP> &b, int quadrant, int w) {
+template <int FP, int NL>
+__device__ __forceinline__ unsigned long long mask_word(const Batch<FP, NL> &b, int quadrant, int w) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)b.qmask[quadrant][w][0]);
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)b.qmask[quadrant][w][1]);
     return ((unsigned long long)hi << 32) | lo;
@@ -333,13 +388,19 @@ __device__ __forceinline__ void sort_keys_two_level(uint64_t *A, uint64_t *S, co
 // SplatState.group_count), sorts them there (sort_keys_two_level) and publishes ids and count for the backward pass: no scan,
 // scatter or sort launch, and the gathers take their ids from LDS instead of a dependent global load.
 template <int C, int CS, bool WITH_DEPTH, bool SORT, bool TRACK = false>
-__global__ __launch_bounds__(256, 6) void render_forward_kernel(SplatCamera cam, const float *colors, SplatState st,
+__global__ __launch_bounds__(256, 5) void render_forward_kernel(SplatCamera cam, const float *colors, SplatState st,
                                                              float *out_color, float *out_depth, int T, int per_xcd,
                                                              TrackLossEpilogue ep = TrackLossEpilogue{}) {
     static_assert(!TRACK || (C == 6 && !WITH_DEPTH), "the tracking-loss epilogue reads the six fused channels");
     constexpr int F = C + (WITH_DEPTH ? 1 : 0);
     constexpr int FP = (F + 3) / 4 * 4;
-    __shared__ Batch<FP> B;
+    // ONE 4x4-PIXEL BLOCK PER 16-LANE ROW: row r of wave w composites block r of quadrant w (gather(): NL = 16) from the block's OWN
+    // visit lists -- the four rows of a wave process four different Gaussians per trip (each lane reads the record of its row's
+    // entry; the vector instructions are shared).  SplaTAM's splats are small ({alpha >= 1/255} radius ~3.8 px at workload B): a
+    // Gaussian that touches an 8x8 quadrant touches ~2 of its four blocks, so a wave takes ~0.6 trips per quadrant visit and ~36 %
+    // of its lanes hold a live pixel instead of ~21 % -- on a kernel bound by the vector pipe.
+    constexpr int NL = 16;
+    __shared__ Batch<FP, NL> B;
     __shared__ __attribute__((aligned(16))) uint64_t s_keys[SORT ? kFusedSortMax + 2 : 2];
     const int tile_local = block_tile(per_xcd, T);              // T: tiles of this launch (SplatState.tile_row_begin: a band of tile rows)
     if (tile_local < 0) return;
@@ -348,7 +409,8 @@ __global__ __launch_bounds__(256, 6) void render_forward_kernel(SplatCamera cam,
     const int tile = tile_local + st.tile_row_begin * gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx = tile % gx, ty = tile / gx;
-    const int px = tx * kTile + (wave & 1) * 8 + (lane & 7), py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
+    const int row = lane >> 4;                                  // this lane's block of the quadrant
+    const int px = tx * kTile + (wave & 1) * 8 + (row & 1) * 4 + (lane & 3), py = ty * kTile + (wave >> 1) * 8 + (row >> 1) * 4 + ((lane >> 2) & 3);
     const float fpx = (float)px, fpy = (float)py;
     const float tile_x0 = (float)(tx * kTile), tile_y0 = (float)(ty * kTile);
     const bool inside = px < W && py < H;
@@ -418,10 +480,11 @@ __global__ __launch_bounds__(256, 6) void render_forward_kernel(SplatCamera cam,
         // One LDS buffer (a tile's list is usually ONE batch; a second buffer would halve the resident workgroups):
         // the next batch's gather is in flight in registers while this one is composited, then barrier - commit - barrier.
         Staged<FP> pre;
-        gather<C, CS, WITH_DEPTH, FP>(pre, st, colors, lo + tid, tid < kBatchEntries && tid < n, tile_x0, tile_y0, lk, tid);
+        gather<C, CS, WITH_DEPTH, FP, NL>(pre, st, colors, lo + tid, tid < kBatchEntries && tid < n, tile_x0, tile_y0, lk, tid);
+        commit_counts(B, pre, tid, 0);
         for (int bi = 0; bi < nb; ++bi) {
-            if (bi > 0) __syncthreads();            // every wave has finished reading the previous batch
-            commit(B, pre, tid, wdone ? 1u : 0u);
+            __syncthreads();                        // every wave has finished reading the previous batch; this batch's list counts are in
+            commit(B, pre, tid, wdone ? 1u : 0u, bi & 1);
             __syncthreads();
             // every wave was finished when this batch was committed: the rest of the list cannot contribute
             const unsigned alldone = B.flag[0] & B.flag[1] & B.flag[2] & B.flag[3];
@@ -429,13 +492,15 @@ __global__ __launch_bounds__(256, 6) void render_forward_kernel(SplatCamera cam,
             const bool more = bi + 1 < nb;
             if (more) {                         // next batch's gather stays in flight while this one is composited
                 const int e = (bi + 1) * kBatchEntries + tid;
-                gather<C, CS, WITH_DEPTH, FP>(pre, st, colors, lo + e, tid < kBatchEntries && e < n, tile_x0, tile_y0, lk, e);
+                gather<C, CS, WITH_DEPTH, FP, NL>(pre, st, colors, lo + e, tid < kBatchEntries && e < n, tile_x0, tile_y0, lk, e);
+                commit_counts(B, pre, tid, (bi + 1) & 1);
             }
             const unsigned base1 = (unsigned)(bi * kBatchEntries + 1);
             unsigned last_loc = ~0u;            // record (byte offset in B.rec) of the pixel's last contributor in this batch (none yet)
             // a list entry -> its record's byte offset in B.rec: a wave-uniform value in a vector register (one byte-select shift per
             // visit, no scalar bookkeeping); the visit identifies its entry by that offset
-            auto rec_of = [&](unsigned e) { return e * (unsigned)(Batch<FP>::R4 * sizeof(float4)); };
+            constexpr int R4 = Batch<FP, NL>::R4;
+            auto rec_of = [&](unsigned e) { return e * (unsigned)(R4 * sizeof(float4)); };
             // one visit of this quadrant: `cur` was fetched from LDS during the previous visit (see Rec)
             auto visit = [&](unsigned rec, const Rec<FP> &cur) {
                 const float dx = cur.m.x - fpx, dy = cur.m.y - fpy;
@@ -463,17 +528,15 @@ __global__ __launch_bounds__(256, 6) void render_forward_kernel(SplatCamera cam,
                 r.a = p[0];
 #pragma unroll
                 for (int v = 0; v < FP / 4; ++v) r.f[v] = p[1 + v];
-                r.m = p[Batch<FP>::R4 - 1];
+                r.m = p[R4 - 1];
             };
-            // front to back over this quadrant's four visit lists (one per gathering wave), four entries per trip; the NEXT record is
-            // in flight while the current one is composited (two register sets, ping-pong).  A list's padding and the look-ahead past
-            // its end name the inert record or some other record of the batch: fetched, and -- the padding -- visited without effect
-            const unsigned cnts = (unsigned)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<const unsigned *>(B.vcnt[wave]));
-#pragma unroll 1
-            for (int g = 0; g < 4 && done_m != ~0ull; ++g) {
-                const int ng = (int)((cnts >> (8 * g)) & 0xFFu);
-                if (ng == 0) continue;
-                const unsigned char *seg = visit_list(B, wave, g);
+            // front to back over every row's block list, four entries per trip; the rows walk their own lists in step (each lane reads
+            // its row's list and records: up to four addresses per instruction), a row whose list is shorter visits the inert record
+            // (the 0xFF padding).  The NEXT record is in flight while the current one is composited (two register sets, ping-pong)
+            const unsigned t4 = (unsigned)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<const unsigned *>(B.vtot + wave * 4));
+            const int ng = (int)max(max(t4 & 0xFFu, (t4 >> 8) & 0xFFu), max((t4 >> 16) & 0xFFu, t4 >> 24));       // the longest of the four rows' lists
+            if (ng > 0 && done_m != ~0ull) {
+                const unsigned char *seg = block_list(B, wave * 4 + row);
                 unsigned cur4 = *reinterpret_cast<const unsigned *>(seg);
                 Rec<FP> ra, rb;
                 unsigned r0 = rec_of(cur4 & 0xFFu);
@@ -497,7 +560,7 @@ __global__ __launch_bounds__(256, 6) void render_forward_kernel(SplatCamera cam,
                     if (done_m == ~0ull) break;     // every pixel of the quadrant is done: nothing left to visit
                 }
             }
-            last = last_loc != ~0u ? base1 + last_loc / (unsigned)(Batch<FP>::R4 * sizeof(float4)) : last;
+            last = last_loc != ~0u ? base1 + last_loc / (unsigned)(R4 * sizeof(float4)) : last;
             wdone = done_m == ~0ull;
         }
     }
