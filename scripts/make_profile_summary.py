@@ -35,13 +35,13 @@ f1, f4, f5 = avg("fused_preprocess_kernel<2") or avg("fused_preprocess"), avg("s
 f6 = avg("fused_backward_kernel<false, false") or avg("fused_backward_kernel<false>") or avg("fused_backward_kernel")   # tracking form
 f6m = avg("fused_backward_kernel<true") or f6                                     # single-view mapping step: Adam inside
 f7, ap, am = avg("pose_finish"), avg("adam_pose"), avg("adam_map")
-out = [f"# `{tag}`: group binning (one record per Gaussian and 2x2-tile group through an LDS histogram; the forward composite filters, sorts and",
-       "publishes its tile's list), generation-5 backward composite, Adam of the map inside F6 for the single-view mapping step\n",
+out = [f"# `{tag}`: composites on compact visit lists (one-byte entries, four per trip), forward composite with one 4x4-pixel block per 16-lane row",
+       "(four Gaussians per trip), group binning, generation-5 backward composite, Adam of the map inside F6 for the single-view mapping step\n",
        "`rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-slam-loop` on MI355X (gfx950), workload B",
        "(300k Gaussians, 1200x680), engine = fused.  The run also times the drop-in path (reference-shaped PyTorch glue around the drop-in",
        f"rasterizer), hence the MIOpen / rocBLAS rows and the 3-channel kernels.  Full CSV: `{tag}_bench_kernel_stats.csv`; bench line of the",
        f"un-profiled run (with `cpu_baseline` and `slam_loop`): `{tag}_bench.json.log` (**{d['value']} iters/s**; tracking {d['tracking_iters_per_s']}/s, mapping",
-       f"{d['mapping_iters_per_s']}/s; drop-in path {d['dropin_iters_per_s']} iters/s; CPU oracle {d['cpu_baseline']['value']} iters/s on {d['cpu_baseline']['cores']} threads)."]
+       f"{d['mapping_iters_per_s']}/s; the reference's loop statements through splatam_amd.plugin {d.get('plugin_iters_per_s')} iters/s, on the drop-in path {d['dropin_iters_per_s']} iters/s; CPU oracle {d['cpu_baseline']['value']} iters/s on {d['cpu_baseline']['cores']} threads)."]
 if pmc:
     out.append(f"PMC passes of the fused path: `{pmc}` (`scripts/pmc.sh`).")
 out += ["", f"Total kernel time {tot / 1e6:.1f} ms.\n", "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
