@@ -546,15 +546,15 @@ def main():
             elapsed = float(t[0])
         # a sustained figure beside the K-step one: the same schedule for >= 6.5 s in ONE block (multiples of the 5-step mix period; the
         # driver samples GPU utilisation every 5 s: at least one sample falls inside).  Tens of thousands of Adam steps on one synthetic
-        # view set would move the map until its lists outgrow the learnt buckets, so every 1 000 steps the map, the poses and the Adam
-        # state go back to their values at the start of the region (a 14 MB device copy: < 0.01 % of the block)
+        # view set would move the map until its lists outgrow the learnt buckets, so every 250 steps the map, the poses and the Adam
+        # state go back to their values at the start of the region (a 14 MB device copy: < 0.1 % of the block)
         n_sus = max(args.steps, int(math.ceil(args.sustain_s * args.steps / max(elapsed, 1e-6) / 5.0)) * 5)
         snapshot = {k: v.detach().clone() for k, v in eparams.items()}
         barrier()
         t1 = time.perf_counter()
         done = 0
         while done < n_sus:
-            nblk = min(1000, n_sus - done)
+            nblk = min(250, n_sus - done)
             steps(nblk, args.warmup + args.steps + done)
             done += nblk
             with torch.no_grad():
