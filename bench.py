@@ -226,41 +226,57 @@ def kernel_roofline(params, frames, shape, dev):
 
 def fused_roofline(eng, frames, shape, dev, workload="B"):
     """Live HIP-event timing of the two 6-channel composite kernels of the fused iteration on the stream they are
-    launched on (splat_iter_time_kernel), after a tracking iteration has left a valid state in the workspace.
+    launched on, inside the iteration (splat_iter_kernel_timing) and back to back (splat_iter_time_kernel), in the learnt list state.
     Algorithmic bytes (DESIGN.md 5): per instance 4 (id) + 8 (xy) + 16 (conic, opacity) + 24 (six colours) = 52 B;
     K6: R*52 + HW*32 (six planes + final_T + n_contrib);  K7: R*52 + HW*32 (six gradient planes + final_T + n_contrib)
     + P*48 (twelve partial sums per Gaussian)."""
     import ctypes as C
     from splatam_amd import _capi, slam
     N, W, H = shape
-    eng.begin_tracking(1)
-    eng.loss_backward(frames[1], 1, slam.REPLICA_TRACKING, tracking=True)
-    torch.cuda.synchronize(dev)
-    R = int(eng.buf['status'][0])
-    ws = eng._workspace(False, False)
     L = _capi.lib()
     stream = torch.cuda.current_stream(dev).cuda_stream
-    out = {}
-    for fn, name in ((0, "render_forward"), (1, "render_backward")):
-        ms = C.c_float(0)
-        for iters in (5, 30):     # warm-up, then measure
-            _capi.check(L.splat_iter_time_kernel(fn, iters, C.byref(eng._cam), N, C.byref(ws), stream, C.byref(ms)), "splat_iter_time_kernel")
-        out[name] = ms.value
-    # the forward composite as the iteration launches it once the list statistics are learnt (filters its group's records, sorts and
-    # publishes its tile's list itself): needs the learnt state -> two more iterations around check_overflow()
-    out["render_forward_sorting"] = None
-    eng.loss_backward(frames[1], 1, slam.REPLICA_TRACKING, tracking=True)
-    torch.cuda.synchronize(dev)
-    if not eng.check_overflow() and eng.tile_stride > 0:
+    eng.begin_tracking(1)
+    # learn the list statistics first (bucketed lists, group binning, the composite sorts its own list): the state the loop runs in
+    for _ in range(3):
         eng.loss_backward(frames[1], 1, slam.REPLICA_TRACKING, tracking=True)
         torch.cuda.synchronize(dev)
-        ws2 = eng._workspace(False, False)
+        eng.check_overflow()
+    R = int(eng.buf['status'][0])
+
+    def in_situ(cfg, tracking, frame, idx, n=30, warm=5):
+        """Durations of the two composites INSIDE the iteration (hipEvent pairs recorded around them on the iteration's stream by
+        splat_iter_loss_backward itself: splat_iter_kernel_timing), averaged over n iterations."""
+        acc = [0.0, 0.0]
+        L.splat_iter_kernel_timing(-1, None)
+        try:
+            for it in range(warm + n):
+                eng.loss_backward(frame, idx, cfg, tracking=tracking)
+                for fn in (0, 1):
+                    ms = C.c_float(0)
+                    _capi.check(L.splat_iter_kernel_timing(fn, C.byref(ms)), "splat_iter_kernel_timing")
+                    if it >= warm:
+                        acc[fn] += ms.value
+        finally:
+            L.splat_iter_kernel_timing(-2, None)
+        return acc[0] / n, acc[1] / n
+
+    out = {}
+    # dominant kernels as the iteration runs them: mapping form (K6 sorts + publishes its list; K7 <6,8,15,15>), tracking form
+    out["render_forward"], out["render_backward"] = in_situ(slam.REPLICA_MAPPING, False, frames[2 % len(frames)], 2 % len(frames))
+    eng.begin_tracking(1)
+    out["render_forward_tracking"], out["render_backward_tracking"] = in_situ(slam.REPLICA_TRACKING, True, frames[1], 1)
+    # back-to-back launches of one kernel between two events (splat_iter_time_kernel): 0 the list-reading forward composite (what the
+    # iteration launches on long lists), 1 the backward composite, 2 the sorting forward composite
+    eng.loss_backward(frames[1], 1, slam.REPLICA_TRACKING, tracking=True)
+    torch.cuda.synchronize(dev)
+    ws = eng._workspace(False, False)
+    b2b = {}
+    for fn, name in ((0, "render_forward_list_reading"), (1, "render_backward"), (2, "render_forward_sorting")):
         ms = C.c_float(0)
         rc = 0
-        for iters in (5, 30):
-            rc = L.splat_iter_time_kernel(2, iters, C.byref(eng._cam), N, C.byref(ws2), stream, C.byref(ms))
-        if rc == 0:
-            out["render_forward_sorting"] = ms.value
+        for iters in (5, 30):     # warm-up, then measure
+            rc = L.splat_iter_time_kernel(fn, iters, C.byref(eng._cam), N, C.byref(ws), stream, C.byref(ms))
+        b2b[name] = ms.value if rc == 0 else None
     HW = W * H
     bytes_fwd = R * 52 + HW * 32
     bytes_bwd = R * 52 + HW * 32 + N * 48
@@ -272,7 +288,7 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
     # /opt/skills/guides/MI355X_MICROARCH.md prescribes); the file names its git head
     pmc = load_pmc(workload)
     k7 = pmc_kernel(pmc, "render_backward_kernel", "<6, 8, 15u, 15u")
-    k6 = pmc_kernel(pmc, "render_forward_kernel", "<6, 8, false, false, false>") or pmc_kernel(pmc, "render_forward_kernel", "<6, 8")
+    k6 = pmc_kernel(pmc, "render_forward_kernel", "<6, 8, false, true, false>") or pmc_kernel(pmc, "render_forward_kernel", "<6, 8")
     dom = k7 if dominant == "render_backward" else k6
     rows = {}
     per_unit = {"fused_preprocess_kernel": N * (48 + 87), "ssim_forward_kernel": HW * (2 * 12 + 36 + 16), "map_loss_backward_kernel": HW * (36 + 24 + 16),
@@ -283,9 +299,12 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
             rows[kname] = {"avg_us": round(d["avg_us"], 1), "algorithmic_bytes": abytes, "GBps": round(abytes / d["avg_us"] / 1e3, 1),
                            "frac_of_hbm_peak": round(abytes / d["avg_us"] / 1e3 / HBM_PEAK_GBS, 4), "traffic_bytes": d.get("traffic_bytes"),
                            "valu_issue_frac": d.get("valu_issue_frac")}
+    r4 = lambda v: None if v is None else round(v, 4)          # noqa: E731
     other = {"render_forward_ms": round(out["render_forward"], 4), "render_forward_GBps": round(gbs_f, 2),
-             "render_forward_sorting_ms": None if out["render_forward_sorting"] is None else round(out["render_forward_sorting"], 4),
              "render_backward_ms": round(out["render_backward"], 4), "render_backward_GBps": round(gbs_b, 2),
+             "render_forward_tracking_ms": round(out["render_forward_tracking"], 4),
+             "render_backward_tracking_ms": round(out["render_backward_tracking"], 4),
+             "back_to_back_ms": {k: r4(v) for k, v in b2b.items()},
              "num_rendered": R,
              # secondary ceiling: live (pixel, Gaussian) pairs; filled from the oracle's count by the cpu_baseline leg
              "pairs_per_launch": None, "pair_evals_per_s": None,
@@ -296,7 +315,9 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
              "valu_insts_per_launch": dom.get("SQ_INSTS_VALU") if dom else None,
              "pmc_source": (f"profiles/{pmc[0]} @ {pmc[1].get('git_head')}" if pmc else None),
              "kernels": rows,
-             "note": "K6 / K7 times are live HIP-event measurements of this run; counters (traffic = 2 x FETCH_SIZE + WRITE_SIZE) and the "
+             "note": "K6 / K7 times are live HIP-event measurements of this run, taken INSIDE the iteration (event pairs around the kernel on the "
+                     "iteration's stream, mapping form unless named; back_to_back_ms = the same kernels launched 30x in a row, which reads "
+                     "5-13 % longer); counters (traffic = 2 x FETCH_SIZE + WRITE_SIZE) and the "
                      "per-kernel rows come from the committed rocprofv3 passes named in pmc_source.  valu_cycles_frac = vector-pipe cycles "
                      "of the kernel's instruction mix / (1024 SIMDs x kernel cycles) with the MEASURED issue costs of gfx950 "
                      "(profiles/r03_valu_issue_bench.txt, r03_visit_replay.txt: plain VALU 2 cycles per wave64 instruction, compares / "

@@ -259,6 +259,26 @@ int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P,
     return check(err);
 }
 
+int splat_iter_kernel_timing(int fn, float *ms) {
+    KernelTimers &t = g_kernel_timers;
+    if (fn == -1 || fn == -2) {             // -1: start recording, -2: stop
+        const int was = t.on ? 1 : 0;
+        if (fn == -1 && !t.ev[0][0]) {
+            for (int k = 0; k < 2; ++k)
+                for (int j = 0; j < 2; ++j)
+                    if (hipEventCreate(&t.ev[k][j]) != hipSuccess) return SPLAT_E_LAUNCH;
+        }
+        t.on = fn == -1;
+        return was;
+    }
+    if (fn < 0 || fn > 1 || !ms || !t.ev[0][0]) return SPLAT_E_INVALID;
+    if (hipEventSynchronize(t.ev[fn][1]) != hipSuccess) return SPLAT_E_LAUNCH;
+    float v = 0.f;
+    if (hipEventElapsedTime(&v, t.ev[fn][0], t.ev[fn][1]) != hipSuccess) return SPLAT_E_LAUNCH;
+    *ms = v;
+    return SPLAT_OK;
+}
+
 static bool valid_iter_common(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame, const SplatIterWorkspace *ws) {
     if (!cam || !map || !frame || !ws) return false;
     if (map->P < 0 || cam->image_width <= 0 || cam->image_height <= 0 || !cam->viewmatrix || !cam->projmatrix) return false;

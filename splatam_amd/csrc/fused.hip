@@ -856,6 +856,8 @@ static void launch_fused_preprocess(const FusedArgs &a, hipStream_t s) {
         hipLaunchKernelGGL((fused_preprocess_kernel<0, kBlock>), dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
 }
 
+KernelTimers g_kernel_timers{};
+
 hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame,
                                      const SplatLossConfig &cfg, SplatIterWorkspace &ws_in, hipStream_t s, const SplatPoseAdam *pose_adam,
                                      const SplatAdamMap *map_adam) {
@@ -887,7 +889,9 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
     const bool fuse_loss = cfg.tracking && !cfg.ignore_outlier_depth_loss;
     // a band of tile rows (SplatState.tile_row_begin): only the loss that is formed per tile in the composite's epilogue is defined
     if (ws.st.tile_row_end > ws.st.tile_row_begin && !fuse_loss) return hipErrorInvalidValue;
+    if (g_kernel_timers.on) (void)hipEventRecord(g_kernel_timers.ev[0][0], s);
     e = launch_render_forward_feat8(cam, ws.feat8, ws.st, ws.out6, sort_in_k6, s, fuse_loss ? &ep : nullptr, fuse_loss ? &loss_done : nullptr);
+    if (g_kernel_timers.on) (void)hipEventRecord(g_kernel_timers.ev[0][1], s);
     if (e != hipSuccess) return e;
     if (cfg.ignore_outlier_depth_loss) {
         // torch.median of the depth error (exact radix selection, mapedit.hip) -> d_cam[13] (its bits through counts[4])
@@ -910,8 +914,10 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
         hipLaunchKernelGGL(ssim_forward_kernel, grid, dim3(kBlock), 0, s, a, W, H);
         hipLaunchKernelGGL(map_loss_backward_kernel, grid, dim3(kBlock), 0, s, a, W, H);
     }
+    if (g_kernel_timers.on) (void)hipEventRecord(g_kernel_timers.ev[1][0], s);
     e = launch_render_backward_feat8(cam, ws.feat8, ws.st, ws.dL_dout6, ws.accum, P, false, ws.d_rgb_colors != nullptr, s,
                                      ws.d_logit_opacities != nullptr);
+    if (g_kernel_timers.on) (void)hipEventRecord(g_kernel_timers.ev[1][1], s);
     if (e != hipSuccess) return e;
     PoseAdam pa{};
     if (pose_adam)
