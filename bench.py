@@ -226,7 +226,7 @@ def kernel_roofline(params, frames, shape, dev):
 
 def fused_roofline(eng, frames, shape, dev, workload="B"):
     """Live HIP-event timing of the two 6-channel composite kernels of the fused iteration on the stream they are
-    launched on, inside the iteration (splat_iter_kernel_timing) and back to back (splat_iter_time_kernel), in the learnt list state.
+    launched on (splat_iter_time_kernel), in the learnt list state the loop runs in.
     Algorithmic bytes (DESIGN.md 5): per instance 4 (id) + 8 (xy) + 16 (conic, opacity) + 24 (six colours) = 52 B;
     K6: R*52 + HW*32 (six planes + final_T + n_contrib);  K7: R*52 + HW*32 (six gradient planes + final_T + n_contrib)
     + P*48 (twelve partial sums per Gaussian)."""
@@ -241,42 +241,27 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
         eng.loss_backward(frames[1], 1, slam.REPLICA_TRACKING, tracking=True)
         torch.cuda.synchronize(dev)
         eng.check_overflow()
-    R = int(eng.buf['status'][0])
-
-    def in_situ(cfg, tracking, frame, idx, n=30, warm=5):
-        """Durations of the two composites INSIDE the iteration (hipEvent pairs recorded around them on the iteration's stream by
-        splat_iter_loss_backward itself: splat_iter_kernel_timing), averaged over n iterations."""
-        acc = [0.0, 0.0]
-        L.splat_iter_kernel_timing(-1, None)
-        try:
-            for it in range(warm + n):
-                eng.loss_backward(frame, idx, cfg, tracking=tracking)
-                for fn in (0, 1):
-                    ms = C.c_float(0)
-                    _capi.check(L.splat_iter_kernel_timing(fn, C.byref(ms)), "splat_iter_kernel_timing")
-                    if it >= warm:
-                        acc[fn] += ms.value
-        finally:
-            L.splat_iter_kernel_timing(-2, None)
-        return acc[0] / n, acc[1] / n
-
-    out = {}
-    # dominant kernels as the iteration runs them: mapping form (K6 sorts + publishes its list; K7 <6,8,15,15>), tracking form
-    out["render_forward"], out["render_backward"] = in_situ(slam.REPLICA_MAPPING, False, frames[2 % len(frames)], 2 % len(frames))
-    eng.begin_tracking(1)
-    out["render_forward_tracking"], out["render_backward_tracking"] = in_situ(slam.REPLICA_TRACKING, True, frames[1], 1)
-    # back-to-back launches of one kernel between two events (splat_iter_time_kernel): 0 the list-reading forward composite (what the
-    # iteration launches on long lists), 1 the backward composite, 2 the sorting forward composite
-    eng.loss_backward(frames[1], 1, slam.REPLICA_TRACKING, tracking=True)
+    # the state the mapping loop runs in: learnt lists, the gradient planes of a mapping iteration
+    eng.loss_backward(frames[2 % len(frames)], 2 % len(frames), slam.REPLICA_MAPPING, tracking=False)
     torch.cuda.synchronize(dev)
+    R = int(eng.buf['status'][0])
     ws = eng._workspace(False, False)
+    # one kernel launched 30x in a row between two events on the iteration's stream (splat_iter_time_kernel): 0 the list-reading forward
+    # composite (what the iteration launches on long lists), 1 the backward composite (mapping form), 2 the sorting forward composite
+    # (what the iteration launches at this workload).  In this state the figures agree with rocprofv3's per-kernel averages of the
+    # bench loop to ~2 % (round 2 timed them on the exact lists of a first iteration: K7 read 13 % long)
     b2b = {}
-    for fn, name in ((0, "render_forward_list_reading"), (1, "render_backward"), (2, "render_forward_sorting")):
+    for fn, name in ((0, "render_forward_list_reading"), (1, "render_backward"), (2, "render_forward_sorting"), (3, "forward_backward_pair")):
         ms = C.c_float(0)
         rc = 0
         for iters in (5, 30):     # warm-up, then measure
             rc = L.splat_iter_time_kernel(fn, iters, C.byref(eng._cam), N, C.byref(ws), stream, C.byref(ms))
         b2b[name] = ms.value if rc == 0 else None
+    if b2b["render_backward"] is None or b2b["render_forward_list_reading"] is None:
+        raise RuntimeError("splat_iter_time_kernel failed")
+    out = {"render_forward": b2b["render_forward_sorting"] or b2b["render_forward_list_reading"]}
+    # the backward composite between other kernels, as in the loop: the alternating pair minus the forward composite alone
+    out["render_backward"] = (b2b["forward_backward_pair"] - out["render_forward"]) if b2b["forward_backward_pair"] else b2b["render_backward"]
     HW = W * H
     bytes_fwd = R * 52 + HW * 32
     bytes_bwd = R * 52 + HW * 32 + N * 48
@@ -302,9 +287,10 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
     r4 = lambda v: None if v is None else round(v, 4)          # noqa: E731
     other = {"render_forward_ms": round(out["render_forward"], 4), "render_forward_GBps": round(gbs_f, 2),
              "render_backward_ms": round(out["render_backward"], 4), "render_backward_GBps": round(gbs_b, 2),
-             "render_forward_tracking_ms": round(out["render_forward_tracking"], 4),
-             "render_backward_tracking_ms": round(out["render_backward_tracking"], 4),
-             "back_to_back_ms": {k: r4(v) for k, v in b2b.items()},
+             "render_forward_is": "sorting form" if b2b["render_forward_sorting"] else "list-reading form",
+             "render_forward_list_reading_ms": r4(b2b["render_forward_list_reading"]),
+             "render_forward_sorting_ms": r4(b2b["render_forward_sorting"]),
+             "render_backward_30_in_a_row_ms": r4(b2b["render_backward"]), "forward_backward_pair_ms": r4(b2b["forward_backward_pair"]),
              "num_rendered": R,
              # secondary ceiling: live (pixel, Gaussian) pairs; filled from the oracle's count by the cpu_baseline leg
              "pairs_per_launch": None, "pair_evals_per_s": None,
@@ -315,9 +301,8 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
              "valu_insts_per_launch": dom.get("SQ_INSTS_VALU") if dom else None,
              "pmc_source": (f"profiles/{pmc[0]} @ {pmc[1].get('git_head')}" if pmc else None),
              "kernels": rows,
-             "note": "K6 / K7 times are live HIP-event measurements of this run, taken INSIDE the iteration (event pairs around the kernel on the "
-                     "iteration's stream, mapping form unless named; back_to_back_ms = the same kernels launched 30x in a row, which reads "
-                     "5-13 % longer); counters (traffic = 2 x FETCH_SIZE + WRITE_SIZE) and the "
+             "note": "K6 / K7 times are live HIP-event measurements of this run (30 launches in a row on the iteration's stream, learnt list "
+                     "state, after a mapping iteration); counters (traffic = 2 x FETCH_SIZE + WRITE_SIZE) and the "
                      "per-kernel rows come from the committed rocprofv3 passes named in pmc_source.  valu_cycles_frac = vector-pipe cycles "
                      "of the kernel's instruction mix / (1024 SIMDs x kernel cycles) with the MEASURED issue costs of gfx950 "
                      "(profiles/r03_valu_issue_bench.txt, r03_visit_replay.txt: plain VALU 2 cycles per wave64 instruction, compares / "

@@ -351,16 +351,10 @@ int splat_iter_mapping_step(const SplatCamera *cam, const SplatMap *map, const S
  * composite backward (the kernel alone: the launches accumulate on top of each other and the accumulator is zeroed again AFTER the
  * timed bracket, so the workspace stays usable), 2 = the forward composite in the form the iteration launches on short lists
  * (it filters its group's records / reads its bucket, sorts and publishes the tile's list itself; needs bucketed lists and a list
- * length hint <= 819, SPLAT_E_INVALID otherwise), launched `iters` times on `stream` between two hipEvents; the workspace must hold
+ * length hint <= 819, SPLAT_E_INVALID otherwise), 3 = forward (sorting form when the state allows it) and backward composite
+ * alternating, `iters` pairs (time(3) - time(2 or 0) = the backward composite between other kernels), launched `iters` times on `stream` between two hipEvents; the workspace must hold
  * the state of a completed splat_iter_loss_backward. */
 int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P, SplatIterWorkspace *ws, void *stream, float *ms);
-
-/* In-situ timing of the two composite kernels INSIDE splat_iter_loss_backward / splat_iter_mapping_step (bench.py's roofline block:
- * the duration the kernel has in the iteration, between the kernels that precede and follow it, which back-to-back launches of
- * splat_iter_time_kernel overstate by 5-13 %).  fn -1: start recording a hipEvent pair around the forward and the backward
- * composite of every following iteration (returns 1 if it was already on, else 0); fn -2: stop; fn 0 / 1: wait for the last
- * iteration's forward / backward composite and return its duration in *ms.  Process-wide, not thread safe: a measurement switch. */
-int splat_iter_kernel_timing(int fn, float *ms);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Map growth and maintenance: the per-frame callers that change the NUMBER of Gaussians.

@@ -127,7 +127,7 @@ EXPORTS = (
     "splat_preprocess_forward", "splat_bin_forward", "splat_render_forward", "splat_forward",
     "splat_render_backward", "splat_preprocess_backward", "splat_backward",
     "splat_mark_visible", "splat_time_kernel", "splat_debug_option",
-    "splat_iter_loss_backward", "splat_iter_adam_map", "splat_iter_adam_pose", "splat_iter_time_kernel", "splat_iter_kernel_timing",
+    "splat_iter_loss_backward", "splat_iter_adam_map", "splat_iter_adam_pose", "splat_iter_time_kernel",
     "splat_iter_tracking_step", "splat_iter_mapping_step", "splat_iter_finish", "splat_iter_render", "splat_map_scratch_words", "splat_map_row_floats", "splat_map_add_new_gaussians", "splat_map_prune",
     "splat_iter_means2d_accumulate", "splat_map_densify_select", "splat_map_duplicate",
 )
@@ -178,8 +178,6 @@ def lib():
     L.splat_iter_adam_pose.restype = C.c_int
     L.splat_iter_adam_pose.argtypes = [C.POINTER(SplatMap), C.c_int32, _fp, _fp, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_float, _fp]
-    L.splat_iter_kernel_timing.restype = C.c_int
-    L.splat_iter_kernel_timing.argtypes = [C.c_int, C.POINTER(C.c_float)]
     L.splat_iter_time_kernel.restype = C.c_int
     L.splat_iter_time_kernel.argtypes = [C.c_int, C.c_int, cam, C.c_int32, C.POINTER(SplatIterWorkspace), _fp, C.POINTER(C.c_float)]
     L.splat_iter_tracking_step.restype = C.c_int

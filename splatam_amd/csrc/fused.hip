@@ -54,11 +54,10 @@ __device__ __forceinline__ void load_gaussian(const SplatMap &m, int i, float *p
     const float4 q = reinterpret_cast<const float4 *>(m.unnorm_rotations)[i];
     u[0] = q.x; u[1] = q.y; u[2] = q.z; u[3] = q.w;
     logit = m.logit_opacities[i];
-    if (m.isotropic) {
-        ls[0] = m.log_scales[i]; ls[1] = ls[0]; ls[2] = ls[0];
-    } else {
-        ls[0] = m.log_scales[3 * i]; ls[1] = m.log_scales[3 * i + 1]; ls[2] = m.log_scales[3 * i + 2];
-    }
+    // (branch-free: a branch on the layout makes the compiler wait for the loads above before it requests the anisotropic scales)
+    const bool iso = m.isotropic != 0;
+    const float *s = m.log_scales + (iso ? (size_t)i : 3 * (size_t)i);
+    ls[0] = s[0]; ls[1] = s[iso ? 0 : 1]; ls[2] = s[iso ? 0 : 2];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -117,6 +116,10 @@ __global__ __launch_bounds__(BLOCK) void fused_preprocess_kernel(FusedArgs a) {
     if (active) {
         Pose P;
         load_pose(a.map, a.frame.time_idx, P);
+        // (requested with the parameters, not behind the stores below: the kernel lasts one wave lifetime = its chain of round trips;
+        //  ahead of load_gaussian, whose isotropic branch waits for the scale)
+        const float rgb[3] = {a.map.rgb_colors[3 * i], a.map.rgb_colors[3 * i + 1], a.map.rgb_colors[3 * i + 2]};
+        const float seen_radius = a.ws.max_2D_radius ? a.ws.max_2D_radius[i] : 0.f;
         float p[3], u[4], logit, ls[3];
         load_gaussian(a.map, i, p, u, logit, ls);
         Glue G;
@@ -134,9 +137,9 @@ __global__ __launch_bounds__(BLOCK) void fused_preprocess_kernel(FusedArgs a) {
         reinterpret_cast<uint2 *>(st.rect)[i] = make_uint2((unsigned)o.x0 | ((unsigned)o.y0 << 16), (unsigned)o.x1 | ((unsigned)o.y1 << 16));
         st.radii[i] = o.radius;
         float4 *f = reinterpret_cast<float4 *>(a.ws.feat8) + 2 * (size_t)i;
-        f[0] = make_float4(a.map.rgb_colors[3 * i], a.map.rgb_colors[3 * i + 1], a.map.rgb_colors[3 * i + 2], G.z);
+        f[0] = make_float4(rgb[0], rgb[1], rgb[2], G.z);
         f[1] = make_float4(1.0f, G.z * G.z, 0.f, 0.f);
-        if (vis && a.ws.max_2D_radius) a.ws.max_2D_radius[i] = fmaxf(a.ws.max_2D_radius[i], (float)o.radius);
+        if (vis && a.ws.max_2D_radius && (float)o.radius > seen_radius) a.ws.max_2D_radius[i] = (float)o.radius;
     }
     if (st.tile_stride == 0) {
         // exact path: count now, scan + scatter later
@@ -159,6 +162,8 @@ __global__ __launch_bounds__(BLOCK) void fused_preprocess_kernel(FusedArgs a) {
                 rank[t] = atomicAdd(&s_grp[(gy0 + yy) * ggx + gx0 + xx], 1u);
             }
         __syncthreads();
+        // (one returning atomic per non-empty group; two in flight per lane -- with a zero added where one of a lane's two groups is
+        //  empty -- was measured: 27.4 -> 34.1 us, the kernel is bound by the NUMBER of L2 atomics, not by their latency)
         for (int g = threadIdx.x; g < num_groups; g += BLOCK) {
             const unsigned cnt = s_grp[g];
             if (cnt) s_grp[g] = atomicAdd(&st.group_count[(size_t)g * SPLAT_COUNTER_STRIDE], cnt);
@@ -672,7 +677,7 @@ __global__ __launch_bounds__(256) void pose_finish_kernel(FusedArgs a, int HW, P
 // MAPGRADS = false (tracking: no per-Gaussian gradient is stored): only the camera partial sums are wanted, and with ISO (Sigma =
 // s^2 I in any camera frame) they depend on dL/dX_c alone -- the covariance adjoints fall away at compile time.
 template <bool ADAM, bool MAPGRADS, bool ISO>
-__global__ __launch_bounds__(kBlock) void fused_backward_kernel(FusedArgs a, SplatAdamMap opt) {
+__global__ __launch_bounds__(kBlock, ISO ? 5 : 4) void fused_backward_kernel(FusedArgs a, SplatAdamMap opt) {
     static_assert(MAPGRADS || !ADAM, "the Adam step consumes the map gradients");
     __shared__ double s_part[kPoseSums * (kBlock / 64)];
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -682,29 +687,40 @@ __global__ __launch_bounds__(kBlock) void fused_backward_kernel(FusedArgs a, Spl
     const SplatIterWorkspace &ws = a.ws;
     constexpr bool iso = ISO;
     if (i < a.map.P) {
+        // Everything this lane reads is requested HERE, before the first use: the kernel is one wave-lifetime long (4 688 waves at
+        // workload B: 4.6 per SIMD), i.e. its duration is the length of its chain of dependent memory round trips.  Round 2 read the
+        // accumulator row only after the radius, the parameters after that, and in the Adam step each of the 12 components' moments,
+        // then its parameter, behind the previous component's stores (22 round trips; 28.5 us).  (A Gaussian outside the view reads
+        // its zero accumulator row and its parameters for nothing: 92 B.)
+        // (camera, pose: ahead of the first store of the kernel, where the compiler can still prove them unclobbered: scalar loads)
+        CamConst c;
+        load_cam(c, a.cam);
+        Pose P;
+        load_pose(a.map, a.frame.time_idx, P);
+        const float w2c_row2[4] = {a.frame.w2c[8], a.frame.w2c[9], a.frame.w2c[10], a.frame.w2c[11]};
+        float acc[SPLAT_GRAD_STRIDE];
+        float4 *a4 = reinterpret_cast<float4 *>(ws.accum + (size_t)i * SPLAT_GRAD_STRIDE);
+#pragma unroll
+        for (int k = 0; k < SPLAT_GRAD_STRIDE / 4; ++k) {
+            const float4 v = a4[k];
+            acc[4 * k] = v.x; acc[4 * k + 1] = v.y; acc[4 * k + 2] = v.z; acc[4 * k + 3] = v.w;
+        }
+        float p[3], u[4], logit, ls[3];
+        load_gaussian(a.map, i, p, u, logit, ls);
+        const float4 co = reinterpret_cast<const float4 *>(ws.st.conic_opacity)[i];
+        // the row is consumed: the next iteration's K7 accumulates from zero without a memset.  (Unconditional -- rows outside the view
+        // are zero already -- and AFTER every load above: a store the compiler can neither sink nor prove disjoint pins them up here,
+        // ahead of the visibility test.)
+#pragma unroll
+        for (int k = 0; k < SPLAT_GRAD_STRIDE / 4; ++k) a4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         const bool vis = ws.st.radii[i] > 0;
         float dp[3] = {0.f, 0.f, 0.f}, du[4] = {0.f, 0.f, 0.f, 0.f}, dlogit = 0.f, dls[3] = {0.f, 0.f, 0.f};
         float drgb[3] = {0.f, 0.f, 0.f};
         if (vis) {
-            float acc[SPLAT_GRAD_STRIDE];
-            float4 *a4 = reinterpret_cast<float4 *>(ws.accum + (size_t)i * SPLAT_GRAD_STRIDE);
-#pragma unroll
-            for (int k = 0; k < SPLAT_GRAD_STRIDE / 4; ++k) {
-                const float4 v = a4[k];
-                acc[4 * k] = v.x; acc[4 * k + 1] = v.y; acc[4 * k + 2] = v.z; acc[4 * k + 3] = v.w;
-                a4[k] = make_float4(0.f, 0.f, 0.f, 0.f);      // consumed: the next iteration's K7 accumulates from zero without a memset
-            }
-            CamConst c;
-            load_cam(c, a.cam);
-            Pose P;
-            load_pose(a.map, a.frame.time_idx, P);
-            float p[3], u[4], logit, ls[3];
-            load_gaussian(a.map, i, p, u, logit, ls);
             Glue G;
-            glue_forward(P, a.frame.w2c + 8, p, u, logit, ls, iso, G);
+            glue_forward(P, w2c_row2, p, u, logit, ls, iso, G);
             float S6[6];
             cov3d_from_scale_rot(G.s, c.scale_modifier, G.rq, S6);
-            const float4 co = reinterpret_cast<const float4 *>(ws.st.conic_opacity)[i];
             const float g_ndc[2] = {-(co.x * acc[0] + co.y * acc[1]) * 0.5f * c.W, -(co.z * acc[1] + co.y * acc[0]) * 0.5f * c.H};
             const float g_conic[3] = {-0.5f * acc[2], -acc[3], -0.5f * acc[4]};
             float dXc[3], dS6[6], ds[3] = {0.f, 0.f, 0.f}, drq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -713,7 +729,22 @@ __global__ __launch_bounds__(kBlock) void fused_backward_kernel(FusedArgs a, Spl
             // colour channels: 6..8 rgb, 9 z, 10 silhouette (constant), 11 z^2
             drgb[0] = acc[6]; drgb[1] = acc[7]; drgb[2] = acc[8];
             const float dz = acc[9] + 2.f * G.z * acc[11];
-            glue_backward(P, a.frame.w2c + 8, p, iso, G, dXc, dz, acc[5], ds, drq, dp, du, &dlogit, dls, pose);
+            glue_backward(P, w2c_row2, p, iso, G, dXc, dz, acc[5], ds, drq, dp, du, &dlogit, dls, pose);
+        }
+        constexpr int kWidth[5] = {3, 3, 4, 1, ISO ? 1 : 3};
+        // (the moments: one more round trip, all 27 loads at once, issued ahead of the gradient stores; holding them across the adjoint
+        //  arithmetic costs 36 registers = one wave per SIMD less, measured slower)
+        float mom1[5][4], mom2[5][4], rgb_old[3] = {0.f, 0.f, 0.f};
+        if constexpr (ADAM) {
+#pragma unroll
+            for (int gidx = 0; gidx < 5; ++gidx)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool on = k < kWidth[gidx] && opt.grad[gidx] != nullptr;       // torch skips parameters without a gradient
+                    mom1[gidx][k] = on ? opt.exp_avg[gidx][(size_t)i * kWidth[gidx] + k] : 0.f;
+                    mom2[gidx][k] = on ? opt.exp_avg_sq[gidx][(size_t)i * kWidth[gidx] + k] : 0.f;
+                }
+            if (opt.grad[1]) { rgb_old[0] = a.map.rgb_colors[3 * i]; rgb_old[1] = a.map.rgb_colors[3 * i + 1]; rgb_old[2] = a.map.rgb_colors[3 * i + 2]; }
         }
         if constexpr (MAPGRADS) {
         if (a.cfg.gaussians_grad) {
@@ -731,25 +762,27 @@ __global__ __launch_bounds__(kBlock) void fused_backward_kernel(FusedArgs a, Spl
         }
         }
         if constexpr (ADAM) {
-            // torch.optim.Adam over every row (a Gaussian outside the view has a zero gradient, but its moments still move it)
-            auto step = [&](int gidx, float *param, int width, const float *g) {
-                if (!opt.grad[gidx]) return;                    // torch skips parameters without a gradient
-                float *m = opt.exp_avg[gidx] + (size_t)i * width, *v = opt.exp_avg_sq[gidx] + (size_t)i * width;
-                float *p = param + (size_t)i * width;
-                for (int k = 0; k < width; ++k) {
-                    float mm = m[k], vv = v[k];
-                    if (g[k] == 0.f && mm == 0.f && vv == 0.f) continue;       // (see adam_map_kernel)
-                    p[k] = adam_update(p[k], g[k], mm, vv, opt.beta1, opt.beta2, opt.step_size[gidx], opt.bc2_sqrt, opt.eps);
-                    m[k] = mm;
-                    v[k] = vv;
-                }
-            };
+            // torch.optim.Adam over every row (a Gaussian outside the view has a zero gradient, but its moments still move it), on
+            // the parameter values and moments read at the top
             const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
-            step(0, a.map.means3D, 3, dp);
-            step(1, a.map.rgb_colors, 3, drgb);
-            step(2, a.map.unnorm_rotations, 4, iso ? zero4 : du);
-            step(3, a.map.logit_opacities, 1, &dlogit);
-            step(4, a.map.log_scales, iso ? 1 : 3, dls);
+            const float *grads[5] = {dp, drgb, iso ? zero4 : du, &dlogit, dls};
+            const float *olds[5] = {p, rgb_old, u, &logit, ls};
+            float *params[5] = {a.map.means3D, a.map.rgb_colors, a.map.unnorm_rotations, a.map.logit_opacities, a.map.log_scales};
+#pragma unroll
+            for (int gidx = 0; gidx < 5; ++gidx) {
+                if (!opt.grad[gidx]) continue;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k >= kWidth[gidx]) continue;
+                    float mm = mom1[gidx][k], vv = mom2[gidx][k];
+                    const float gk = grads[gidx][k];
+                    if (gk == 0.f && mm == 0.f && vv == 0.f) continue;          // (see adam_map_kernel)
+                    const size_t j = (size_t)i * kWidth[gidx] + k;
+                    params[gidx][j] = adam_update(olds[gidx][k], gk, mm, vv, opt.beta1, opt.beta2, opt.step_size[gidx], opt.bc2_sqrt, opt.eps);
+                    opt.exp_avg[gidx][j] = mm;
+                    opt.exp_avg_sq[gidx][j] = vv;
+                }
+            }
         }
     }
     if (ws.st.tile_stride > 0) {
@@ -856,8 +889,6 @@ static void launch_fused_preprocess(const FusedArgs &a, hipStream_t s) {
         hipLaunchKernelGGL((fused_preprocess_kernel<0, kBlock>), dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
 }
 
-KernelTimers g_kernel_timers{};
-
 hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame,
                                      const SplatLossConfig &cfg, SplatIterWorkspace &ws_in, hipStream_t s, const SplatPoseAdam *pose_adam,
                                      const SplatAdamMap *map_adam) {
@@ -889,9 +920,7 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
     const bool fuse_loss = cfg.tracking && !cfg.ignore_outlier_depth_loss;
     // a band of tile rows (SplatState.tile_row_begin): only the loss that is formed per tile in the composite's epilogue is defined
     if (ws.st.tile_row_end > ws.st.tile_row_begin && !fuse_loss) return hipErrorInvalidValue;
-    if (g_kernel_timers.on) (void)hipEventRecord(g_kernel_timers.ev[0][0], s);
     e = launch_render_forward_feat8(cam, ws.feat8, ws.st, ws.out6, sort_in_k6, s, fuse_loss ? &ep : nullptr, fuse_loss ? &loss_done : nullptr);
-    if (g_kernel_timers.on) (void)hipEventRecord(g_kernel_timers.ev[0][1], s);
     if (e != hipSuccess) return e;
     if (cfg.ignore_outlier_depth_loss) {
         // torch.median of the depth error (exact radix selection, mapedit.hip) -> d_cam[13] (its bits through counts[4])
@@ -914,10 +943,8 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
         hipLaunchKernelGGL(ssim_forward_kernel, grid, dim3(kBlock), 0, s, a, W, H);
         hipLaunchKernelGGL(map_loss_backward_kernel, grid, dim3(kBlock), 0, s, a, W, H);
     }
-    if (g_kernel_timers.on) (void)hipEventRecord(g_kernel_timers.ev[1][0], s);
     e = launch_render_backward_feat8(cam, ws.feat8, ws.st, ws.dL_dout6, ws.accum, P, false, ws.d_rgb_colors != nullptr, s,
                                      ws.d_logit_opacities != nullptr);
-    if (g_kernel_timers.on) (void)hipEventRecord(g_kernel_timers.ev[1][1], s);
     if (e != hipSuccess) return e;
     PoseAdam pa{};
     if (pose_adam)

@@ -435,20 +435,40 @@ __global__ __launch_bounds__(256, 5) void render_forward_kernel(SplatCamera cam,
             __syncthreads();
             const int ggx = (gx + SPLAT_GROUP_TILES - 1) / SPLAT_GROUP_TILES;
             const int grp = (ty / SPLAT_GROUP_TILES) * ggx + tx / SPLAT_GROUP_TILES;
-            const int cnt = min((int)st.group_count[(size_t)grp * SPLAT_COUNTER_STRIDE], st.group_stride);
             const uint4 *recs = reinterpret_cast<const uint4 *>(st.group_recs) + (size_t)grp * st.group_stride;
-            for (int i0 = 0; i0 < cnt; i0 += 256) {
-                const int i = i0 + tid;
-                uint4 r = make_uint4(0u, 0u, 0u, 0u);
-                if (i < cnt) r = recs[i];
-                const unsigned utx = (unsigned)tx, uty = (unsigned)ty;
-                const bool hit = i < cnt && utx >= (r.z & 0xFFFFu) && utx < (r.w & 0xFFFFu) && uty >= (r.z >> 16) && uty < (r.w >> 16);
+            // The prologue is a chain of dependent round trips that every workgroup of the first round pays at once, with nothing to
+            // hide it behind: the first two chunks of records are requested TOGETHER with the group's count (slots below the stride are
+            // allocated, a group of workload B holds ~580 records), the rest as soon as the count is known -- two round trips for
+            // what was one per chunk after the count's.
+            constexpr int kChunks = 4;
+            uint4 r[kChunks];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = k * 256 + tid;
+                r[k] = i < st.group_stride ? recs[i] : make_uint4(0u, 0u, 0u, 0u);
+            }
+            const int cnt = min((int)st.group_count[(size_t)grp * SPLAT_COUNTER_STRIDE], st.group_stride);
+#pragma unroll
+            for (int k = 2; k < kChunks; ++k) {
+                const int i = k * 256 + tid;
+                r[k] = i < cnt ? recs[i] : make_uint4(0u, 0u, 0u, 0u);
+            }
+            const unsigned utx = (unsigned)tx, uty = (unsigned)ty;
+            auto file = [&](const uint4 &rec, int i) {
+                const bool hit = i < cnt && utx >= (rec.z & 0xFFFFu) && utx < (rec.w & 0xFFFFu) && uty >= (rec.z >> 16) && uty < (rec.w >> 16);
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
                 int base = 0;
                 if (lane == 0 && m) base = atomicAdd(&s_n, __builtin_popcountll(m));
                 base = __builtin_amdgcn_readfirstlane(base);
                 const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-                if (hit && pos < kFusedSortMax) s_keys[pos] = ((uint64_t)r.y << 32) | r.x;
+                if (hit && pos < kFusedSortMax) s_keys[pos] = ((uint64_t)rec.y << 32) | rec.x;
+            };
+#pragma unroll
+            for (int k = 0; k < kChunks; ++k)
+                if (k * 256 < cnt) file(r[k], k * 256 + tid);
+            for (int i0 = kChunks * 256; i0 < cnt; i0 += 256) {
+                const int i = i0 + tid;
+                file(i < cnt ? recs[i] : make_uint4(0u, 0u, 0u, 0u), i);
             }
             __syncthreads();
             n = s_n;

@@ -63,12 +63,6 @@ hipError_t launch_render_backward_rgb_only(const SplatCamera &cam, const float *
 size_t map_scratch_words(long long n);
 int map_row_floats(const SplatMapStore &st);
 extern int g_debug_skip_count;
-// in-situ kernel timing of the fused iteration (splat_iter_kernel_timing): event pairs around the forward (0) and backward (1) composite
-struct KernelTimers {
-    bool on;
-    hipEvent_t ev[2][2];
-};
-extern KernelTimers g_kernel_timers;
 extern int g_debug_composite_version;
 extern int g_debug_entries_per_trip;
 extern int g_debug_k7_generation;

@@ -135,33 +135,6 @@ def test_time_kernel_leaves_the_accumulator_zeroed():
     assert torch.allclose(eng.grads['means3D'], g0, rtol=1e-4, atol=1e-7 * float(g0.abs().max()))
 
 
-def test_in_situ_kernel_timing_changes_nothing_and_reports_both_composites():
-    """splat_iter_kernel_timing: event pairs around the two composites inside the iteration (bench.py's roofline block)."""
-    import ctypes as C
-    from splatam_amd import _capi, slam
-    eng, params, variables, frame, cam, k = _engine()
-    cfg = slam.REPLICA_MAPPING
-    eng.loss_backward(frame, 1, cfg, tracking=False)
-    torch.cuda.synchronize()
-    g0, loss0 = eng.grads['means3D'].clone(), eng.loss()
-    ms = C.c_float(0)
-    assert eng.L.splat_iter_kernel_timing(0, C.byref(ms)) in (1, 0)       # nothing recorded yet (or an earlier test's pair)
-    assert eng.L.splat_iter_kernel_timing(-1, None) == 0
-    try:
-        eng.loss_backward(frame, 1, cfg, tracking=False)
-        t = []
-        for fn in (0, 1):
-            _capi.check(eng.L.splat_iter_kernel_timing(fn, C.byref(ms)), "timing")
-            t.append(ms.value)
-    finally:
-        assert eng.L.splat_iter_kernel_timing(-2, None) == 1
-    assert 0.0 < t[0] < 50.0 and 0.0 < t[1] < 50.0, t
-    assert eng.L.splat_iter_kernel_timing(2, C.byref(ms)) == 1
-    torch.cuda.synchronize()
-    assert abs(eng.loss() - loss0) <= 1e-6 * abs(loss0)
-    assert torch.allclose(eng.grads['means3D'], g0, rtol=1e-4, atol=1e-7 * float(g0.abs().max()))
-
-
 # ---- round-2 advisor findings ------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("stale_hint", [2000, 3000])

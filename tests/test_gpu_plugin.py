@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from tests.test_gpu_fused import _scene
+from tests.util import track_loop_loss_rtol
 
 pytestmark = pytest.mark.gpu
 
@@ -72,8 +73,8 @@ def test_tracking_statements_run_fused_and_match_the_dropin_path():
         stats = plugin.session_stats()
     assert slam.get_loss is not plugin.get_loss                     # uninstalled
     assert stats["iterations"] == 6 and stats["rebuilds"] == 1, stats
-    for a, b in zip(my_losses, ref_losses):
-        assert abs(a - b) <= 1e-3 * abs(b), (my_losses, ref_losses)
+    for it, (a, b) in enumerate(zip(my_losses, ref_losses)):
+        assert abs(a - b) <= track_loop_loss_rtol(it) * abs(b), (my_losses, ref_losses)
     assert (mine['cam_unnorm_rots'] - ref['cam_unnorm_rots']).abs().max() <= 1e-4
     assert (mine['cam_trans'] - ref['cam_trans']).abs().max() <= 4e-4
     assert torch.equal(mine['means3D'], ref['means3D'])

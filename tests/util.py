@@ -116,3 +116,12 @@ def assert_grad_calibrated(got, ref32, ref64, what="", factor=1.3, tail_factor=2
     nbad = int((err > 1e-3 * scale).sum())
     assert nbad <= int(np.floor(max_outlier_frac * err.size)), report + f"; {nbad} elements beyond 1e-3 of max"
     assert err.max() <= outlier_rel * scale, report
+
+
+def track_loop_loss_rtol(it):
+    """Tolerance on the loss of iteration `it` of a fused tracking LOOP against the reference-shaped loop on the drop-in path.  The two
+    loops are separate float32 computations of a pose optimisation: a pixel whose silhouette sits at the 0.99 threshold (or whose
+    gradient sign flips) enters one loss and not the other, Adam normalises the step, and the poses -- hence every later loss --
+    differ from then on.  Measured on the 12 000-Gaussian scene of these tests over builds of the same kernels (deterministic per
+    build; scripts/track_loop_spread.py): 7e-8 until the first such pixel, then 6e-5 .. 1.3e-3 by iteration 5."""
+    return 1e-3 if it < 3 else 3e-3
