@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define SPLAT_ABI_VERSION 6        /* 6: SplatState.tile_row_begin / _end, SplatLossConfig.defer_finish, splat_iter_finish (tile-row-sharded tracking);
+#define SPLAT_ABI_VERSION 7        /* 7: SplatState.long_items (work-item table of the multi-workgroup sort);
+                                      6: SplatState.tile_row_begin / _end, SplatLossConfig.defer_finish, splat_iter_finish (tile-row-sharded tracking);
                                       5: SplatState.group_count / group_recs / group_stride (group binning), splat_iter_mapping_step; 4: densification (splat_iter_means2d_accumulate, splat_map_densify_select / _duplicate);
                                       3: SplatState.keys_alt / long_base (multi-workgroup sort of lists beyond LDS); 2: map edits,
                                       splat_iter_render / _tracking_step, outlier scratch in SplatIterWorkspace */
@@ -104,6 +105,9 @@ typedef struct SplatState {
      * by one workgroup -- correct, but O(n log^2 n) barrier stages) */
     uint64_t *keys_alt;          /* [capacity] ping-pong partner of `keys` for the merge passes */
     uint32_t *long_base;         /* [T+1] first work item of every tile with a long list */
+    uint32_t *long_items;        /* [capacity / 1024 + T + 1] tile of every work item (1024 keys of a long list), written by the scan
+                                  * with long_base; NULL: the kernels find an item's tile by a binary search of long_base (13 dependent
+                                  * reads per item: ~4x slower run sort) */
     /* group binning (fused iteration, bucketed lists short enough for the composite's own sort): the per-Gaussian kernel
      * files ONE record per touched GROUP of SPLAT_GROUP_TILES x SPLAT_GROUP_TILES tiles (slots taken per (workgroup, group)
      * through an LDS histogram: ~1 global atomic per Gaussian in random row order, far fewer in creation order, instead of one

@@ -18,7 +18,7 @@ SPLAT_MAX_CHANNELS = 8
 SPLAT_GRAD_STRIDE = 16
 SPLAT_COUNTER_STRIDE = 32
 SPLAT_GROUP_TILES = 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -42,7 +42,7 @@ class SplatState(C.Structure):
     _fields_ = [("depth", _fp), ("xy", _fp), ("conic_opacity", _fp), ("rect", _fp), ("radii", _fp),
                 ("rgb", _fp), ("clamped", _fp),
                 ("tile_count", _fp), ("tile_base", _fp), ("tile_cursor", _fp),
-                ("keys", _fp), ("point_list", _fp), ("capacity", C.c_int64), ("keys_alt", _fp), ("long_base", _fp),
+                ("keys", _fp), ("point_list", _fp), ("capacity", C.c_int64), ("keys_alt", _fp), ("long_base", _fp), ("long_items", _fp),
                 ("group_count", _fp), ("group_recs", _fp),
                 ("max_list_hint", C.c_int32), ("order_hint", C.c_int32), ("sub_bins", C.c_int32), ("tile_stride", C.c_int32),
                 ("group_stride", C.c_int32), ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),

@@ -57,7 +57,8 @@ __host__ __device__ inline bool long_sort_skipped(int max_list_hint) {
 }
 
 __global__ __launch_bounds__(64) void tile_sort_wave_kernel(SplatState st) {
-    __shared__ uint64_t s_keys[kSortWave];
+    __shared__ uint64_t s_keys[kSortWave], s_alt[kSortWave];
+    __shared__ __attribute__((aligned(8))) unsigned s_hist[256];
     const int tile = blockIdx.x, tid = threadIdx.x;
     if (st.tile_stride == 0) {
         if ((long long)st.status[0] > st.capacity) {
@@ -82,46 +83,50 @@ __global__ __launch_bounds__(64) void tile_sort_wave_kernel(SplatState st) {
     const uint64_t *gk = st.keys + lo;
     for (int i = tid; i < n; i += 64) s_keys[i] = gk[i];
     __syncthreads();
-    if (n > 1) bitonic_sort(s_keys, n, tid, 64);
-    for (int i = tid; i < n; i += 64) st.point_list[lo + i] = (uint32_t)s_keys[i];
+    const uint64_t *sorted = radix_sort_lds<1>(s_keys, s_alt, s_hist, n, tid);
+    for (int i = tid; i < n; i += 64) st.point_list[lo + i] = (uint32_t)sorted[i];
 }
 
 // `long_launched`: the host launches the multi-workgroup kernels below in this call (it decides from its list-length hint, which may
 // be stale: a list beyond LDS that nobody is going to sort is flagged -- status[3], the host repeats the iteration -- and published
 // unsorted, so that the composites of the invalid iteration still read valid Gaussian indices).
-__global__ __launch_bounds__(kBlock) void tile_sort_block_kernel(SplatState st, bool long_launched) {
-    __shared__ uint64_t s_keys[kSortLds];
+__global__ __launch_bounds__(kBlock) void tile_sort_block_kernel(SplatState st, bool long_launched, int T) {
+    __shared__ uint64_t s_keys[kSortLds], s_alt[kSortLds];
+    __shared__ __attribute__((aligned(8))) unsigned s_hist[4 * 256];
     if (st.tile_stride == 0 && (long long)st.status[0] > st.capacity) return;
-    const int tile = blockIdx.x, tid = threadIdx.x;
-    unsigned lo;
-    int n;
-    tile_range(st, tile, lo, n);
-    if (n <= kSortWave) return;
-    uint64_t *gk = st.keys + lo;
-    if (n <= kSortLds) {
-        for (int i = tid; i < n; i += kBlock) s_keys[i] = gk[i];
-        __syncthreads();
-        bitonic_sort(s_keys, n, tid, kBlock);
-        for (int i = tid; i < n; i += kBlock) st.point_list[lo + i] = (uint32_t)s_keys[i];
-    } else if (!st.keys_alt || !st.long_base) {
-        // list beyond LDS and no scratch from the caller: the same network run in place on the HBM bucket by this ONE workgroup
-        // (correct, slow: O(n log^2 n) barrier-separated stages); with scratch the multi-workgroup kernels below take the tile
-        bitonic_sort(gk, n, tid, kBlock);
-        for (int i = tid; i < n; i += kBlock) st.point_list[lo + i] = (uint32_t)gk[i];
-    } else if (!long_launched) {
-        if (tid == 0) atomicOr((unsigned *)&st.status[3], 1u);
-        for (int i = tid; i < n; i += kBlock) st.point_list[lo + i] = (uint32_t)gk[i];
+    const int tid = threadIdx.x;
+    // (68 KB of LDS: two workgroups per CU -- a fixed grid walks the tiles, most of which have nothing for this kernel)
+    for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
+        unsigned lo;
+        int n;
+        tile_range(st, tile, lo, n);
+        if (n <= kSortWave) continue;
+        uint64_t *gk = st.keys + lo;
+        if (n <= kSortLds) {
+            __syncthreads();                            // (the previous tile's result is still being read out of LDS)
+            for (int i = tid; i < n; i += kBlock) s_keys[i] = gk[i];
+            __syncthreads();
+            const uint64_t *sorted = radix_sort_lds<4>(s_keys, s_alt, s_hist, n, tid);
+            for (int i = tid; i < n; i += kBlock) st.point_list[lo + i] = (uint32_t)sorted[i];
+        } else if (!st.keys_alt || !st.long_base) {
+            // list beyond LDS and no scratch from the caller: the bitonic network run in place on the HBM bucket by this ONE workgroup
+            // (correct, slow: O(n log^2 n) barrier-separated stages); with scratch the multi-workgroup kernels below take the tile
+            bitonic_sort(gk, n, tid, kBlock);
+            for (int i = tid; i < n; i += kBlock) st.point_list[lo + i] = (uint32_t)gk[i];
+        } else if (!long_launched) {
+            if (tid == 0) atomicOr((unsigned *)&st.status[3], 1u);
+            for (int i = tid; i < n; i += kBlock) st.point_list[lo + i] = (uint32_t)gk[i];
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Lists beyond LDS (BASELINE config 5: "per-tile Gaussian list spilling HBM"): many workgroups per tile.
 //   L1 long_scan_kernel       item space: tile t owns ceil(n_t / 1024) items when n_t > 4096 (exclusive scan -> long_base)
-//   L2 long_run_sort_kernel   every 4th item of a tile: one 4096-key run sorted in LDS (bitonic), in place
-//   L3 long_merge_kernel      pass p merges neighbouring runs of 4096 * 2^p keys, keys <-> keys_alt ping-pong.  Keys are
-//                             unique, so an element's merged position is its index in its own run + the number of smaller
-//                             keys in the partner run (one binary search of an L2-resident run per element): every element
-//                             is independent, any number of workgroups per tile, one streaming read + write per pass
+//   L2 long_run_sort_kernel   every 4th item of a tile: one 4096-key run sorted in LDS (radix_sort_lds), in place
+//   L3 long_merge_kernel      pass p merges neighbouring runs of 4096 * 2^p keys, keys <-> keys_alt ping-pong: merge-path partitions
+//                             of 1024 outputs, the two input pieces staged in LDS, rank-merged there (keys are unique): any
+//                             number of workgroups per tile, one streaming read + write per pass
 //   L4 long_publish_kernel    ids of the sorted keys (from whichever buffer the tile's last pass wrote) -> point_list
 // A tile of n keys takes ceil(log2(n / 4096)) passes; tiles that are done sit out the later passes.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -146,8 +151,15 @@ __global__ __launch_bounds__(1024) void long_scan_kernel(SplatState st, int T) {
         tile_range(st, t, l, n);
         return (!dead && n > kRun) ? (unsigned)((n + kItemKeys - 1) / kItemKeys) : 0u;
     };
+    // (the counts of a thread's tiles are read once, all loads in flight together: this single workgroup is a chain of round trips)
+    constexpr int kCache = 16;
+    unsigned cached[kCache];
+#pragma unroll
+    for (int k = 0; k < kCache; ++k) cached[k] = (lo + k < hi) ? items_of(lo + k) : 0u;
     unsigned sum = 0;
-    for (int t = lo; t < hi; ++t) sum += items_of(t);
+#pragma unroll
+    for (int k = 0; k < kCache; ++k) sum += cached[k];
+    for (int t = lo + kCache; t < hi; ++t) sum += items_of(t);
     unsigned incl = sum;
     for (int d = 1; d < 64; d <<= 1) {
         const unsigned o = (unsigned)__shfl_up((int)incl, d, 64);
@@ -161,10 +173,18 @@ __global__ __launch_bounds__(1024) void long_scan_kernel(SplatState st, int T) {
         total += wave_tot[w];
     }
     unsigned run = wave_off + incl - sum;
-    for (int t = lo; t < hi; ++t) {
+    const long long table = st.capacity / kItemKeys + T + 1;       // words of SplatState.long_items
+    auto emit = [&](int t, unsigned cnt) {
         st.long_base[t] = run;
-        run += items_of(t);
-    }
+        if (st.long_items)
+            for (unsigned k = 0; k < cnt; ++k)
+                if ((long long)(run + k) < table) st.long_items[run + k] = (unsigned)t;
+        run += cnt;
+    };
+#pragma unroll
+    for (int k = 0; k < kCache; ++k)
+        if (lo + k < hi) emit(lo + k, cached[k]);
+    for (int t = lo + kCache; t < hi; ++t) emit(t, items_of(t));
     if (tid == 0) st.long_base[T] = total;
 }
 
@@ -172,9 +192,13 @@ __global__ __launch_bounds__(1024) void long_scan_kernel(SplatState st, int T) {
 __device__ __forceinline__ bool long_item(const SplatState &st, int T, unsigned item, int &tile, int &chunk, unsigned &lo, int &n) {
     if (item >= st.long_base[T]) return false;
     int a = 0, b = T;                   // invariant: long_base[a] <= item < long_base[b]
-    while (b - a > 1) {
-        const int m = (a + b) >> 1;
-        if (st.long_base[m] <= item) a = m; else b = m;
+    if (st.long_items) {
+        a = (int)st.long_items[item];   // the scan's table (sum of ceil(n_t / 1024) <= capacity / 1024 + T: every item has an entry)
+    } else {
+        while (b - a > 1) {
+            const int m = (a + b) >> 1;
+            if (st.long_base[m] <= item) a = m; else b = m;
+        }
     }
     tile = a;
     chunk = (int)(item - st.long_base[a]);
@@ -184,17 +208,16 @@ __device__ __forceinline__ bool long_item(const SplatState &st, int T, unsigned 
 
 // (the long-list kernels walk the item space with a grid stride: the number of items is only known on the device, long_base[T])
 __global__ __launch_bounds__(kBlock) void long_run_sort_kernel(SplatState st, int T) {
-    __shared__ uint64_t s_keys[kRun];
+    __shared__ uint64_t s_keys[kRun], s_alt[kRun];
+    __shared__ __attribute__((aligned(8))) unsigned s_hist[4 * 256];
     const unsigned total = st.long_base[T];
-    for (unsigned item = blockIdx.x * 4u; item < total; item += gridDim.x * 4u) {      // one workgroup per run of 4 items
-        int tile, chunk, n;
-        unsigned lo;
-        // items of a tile come in groups of 4 only at its start: find the run through the tile of the group's first item
-        if (!long_item(st, T, item, tile, chunk, lo, n)) break;
-        const int tid = threadIdx.x;
-        // the 4 items starting at `item` may straddle two tiles (a tile's item count need not be a multiple of 4): handle
-        // every run that STARTS inside [item, item + 4)
+    const int tid = threadIdx.x;
+    // a run starts at every item whose chunk index within its tile is a multiple of 4 (an item is 1024 keys, a run 4096): the
+    // workgroups walk the items four at a time and sort the runs that START among their four
+    for (unsigned item = blockIdx.x * 4u; item < total; item += gridDim.x * 4u) {
         for (unsigned it = item; it < item + 4u && it < total; ++it) {
+            int tile, chunk, n;
+            unsigned lo;
             if (!long_item(st, T, it, tile, chunk, lo, n)) break;
             if (chunk & 3) continue;
             const int off = (chunk >> 2) * kRun, m = min(kRun, n - off);
@@ -202,17 +225,32 @@ __global__ __launch_bounds__(kBlock) void long_run_sort_kernel(SplatState st, in
             __syncthreads();
             for (int i = tid; i < m; i += kBlock) s_keys[i] = gk[i];
             __syncthreads();
-            bitonic_sort(s_keys, m, tid, kBlock);
-            for (int i = tid; i < m; i += kBlock) gk[i] = s_keys[i];
+            const uint64_t *sorted = radix_sort_lds<4>(s_keys, s_alt, s_hist, m, tid);
+            for (int i = tid; i < m; i += kBlock) gk[i] = sorted[i];
         }
     }
 }
 
+// merge path: how many of the first k keys of merge(A[0, la), B[0, lb)) come from A (keys are unique)
+__device__ __forceinline__ int merge_path(const uint64_t *A, int la, const uint64_t *B, int lb, int k) {
+    int lo = max(0, k - lb), hi = min(k, la);
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (A[mid] < B[k - mid - 1]) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// One item = 1024 consecutive OUTPUT keys of a tile's list.  Two merge-path searches (uniform over the workgroup: ~13 dependent
+// reads each, of two 8-byte keys) cut the pair of runs at the item's first and last output; the two input pieces -- 1024 keys together,
+// contiguous -- are staged in LDS, and every key finds its place among the other piece's keys by a binary search IN LDS.  One
+// streaming read and one write of the keys per pass (round 2 searched the partner run in L2 for every key: 13 scattered reads per key).
 __global__ __launch_bounds__(kBlock) void long_merge_kernel(SplatState st, int T, int pass) {
+    __shared__ uint64_t s_in[kItemKeys];
     const long long L = (long long)kRun << pass;               // run length going into this pass
     if (st.tile_stride == 0 && L >= (long long)st.status[2]) return;      // (exact lists: the scan knows the longest list of this iteration)
     const unsigned total = st.long_base[T];
-    const int Li = (int)L;
+    const int Li = (int)L, tid = threadIdx.x;
     for (unsigned item = blockIdx.x; item < total; item += gridDim.x) {
         int tile, chunk, n;
         unsigned lo;
@@ -220,23 +258,33 @@ __global__ __launch_bounds__(kBlock) void long_merge_kernel(SplatState st, int T
         if ((long long)n <= L) continue;                           // this tile was finished by an earlier pass
         const uint64_t *src = ((pass & 1) ? st.keys_alt : st.keys) + lo;
         uint64_t *dst = ((pass & 1) ? st.keys : st.keys_alt) + lo;
-#pragma unroll
-        for (int k = 0; k < kItemKeys / kBlock; ++k) {
-            const int j = chunk * kItemKeys + k * kBlock + threadIdx.x;
-            if (j >= n) continue;
-            const uint64_t key = src[j];
-            const int a = j / Li, a0 = a * Li, b0 = (a ^ 1) * Li;
-            int pos = j;
-            if (b0 < n) {
-                const uint64_t *B = src + b0;
-                int lo_ = 0, hi_ = min(Li, n - b0);                // number of partner keys smaller than `key`
-                while (lo_ < hi_) {
-                    const int mid = (lo_ + hi_) >> 1;
-                    if (B[mid] < key) lo_ = mid + 1; else hi_ = mid;
-                }
-                pos = min(a0, b0) + (j - a0) + lo_;
+        const int o0 = chunk * kItemKeys;                           // first output of this item (2 Li is a multiple of the item size)
+        if (o0 >= n) continue;
+        const int base = (o0 / (2 * Li)) * (2 * Li);                // the pair of runs this item's outputs belong to
+        const int la = min(Li, n - base), lb = max(0, min(Li, n - base - Li));
+        const uint64_t *A = src + base, *B = src + base + Li;
+        const int k0 = o0 - base, k1 = min(k0 + kItemKeys, la + lb);
+        if (lb == 0) {                                              // a run without a partner: copied through
+            for (int k = k0 + tid; k < k1; k += kBlock) dst[base + k] = A[k];
+            continue;
+        }
+        const int a0 = merge_path(A, la, B, lb, k0), a1 = merge_path(A, la, B, lb, k1);
+        const int b0 = k0 - a0, b1 = k1 - a1;
+        const int na = a1 - a0, nb = b1 - b0;                       // na + nb = k1 - k0 <= 1024
+        __syncthreads();                                            // (the previous item's searches are done with s_in)
+        for (int i = tid; i < na; i += kBlock) s_in[i] = A[a0 + i];
+        for (int i = tid; i < nb; i += kBlock) s_in[na + i] = B[b0 + i];
+        __syncthreads();
+        for (int i = tid; i < na + nb; i += kBlock) {
+            const uint64_t key = s_in[i];
+            const bool from_a = i < na;
+            const uint64_t *other = from_a ? s_in + na : s_in;
+            int lo_ = 0, hi_ = from_a ? nb : na;                    // number of keys of the other piece below `key`
+            while (lo_ < hi_) {
+                const int mid = (lo_ + hi_) >> 1;
+                if (other[mid] < key) lo_ = mid + 1; else hi_ = mid;
             }
-            dst[pos] = key;
+            dst[base + k0 + (from_a ? i : i - na) + lo_] = key;
         }
     }
 }
@@ -274,7 +322,7 @@ hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, S
         if (!long_sort_skipped(st.max_list_hint)) {
             const long long hint = st.max_list_hint > 0 ? (long long)st.max_list_hint + st.max_list_hint / 2 : (long long)1 << 40;
             const bool long_path = st.keys_alt && st.long_base && hint > kRun && st.capacity > kRun;
-            hipLaunchKernelGGL(tile_sort_block_kernel, dim3(T), dim3(kBlock), 0, s, st, long_path);
+            hipLaunchKernelGGL(tile_sort_block_kernel, dim3(T < 512 ? T : 512), dim3(kBlock), 0, s, st, long_path, T);
             if (long_path) {
                 // no list is longer than `bound`: the hint, the capacity, or -- bucketed lists -- the bucket
                 long long bound = st.capacity < hint ? st.capacity : hint;
@@ -283,11 +331,14 @@ hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, S
                 long long items = st.capacity / kItemKeys + T + 1;
                 if (items > 16384) items = 16384;
                 hipLaunchKernelGGL(long_scan_kernel, dim3(1), dim3(1024), 0, s, st, T);
-                hipLaunchKernelGGL(long_run_sort_kernel, dim3((unsigned)((items + 3) / 4)), dim3(kBlock), 0, s, st, T);
+                // (fixed grids: a workgroup that finds nothing to do still costs its launch -- 4096 of them with 69 KB of LDS, two per
+                //  CU at a time, cost more than the sort itself.  Two run-sort workgroups per CU, eight of the light kernels)
+                const long long run_wgs = (items + 3) / 4 < 512 ? (items + 3) / 4 : 512, item_wgs = items < 2048 ? items : 2048;
+                hipLaunchKernelGGL(long_run_sort_kernel, dim3((unsigned)run_wgs), dim3(kBlock), 0, s, st, T);
                 const int passes = long_passes(bound);
                 for (int p = 0; p < passes; ++p)
-                    hipLaunchKernelGGL(long_merge_kernel, dim3((unsigned)items), dim3(kBlock), 0, s, st, T, p);
-                hipLaunchKernelGGL(long_publish_kernel, dim3((unsigned)items), dim3(kBlock), 0, s, st, T, passes);
+                    hipLaunchKernelGGL(long_merge_kernel, dim3((unsigned)item_wgs), dim3(kBlock), 0, s, st, T, p);
+                hipLaunchKernelGGL(long_publish_kernel, dim3((unsigned)item_wgs), dim3(kBlock), 0, s, st, T, passes);
             }
         }
     }
@@ -311,6 +362,15 @@ __global__ __launch_bounds__(kBlock) void selftest_sort_lds_kernel(const uint64_
     if (n > 1) bitonic_sort(s_keys, n, threadIdx.x, kBlock);
     for (int i = threadIdx.x; i < n; i += kBlock) out[i] = s_keys[i];
 }
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void selftest_radix_lds_kernel(const uint64_t *in, uint64_t *out, int n) {
+    __shared__ uint64_t s_keys[NW * 1024], s_alt[NW * 1024];
+    __shared__ __attribute__((aligned(8))) unsigned s_hist[NW * 256];
+    for (int i = threadIdx.x; i < n; i += 64 * NW) s_keys[i] = in[i];
+    __syncthreads();
+    const uint64_t *sorted = radix_sort_lds<NW>(s_keys, s_alt, s_hist, n, threadIdx.x);
+    for (int i = threadIdx.x; i < n; i += 64 * NW) out[i] = sorted[i];
+}
 __global__ __launch_bounds__(kBlock) void selftest_sort_global_kernel(uint64_t *keys, int n) {
     if (n > 1) bitonic_sort(keys, n, threadIdx.x, kBlock);
 }
@@ -325,6 +385,10 @@ hipError_t launch_selftest(int which, const void *in, void *out, int n, hipStrea
         hipError_t e = hipMemcpyAsync(out, in, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(selftest_sort_global_kernel, dim3(1), dim3(kBlock), 0, s, (uint64_t *)out, n);
+    } else if (which == 3 || which == 4) {              // radix_sort_lds: 3 = 256-thread workgroup (n <= 4096), 4 = one wave (n <= 1024)
+        if (n > (which == 3 ? kSortLds : kSortWave)) return hipErrorInvalidValue;
+        if (which == 3) hipLaunchKernelGGL(selftest_radix_lds_kernel<4>, dim3(1), dim3(256), 0, s, (const uint64_t *)in, (uint64_t *)out, n);
+        else hipLaunchKernelGGL(selftest_radix_lds_kernel<1>, dim3(1), dim3(64), 0, s, (const uint64_t *)in, (uint64_t *)out, n);
     } else {
         return hipErrorInvalidValue;
     }

@@ -83,6 +83,39 @@ constexpr int kGroupPerLane = 4;            // groups a lane files through the h
 constexpr int kGT = SPLAT_GROUP_TILES;
 static_assert(kGT == 2, "the group index is tile >> 1");
 
+// One Gaussian of F1: pose transform, activations, projection; writes its geometry, feature record and (mapping) seen radius.
+// Returns its visibility; `o` holds the tile rectangle (clipped to the launch's band of tile rows) and the depth.
+__device__ __forceinline__ bool preprocess_one(const FusedArgs &a, const CamConst &c, int i, Projected &o) {
+    const SplatState &st = a.ws.st;
+    Pose P;
+    load_pose(a.map, a.frame.time_idx, P);
+    // (requested with the parameters, not behind the stores below: the kernel lasts one wave lifetime = its chain of round trips;
+    //  ahead of load_gaussian)
+    const float rgb[3] = {a.map.rgb_colors[3 * i], a.map.rgb_colors[3 * i + 1], a.map.rgb_colors[3 * i + 2]};
+    const float seen_radius = a.ws.max_2D_radius ? a.ws.max_2D_radius[i] : 0.f;
+    float p[3], u[4], logit, ls[3];
+    load_gaussian(a.map, i, p, u, logit, ls);
+    Glue G;
+    glue_forward(P, a.frame.w2c + 8, p, u, logit, ls, a.map.isotropic != 0, G);
+    float S6[6];
+    cov3d_from_scale_rot(G.s, c.scale_modifier, G.rq, S6);
+    const bool vis = project_gaussian(c, G.Xc, S6, o);
+    if (st.tile_row_end > st.tile_row_begin) {      // a band of tile rows is composited: instances outside it are not filed
+        o.y0 = max(o.y0, st.tile_row_begin);
+        o.y1 = max(o.y0, min(o.y1, st.tile_row_end));
+    }
+    st.depth[i] = o.depth;
+    reinterpret_cast<float2 *>(st.xy)[i] = make_float2(o.px, o.py);
+    reinterpret_cast<float4 *>(st.conic_opacity)[i] = make_float4(o.conic[0], o.conic[1], o.conic[2], G.op);
+    reinterpret_cast<uint2 *>(st.rect)[i] = make_uint2((unsigned)o.x0 | ((unsigned)o.y0 << 16), (unsigned)o.x1 | ((unsigned)o.y1 << 16));
+    st.radii[i] = o.radius;
+    float4 *f = reinterpret_cast<float4 *>(a.ws.feat8) + 2 * (size_t)i;
+    f[0] = make_float4(rgb[0], rgb[1], rgb[2], G.z);
+    f[1] = make_float4(1.0f, G.z * G.z, 0.f, 0.f);
+    if (vis && a.ws.max_2D_radius && (float)o.radius > seen_radius) a.ws.max_2D_radius[i] = (float)o.radius;
+    return vis;
+}
+
 template <int MODE, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void fused_preprocess_kernel(FusedArgs a) {
     constexpr bool AGG = MODE == 1;
@@ -113,34 +146,7 @@ __global__ __launch_bounds__(BLOCK) void fused_preprocess_kernel(FusedArgs a) {
     bool vis = false;
     CamConst c;
     load_cam(c, a.cam);
-    if (active) {
-        Pose P;
-        load_pose(a.map, a.frame.time_idx, P);
-        // (requested with the parameters, not behind the stores below: the kernel lasts one wave lifetime = its chain of round trips;
-        //  ahead of load_gaussian, whose isotropic branch waits for the scale)
-        const float rgb[3] = {a.map.rgb_colors[3 * i], a.map.rgb_colors[3 * i + 1], a.map.rgb_colors[3 * i + 2]};
-        const float seen_radius = a.ws.max_2D_radius ? a.ws.max_2D_radius[i] : 0.f;
-        float p[3], u[4], logit, ls[3];
-        load_gaussian(a.map, i, p, u, logit, ls);
-        Glue G;
-        glue_forward(P, a.frame.w2c + 8, p, u, logit, ls, a.map.isotropic != 0, G);
-        float S6[6];
-        cov3d_from_scale_rot(G.s, c.scale_modifier, G.rq, S6);
-        vis = project_gaussian(c, G.Xc, S6, o);
-        if (st.tile_row_end > st.tile_row_begin) {      // a band of tile rows is composited: instances outside it are not filed
-            o.y0 = max(o.y0, st.tile_row_begin);
-            o.y1 = max(o.y0, min(o.y1, st.tile_row_end));
-        }
-        st.depth[i] = o.depth;
-        reinterpret_cast<float2 *>(st.xy)[i] = make_float2(o.px, o.py);
-        reinterpret_cast<float4 *>(st.conic_opacity)[i] = make_float4(o.conic[0], o.conic[1], o.conic[2], G.op);
-        reinterpret_cast<uint2 *>(st.rect)[i] = make_uint2((unsigned)o.x0 | ((unsigned)o.y0 << 16), (unsigned)o.x1 | ((unsigned)o.y1 << 16));
-        st.radii[i] = o.radius;
-        float4 *f = reinterpret_cast<float4 *>(a.ws.feat8) + 2 * (size_t)i;
-        f[0] = make_float4(rgb[0], rgb[1], rgb[2], G.z);
-        f[1] = make_float4(1.0f, G.z * G.z, 0.f, 0.f);
-        if (vis && a.ws.max_2D_radius && (float)o.radius > seen_radius) a.ws.max_2D_radius[i] = (float)o.radius;
-    }
+    if (active) vis = preprocess_one(a, c, i, o);
     if (st.tile_stride == 0) {
         // exact path: count now, scan + scatter later
         if (vis && o.y1 > o.y0)
@@ -248,6 +254,66 @@ __global__ __launch_bounds__(BLOCK) void fused_preprocess_kernel(FusedArgs a) {
         for (int uu = 0; uu < 4; ++uu)
             if (t0 + uu < nt) {
                 if (slot[uu] < stride) st.keys[(size_t)tix[uu] * stride + slot[uu]] = key;
+                else spilled = true;
+            }
+    }
+    if (spilled) st.status[1] = 1;
+}
+
+// F1 for LONG bucketed lists of a map in ANY order (BASELINE config E: millions of Gaussians on a few hundred tiles).  One returning
+// global atomic per instance serialises on the tiles' counters (one L2 atomic unit per address, ~12 ns each: 1 M Gaussians on 400
+// tiles -> 201 us, 5 M -> 900 us).  Here a 1024-thread workgroup takes kDensePerThread Gaussians per thread, counts their instances per
+// TILE in an LDS table of the whole frame (4 bytes x tiles, dynamic LDS), reserves each non-empty tile's slots with ONE global atomic,
+// and hands them out through the same table: 4096 Gaussians per global atomic round instead of one.
+constexpr int kDenseBlock = 1024;
+constexpr int kDensePerThread = 4;
+constexpr int kDenseMaxTiles = 12 * 1024;          // 48 KB of LDS
+
+__global__ __launch_bounds__(kDenseBlock) void fused_preprocess_dense_kernel(FusedArgs a) {
+    extern __shared__ unsigned s_tile[];            // instances per tile of this workgroup, then the tile's next free slot
+    const int tid = threadIdx.x;
+    CamConst c;
+    load_cam(c, a.cam);
+    const int T = c.gx * c.gy;
+    for (int t = tid; t < T; t += kDenseBlock) s_tile[t] = 0u;
+    if (blockIdx.x == 0 && tid == 0) { a.ws.st.status[0] = 0; a.ws.st.status[2] = 0; a.ws.st.status[3] = 0; }     // (see fused_preprocess_kernel)
+    __syncthreads();
+    const SplatState &st = a.ws.st;
+    unsigned r0[kDensePerThread], r1[kDensePerThread], dbits[kDensePerThread];
+#pragma unroll
+    for (int g = 0; g < kDensePerThread; ++g) {
+        const int i = (blockIdx.x * kDensePerThread + g) * kDenseBlock + tid;
+        r0[g] = r1[g] = dbits[g] = 0u;
+        if (i < a.map.P) {
+            Projected o{};
+            const bool vis = preprocess_one(a, c, i, o);
+            if (vis && o.y1 > o.y0 && o.x1 > o.x0) {
+                r0[g] = (unsigned)o.x0 | ((unsigned)o.y0 << 16);
+                r1[g] = (unsigned)o.x1 | ((unsigned)o.y1 << 16);
+                dbits[g] = __float_as_uint(o.depth);
+                for (int y = o.y0; y < o.y1; ++y)
+                    for (int x = o.x0; x < o.x1; ++x) atomicAdd(&s_tile[y * c.gx + x], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += kDenseBlock) {
+        const unsigned cnt = s_tile[t];
+        if (cnt) s_tile[t] = atomicAdd(&st.tile_count[(size_t)t * SPLAT_COUNTER_STRIDE], cnt);
+    }
+    __syncthreads();
+    const unsigned stride = (unsigned)st.tile_stride;
+    bool spilled = false;
+#pragma unroll
+    for (int g = 0; g < kDensePerThread; ++g) {
+        const int i = (blockIdx.x * kDensePerThread + g) * kDenseBlock + tid;
+        const int x0 = r0[g] & 0xFFFF, y0 = r0[g] >> 16, x1 = r1[g] & 0xFFFF, y1 = r1[g] >> 16;
+        const uint64_t key = ((uint64_t)dbits[g] << 32) | (uint32_t)i;
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
+                const unsigned tix = (unsigned)(y * c.gx + x);
+                const unsigned slot = atomicAdd(&s_tile[tix], 1u);
+                if (slot < stride) st.keys[(size_t)tix * stride + slot] = key;
                 else spilled = true;
             }
     }
@@ -904,6 +970,12 @@ static void launch_fused_preprocess(const FusedArgs &a, hipStream_t s) {
                            sizeof(unsigned) * (size_t)num_tile_groups(a.cam), s, a);
     else if (st.order_hint && st.tile_stride > 0)
         hipLaunchKernelGGL((fused_preprocess_kernel<1, kBlock>), dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    else if (st.tile_stride > 0 && !lists_sorted_by_composite(st) && P >= 8 * kDenseBlock * kDensePerThread &&
+             (int)splat_num_tiles(a.cam.image_width, a.cam.image_height) <= kDenseMaxTiles)
+        // long bucketed lists, no order known: the workgroup-level tile histogram (a map of a few thousand Gaussians stays on the
+        // one-Gaussian-per-lane kernels: 4096 Gaussians per workgroup would leave most CUs idle)
+        hipLaunchKernelGGL(fused_preprocess_dense_kernel, dim3((P + kDenseBlock * kDensePerThread - 1) / (kDenseBlock * kDensePerThread)),
+                           dim3(kDenseBlock), sizeof(unsigned) * splat_num_tiles(a.cam.image_width, a.cam.image_height), s, a);
     else
         hipLaunchKernelGGL((fused_preprocess_kernel<0, kBlock>), dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
 }

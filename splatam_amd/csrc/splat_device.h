@@ -176,6 +176,173 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr keys, const int n, const int
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS radix sort on the depth key (the "per-tile radix sort on depth key" of the path's design): n <= NW * 1024 unique 64-bit keys
+// (float bits of depth << 32 | Gaussian id) ascending, by NW waves (workgroup of 64 * NW threads).
+//   * least-significant-digit passes over the 32 DEPTH bits, 8 bits per pass; a pass whose digit is the same in every key (the
+//     exponent byte of a tile's depth range, usually) is skipped;
+//   * wave-ballot ranking: wave w owns the contiguous segment w of the keys and walks it 64 keys per round.  match_any (8 ballots)
+//     gives every lane the set of lanes of its round with the same digit: its rank among them, and ONE lane per distinct digit
+//     counts / reserves slots for all of them in the wave's own histogram row -- no LDS atomics, no same-address serialisation;
+//   * offsets: exclusive scan over (digit, wave) -- stable: segments in wave order, rounds in order, lanes in order;
+//   * equal depths (rare) come out in scatter order; one last pass moves a key by (#smaller ids right of it - #larger ids left of
+//     it) within its run of equal depth: "ascending depth, ties by ascending id", the order the bitonic network produces.
+// buf_a holds the keys on entry; buf_b is scratch of the same size; hist: NW * 256 words.  Returns the buffer that holds the
+// result.  Barriers inside: every thread of the workgroup must call it (n is uniform).
+// Cost: ~110 vector instructions per 64 keys and pass -- a 4096-key run takes ~8 us on one CU (the bitonic network: ~150 us, its
+// stride-2^k exchanges of 8-byte keys are 16-way bank conflicts).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long match_any8(unsigned d, bool valid) {
+    unsigned long long peers = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(bit);
+        peers &= bit ? m : ~m;
+    }
+    return valid ? peers : 0ull;
+}
+
+template <int NW>
+__device__ __forceinline__ uint64_t *radix_sort_lds(uint64_t *buf_a, uint64_t *buf_b, unsigned *hist, const int n, const int tid) {
+    static_assert(NW == 1 || NW == 4, "one wave per list, or a 256-thread workgroup");
+    constexpr int kRounds = 16;                         // 64-key rounds per wave: NW * 1024 keys at most
+    constexpr int kTieRun = 32;                         // longest run of equal depths the neighbour pass orders
+    __shared__ unsigned s_x[8];                         // wave totals of the digit scan / flags
+    const int lane = tid & 63, wave = tid >> 6;
+    const int seg = ((n + NW - 1) / NW + 63) & ~63;     // keys per wave segment (whole rounds)
+    const int seg_lo = wave * seg, seg_hi = min(n, seg_lo + seg);
+    // which bit positions differ at all
+    uint64_t all_or = 0ull, all_and = ~0ull;
+    for (int i = tid; i < n; i += 64 * NW) {
+        const uint64_t k = buf_a[i];
+        all_or |= k;
+        all_and &= k;
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        all_or |= (uint64_t)__shfl_xor((long long)all_or, m, 64);
+        all_and &= (uint64_t)__shfl_xor((long long)all_and, m, 64);
+    }
+    uint64_t *xch = reinterpret_cast<uint64_t *>(hist);
+    if (lane == 0) { xch[2 * wave] = all_or; xch[2 * wave + 1] = all_and; }
+    __syncthreads();
+    uint64_t diff;
+    {
+        uint64_t o = 0ull, a = ~0ull;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { o |= xch[2 * w]; a &= xch[2 * w + 1]; }
+        diff = o ^ a;
+    }
+    if (tid == 0) s_x[4] = 0u;
+    __syncthreads();
+    uint64_t *src = buf_a, *dst = buf_b;
+    unsigned *row = hist + wave * 256;
+    // attempt 0: the four depth bytes, then the neighbour pass.  Only when that finds a run of > kTieRun equal depths (a fronto-parallel
+    // plane of Gaussians): attempt 1, all eight bytes, least significant first -- the id bytes, then the depth bytes again.
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int byte = attempt == 0 ? 4 : 0; byte < 8; ++byte) {
+            if (((diff >> (8 * byte)) & 0xFFull) == 0ull) continue;      // (uniform) every key holds the same digit here
+            const int shift = 8 * byte;
+            for (int k = tid; k < NW * 256; k += 64 * NW) hist[k] = 0u;
+            __syncthreads();
+            unsigned info[kRounds];                     // rank | leader lane << 8 | group size << 16 | is-leader << 24
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) {
+                info[r] = 0u;
+                if (seg_lo + r * 64 < seg_hi) {          // (uniform per wave)
+                    const int i = seg_lo + r * 64 + lane;
+                    const bool valid = i < seg_hi;
+                    const unsigned d = valid ? (unsigned)(src[i] >> shift) & 0xFFu : 0u;
+                    const unsigned long long peers = match_any8(d, valid);
+                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(peers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)peers, 0u));
+                    const unsigned cnt = (unsigned)__builtin_popcountll(peers);
+                    const unsigned leader = valid ? (unsigned)__builtin_ctzll(peers) : 0u;
+                    const bool is_leader = valid && leader == (unsigned)lane;
+                    if (is_leader) row[d] += cnt;       // leaders of one round hold distinct digits; rounds of a wave are in program order
+                    info[r] = rank | (leader << 8) | (cnt << 16) | ((is_leader ? 1u : 0u) << 24);
+                }
+            }
+            __syncthreads();
+            // exclusive scan over (digit, wave)
+            if constexpr (NW == 4) {                    // thread t owns digit t
+                unsigned c[NW], tot = 0u;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { c[w] = hist[w * 256 + tid]; tot += c[w]; }
+                unsigned incl = tot;
+                for (int dd = 1; dd < 64; dd <<= 1) {
+                    const unsigned o = (unsigned)__shfl_up((int)incl, dd, 64);
+                    if (lane >= dd) incl += o;
+                }
+                if (lane == 63) s_x[wave] = incl;
+                __syncthreads();
+                unsigned base = incl - tot;
+                for (int w = 0; w < wave; ++w) base += s_x[w];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { hist[w * 256 + tid] = base; base += c[w]; }
+            } else {                                    // one wave: the four 64-digit quarters in turn
+                unsigned run = 0u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned cq = hist[q * 64 + lane];
+                    unsigned incl = cq;
+                    for (int dd = 1; dd < 64; dd <<= 1) {
+                        const unsigned o = (unsigned)__shfl_up((int)incl, dd, 64);
+                        if (lane >= dd) incl += o;
+                    }
+                    hist[q * 64 + lane] = run + incl - cq;
+                    run += (unsigned)__shfl((int)incl, 63, 64);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) {
+                if (seg_lo + r * 64 < seg_hi) {
+                    const int i = seg_lo + r * 64 + lane;
+                    const bool valid = i < seg_hi;
+                    const uint64_t key = valid ? src[i] : 0ull;
+                    const unsigned d = (unsigned)(key >> shift) & 0xFFu;
+                    unsigned base = 0u;
+                    if ((info[r] >> 24) & 1u) {
+                        base = row[d];
+                        row[d] = base + ((info[r] >> 16) & 0xFFu);
+                    }
+                    base = (unsigned)__shfl((int)base, (int)((info[r] >> 8) & 0xFFu), 64);
+                    if (valid) dst[base + (info[r] & 0xFFu)] = key;
+                }
+            }
+            __syncthreads();
+            uint64_t *t = src; src = dst; dst = t;
+        }
+        if (attempt == 1) return src;                    // sorted on all 64 bits
+        // a run of more than kTieRun equal depths?
+        bool long_run = false;
+        for (int i = tid; i < n; i += 64 * NW)
+            if (i >= kTieRun && (unsigned)(src[i] >> 32) == (unsigned)(src[i - kTieRun] >> 32)) long_run = true;
+        if (long_run) s_x[4] = 1u;
+        __syncthreads();
+        if (s_x[4] == 0u) break;
+    }
+    // ties of equal depth (runs of at most kTieRun) -> ascending id
+    for (int i = tid; i < n; i += 64 * NW) {
+        const uint64_t key = src[i];
+        const unsigned depth = (unsigned)(key >> 32);
+        int pos = i;
+        for (int j = i - 1; j >= 0; --j) {
+            const uint64_t o = src[j];
+            if ((unsigned)(o >> 32) != depth) break;
+            if (o > key) --pos;
+        }
+        for (int j = i + 1; j < n; ++j) {
+            const uint64_t o = src[j];
+            if ((unsigned)(o >> 32) != depth) break;
+            if (o < key) ++pos;
+        }
+        dst[pos] = key;
+    }
+    __syncthreads();
+    return dst;
+}
+
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     for (int m = 32; m >= 1; m >>= 1) {
         const unsigned o = (unsigned)__shfl_xor((int)v, m, 64);

@@ -472,6 +472,8 @@ class FusedEngine:
         self.buf['keys'] = torch.empty(self.capacity, dtype=torch.int64, device=self.dev)
         self.buf['keys_alt'] = torch.empty(self.capacity, dtype=torch.int64, device=self.dev)     # merge passes of lists beyond LDS
         self.buf['point_list'] = torch.empty(self.capacity, dtype=torch.int32, device=self.dev)
+        # work-item table of the multi-workgroup sort (SplatState.long_items): one word per 1024 keys of a long list
+        self.buf['long_items'] = torch.empty(self.capacity // 1024 + self.num_tiles + 1, dtype=torch.int32, device=self.dev)
 
     def _make_cam(self, settings):
         bg = _cached_contiguous(settings.bg)
@@ -530,6 +532,7 @@ class FusedEngine:
         st.tile_count, st.tile_base, st.tile_cursor = b['tile_count'].data_ptr(), b['tile_base'].data_ptr(), b['tile_cursor'].data_ptr()
         st.keys, st.point_list, st.capacity = b['keys'].data_ptr(), b['point_list'].data_ptr(), self.capacity
         st.keys_alt, st.long_base = b['keys_alt'].data_ptr(), b['long_base'].data_ptr()
+        st.long_items = b['long_items'].data_ptr()
         st.max_list_hint = self.max_list_hint
         st.tile_stride = self.tile_stride
         st.tile_row_begin, st.tile_row_end = self._tile_rows if self._tile_rows else (0, 0)

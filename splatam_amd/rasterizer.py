@@ -206,8 +206,9 @@ def _alloc_lists(pk: _Pack, dev, capacity: int, longest=None):
     pk.tensors.update(keys=keys, point_list=plist)
     if longest is None or longest > LONG_LIST:
         alt = torch.empty(capacity, dtype=torch.int64, device=dev)
-        pk.st.keys_alt = alt.data_ptr()
-        pk.tensors.update(keys_alt=alt)
+        items = torch.empty(capacity // 1024 + pk.num_tiles + 1, dtype=torch.int32, device=dev)      # SplatState.long_items
+        pk.st.keys_alt, pk.st.long_items = alt.data_ptr(), items.data_ptr()
+        pk.tensors.update(keys_alt=alt, long_items=items)
 
 
 def _stream(dev) -> int:

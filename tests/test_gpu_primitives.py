@@ -41,6 +41,46 @@ def test_lds_bitonic_sort(n):
     assert torch.equal(out.cpu(), torch.sort(keys.cpu())[0])
 
 
+def _depth_id_keys(n, kind, seed):
+    """Keys as the binning builds them: float32 bits of a positive depth << 32 | Gaussian id (unique ids)."""
+    rng = np.random.default_rng(seed)
+    ids = rng.permutation(5_000_000)[:n].astype(np.uint64)
+    if kind == "wide":                                  # every depth byte varies
+        depth = rng.uniform(0.01, 900.0, n).astype(np.float32)
+    elif kind == "narrow":                              # a tile's depth range: the exponent byte never varies (pass skipped)
+        depth = rng.uniform(2.0, 2.4, n).astype(np.float32)
+    elif kind == "short_ties":                          # a few equal depths next to each other (neighbour pass)
+        depth = np.round(rng.uniform(1.0, 3.0, n) * (max(n, 8) / 4)).astype(np.float32)
+    elif kind == "plane":                               # long runs of equal depth (the all-bytes attempt)
+        depth = rng.choice(np.array([1.5, 2.0, 2.0000002], np.float32), n)
+    else:                                               # one depth
+        depth = np.full(n, 3.25, np.float32)
+    return (depth.view(np.uint32).astype(np.uint64) << np.uint64(32)) | ids
+
+
+@pytest.mark.parametrize("kind", ["wide", "narrow", "short_ties", "plane", "constant"])
+@pytest.mark.parametrize("which,n", [(3, 1), (3, 2), (3, 63), (3, 64), (3, 65), (3, 257), (3, 1000), (3, 2500), (3, 4095), (3, 4096),
+                                     (4, 1), (4, 5), (4, 64), (4, 65), (4, 200), (4, 777), (4, 1023), (4, 1024)])
+def test_lds_radix_sort_on_depth_key(which, n, kind):
+    """radix_sort_lds (splat_device.h): the per-tile sort of the list kernels -- 8-bit passes over the depth bits with wave-ballot
+    ranking, equal depths ordered by id: exactly numpy's sort of the 64-bit keys."""
+    L = _lib()
+    keys_np = _depth_id_keys(n, kind, seed=1000 * which + n)
+    keys = torch.from_numpy(keys_np.view(np.int64)).cuda()
+    out = torch.zeros_like(keys)
+    rc = L.splat_selftest(which, keys.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint64), np.sort(keys_np))
+
+
+def test_lds_radix_sort_rejects_lists_beyond_lds():
+    L = _lib()
+    keys = torch.zeros(5000, dtype=torch.int64, device="cuda")
+    assert L.splat_selftest(3, keys.data_ptr(), keys.data_ptr(), 4097, torch.cuda.current_stream().cuda_stream) != 0
+    assert L.splat_selftest(4, keys.data_ptr(), keys.data_ptr(), 1025, torch.cuda.current_stream().cuda_stream) != 0
+
+
 @pytest.mark.parametrize("n", [4097, 10000, 40000])
 def test_global_bitonic_sort(n):
     L = _lib()
