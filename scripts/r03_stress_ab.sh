@@ -4,10 +4,10 @@
 tag=${1:-r03_s1}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_gpu_primitives.py tests/test_gpu_parity.py tests/test_gpu_advice.py -m gpu -q --timeout 900 -p no:cacheprovider > gpurun_out/${tag}_tests.log 2>&1
+timeout 1500 python -m pytest tests/test_gpu_primitives.py -m gpu -q --timeout 900 -p no:cacheprovider > gpurun_out/${tag}_tests.log 2>&1
 echo "pytest rc $?" >> gpurun_out/${tag}_tests.log
 tail -4 gpurun_out/${tag}_tests.log
-timeout 120 python scripts/time_radix_sort.py 2>&1 | tail -9
+timeout 120 python scripts/time_radix_sort.py 2>&1 | tail -12
 for v in A B; do
   if [ $v = B ]; then export SPLAT_HIP_LIB=$PWD/splatam_amd/lib_ab/libsplat_hip.so; fi
   for wl in E-clustered E-clustered-5M; do

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time of ONE LDS sort of n keys by one workgroup (splat_selftest: 1 bitonic network, 3 radix_sort_lds with 4 waves, 4 with one wave).
+"""Time of ONE LDS sort of n keys by one workgroup (splat_selftest: 1 bitonic network on 256 threads, radix_sort_lds: 3 with 4 waves, 5 with 16 waves, 4 with one wave).
 Developer tool (gpurun)."""
 import os
 import sys
@@ -13,7 +13,7 @@ from test_gpu_primitives import _depth_id_keys  # noqa: E402
 
 L = _capi.lib()
 s = torch.cuda.current_stream().cuda_stream
-for which, n, kind in ((1, 4096, "narrow"), (3, 4096, "narrow"), (3, 4096, "wide"), (3, 4096, "plane"), (3, 2000, "narrow"), (1, 1024, "narrow"),
+for which, n, kind in ((1, 4096, "narrow"), (5, 4096, "narrow"), (5, 4096, "wide"), (5, 2000, "narrow"), (3, 4096, "narrow"), (3, 4096, "wide"), (3, 4096, "plane"), (3, 2000, "narrow"), (1, 1024, "narrow"),
                        (4, 1024, "narrow"), (4, 200, "narrow"), (1, 200, "narrow")):
     keys = torch.from_numpy(_depth_id_keys(n, kind, 1).view("int64")).cuda()
     out = torch.empty_like(keys)

@@ -14,6 +14,10 @@ namespace splat {
 
 constexpr int kBlock = 256;
 constexpr int kSortLds = 4096;                 // keys sorted in LDS per tile (32 KiB); longer lists spill to HBM
+// workgroup of the LDS radix sort of up to kSortLds keys: 16 waves, one workgroup per CU (82 KB of LDS).  Measured against 4 waves x two
+// workgroups per CU (long_run_sort at 1 M / 5 M clustered: 117 / 333 us) and against 16 waves x two per CU with 16-bit histogram words and
+// 64 registers (108 / 304 us): 92 / 334 us
+constexpr int kSortWaves = 16, kSortBlock = 64 * kSortWaves;
 
 // K3: one lane per Gaussian, one bucket slot per touched tile.  The slot comes from a
 // returning atomic on the tile cursor (a fabric round trip of a few microseconds under
@@ -83,16 +87,23 @@ __global__ __launch_bounds__(64) void tile_sort_wave_kernel(SplatState st) {
     const uint64_t *gk = st.keys + lo;
     for (int i = tid; i < n; i += 64) s_keys[i] = gk[i];
     __syncthreads();
-    const uint64_t *sorted = radix_sort_lds<1>(s_keys, s_alt, s_hist, n, tid);
+    // one wave: the radix passes are a latency chain (nothing else runs on its SIMD lane of the workgroup); below a few hundred keys
+    // the bitonic network's log^2 n short stages are faster (measured: 200 keys 7 vs 12 us, 1 024 keys: the radix sort wins)
+    const uint64_t *sorted = s_keys;
+    if (n <= 256) {
+        if (n > 1) bitonic_sort(s_keys, n, tid, 64);
+    } else {
+        sorted = radix_sort_lds<1>(s_keys, s_alt, s_hist, n, tid);
+    }
     for (int i = tid; i < n; i += 64) st.point_list[lo + i] = (uint32_t)sorted[i];
 }
 
 // `long_launched`: the host launches the multi-workgroup kernels below in this call (it decides from its list-length hint, which may
 // be stale: a list beyond LDS that nobody is going to sort is flagged -- status[3], the host repeats the iteration -- and published
 // unsorted, so that the composites of the invalid iteration still read valid Gaussian indices).
-__global__ __launch_bounds__(kBlock) void tile_sort_block_kernel(SplatState st, bool long_launched, int T) {
+__global__ __launch_bounds__(kSortBlock) void tile_sort_block_kernel(SplatState st, bool long_launched, int T) {
     __shared__ uint64_t s_keys[kSortLds], s_alt[kSortLds];
-    __shared__ __attribute__((aligned(8))) unsigned s_hist[4 * 256];
+    __shared__ __attribute__((aligned(8))) unsigned s_hist[kSortWaves * 256];
     if (st.tile_stride == 0 && (long long)st.status[0] > st.capacity) return;
     const int tid = threadIdx.x;
     // (68 KB of LDS: two workgroups per CU -- a fixed grid walks the tiles, most of which have nothing for this kernel)
@@ -104,18 +115,18 @@ __global__ __launch_bounds__(kBlock) void tile_sort_block_kernel(SplatState st, 
         uint64_t *gk = st.keys + lo;
         if (n <= kSortLds) {
             __syncthreads();                            // (the previous tile's result is still being read out of LDS)
-            for (int i = tid; i < n; i += kBlock) s_keys[i] = gk[i];
+            for (int i = tid; i < n; i += kSortBlock) s_keys[i] = gk[i];
             __syncthreads();
-            const uint64_t *sorted = radix_sort_lds<4>(s_keys, s_alt, s_hist, n, tid);
-            for (int i = tid; i < n; i += kBlock) st.point_list[lo + i] = (uint32_t)sorted[i];
+            const uint64_t *sorted = radix_sort_lds<kSortWaves, kSortLds>(s_keys, s_alt, s_hist, n, tid);
+            for (int i = tid; i < n; i += kSortBlock) st.point_list[lo + i] = (uint32_t)sorted[i];
         } else if (!st.keys_alt || !st.long_base) {
             // list beyond LDS and no scratch from the caller: the bitonic network run in place on the HBM bucket by this ONE workgroup
             // (correct, slow: O(n log^2 n) barrier-separated stages); with scratch the multi-workgroup kernels below take the tile
-            bitonic_sort(gk, n, tid, kBlock);
-            for (int i = tid; i < n; i += kBlock) st.point_list[lo + i] = (uint32_t)gk[i];
+            bitonic_sort(gk, n, tid, kSortBlock);
+            for (int i = tid; i < n; i += kSortBlock) st.point_list[lo + i] = (uint32_t)gk[i];
         } else if (!long_launched) {
             if (tid == 0) atomicOr((unsigned *)&st.status[3], 1u);
-            for (int i = tid; i < n; i += kBlock) st.point_list[lo + i] = (uint32_t)gk[i];
+            for (int i = tid; i < n; i += kSortBlock) st.point_list[lo + i] = (uint32_t)gk[i];
         }
     }
 }
@@ -207,9 +218,9 @@ __device__ __forceinline__ bool long_item(const SplatState &st, int T, unsigned 
 }
 
 // (the long-list kernels walk the item space with a grid stride: the number of items is only known on the device, long_base[T])
-__global__ __launch_bounds__(kBlock) void long_run_sort_kernel(SplatState st, int T) {
+__global__ __launch_bounds__(kSortBlock) void long_run_sort_kernel(SplatState st, int T) {
     __shared__ uint64_t s_keys[kRun], s_alt[kRun];
-    __shared__ __attribute__((aligned(8))) unsigned s_hist[4 * 256];
+    __shared__ __attribute__((aligned(8))) unsigned s_hist[kSortWaves * 256];
     const unsigned total = st.long_base[T];
     const int tid = threadIdx.x;
     // a run starts at every item whose chunk index within its tile is a multiple of 4 (an item is 1024 keys, a run 4096): the
@@ -223,10 +234,10 @@ __global__ __launch_bounds__(kBlock) void long_run_sort_kernel(SplatState st, in
             const int off = (chunk >> 2) * kRun, m = min(kRun, n - off);
             uint64_t *gk = st.keys + lo + off;
             __syncthreads();
-            for (int i = tid; i < m; i += kBlock) s_keys[i] = gk[i];
+            for (int i = tid; i < m; i += kSortBlock) s_keys[i] = gk[i];
             __syncthreads();
-            const uint64_t *sorted = radix_sort_lds<4>(s_keys, s_alt, s_hist, m, tid);
-            for (int i = tid; i < m; i += kBlock) gk[i] = sorted[i];
+            const uint64_t *sorted = radix_sort_lds<kSortWaves, kRun>(s_keys, s_alt, s_hist, m, tid);
+            for (int i = tid; i < m; i += kSortBlock) gk[i] = sorted[i];
         }
     }
 }
@@ -322,7 +333,7 @@ hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, S
         if (!long_sort_skipped(st.max_list_hint)) {
             const long long hint = st.max_list_hint > 0 ? (long long)st.max_list_hint + st.max_list_hint / 2 : (long long)1 << 40;
             const bool long_path = st.keys_alt && st.long_base && hint > kRun && st.capacity > kRun;
-            hipLaunchKernelGGL(tile_sort_block_kernel, dim3(T < 512 ? T : 512), dim3(kBlock), 0, s, st, long_path, T);
+            hipLaunchKernelGGL(tile_sort_block_kernel, dim3(T < 512 ? T : 512), dim3(kSortBlock), 0, s, st, long_path, T);
             if (long_path) {
                 // no list is longer than `bound`: the hint, the capacity, or -- bucketed lists -- the bucket
                 long long bound = st.capacity < hint ? st.capacity : hint;
@@ -334,7 +345,7 @@ hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, S
                 // (fixed grids: a workgroup that finds nothing to do still costs its launch -- 4096 of them with 69 KB of LDS, two per
                 //  CU at a time, cost more than the sort itself.  Two run-sort workgroups per CU, eight of the light kernels)
                 const long long run_wgs = (items + 3) / 4 < 512 ? (items + 3) / 4 : 512, item_wgs = items < 2048 ? items : 2048;
-                hipLaunchKernelGGL(long_run_sort_kernel, dim3((unsigned)run_wgs), dim3(kBlock), 0, s, st, T);
+                hipLaunchKernelGGL(long_run_sort_kernel, dim3((unsigned)run_wgs), dim3(kSortBlock), 0, s, st, T);
                 const int passes = long_passes(bound);
                 for (int p = 0; p < passes; ++p)
                     hipLaunchKernelGGL(long_merge_kernel, dim3((unsigned)item_wgs), dim3(kBlock), 0, s, st, T, p);
@@ -362,13 +373,13 @@ __global__ __launch_bounds__(kBlock) void selftest_sort_lds_kernel(const uint64_
     if (n > 1) bitonic_sort(s_keys, n, threadIdx.x, kBlock);
     for (int i = threadIdx.x; i < n; i += kBlock) out[i] = s_keys[i];
 }
-template <int NW>
+template <int NW, int MAXN>
 __global__ __launch_bounds__(64 * NW) void selftest_radix_lds_kernel(const uint64_t *in, uint64_t *out, int n) {
-    __shared__ uint64_t s_keys[NW * 1024], s_alt[NW * 1024];
+    __shared__ uint64_t s_keys[MAXN], s_alt[MAXN];
     __shared__ __attribute__((aligned(8))) unsigned s_hist[NW * 256];
     for (int i = threadIdx.x; i < n; i += 64 * NW) s_keys[i] = in[i];
     __syncthreads();
-    const uint64_t *sorted = radix_sort_lds<NW>(s_keys, s_alt, s_hist, n, threadIdx.x);
+    const uint64_t *sorted = radix_sort_lds<NW, MAXN>(s_keys, s_alt, s_hist, n, threadIdx.x);
     for (int i = threadIdx.x; i < n; i += 64 * NW) out[i] = sorted[i];
 }
 __global__ __launch_bounds__(kBlock) void selftest_sort_global_kernel(uint64_t *keys, int n) {
@@ -385,10 +396,11 @@ hipError_t launch_selftest(int which, const void *in, void *out, int n, hipStrea
         hipError_t e = hipMemcpyAsync(out, in, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(selftest_sort_global_kernel, dim3(1), dim3(kBlock), 0, s, (uint64_t *)out, n);
-    } else if (which == 3 || which == 4) {              // radix_sort_lds: 3 = 256-thread workgroup (n <= 4096), 4 = one wave (n <= 1024)
-        if (n > (which == 3 ? kSortLds : kSortWave)) return hipErrorInvalidValue;
-        if (which == 3) hipLaunchKernelGGL(selftest_radix_lds_kernel<4>, dim3(1), dim3(256), 0, s, (const uint64_t *)in, (uint64_t *)out, n);
-        else hipLaunchKernelGGL(selftest_radix_lds_kernel<1>, dim3(1), dim3(64), 0, s, (const uint64_t *)in, (uint64_t *)out, n);
+    } else if (which >= 3 && which <= 5) {              // radix_sort_lds: 3 = 256 threads, 5 = 1024 threads (n <= 4096), 4 = one wave (n <= 1024)
+        if (n > (which == 4 ? kSortWave : kSortLds)) return hipErrorInvalidValue;
+        if (which == 3) hipLaunchKernelGGL((selftest_radix_lds_kernel<4, 4096>), dim3(1), dim3(256), 0, s, (const uint64_t *)in, (uint64_t *)out, n);
+        else if (which == 5) hipLaunchKernelGGL((selftest_radix_lds_kernel<16, 4096>), dim3(1), dim3(1024), 0, s, (const uint64_t *)in, (uint64_t *)out, n);
+        else hipLaunchKernelGGL((selftest_radix_lds_kernel<1, 1024>), dim3(1), dim3(64), 0, s, (const uint64_t *)in, (uint64_t *)out, n);
     } else {
         return hipErrorInvalidValue;
     }

@@ -178,7 +178,7 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr keys, const int n, const int
 
 // ---------------------------------------------------------------------------------------------------------------------
 // LDS radix sort on the depth key (the "per-tile radix sort on depth key" of the path's design): n <= NW * 1024 unique 64-bit keys
-// (float bits of depth << 32 | Gaussian id) ascending, by NW waves (workgroup of 64 * NW threads).
+// (float bits of depth << 32 | Gaussian id) ascending, by NW waves (workgroup of 64 * NW threads; n <= MAXN).
 //   * least-significant-digit passes over the 32 DEPTH bits, 8 bits per pass; a pass whose digit is the same in every key (the
 //     exponent byte of a tile's depth range, usually) is skipped;
 //   * wave-ballot ranking: wave w owns the contiguous segment w of the keys and walks it 64 keys per round.  match_any (8 ballots)
@@ -187,10 +187,10 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr keys, const int n, const int
 //   * offsets: exclusive scan over (digit, wave) -- stable: segments in wave order, rounds in order, lanes in order;
 //   * equal depths (rare) come out in scatter order; one last pass moves a key by (#smaller ids right of it - #larger ids left of
 //     it) within its run of equal depth: "ascending depth, ties by ascending id", the order the bitonic network produces.
-// buf_a holds the keys on entry; buf_b is scratch of the same size; hist: NW * 256 words.  Returns the buffer that holds the
+// buf_a holds the keys on entry; buf_b is scratch of the same size; hist: NW * 256 counters (8-byte aligned, >= 16 NW bytes).  Returns the buffer that holds the
 // result.  Barriers inside: every thread of the workgroup must call it (n is uniform).
-// Cost: ~110 vector instructions per 64 keys and pass -- a 4096-key run takes ~8 us on one CU (the bitonic network: ~150 us, its
-// stride-2^k exchanges of 8-byte keys are 16-way bank conflicts).
+// Measured, one workgroup alone on the GPU, 4 096 keys of a tile's depth range (3 passes): 256 threads 28 us (the bitonic network 73 us),
+// see scripts/time_radix_sort.py; the list kernels use 1 024 threads.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long match_any8(unsigned d, bool valid) {
     unsigned long long peers = __builtin_amdgcn_ballot_w64(valid);
@@ -203,10 +203,15 @@ __device__ __forceinline__ unsigned long long match_any8(unsigned d, bool valid)
     return valid ? peers : 0ull;
 }
 
-template <int NW>
-__device__ __forceinline__ uint64_t *radix_sort_lds(uint64_t *buf_a, uint64_t *buf_b, unsigned *hist, const int n, const int tid) {
-    static_assert(NW == 1 || NW == 4, "one wave per list, or a 256-thread workgroup");
-    constexpr int kRounds = 16;                         // 64-key rounds per wave: NW * 1024 keys at most
+template <int NW, int MAXN = NW * 1024, typename HistT = unsigned>
+__device__ __forceinline__ uint64_t *radix_sort_lds(uint64_t *buf_a, uint64_t *buf_b, HistT *hist, const int n, const int tid) {
+    static_assert(MAXN <= 65535 || sizeof(HistT) == 4, "a histogram word holds an offset into the keys");
+    static_assert(NW == 1 || NW == 4 || NW == 16, "one wave per list, or a workgroup of 256 / 1024 threads");
+    static_assert(MAXN % (NW * 64) == 0, "whole rounds");
+    // 64-key rounds per wave.  The rounds of a wave are a chain of dependent steps (eight ballots -- vector compare to scalar mask and
+    // back, ~30 cycles each -- then an LDS read-modify-write): measured 1 400 cycles per round with ONE wave per SIMD.  Sixteen waves
+    // on 4 096 keys (4 rounds each, 4 waves per SIMD) hide that latency behind each other.
+    constexpr int kRounds = MAXN / (NW * 64);
     constexpr int kTieRun = 32;                         // longest run of equal depths the neighbour pass orders
     __shared__ unsigned s_x[8];                         // wave totals of the digit scan / flags
     const int lane = tid & 63, wave = tid >> 6;
@@ -236,14 +241,14 @@ __device__ __forceinline__ uint64_t *radix_sort_lds(uint64_t *buf_a, uint64_t *b
     if (tid == 0) s_x[4] = 0u;
     __syncthreads();
     uint64_t *src = buf_a, *dst = buf_b;
-    unsigned *row = hist + wave * 256;
+    HistT *row = hist + wave * 256;
     // attempt 0: the four depth bytes, then the neighbour pass.  Only when that finds a run of > kTieRun equal depths (a fronto-parallel
     // plane of Gaussians): attempt 1, all eight bytes, least significant first -- the id bytes, then the depth bytes again.
     for (int attempt = 0; attempt < 2; ++attempt) {
         for (int byte = attempt == 0 ? 4 : 0; byte < 8; ++byte) {
             if (((diff >> (8 * byte)) & 0xFFull) == 0ull) continue;      // (uniform) every key holds the same digit here
             const int shift = 8 * byte;
-            for (int k = tid; k < NW * 256; k += 64 * NW) hist[k] = 0u;
+            for (int k = tid; k < NW * 256; k += 64 * NW) hist[k] = (HistT)0;
             __syncthreads();
             unsigned info[kRounds];                     // rank | leader lane << 8 | group size << 16 | is-leader << 24
 #pragma unroll
@@ -258,27 +263,35 @@ __device__ __forceinline__ uint64_t *radix_sort_lds(uint64_t *buf_a, uint64_t *b
                     const unsigned cnt = (unsigned)__builtin_popcountll(peers);
                     const unsigned leader = valid ? (unsigned)__builtin_ctzll(peers) : 0u;
                     const bool is_leader = valid && leader == (unsigned)lane;
-                    if (is_leader) row[d] += cnt;       // leaders of one round hold distinct digits; rounds of a wave are in program order
+                    if (is_leader) row[d] = (HistT)(row[d] + cnt);       // leaders of one round hold distinct digits; rounds of a wave are in program order
                     info[r] = rank | (leader << 8) | (cnt << 16) | ((is_leader ? 1u : 0u) << 24);
                 }
             }
             __syncthreads();
             // exclusive scan over (digit, wave)
-            if constexpr (NW == 4) {                    // thread t owns digit t
-                unsigned c[NW], tot = 0u;
+            if constexpr (NW >= 4) {                    // thread t < 256 owns digit t
+                unsigned tot = 0u, incl = 0u;
+                if (tid < 256) {
 #pragma unroll
-                for (int w = 0; w < NW; ++w) { c[w] = hist[w * 256 + tid]; tot += c[w]; }
-                unsigned incl = tot;
-                for (int dd = 1; dd < 64; dd <<= 1) {
-                    const unsigned o = (unsigned)__shfl_up((int)incl, dd, 64);
-                    if (lane >= dd) incl += o;
+                    for (int w = 0; w < NW; ++w) tot += hist[w * 256 + tid];
+                    incl = tot;
+                    for (int dd = 1; dd < 64; dd <<= 1) {
+                        const unsigned o = (unsigned)__shfl_up((int)incl, dd, 64);
+                        if (lane >= dd) incl += o;
+                    }
+                    if (lane == 63) s_x[wave] = incl;
                 }
-                if (lane == 63) s_x[wave] = incl;
                 __syncthreads();
-                unsigned base = incl - tot;
-                for (int w = 0; w < wave; ++w) base += s_x[w];
+                if (tid < 256) {
+                    unsigned base = incl - tot;
+                    for (int w = 0; w < wave; ++w) base += s_x[w];
 #pragma unroll
-                for (int w = 0; w < NW; ++w) { hist[w * 256 + tid] = base; base += c[w]; }
+                    for (int w = 0; w < NW; ++w) {
+                        const unsigned c = hist[w * 256 + tid];
+                        hist[w * 256 + tid] = (HistT)base;
+                        base += c;
+                    }
+                }
             } else {                                    // one wave: the four 64-digit quarters in turn
                 unsigned run = 0u;
 #pragma unroll
@@ -289,7 +302,7 @@ __device__ __forceinline__ uint64_t *radix_sort_lds(uint64_t *buf_a, uint64_t *b
                         const unsigned o = (unsigned)__shfl_up((int)incl, dd, 64);
                         if (lane >= dd) incl += o;
                     }
-                    hist[q * 64 + lane] = run + incl - cq;
+                    hist[q * 64 + lane] = (HistT)(run + incl - cq);
                     run += (unsigned)__shfl((int)incl, 63, 64);
                 }
             }
@@ -304,7 +317,7 @@ __device__ __forceinline__ uint64_t *radix_sort_lds(uint64_t *buf_a, uint64_t *b
                     unsigned base = 0u;
                     if ((info[r] >> 24) & 1u) {
                         base = row[d];
-                        row[d] = base + ((info[r] >> 16) & 0xFFu);
+                        row[d] = (HistT)(base + ((info[r] >> 16) & 0xFFu));
                     }
                     base = (unsigned)__shfl((int)base, (int)((info[r] >> 8) & 0xFFu), 64);
                     if (valid) dst[base + (info[r] & 0xFFu)] = key;

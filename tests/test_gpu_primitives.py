@@ -60,10 +60,12 @@ def _depth_id_keys(n, kind, seed):
 
 @pytest.mark.parametrize("kind", ["wide", "narrow", "short_ties", "plane", "constant"])
 @pytest.mark.parametrize("which,n", [(3, 1), (3, 2), (3, 63), (3, 64), (3, 65), (3, 257), (3, 1000), (3, 2500), (3, 4095), (3, 4096),
-                                     (4, 1), (4, 5), (4, 64), (4, 65), (4, 200), (4, 777), (4, 1023), (4, 1024)])
+                                     (4, 1), (4, 5), (4, 64), (4, 65), (4, 200), (4, 777), (4, 1023), (4, 1024),
+                                     (5, 1), (5, 2), (5, 64), (5, 65), (5, 1000), (5, 1025), (5, 3000), (5, 4095), (5, 4096)])
 def test_lds_radix_sort_on_depth_key(which, n, kind):
     """radix_sort_lds (splat_device.h): the per-tile sort of the list kernels -- 8-bit passes over the depth bits with wave-ballot
-    ranking, equal depths ordered by id: exactly numpy's sort of the 64-bit keys."""
+    ranking, equal depths ordered by id: exactly numpy's sort of the 64-bit keys.  which: 3 = 4 waves, 5 = 16 waves (the list
+    kernels' workgroup), 4 = one wave (tile_sort_wave_kernel)."""
     L = _lib()
     keys_np = _depth_id_keys(n, kind, seed=1000 * which + n)
     keys = torch.from_numpy(keys_np.view(np.int64)).cuda()
