@@ -461,6 +461,8 @@ def main():
     ap.add_argument("--sync-mode", default="exact", choices=["exact", "lazy"])
     ap.add_argument("--engine", default="fused", choices=["fused", "dropin"])
     ap.add_argument("--sustain-s", type=float, default=6.5, help="length of the sustained region in seconds")
+    ap.add_argument("--instream-rccl", action="store_true",
+                    help="N > 1 over RCCL: issue the per-iteration all-reduces on the iteration's own stream (splatam_amd.dist.InStreamRccl)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-slam-loop", action="store_true", help="skip the informational end-to-end frame-loop figure")
@@ -474,6 +476,8 @@ def main():
     from splatam_amd import rasterizer as rz
     from splatam_amd import slam
     from splatam_amd.fused import FusedEngine
+    if args.instream_rccl:
+        os.environ["SPLAT_INSTREAM_RCCL"] = "1"
     rank, world, local_rank = sdist.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP rasterizer has no CPU path)")
@@ -686,6 +690,8 @@ def main():
                                              if world > 1 else "1 process/GPU")))},
             "sustained": ({"steps": n_sus, "seconds": round(sustained_s, 3), "iters_per_s": round(units(n_sus) / sustained_s, 3)} if sustained_ok
                           else {"steps": n_sus, "invalid": "a per-tile list outgrew its bucket during the sustained region"}),
+            "collectives": ("in-stream RCCL (splatam_amd.dist.InStreamRccl)" if sdist._instream is not None else
+                            ("torch.distributed " + torch.distributed.get_backend() if world > 1 else None)),
             "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4),
             "allreduce_small_ms": None if allreduce_small_ms is None else round(allreduce_small_ms, 4),
             "tracking_replicated_iters_per_s": None if not (fused and world > 1) else round(track_rate_repl, 3),

@@ -242,16 +242,7 @@ __global__ __launch_bounds__(kSortBlock) void long_run_sort_kernel(SplatState st
     }
 }
 
-// merge path: how many of the first k keys of merge(A[0, la), B[0, lb)) come from A (keys are unique)
-__device__ __forceinline__ int merge_path(const uint64_t *A, int la, const uint64_t *B, int lb, int k) {
-    int lo = max(0, k - lb), hi = min(k, la);
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (A[mid] < B[k - mid - 1]) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
+// (merge path: `a` = how many of the first k keys of merge(A[0, la), B[0, lb)) come from A; keys are unique)
 // One item = 1024 consecutive OUTPUT keys of a tile's list.  Two merge-path searches (uniform over the workgroup: ~13 dependent
 // reads each, of two 8-byte keys) cut the pair of runs at the item's first and last output; the two input pieces -- 1024 keys together,
 // contiguous -- are staged in LDS, and every key finds its place among the other piece's keys by a binary search IN LDS.  One
@@ -279,7 +270,17 @@ __global__ __launch_bounds__(kBlock) void long_merge_kernel(SplatState st, int T
             for (int k = k0 + tid; k < k1; k += kBlock) dst[base + k] = A[k];
             continue;
         }
-        const int a0 = merge_path(A, la, B, lb, k0), a1 = merge_path(A, la, B, lb, k1);
+        // the two searches in lockstep: their reads are in flight together (each step is a dependent round trip to L2)
+        int lo0 = max(0, k0 - lb), hi0 = min(k0, la), lo1 = max(0, k1 - lb), hi1 = min(k1, la);
+        while (lo0 < hi0 || lo1 < hi1) {
+            const int m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
+            const bool on0 = lo0 < hi0, on1 = lo1 < hi1;
+            const uint64_t xa0 = on0 ? A[m0] : 0ull, xb0 = on0 ? B[k0 - m0 - 1] : 0ull;
+            const uint64_t xa1 = on1 ? A[m1] : 0ull, xb1 = on1 ? B[k1 - m1 - 1] : 0ull;
+            if (on0) { if (xa0 < xb0) lo0 = m0 + 1; else hi0 = m0; }
+            if (on1) { if (xa1 < xb1) lo1 = m1 + 1; else hi1 = m1; }
+        }
+        const int a0 = lo0, a1 = lo1;
         const int b0 = k0 - a0, b1 = k1 - a1;
         const int na = a1 - a0, nb = b1 - b0;                       // na + nb = k1 - k0 <= 1024
         __syncthreads();                                            // (the previous item's searches are done with s_in)

@@ -6,8 +6,9 @@ exchange step per iteration: a sum all-reduce of the Gaussian gradients
 (one flat bucket: 12 floats per isotropic Gaussian on the drop-in path, 8 on the fused path, which knows that the
 rotation gradient of an isotropic map is exactly zero), followed by the identical
 Adam step on every rank.  One process per GPU; backend "nccl" is RCCL over xGMI
-on ROCm, "gloo" is used by the CPU tests.  Tracking has no exchange step
-(replicas only).
+on ROCm, "gloo" is used by the CPU tests.  Tracking shards over tile rows with one 16 KB
+all-reduce of its partial sums per iteration (FusedEngine.tracking_iteration(shard=...)).
+The two per-iteration all-reduces can be issued on the iteration's own stream (InStreamRccl, opt-in).
 """
 from __future__ import annotations
 
@@ -74,12 +75,78 @@ class GradBucket:
                     params[k].grad.copy_(v)
 
 
+class InStreamRccl:
+    """RCCL collectives issued ON the caller's HIP stream (``torch.cuda.nccl``: ncclAllReduce with the stream passed in), on a
+    communicator of its own.  ``torch.distributed``'s NCCL backend runs every collective on the process group's internal stream:
+    each call is two event hand-offs (caller's stream -> comm stream -> caller's stream) around a message that, for the two
+    per-iteration exchanges of this path (the 16 KB of tracking partial sums; the gradient bucket), takes less time than the
+    hand-offs.  In stream, the all-reduce is one more kernel in the iteration's queue: K7 -> F6 -> all-reduce -> Adam, no host or
+    event synchronisation at all.
+
+    Opt-in (``SPLAT_INSTREAM_RCCL=1``, ``bench.py --instream-rccl``): it has run on hardware with ONE rank only (the development
+    boxes have one GPU; tests/test_gpu_dist_pipeline.py::test_instream_rccl_single_rank) -- the default stays torch.distributed."""
+
+    SUM, PROD, MAX, MIN, AVG = 0, 1, 2, 3, 4        # ncclRedOp_t
+
+    def __init__(self, rank: int, world: int, uid: Optional[bytes] = None, group=None):
+        import torch.cuda.nccl as nccl
+        self.nccl, self.rank, self.world = nccl, rank, world
+        if uid is None:
+            # rank 0 draws the id; it travels over the existing process group (any backend)
+            box = [nccl.unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0, group=group)
+            uid = box[0]
+        self.comm = nccl.init_rank(world, uid, rank)
+
+    def all_reduce(self, t: torch.Tensor, op: int = 0) -> None:
+        """In place, on ``torch.cuda.current_stream(t.device)``."""
+        if not t.is_contiguous():
+            raise ValueError("in-stream all-reduce needs a contiguous tensor")
+        self.nccl.all_reduce([t], [t], op=op, streams=[torch.cuda.current_stream(t.device)], comms=[self.comm])
+
+
+_instream: Optional[InStreamRccl] = None
+_instream_failed = False
+
+
+def instream(group=None) -> Optional[InStreamRccl]:
+    """The in-stream communicator when it is switched on (SPLAT_INSTREAM_RCCL=1) and the job runs over RCCL, else None."""
+    global _instream, _instream_failed
+    if _instream is not None or _instream_failed:
+        return _instream
+    if os.environ.get("SPLAT_INSTREAM_RCCL", "0") != "1" or not dist.is_initialized() or dist.get_backend(group) != "nccl":
+        return None
+    comm, err, good = None, None, 0
+    dev = torch.device("cuda", torch.cuda.current_device())
+    try:
+        comm = InStreamRccl(dist.get_rank(group), dist.get_world_size(group), group=group)
+        # self-check before anything depends on it: sum of (rank + 1)
+        probe = torch.full((8,), float(comm.rank + 1), device=dev)
+        comm.all_reduce(probe, InStreamRccl.SUM)
+        good = 1 if bool((probe == comm.world * (comm.world + 1) / 2).all()) else 0
+    except Exception as e:                                 # noqa: BLE001  (fall back to the process group, loudly)
+        err = e
+    ok = torch.tensor([good], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)   # every rank takes the same path
+    if int(ok[0]) == 1:
+        _instream = comm
+    else:
+        _instream_failed = True
+        import warnings
+        warnings.warn(f"SPLAT_INSTREAM_RCCL=1 but the in-stream communicator is unavailable on some rank ({err!r}); using torch.distributed")
+    return _instream
+
+
 def all_reduce_mean_flat(flat: torch.Tensor, group=None) -> None:
     """In-place mean over ranks of ONE flat gradient buffer -- the exchange step of the fused mapping iteration
     (splatam_amd.fused.FusedEngine.grad_flat is already laid out as the bucket: no packing)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    if dist.get_backend(group) == "nccl":            # RCCL averages inside the collective: no separate scaling kernel
+    comm = instream(group)
+    if comm is not None:
+        comm.all_reduce(flat, InStreamRccl.AVG)
+    elif dist.get_backend(group) == "nccl":          # RCCL averages inside the collective: no separate scaling kernel
         dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
     else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
@@ -89,7 +156,11 @@ def all_reduce_mean_flat(flat: torch.Tensor, group=None) -> None:
 def all_reduce_sum_flat(flat: torch.Tensor, group=None) -> None:
     """In-place sum over ranks of one flat gradient buffer (the caller divides by the number of views of all ranks)."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        comm = instream(group)
+        if comm is not None:
+            comm.all_reduce(flat, InStreamRccl.SUM)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
 
 
 def any_rank(flag: bool, device=None, group=None) -> bool:

@@ -73,3 +73,28 @@ def test_rccl_two_ranks(tmp_path):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
     _check_two_ranks(tmp_path, "nccl")
+
+
+def test_instream_rccl_single_rank():
+    """splatam_amd.dist.InStreamRccl (ncclAllReduce on the caller's stream, own communicator): what one GPU can show -- the
+    communicator initialises, the collective is ordered with the kernels queued before and after it on the SAME non-default stream
+    without any synchronisation, sums of doubles (the tracking partial sums) and averages of floats (the gradient bucket) come back
+    unchanged with one rank."""
+    from splatam_amd.dist import InStreamRccl
+    dev = torch.device("cuda", 0)
+    comm = InStreamRccl(0, 1)
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        sums = torch.zeros(64 * 32, dtype=torch.float64, device=dev)
+        for k in range(50):                         # queued back to back: add, all-reduce, add, ...
+            sums += 1.0
+            comm.all_reduce(sums, InStreamRccl.SUM)
+        grads = torch.arange(3_600_000, dtype=torch.float32, device=dev)
+        grads *= 2.0
+        comm.all_reduce(grads, InStreamRccl.AVG)
+        grads += 1.0
+    side.synchronize()
+    assert float(sums.min()) == 50.0 and float(sums.max()) == 50.0
+    assert torch.equal(grads, torch.arange(3_600_000, dtype=torch.float32, device=dev) * 2.0 + 1.0)
+    with pytest.raises(ValueError):
+        comm.all_reduce(torch.zeros(4, 4, device=dev).t())
