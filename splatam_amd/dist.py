@@ -12,6 +12,7 @@ The two per-iteration all-reduces can be issued on the iteration's own stream (I
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 from typing import Dict, Iterable, Optional
 
@@ -75,35 +76,84 @@ class GradBucket:
                     params[k].grad.copy_(v)
 
 
+class _NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]            # NCCL_UNIQUE_ID_BYTES (rccl.h)
+
+
+def _load_rccl():
+    """The RCCL library torch itself has loaded (torch/lib/librccl.so: the same instance), else ROCm's."""
+    cands = [os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "/opt/rocm/lib/librccl.so", "librccl.so"]
+    last = None
+    for path in cands:
+        try:
+            L = C.CDLL(path)
+            break
+        except OSError as e:
+            last = e
+    else:
+        raise OSError(f"librccl.so not found ({last})")
+    L.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
+    L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+    L.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.ncclCommDestroy.argtypes = [C.c_void_p]
+    L.ncclGetErrorString.argtypes = [C.c_int]
+    L.ncclGetErrorString.restype = C.c_char_p
+    for f in (L.ncclGetUniqueId, L.ncclCommInitRank, L.ncclAllReduce, L.ncclCommDestroy):
+        f.restype = C.c_int
+    return L
+
+
 class InStreamRccl:
-    """RCCL collectives issued ON the caller's HIP stream (``torch.cuda.nccl``: ncclAllReduce with the stream passed in), on a
-    communicator of its own.  ``torch.distributed``'s NCCL backend runs every collective on the process group's internal stream:
-    each call is two event hand-offs (caller's stream -> comm stream -> caller's stream) around a message that, for the two
-    per-iteration exchanges of this path (the 16 KB of tracking partial sums; the gradient bucket), takes less time than the
-    hand-offs.  In stream, the all-reduce is one more kernel in the iteration's queue: K7 -> F6 -> all-reduce -> Adam, no host or
-    event synchronisation at all.
+    """RCCL collectives issued ON the caller's HIP stream (ncclAllReduce through ctypes on the librccl.so torch has loaded, with
+    ``torch.cuda.current_stream()``), on a communicator of its own.  ``torch.distributed``'s NCCL backend runs every collective on
+    the process group's internal stream: each call is two event hand-offs (caller's stream -> comm stream -> caller's stream) around a
+    message that, for the two per-iteration exchanges of this path (the 16 KB of tracking partial sums; the gradient bucket), takes
+    less time than the hand-offs.  In stream, the all-reduce is one more kernel in the iteration's queue: K7 -> F6 -> all-reduce ->
+    Adam, no host or event synchronisation at all.  (``torch.cuda.nccl.init_rank`` would be the torch-native way to get such a
+    communicator; under Python 3.10 it raises "PY_SSIZE_T_CLEAN macro must be defined" in torch 2.10.)
 
     Opt-in (``SPLAT_INSTREAM_RCCL=1``, ``bench.py --instream-rccl``): it has run on hardware with ONE rank only (the development
     boxes have one GPU; tests/test_gpu_dist_pipeline.py::test_instream_rccl_single_rank) -- the default stays torch.distributed."""
 
     SUM, PROD, MAX, MIN, AVG = 0, 1, 2, 3, 4        # ncclRedOp_t
+    _DTYPES = {torch.int32: 2, torch.int64: 4, torch.float32: 7, torch.float64: 8}       # ncclDataType_t
 
     def __init__(self, rank: int, world: int, uid: Optional[bytes] = None, group=None):
-        import torch.cuda.nccl as nccl
-        self.nccl, self.rank, self.world = nccl, rank, world
+        self.L, self.rank, self.world = _load_rccl(), rank, world
         if uid is None:
             # rank 0 draws the id; it travels over the existing process group (any backend)
-            box = [nccl.unique_id() if rank == 0 else None]
+            box = [None]
+            if rank == 0:
+                u = _NcclUniqueId()
+                self._check(self.L.ncclGetUniqueId(C.byref(u)), "ncclGetUniqueId")
+                box[0] = bytes(u.internal)
             if world > 1:
                 dist.broadcast_object_list(box, src=0, group=group)
             uid = box[0]
-        self.comm = nccl.init_rank(world, uid, rank)
+        u = _NcclUniqueId()
+        C.memmove(C.byref(u), uid, 128)
+        comm = C.c_void_p()
+        self._check(self.L.ncclCommInitRank(C.byref(comm), world, u, rank), "ncclCommInitRank")
+        self.comm = comm
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            raise RuntimeError(f"{what} failed: {self.L.ncclGetErrorString(rc).decode()} ({rc})")
 
     def all_reduce(self, t: torch.Tensor, op: int = 0) -> None:
         """In place, on ``torch.cuda.current_stream(t.device)``."""
         if not t.is_contiguous():
             raise ValueError("in-stream all-reduce needs a contiguous tensor")
-        self.nccl.all_reduce([t], [t], op=op, streams=[torch.cuda.current_stream(t.device)], comms=[self.comm])
+        if t.dtype not in self._DTYPES:
+            raise ValueError(f"in-stream all-reduce: unsupported dtype {t.dtype}")
+        with torch.cuda.device(t.device):
+            stream = torch.cuda.current_stream(t.device).cuda_stream
+            self._check(self.L.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), self._DTYPES[t.dtype], op, self.comm, stream), "ncclAllReduce")
+
+    def close(self) -> None:
+        if self.comm:
+            self.L.ncclCommDestroy(self.comm)
+            self.comm = None
 
 
 _instream: Optional[InStreamRccl] = None

@@ -98,3 +98,6 @@ def test_instream_rccl_single_rank():
     assert torch.equal(grads, torch.arange(3_600_000, dtype=torch.float32, device=dev) * 2.0 + 1.0)
     with pytest.raises(ValueError):
         comm.all_reduce(torch.zeros(4, 4, device=dev).t())
+    with pytest.raises(ValueError):
+        comm.all_reduce(torch.zeros(4, dtype=torch.float16, device=dev))
+    comm.close()
