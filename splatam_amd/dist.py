@@ -77,7 +77,7 @@ class GradBucket:
 
 
 class _NcclUniqueId(C.Structure):
-    _fields_ = [("internal", C.c_char * 128)]            # NCCL_UNIQUE_ID_BYTES (rccl.h)
+    _fields_ = [("internal", C.c_ubyte * 128)]           # NCCL_UNIQUE_ID_BYTES (rccl.h); (c_char would truncate at the first NUL)
 
 
 def _load_rccl():
@@ -126,11 +126,13 @@ class InStreamRccl:
             if rank == 0:
                 u = _NcclUniqueId()
                 self._check(self.L.ncclGetUniqueId(C.byref(u)), "ncclGetUniqueId")
-                box[0] = bytes(u.internal)
+                box[0] = C.string_at(C.byref(u), 128)
             if world > 1:
                 dist.broadcast_object_list(box, src=0, group=group)
             uid = box[0]
         u = _NcclUniqueId()
+        if len(uid) != 128:
+            raise ValueError("ncclUniqueId is 128 bytes")
         C.memmove(C.byref(u), uid, 128)
         comm = C.c_void_p()
         self._check(self.L.ncclCommInitRank(C.byref(comm), world, u, rank), "ncclCommInitRank")
