@@ -4,7 +4,7 @@
 tag=${1:-r03_s1}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_gpu_primitives.py -m gpu -q --timeout 900 -p no:cacheprovider > gpurun_out/${tag}_tests.log 2>&1
+timeout 1500 python -m pytest tests/test_gpu_primitives.py tests/test_gpu_dist_pipeline.py -m gpu -q --timeout 900 -p no:cacheprovider > gpurun_out/${tag}_tests.log 2>&1
 echo "pytest rc $?" >> gpurun_out/${tag}_tests.log
 tail -4 gpurun_out/${tag}_tests.log
 timeout 120 python scripts/time_radix_sort.py 2>&1 | tail -12

@@ -13,7 +13,7 @@ from test_gpu_primitives import _depth_id_keys  # noqa: E402
 
 L = _capi.lib()
 s = torch.cuda.current_stream().cuda_stream
-for which, n, kind in ((1, 4096, "narrow"), (5, 4096, "narrow"), (5, 4096, "wide"), (5, 2000, "narrow"), (3, 4096, "narrow"), (3, 4096, "wide"), (3, 4096, "plane"), (3, 2000, "narrow"), (1, 1024, "narrow"),
+for which, n, kind in ((1, 4096, "narrow"), (7, 8192, "narrow"), (7, 8192, "wide"), (8, 4096, "narrow"), (8, 2000, "narrow"), (6, 8192, "narrow"), (5, 4096, "narrow"), (5, 4096, "wide"), (5, 2000, "narrow"), (3, 4096, "narrow"), (3, 4096, "wide"), (3, 4096, "plane"), (3, 2000, "narrow"), (1, 1024, "narrow"),
                        (4, 1024, "narrow"), (4, 200, "narrow"), (1, 200, "narrow")):
     keys = torch.from_numpy(_depth_id_keys(n, kind, 1).view("int64")).cuda()
     out = torch.empty_like(keys)
@@ -25,4 +25,4 @@ for which, n, kind in ((1, 4096, "narrow"), (5, 4096, "narrow"), (5, 4096, "wide
         L.splat_selftest(which, keys.data_ptr(), out.data_ptr(), n, s)
     e1.record()
     torch.cuda.synchronize()
-    print(f"selftest {which} ({'bitonic' if which == 1 else 'radix'}), n = {n}, {kind}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per launch (one workgroup)", flush=True)
+    print(f"selftest {which} ({'bitonic' if which == 1 else ('radix, private ranking' if which >= 7 else 'radix')}), n = {n}, {kind}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per launch (one workgroup)", flush=True)

@@ -102,8 +102,8 @@ __global__ __launch_bounds__(64) void tile_sort_wave_kernel(SplatState st) {
 // be stale: a list beyond LDS that nobody is going to sort is flagged -- status[3], the host repeats the iteration -- and published
 // unsorted, so that the composites of the invalid iteration still read valid Gaussian indices).
 __global__ __launch_bounds__(kSortBlock) void tile_sort_block_kernel(SplatState st, bool long_launched, int T) {
-    __shared__ uint64_t s_keys[kSortLds], s_alt[kSortLds];
-    __shared__ __attribute__((aligned(8))) unsigned s_hist[kSortWaves * 256];
+    __shared__ __attribute__((aligned(16))) uint64_t s_keys[kSortLds + 1024], s_alt[kSortLds + 1024];
+    __shared__ __attribute__((aligned(8))) unsigned s_scratch[400];
     if (st.tile_stride == 0 && (long long)st.status[0] > st.capacity) return;
     const int tid = threadIdx.x;
     // (68 KB of LDS: two workgroups per CU -- a fixed grid walks the tiles, most of which have nothing for this kernel)
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kSortBlock) void tile_sort_block_kernel(SplatState 
             __syncthreads();                            // (the previous tile's result is still being read out of LDS)
             for (int i = tid; i < n; i += kSortBlock) s_keys[i] = gk[i];
             __syncthreads();
-            const uint64_t *sorted = radix_sort_lds<kSortWaves, kSortLds>(s_keys, s_alt, s_hist, n, tid);
+            const uint64_t *sorted = radix_sort_lds_private<kSortLds>(s_keys, s_alt, s_scratch, n, tid);
             for (int i = tid; i < n; i += kSortBlock) st.point_list[lo + i] = (uint32_t)sorted[i];
         } else if (!st.keys_alt || !st.long_base) {
             // list beyond LDS and no scratch from the caller: the bitonic network run in place on the HBM bucket by this ONE workgroup
@@ -134,14 +134,17 @@ __global__ __launch_bounds__(kSortBlock) void tile_sort_block_kernel(SplatState 
 // ---------------------------------------------------------------------------------------------------------------------
 // Lists beyond LDS (BASELINE config 5: "per-tile Gaussian list spilling HBM"): many workgroups per tile.
 //   L1 long_scan_kernel       item space: tile t owns ceil(n_t / 1024) items when n_t > 4096 (exclusive scan -> long_base)
-//   L2 long_run_sort_kernel   every 4th item of a tile: one 4096-key run sorted in LDS (radix_sort_lds), in place
-//   L3 long_merge_kernel      pass p merges neighbouring runs of 4096 * 2^p keys, keys <-> keys_alt ping-pong: merge-path partitions
+//   L2 long_run_sort_kernel   every 8th item of a tile: one 8192-key run sorted in LDS (radix_sort_lds), in place
+//   L3 long_merge_kernel      pass p merges neighbouring runs of 8192 * 2^p keys, keys <-> keys_alt ping-pong: merge-path partitions
 //                             of 1024 outputs, the two input pieces staged in LDS, rank-merged there (keys are unique): any
 //                             number of workgroups per tile, one streaming read + write per pass
 //   L4 long_publish_kernel    ids of the sorted keys (from whichever buffer the tile's last pass wrote) -> point_list
-// A tile of n keys takes ceil(log2(n / 4096)) passes; tiles that are done sit out the later passes.
+// A tile of n keys takes ceil(log2(n / 8192)) passes (none up to 8192 keys); tiles that are done sit out the later passes.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kRun = kSortLds;          // keys per LDS-sorted run
+// keys per LDS-sorted run of a list beyond kSortLds: 8192 (128 KB of keys + 16 KB of histogram rows: one workgroup per CU, as with 4096 --
+// the sort's cost per key is the same and every list needs one merge pass less; a list of up to 8192 keys needs none)
+constexpr int kRun = 2 * kSortLds;
+constexpr int kRunItems = kRun / 1024;  // work items per run
 constexpr int kItemKeys = 1024;         // keys per workgroup item in the merge / publish kernels (4 per thread)
 
 __host__ __device__ inline int long_passes(long long n) {      // merge passes a list of n keys needs
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(1024) void long_scan_kernel(SplatState st, int T) {
         unsigned l;
         int n;
         tile_range(st, t, l, n);
-        return (!dead && n > kRun) ? (unsigned)((n + kItemKeys - 1) / kItemKeys) : 0u;
+        return (!dead && n > kSortLds) ? (unsigned)((n + kItemKeys - 1) / kItemKeys) : 0u;
     };
     // (the counts of a thread's tiles are read once, all loads in flight together: this single workgroup is a chain of round trips)
     constexpr int kCache = 16;
@@ -219,24 +222,24 @@ __device__ __forceinline__ bool long_item(const SplatState &st, int T, unsigned 
 
 // (the long-list kernels walk the item space with a grid stride: the number of items is only known on the device, long_base[T])
 __global__ __launch_bounds__(kSortBlock) void long_run_sort_kernel(SplatState st, int T) {
-    __shared__ uint64_t s_keys[kRun], s_alt[kRun];
-    __shared__ __attribute__((aligned(8))) unsigned s_hist[kSortWaves * 256];
+    __shared__ __attribute__((aligned(16))) uint64_t s_keys[kRun + 1024], s_alt[kRun + 1024];
+    __shared__ __attribute__((aligned(8))) unsigned s_scratch[400];
     const unsigned total = st.long_base[T];
     const int tid = threadIdx.x;
-    // a run starts at every item whose chunk index within its tile is a multiple of 4 (an item is 1024 keys, a run 4096): the
-    // workgroups walk the items four at a time and sort the runs that START among their four
-    for (unsigned item = blockIdx.x * 4u; item < total; item += gridDim.x * 4u) {
-        for (unsigned it = item; it < item + 4u && it < total; ++it) {
+    // a run starts at every item whose chunk index within its tile is a multiple of kRunItems (an item is 1024 keys): the workgroups
+    // walk the items kRunItems at a time and sort the runs that START among theirs
+    for (unsigned item = blockIdx.x * (unsigned)kRunItems; item < total; item += gridDim.x * (unsigned)kRunItems) {
+        for (unsigned it = item; it < item + (unsigned)kRunItems && it < total; ++it) {
             int tile, chunk, n;
             unsigned lo;
             if (!long_item(st, T, it, tile, chunk, lo, n)) break;
-            if (chunk & 3) continue;
-            const int off = (chunk >> 2) * kRun, m = min(kRun, n - off);
+            if (chunk % kRunItems) continue;
+            const int off = (chunk / kRunItems) * kRun, m = min(kRun, n - off);
             uint64_t *gk = st.keys + lo + off;
             __syncthreads();
             for (int i = tid; i < m; i += kSortBlock) s_keys[i] = gk[i];
             __syncthreads();
-            const uint64_t *sorted = radix_sort_lds<kSortWaves, kRun>(s_keys, s_alt, s_hist, m, tid);
+            const uint64_t *sorted = radix_sort_lds_private<kRun>(s_keys, s_alt, s_scratch, m, tid);
             for (int i = tid; i < m; i += kSortBlock) gk[i] = sorted[i];
         }
     }
@@ -333,7 +336,7 @@ hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, S
         // the host may know the longest list (status[2]); only then can the long-list kernels be skipped
         if (!long_sort_skipped(st.max_list_hint)) {
             const long long hint = st.max_list_hint > 0 ? (long long)st.max_list_hint + st.max_list_hint / 2 : (long long)1 << 40;
-            const bool long_path = st.keys_alt && st.long_base && hint > kRun && st.capacity > kRun;
+            const bool long_path = st.keys_alt && st.long_base && hint > kSortLds && st.capacity > kSortLds;
             hipLaunchKernelGGL(tile_sort_block_kernel, dim3(T < 512 ? T : 512), dim3(kSortBlock), 0, s, st, long_path, T);
             if (long_path) {
                 // no list is longer than `bound`: the hint, the capacity, or -- bucketed lists -- the bucket
@@ -345,7 +348,7 @@ hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, S
                 hipLaunchKernelGGL(long_scan_kernel, dim3(1), dim3(1024), 0, s, st, T);
                 // (fixed grids: a workgroup that finds nothing to do still costs its launch -- 4096 of them with 69 KB of LDS, two per
                 //  CU at a time, cost more than the sort itself.  Two run-sort workgroups per CU, eight of the light kernels)
-                const long long run_wgs = (items + 3) / 4 < 512 ? (items + 3) / 4 : 512, item_wgs = items < 2048 ? items : 2048;
+                const long long run_wgs = (items + kRunItems - 1) / kRunItems < 512 ? (items + kRunItems - 1) / kRunItems : 512, item_wgs = items < 2048 ? items : 2048;
                 hipLaunchKernelGGL(long_run_sort_kernel, dim3((unsigned)run_wgs), dim3(kSortBlock), 0, s, st, T);
                 const int passes = long_passes(bound);
                 for (int p = 0; p < passes; ++p)
@@ -383,6 +386,15 @@ __global__ __launch_bounds__(64 * NW) void selftest_radix_lds_kernel(const uint6
     const uint64_t *sorted = radix_sort_lds<NW, MAXN>(s_keys, s_alt, s_hist, n, threadIdx.x);
     for (int i = threadIdx.x; i < n; i += 64 * NW) out[i] = sorted[i];
 }
+template <int MAXN>
+__global__ __launch_bounds__(1024) void selftest_radix_private_kernel(const uint64_t *in, uint64_t *out, int n) {
+    __shared__ __attribute__((aligned(16))) uint64_t s_keys[MAXN + 1024], s_alt[MAXN + 1024];
+    __shared__ __attribute__((aligned(8))) unsigned s_scratch[400];
+    for (int i = threadIdx.x; i < n; i += 1024) s_keys[i] = in[i];
+    __syncthreads();
+    const uint64_t *sorted = radix_sort_lds_private<MAXN>(s_keys, s_alt, s_scratch, n, threadIdx.x);
+    for (int i = threadIdx.x; i < n; i += 1024) out[i] = sorted[i];
+}
 __global__ __launch_bounds__(kBlock) void selftest_sort_global_kernel(uint64_t *keys, int n) {
     if (n > 1) bitonic_sort(keys, n, threadIdx.x, kBlock);
 }
@@ -397,6 +409,13 @@ hipError_t launch_selftest(int which, const void *in, void *out, int n, hipStrea
         hipError_t e = hipMemcpyAsync(out, in, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(selftest_sort_global_kernel, dim3(1), dim3(kBlock), 0, s, (uint64_t *)out, n);
+    } else if (which == 7 || which == 8) {              // radix_sort_lds_private: 7 = n <= 8192 (the run sort), 8 = n <= 4096 (the block sort)
+        if (n > (which == 7 ? kRun : kSortLds)) return hipErrorInvalidValue;
+        if (which == 7) hipLaunchKernelGGL(selftest_radix_private_kernel<kRun>, dim3(1), dim3(1024), 0, s, (const uint64_t *)in, (uint64_t *)out, n);
+        else hipLaunchKernelGGL(selftest_radix_private_kernel<kSortLds>, dim3(1), dim3(1024), 0, s, (const uint64_t *)in, (uint64_t *)out, n);
+    } else if (which == 6) {                            // radix_sort_lds as the run sort uses it: 1024 threads, n <= 8192
+        if (n > kRun) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((selftest_radix_lds_kernel<16, kRun>), dim3(1), dim3(1024), 0, s, (const uint64_t *)in, (uint64_t *)out, n);
     } else if (which >= 3 && which <= 5) {              // radix_sort_lds: 3 = 256 threads, 5 = 1024 threads (n <= 4096), 4 = one wave (n <= 1024)
         if (n > (which == 4 ? kSortWave : kSortLds)) return hipErrorInvalidValue;
         if (which == 3) hipLaunchKernelGGL((selftest_radix_lds_kernel<4, 4096>), dim3(1), dim3(256), 0, s, (const uint64_t *)in, (uint64_t *)out, n);

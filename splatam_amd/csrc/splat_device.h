@@ -356,6 +356,169 @@ __device__ __forceinline__ uint64_t *radix_sort_lds(uint64_t *buf_a, uint64_t *b
     return dst;
 }
 
+// wave64 inclusive prefix sum in 6 DPP adds (row_shr 1, 2, 4, 8 inside the 16-lane rows, then row_bcast:15 into rows 1 and 3 and
+// row_bcast:31 into rows 2 and 3 -- the sequence LLVM's atomic optimizer emits for gfx9)
+__device__ __forceinline__ unsigned wave_scan_incl_u32(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same sort with THREAD-PRIVATE ranking (the run sort of lists beyond LDS, the block sort): 1 024 threads, thread t owns the
+// KPT = MAXN / 1024 consecutive keys [KPT t, KPT t + KPT).  4-bit digits; a thread counts its keys per digit in two registers (16 x
+// 4-bit counters, which also give a key its rank among the thread's earlier keys of that digit), the counters are widened to eight
+// registers of two 16-bit fields and prefix-summed over the wave with DPP (48 adds for 16 digits x 64 lanes), wave totals are scanned in
+// (digit, wave) order by one wave, and a key's place is base(digit, wave) + the lanes below + its rank in the thread: no ballots, no
+// vector -> scalar -> vector round trips (the wave-ballot ranking above costs ~430 vector-pipe cycles per 64 keys and pass: its 8-bit
+// passes are fewer, but the run sort was bound by exactly that).  The lane prefixes live in eight registers and a key's digit picks one of
+// them at run time: they are parked in the destination buffer (own column [j][tid], read back by the same thread with a computed
+// address) until the scatter overwrites it.  Stable; nibbles that are the same in every key are skipped; ties of equal depth and the
+// all-bits second attempt as in radix_sort_lds.  buf_a / buf_b: MAXN + 1024 keys each (padded layout, below); scratch: 400 words; the
+// result is compact.  Every thread of the workgroup must call it.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MAXN>
+__device__ __forceinline__ uint64_t *radix_sort_lds_private(uint64_t *buf_a, uint64_t *buf_b, unsigned *scratch, const int n, const int tid) {
+    constexpr int NT = 1024, KPT = MAXN / NT, kTieRun = 32;
+    static_assert(MAXN % NT == 0 && KPT >= 1 && KPT <= 15, "a 4-bit counter holds a thread's keys of one digit");
+    static_assert((KPT & (KPT - 1)) == 0, "the padded index is i + i / KPT");
+    // A thread reads its KPT consecutive keys: lane stride 2 KPT words, i.e. the 64 lanes of a read would share 64 / (2 KPT) banks (the
+    // first version: half of the sort's LDS cycles were bank conflicts).  The keys of every pass but the first live PADDED, one empty slot
+    // after every KPT keys (lane stride 2 KPT + 2 words: all 64 banks); the buffers hold MAXN + NT keys.
+    auto phys = [](int i) { return i + i / KPT; };
+    static_assert(MAXN * 8 >= 8 * NT * 4, "the destination buffer parks eight prefix words per thread");
+    const int lane = tid & 63, wave = tid >> 6;
+    unsigned *wave_tot = scratch;               // [16 waves][8 registers of two 16-bit digit totals]
+    unsigned *gbase = scratch + 128;            // [16 waves][16 digits]: first output slot of (digit, wave)
+    unsigned *s_flag = scratch + 384;
+    uint64_t all_or = 0ull, all_and = ~0ull;
+    for (int i = tid; i < n; i += NT) {
+        const uint64_t k = buf_a[i];
+        all_or |= k;
+        all_and &= k;
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        all_or |= (uint64_t)__shfl_xor((long long)all_or, m, 64);
+        all_and &= (uint64_t)__shfl_xor((long long)all_and, m, 64);
+    }
+    uint64_t *xch = reinterpret_cast<uint64_t *>(scratch);
+    if (lane == 0) { xch[2 * wave] = all_or; xch[2 * wave + 1] = all_and; }
+    if (tid == 0) *s_flag = 0u;
+    __syncthreads();
+    uint64_t diff;
+    {
+        uint64_t o = 0ull, a = ~0ull;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { o |= xch[2 * w]; a &= xch[2 * w + 1]; }
+        diff = o ^ a;
+    }
+    __syncthreads();
+    uint64_t *src = buf_a, *dst = buf_b;
+    bool padded = false;                        // layout of src (the caller's keys are compact)
+    const int first = tid * KPT;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int nib = attempt == 0 ? 8 : 0; nib < 16; ++nib) {
+            if (((diff >> (4 * nib)) & 0xFull) == 0ull) continue;        // (uniform)
+            const int shift = 4 * nib;
+            uint64_t key[KPT];
+            unsigned dig[KPT], lrank[KPT];
+            unsigned c_lo = 0u, c_hi = 0u;              // 4-bit counters of digits 0..7 / 8..15
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) {
+                const bool valid = first + k < n;
+                key[k] = valid ? src[padded ? first + tid + k : first + k] : 0ull;        // phys(first + k) = first + tid + k
+                const unsigned d = (unsigned)(key[k] >> shift) & 15u, sh = (d & 7u) * 4u;
+                const bool hi = d >= 8u;
+                dig[k] = d;
+                lrank[k] = ((hi ? c_hi : c_lo) >> sh) & 15u;
+                const unsigned inc = valid ? (1u << sh) : 0u;
+                c_lo += hi ? 0u : inc;
+                c_hi += hi ? inc : 0u;
+            }
+            unsigned excl[8];
+            unsigned *park = reinterpret_cast<unsigned *>(dst);          // [8][NT]: this thread's lane prefixes
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned c = j < 4 ? c_lo : c_hi;
+                const unsigned e = ((c >> (8 * (j & 3))) & 15u) | (((c >> (8 * (j & 3) + 4)) & 15u) << 16);
+                const unsigned incl = wave_scan_incl_u32(e);             // (<= 64 * 15 per field: no carry into the upper field)
+                excl[j] = incl - e;
+                park[j * NT + tid] = excl[j];
+                if (lane == 63) wave_tot[wave * 8 + j] = incl;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                // 256 totals in (digit, wave) order, four per lane: lane l holds t = 4 l .. 4 l + 3, digit t >> 4, wave t & 15
+                unsigned v[4], sum = 0u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int t = 4 * lane + q, d = t >> 4, w = t & 15;
+                    const unsigned word = wave_tot[w * 8 + (d >> 1)];
+                    v[q] = (d & 1) ? word >> 16 : word & 0xFFFFu;
+                    sum += v[q];
+                }
+                unsigned run = wave_scan_incl_u32(sum) - sum;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int t = 4 * lane + q, d = t >> 4, w = t & 15;
+                    gbase[w * 16 + d] = run;
+                    run += v[q];
+                }
+            }
+            __syncthreads();
+            unsigned pos[KPT];
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) {
+                const unsigned d = dig[k];
+                const unsigned word = park[(d >> 1) * NT + tid];
+                pos[k] = gbase[wave * 16 + d] + ((d & 1u) ? word >> 16 : word & 0xFFFFu) + lrank[k];
+            }
+            __syncthreads();                            // every thread has read its parked prefixes: the scatter may overwrite them
+#pragma unroll
+            for (int k = 0; k < KPT; ++k)
+                if (first + k < n) dst[phys((int)pos[k])] = key[k];
+            __syncthreads();
+            uint64_t *t = src; src = dst; dst = t;
+            padded = true;
+        }
+        auto at = [&](int i) { return src[padded ? phys(i) : i]; };
+        if (attempt == 1) {                              // sorted on all 64 bits: compact it
+            for (int i = tid; i < n; i += NT) dst[i] = at(i);
+            __syncthreads();
+            return dst;
+        }
+        bool long_run = false;
+        for (int i = tid; i < n; i += NT)
+            if (i >= kTieRun && (unsigned)(at(i) >> 32) == (unsigned)(at(i - kTieRun) >> 32)) long_run = true;
+        if (long_run) *s_flag = 1u;
+        __syncthreads();
+        if (*s_flag == 0u) break;
+    }
+    auto at = [&](int i) { return src[padded ? phys(i) : i]; };
+    for (int i = tid; i < n; i += NT) {                 // ties of equal depth (runs of at most kTieRun) -> ascending id; compact output
+        const uint64_t key = at(i);
+        const unsigned depth = (unsigned)(key >> 32);
+        int pos = i;
+        for (int j = i - 1; j >= 0; --j) {
+            const uint64_t o = at(j);
+            if ((unsigned)(o >> 32) != depth) break;
+            if (o > key) --pos;
+        }
+        for (int j = i + 1; j < n; ++j) {
+            const uint64_t o = at(j);
+            if ((unsigned)(o >> 32) != depth) break;
+            if (o < key) ++pos;
+        }
+        dst[pos] = key;
+    }
+    __syncthreads();
+    return dst;
+}
+
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     for (int m = 32; m >= 1; m >>= 1) {
         const unsigned o = (unsigned)__shfl_xor((int)v, m, 64);

@@ -61,11 +61,15 @@ def _depth_id_keys(n, kind, seed):
 @pytest.mark.parametrize("kind", ["wide", "narrow", "short_ties", "plane", "constant"])
 @pytest.mark.parametrize("which,n", [(3, 1), (3, 2), (3, 63), (3, 64), (3, 65), (3, 257), (3, 1000), (3, 2500), (3, 4095), (3, 4096),
                                      (4, 1), (4, 5), (4, 64), (4, 65), (4, 200), (4, 777), (4, 1023), (4, 1024),
-                                     (5, 1), (5, 2), (5, 64), (5, 65), (5, 1000), (5, 1025), (5, 3000), (5, 4095), (5, 4096)])
+                                     (5, 1), (5, 2), (5, 64), (5, 65), (5, 1000), (5, 1025), (5, 3000), (5, 4095), (5, 4096),
+                                     (6, 3), (6, 4097), (6, 6000), (6, 8191), (6, 8192),
+                                     (7, 1), (7, 2), (7, 7), (7, 8), (7, 9), (7, 513), (7, 4097), (7, 6000), (7, 8191), (7, 8192),
+                                     (8, 1), (8, 3), (8, 4), (8, 5), (8, 255), (8, 1025), (8, 3000), (8, 4095), (8, 4096)])
 def test_lds_radix_sort_on_depth_key(which, n, kind):
     """radix_sort_lds (splat_device.h): the per-tile sort of the list kernels -- 8-bit passes over the depth bits with wave-ballot
     ranking, equal depths ordered by id: exactly numpy's sort of the 64-bit keys.  which: 3 = 4 waves, 5 = 16 waves (the list
-    kernels' workgroup), 4 = one wave (tile_sort_wave_kernel)."""
+    kernels' workgroup), 6 = 16 waves on up to 8 192 keys, 4 = one wave (tile_sort_wave_kernel); 7 / 8 = radix_sort_lds_private (thread-private
+    ranking, 4-bit digits) on up to 8 192 / 4 096 keys: the run sort and the block sort."""
     L = _lib()
     keys_np = _depth_id_keys(n, kind, seed=1000 * which + n)
     keys = torch.from_numpy(keys_np.view(np.int64)).cuda()
@@ -81,6 +85,8 @@ def test_lds_radix_sort_rejects_lists_beyond_lds():
     keys = torch.zeros(5000, dtype=torch.int64, device="cuda")
     assert L.splat_selftest(3, keys.data_ptr(), keys.data_ptr(), 4097, torch.cuda.current_stream().cuda_stream) != 0
     assert L.splat_selftest(4, keys.data_ptr(), keys.data_ptr(), 1025, torch.cuda.current_stream().cuda_stream) != 0
+    big = torch.zeros(9000, dtype=torch.int64, device="cuda")
+    assert L.splat_selftest(6, big.data_ptr(), big.data_ptr(), 8193, torch.cuda.current_stream().cuda_stream) != 0
 
 
 @pytest.mark.parametrize("n", [4097, 10000, 40000])
