@@ -85,18 +85,24 @@ static_assert(kGT == 2, "the group index is tile >> 1");
 
 // One Gaussian of F1: pose transform, activations, projection; writes its geometry, feature record and (mapping) seen radius.
 // Returns its visibility; `o` holds the tile rectangle (clipped to the launch's band of tile rows) and the depth.
-__device__ __forceinline__ bool preprocess_one(const FusedArgs &a, const CamConst &c, int i, Projected &o) {
+// In two halves -- everything it reads, then everything else -- so that a thread that takes several Gaussians
+// (fused_preprocess_dense_kernel) has all their loads in flight before the first one's stores.
+struct GaussianIn {
+    float rgb[3], seen_radius, p[3], u[4], logit, ls[3];
+};
+
+__device__ __forceinline__ void preprocess_load(const FusedArgs &a, int i, GaussianIn &g) {
+    // (colour and seen radius requested with the parameters, not behind the geometry stores: the kernel lasts one wave lifetime = its
+    //  chain of round trips)
+    g.rgb[0] = a.map.rgb_colors[3 * i]; g.rgb[1] = a.map.rgb_colors[3 * i + 1]; g.rgb[2] = a.map.rgb_colors[3 * i + 2];
+    g.seen_radius = a.ws.max_2D_radius ? a.ws.max_2D_radius[i] : 0.f;
+    load_gaussian(a.map, i, g.p, g.u, g.logit, g.ls);
+}
+
+__device__ __forceinline__ bool preprocess_finish(const FusedArgs &a, const CamConst &c, const Pose &P, int i, const GaussianIn &g, Projected &o) {
     const SplatState &st = a.ws.st;
-    Pose P;
-    load_pose(a.map, a.frame.time_idx, P);
-    // (requested with the parameters, not behind the stores below: the kernel lasts one wave lifetime = its chain of round trips;
-    //  ahead of load_gaussian)
-    const float rgb[3] = {a.map.rgb_colors[3 * i], a.map.rgb_colors[3 * i + 1], a.map.rgb_colors[3 * i + 2]};
-    const float seen_radius = a.ws.max_2D_radius ? a.ws.max_2D_radius[i] : 0.f;
-    float p[3], u[4], logit, ls[3];
-    load_gaussian(a.map, i, p, u, logit, ls);
     Glue G;
-    glue_forward(P, a.frame.w2c + 8, p, u, logit, ls, a.map.isotropic != 0, G);
+    glue_forward(P, a.frame.w2c + 8, g.p, g.u, g.logit, g.ls, a.map.isotropic != 0, G);
     float S6[6];
     cov3d_from_scale_rot(G.s, c.scale_modifier, G.rq, S6);
     const bool vis = project_gaussian(c, G.Xc, S6, o);
@@ -110,10 +116,18 @@ __device__ __forceinline__ bool preprocess_one(const FusedArgs &a, const CamCons
     reinterpret_cast<uint2 *>(st.rect)[i] = make_uint2((unsigned)o.x0 | ((unsigned)o.y0 << 16), (unsigned)o.x1 | ((unsigned)o.y1 << 16));
     st.radii[i] = o.radius;
     float4 *f = reinterpret_cast<float4 *>(a.ws.feat8) + 2 * (size_t)i;
-    f[0] = make_float4(rgb[0], rgb[1], rgb[2], G.z);
+    f[0] = make_float4(g.rgb[0], g.rgb[1], g.rgb[2], G.z);
     f[1] = make_float4(1.0f, G.z * G.z, 0.f, 0.f);
-    if (vis && a.ws.max_2D_radius && (float)o.radius > seen_radius) a.ws.max_2D_radius[i] = (float)o.radius;
+    if (vis && a.ws.max_2D_radius && (float)o.radius > g.seen_radius) a.ws.max_2D_radius[i] = (float)o.radius;
     return vis;
+}
+
+__device__ __forceinline__ bool preprocess_one(const FusedArgs &a, const CamConst &c, int i, Projected &o) {
+    Pose P;
+    load_pose(a.map, a.frame.time_idx, P);
+    GaussianIn g;
+    preprocess_load(a, i, g);
+    return preprocess_finish(a, c, P, i, g, o);
 }
 
 template <int MODE, int BLOCK>
@@ -280,13 +294,21 @@ __global__ __launch_bounds__(kDenseBlock) void fused_preprocess_dense_kernel(Fus
     __syncthreads();
     const SplatState &st = a.ws.st;
     unsigned r0[kDensePerThread], r1[kDensePerThread], dbits[kDensePerThread];
+    Pose P;
+    load_pose(a.map, a.frame.time_idx, P);
+    GaussianIn in[kDensePerThread];
+#pragma unroll
+    for (int g = 0; g < kDensePerThread; ++g) {         // every Gaussian's loads in flight before the first one's stores
+        const int i = (blockIdx.x * kDensePerThread + g) * kDenseBlock + tid;
+        preprocess_load(a, min(i, a.map.P - 1), in[g]);
+    }
 #pragma unroll
     for (int g = 0; g < kDensePerThread; ++g) {
         const int i = (blockIdx.x * kDensePerThread + g) * kDenseBlock + tid;
         r0[g] = r1[g] = dbits[g] = 0u;
         if (i < a.map.P) {
             Projected o{};
-            const bool vis = preprocess_one(a, c, i, o);
+            const bool vis = preprocess_finish(a, c, P, i, in[g], o);
             if (vis && o.y1 > o.y0 && o.x1 > o.x0) {
                 r0[g] = (unsigned)o.x0 | ((unsigned)o.y0 << 16);
                 r1[g] = (unsigned)o.x1 | ((unsigned)o.y1 << 16);
@@ -497,12 +519,46 @@ __global__ __launch_bounds__(kBlock) void ssim_forward_kernel(FusedArgs a, int W
     const int x0 = bx * kTW, y0 = by * kTH;
     const size_t HW = (size_t)H * W;
     const float *X = a.ws.out6 + ch * HW, *Y = a.frame.im + ch * HW;
-    for (int k = tid; k < kHH_ * kHW_; k += kBlock) {
-        const int r = k / kHW_, c = k - r * kHW_;
-        const int yy = y0 + r - kSsimR, xx = x0 + c - kSsimR;
-        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-        sx[r][c] = in ? X[(size_t)yy * W + xx] : 0.f;
-        sy[r][c] = in ? Y[(size_t)yy * W + xx] : 0.f;
+    // (the z == 0 slice's depth-loss inputs: requested here with the halo, not one round trip per output row at the very end)
+    float pre[kRPT][4];
+#pragma unroll
+    for (int j = 0; j < kRPT; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pre[j][q] = 0.f;
+    if (ch == 0) {
+        const int c = tid & (kTW - 1), r0 = (tid / kTW) * kRPT;
+#pragma unroll
+        for (int j = 0; j < kRPT; ++j) {
+            const size_t pix = (size_t)min(y0 + r0 + j, H - 1) * W + min(x0 + c, W - 1);
+            const float *o = a.ws.out6;
+            pre[j][0] = o[3 * HW + pix]; pre[j][1] = o[4 * HW + pix]; pre[j][2] = o[5 * HW + pix]; pre[j][3] = a.frame.depth[pix];
+        }
+    }
+    // The halo: every load of the workgroup's window in flight at once (clamped address + select; round 2's loop took its five trips
+    // one after the other, and the y load of a trip behind the x load: ten dependent round trips at the head of every workgroup)
+    {
+        constexpr int kTrips = (kHH_ * kHW_ + kBlock - 1) / kBlock;
+        float vx[kTrips], vy[kTrips];
+#pragma unroll
+        for (int q = 0; q < kTrips; ++q) {
+            const int k = min(tid + q * kBlock, kHH_ * kHW_ - 1);
+            const int r = k / kHW_, c = k - r * kHW_;
+            const int yy = y0 + r - kSsimR, xx = x0 + c - kSsimR;
+            const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const size_t pix = (size_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1);
+            const float tx = X[pix], ty = Y[pix];
+            vx[q] = in ? tx : 0.f;
+            vy[q] = in ? ty : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < kTrips; ++q) {
+            const int k = tid + q * kBlock;
+            if (k < kHH_ * kHW_) {
+                const int r = k / kHW_, c = k - r * kHW_;
+                sx[r][c] = vx[q];
+                sy[r][c] = vy[q];
+            }
+        }
     }
     __syncthreads();
     // horizontal pass: one work item per (halo row, group of 4 columns): 14 + 14 LDS reads feed 4 outputs x 5 statistics
@@ -568,8 +624,7 @@ __global__ __launch_bounds__(kBlock) void ssim_forward_kernel(FusedArgs a, int W
                 M[pix] = dmu1; M[HW + pix] = de11; M[2 * HW + pix] = de12;
                 acc[1] += fabsf(sx[r + kSsimR][c + kSsimR] - sy[r + kSsimR][c + kSsimR]);
                 if (ch == 0) {
-                    const float *o = a.ws.out6;
-                    const Pixel px = depth_pixel(a.cfg, o[3 * HW + pix], o[4 * HW + pix], o[5 * HW + pix], a.frame.depth[pix], median);
+                    const Pixel px = depth_pixel(a.cfg, pre[j][0], pre[j][1], pre[j][2], pre[j][3], median);
                     acc[0] += px.d_err;
                     acc[2] += px.mask ? 1.f : 0.f;
                 }
@@ -600,13 +655,48 @@ __global__ __launch_bounds__(kBlock) void map_loss_backward_kernel(FusedArgs a, 
         const double c = sum_total(a.ws.sums, 2);
         if (tid == 0) s_count = (float)c;
     }
-    for (int k = tid; k < kHH_ * kHW_; k += kBlock) {
-        const int r = k / kHW_, c = k - r * kHW_;
-        const int yy = y0 + r - kSsimR, xx = x0 + c - kSsimR;
-        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const size_t pix = (size_t)yy * W + xx;
-        smA[r][c] = in ? (f2){M[pix], M[HW + pix]} : (f2)(0.f);
-        smC[r][c] = in ? M[2 * HW + pix] : 0.f;
+    // (the output pixels' own inputs -- x, y and, in the z == 0 slice, the depth-loss inputs -- requested here with the window)
+    float px_x[kRPT], px_y[kRPT], pre[kRPT][4];
+    {
+        const int c = tid & (kTW - 1), r0 = (tid / kTW) * kRPT;
+        const float *Xp = a.ws.out6 + ch * HW, *Yp = a.frame.im + ch * HW;
+#pragma unroll
+        for (int j = 0; j < kRPT; ++j) {
+            const size_t pix = (size_t)min(y0 + r0 + j, H - 1) * W + min(x0 + c, W - 1);
+            px_x[j] = Xp[pix];
+            px_y[j] = Yp[pix];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pre[j][q] = 0.f;
+            if (ch == 0) {
+                const float *o = a.ws.out6;
+                pre[j][0] = o[3 * HW + pix]; pre[j][1] = o[4 * HW + pix]; pre[j][2] = o[5 * HW + pix]; pre[j][3] = a.frame.depth[pix];
+            }
+        }
+    }
+    {   // (every load of the window in flight at once: see ssim_forward_kernel)
+        constexpr int kTrips = (kHH_ * kHW_ + kBlock - 1) / kBlock;
+        float v0[kTrips], v1[kTrips], v2[kTrips];
+#pragma unroll
+        for (int q = 0; q < kTrips; ++q) {
+            const int k = min(tid + q * kBlock, kHH_ * kHW_ - 1);
+            const int r = k / kHW_, c = k - r * kHW_;
+            const int yy = y0 + r - kSsimR, xx = x0 + c - kSsimR;
+            const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const size_t pix = (size_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1);
+            const float t0 = M[pix], t1 = M[HW + pix], t2 = M[2 * HW + pix];
+            v0[q] = in ? t0 : 0.f;
+            v1[q] = in ? t1 : 0.f;
+            v2[q] = in ? t2 : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < kTrips; ++q) {
+            const int k = tid + q * kBlock;
+            if (k < kHH_ * kHW_) {
+                const int r = k / kHW_, c = k - r * kHW_;
+                smA[r][c] = (f2){v0[q], v1[q]};
+                smC[r][c] = v2[q];
+            }
+        }
     }
     __syncthreads();
     for (int item = tid; item < kHItems; item += kBlock) {       // horizontal pass: (halo row, group of 4 columns)
@@ -635,7 +725,6 @@ __global__ __launch_bounds__(kBlock) void map_loss_backward_kernel(FusedArgs a, 
     const float inv_n = 1.0f / (3.0f * (float)HW);
     const float median = a.cfg.ignore_outlier_depth_loss ? a.ws.d_cam[13] : 0.f;
     const float count = s_count;            // written before the first __syncthreads above
-    const float *X = a.ws.out6 + ch * HW, *Y = a.frame.im + ch * HW;
     float *Gout = a.ws.dL_dout6;
     {                                        // vertical pass: (column, group of kRPT rows) per thread
         const int c = tid & (kTW - 1), r0 = (tid / kTW) * kRPT;
@@ -661,12 +750,11 @@ __global__ __launch_bounds__(kBlock) void map_loss_backward_kernel(FusedArgs a, 
             const int yy = y0 + r0 + j, xx = x0 + c;
             if (yy < H && xx < W) {
                 const size_t pix = (size_t)yy * W + xx;
-                const float xv = X[pix], yv = Y[pix];
+                const float xv = px_x[j], yv = px_y[j];
                 const float dssim = vA[j].x + 2.f * xv * vA[j].y + yv * vC[j];
                 Gout[ch * HW + pix] = a.cfg.w_im * (0.8f * sgn(xv - yv) * inv_n - 0.2f * inv_n * dssim);
                 if (ch == 0) {
-                    const float *o = a.ws.out6;
-                    const Pixel px = depth_pixel(a.cfg, o[3 * HW + pix], o[4 * HW + pix], o[5 * HW + pix], a.frame.depth[pix], median);
+                    const Pixel px = depth_pixel(a.cfg, pre[j][0], pre[j][1], pre[j][2], pre[j][3], median);
                     Gout[3 * HW + pix] = a.cfg.use_l1 ? a.cfg.w_depth * px.d_sign / count : 0.f;
                 }
             }
@@ -681,25 +769,48 @@ struct PoseAdam {
     float beta1, beta2, eps, bc2_sqrt, ss_rot, ss_trans;
 };
 
-__device__ __forceinline__ void pose_adam_step(const SplatMap &map, int time_idx, const float *g, float loss, const PoseAdam &pa) {
-    float *state = pa.state;
-    float q[4], t[3];
-    for (int k = 0; k < 4; ++k) {
-        float *p = map.cam_unnorm_rots + k * map.num_frames + time_idx;
-        q[k] = adam_update(*p, g[k], state[k], state[7 + k], pa.beta1, pa.beta2, pa.ss_rot, pa.bc2_sqrt, pa.eps);
-        *p = q[k];
+// The pose's Adam step + the reference's best-candidate bookkeeping, by ONE thread: every load first (pose_adam_load: 22 values in
+// flight; F7 issues them at the top of the kernel, ahead of its first store), then the arithmetic, then the stores -- parameter by
+// parameter it was a chain of fourteen dependent round trips.
+struct PoseAdamRegs {
+    float *pp[7];
+    float par[7], m[7], v[7], best;
+};
+
+__device__ __forceinline__ void pose_adam_load(const SplatMap &map, int time_idx, const PoseAdam &pa, PoseAdamRegs &r) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        r.pp[k] = k < 4 ? map.cam_unnorm_rots + k * map.num_frames + time_idx : map.cam_trans + (k - 4) * map.num_frames + time_idx;
+        r.par[k] = *r.pp[k];
+        r.m[k] = pa.state[k];
+        r.v[k] = pa.state[7 + k];
     }
-    for (int k = 0; k < 3; ++k) {
-        float *p = map.cam_trans + k * map.num_frames + time_idx;
-        t[k] = adam_update(*p, g[4 + k], state[4 + k], state[11 + k], pa.beta1, pa.beta2, pa.ss_trans, pa.bc2_sqrt, pa.eps);
-        *p = t[k];
+    r.best = pa.state[14];
+}
+
+__device__ __forceinline__ void pose_adam_apply(PoseAdamRegs &r, const float *g, float loss, const PoseAdam &pa) {
+    float *state = pa.state;
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+        r.par[k] = adam_update(r.par[k], g[k], r.m[k], r.v[k], pa.beta1, pa.beta2, k < 4 ? pa.ss_rot : pa.ss_trans, pa.bc2_sqrt, pa.eps);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        *r.pp[k] = r.par[k];
+        state[k] = r.m[k];
+        state[7 + k] = r.v[k];
     }
     // the reference compares the loss of THIS iteration and stores the parameters AFTER the step
-    if (loss < state[14]) {
+    if (loss < r.best) {
         state[14] = loss;
-        for (int k = 0; k < 4; ++k) state[15 + k] = q[k];
-        for (int k = 0; k < 3; ++k) state[19 + k] = t[k];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) state[15 + k] = r.par[k];
     }
+}
+
+__device__ __forceinline__ void pose_adam_step(const SplatMap &map, int time_idx, const float *g, float loss, const PoseAdam &pa) {
+    PoseAdamRegs r;
+    pose_adam_load(map, time_idx, pa, r);
+    pose_adam_apply(r, g, loss, pa);
 }
 
 // F7: one thread: pose partial sums -> gradients of the raw camera parameters; loss value (+ the pose's Adam step when the
@@ -708,12 +819,24 @@ __global__ __launch_bounds__(256) void pose_finish_kernel(FusedArgs a, int HW, P
     static_assert(SPLAT_ITER_SUMS * 8 == 256 && SPLAT_ITER_SUM_COPIES == 64, "thread t: sum k = t / 8, copies (t % 8) * 8 .. + 7");
     __shared__ double S[SPLAT_ITER_SUMS];
     const int t = threadIdx.x, k = t >> 3, part = t & 7;
+    // what the closing thread needs -- the pose, the Adam state, the capacity flags -- is requested here, ahead of the first store
+    Pose P{};
+    PoseAdamRegs adam{};
+    int flagged = 0;
+    if (t == 0) {
+        if (a.cfg.camera_grad) load_pose(a.map, a.frame.time_idx, P);
+        if (pa.state) pose_adam_load(a.map, a.frame.time_idx, pa, adam);
+        flagged = a.ws.st.status[1] | a.ws.st.status[3];
+    }
+    // (all eight loads first, then the resets: a store between two loads makes the second wait for the first)
+    double part_sum[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) part_sum[c] = a.ws.sums[(size_t)(part * 8 + c) * SPLAT_ITER_SUMS + k];
     double v = 0.0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        double *p = a.ws.sums + (size_t)(part * 8 + c) * SPLAT_ITER_SUMS + k;
-        v += *p;
-        *p = 0.0;                       // reset for the next iteration (no memset launch)
+        v += part_sum[c];
+        a.ws.sums[(size_t)(part * 8 + c) * SPLAT_ITER_SUMS + k] = 0.0;      // reset for the next iteration (no memset launch)
     }
     v += __shfl_xor(v, 1, 64);
     v += __shfl_xor(v, 2, 64);
@@ -724,8 +847,6 @@ __global__ __launch_bounds__(256) void pose_finish_kernel(FusedArgs a, int HW, P
     float *out = a.ws.d_cam;
     float dq[4] = {0.f, 0.f, 0.f, 0.f}, dt[3] = {0.f, 0.f, 0.f};
     if (a.cfg.camera_grad) {
-        Pose P;
-        load_pose(a.map, a.frame.time_idx, P);
         float sums[kPoseSums];
         for (int k = 0; k < kPoseSums; ++k) sums[k] = (float)S[8 + k];
         pose_backward(P, sums, dq, dt);
@@ -743,12 +864,12 @@ __global__ __launch_bounds__(256) void pose_finish_kernel(FusedArgs a, int HW, P
     }
     out[7] = loss;
     for (int k = 0; k < 4; ++k) out[8 + k] = (float)S[k];       // raw sums, for inspection
-    if (a.ws.st.status[1] != 0 || a.ws.st.status[3] != 0) out[12] = 1.0f;     // sticky until the host clears it
+    if (flagged != 0) out[12] = 1.0f;     // sticky until the host clears it
     if (pa.state) {
         float g[7];
         for (int k = 0; k < 4; ++k) g[k] = dq[k];
         for (int k = 0; k < 3; ++k) g[4 + k] = dt[k];
-        pose_adam_step(a.map, a.frame.time_idx, g, loss, pa);
+        pose_adam_apply(adam, g, loss, pa);
     }
 }
 

@@ -599,7 +599,10 @@ __global__ __launch_bounds__(256, 5) void render_forward_kernel(SplatCamera cam,
         if constexpr (WITH_DEPTH) out_depth[pix] = D;
         if constexpr (TRACK) {
             // channels: r, g, b, depth, silhouette, depth^2; mask = (gt > 0) & ~isnan(depth) & ~isnan(uncertainty) [& sil > thres]
+            // (the four inputs of the loss requested together, ahead of the gradient stores: the compiler cannot move a load over a store
+            //  it cannot prove disjoint, and the epilogue is a tail nothing hides)
             const float gt = ep.depth[pix];
+            const float im3[3] = {ep.im[pix], ep.im[HW + pix], ep.im[2 * HW + pix]};
             const float unc = o[5] - o[3] * o[3];
             bool m = gt > 0.f && !(o[3] != o[3]) && !(unc != unc);
             if (ep.use_sil_for_loss) m = m && (o[4] > ep.sil_thres);
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(256, 5) void render_forward_kernel(SplatCamera cam,
             const bool cm = ep.use_sil_for_loss ? m : true;
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                const float di = ep.im[ch * HW + pix] - o[ch];
+                const float di = im3[ch] - o[ch];
                 acc_im += cm ? fabsf(di) : 0.f;
                 ep.dL_dout6[ch * HW + pix] = cm ? -ep.w_im * ((di > 0.f) ? 1.f : ((di < 0.f) ? -1.f : 0.f)) : 0.f;
             }
