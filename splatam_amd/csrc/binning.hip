@@ -4,7 +4,9 @@
 // (tile | depth) keys (5-6 passes over R instances in HBM).  Here every
 // instance is scattered ONCE into its tile's bucket (bucket offsets come from
 // the tile scan), and each bucket is then sorted on its own inside LDS by one
-// workgroup: one read + one write of the instance stream in HBM in total.
+// workgroup -- an LDS radix sort on the depth key (radix_sort_lds / radix_sort_lds_private,
+// splat_device.h) -- : one read + one write of the instance stream in HBM in total
+// (lists beyond 4096 keys: 8192-key runs + merge-path passes, below).
 // Keys are (float bits of depth << 32) | Gaussian id -- unique, so the order
 // is exactly "ascending depth, ties by ascending index" (the order a stable
 // sort of index-ordered emission produces), independent of scatter order.
@@ -49,9 +51,10 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(SplatGaussians g, Splat
 
 // K4(+K5).  tile_base already holds the ranges.  Two kernels:
 //  * short lists (n <= kSortWave, the normal case: ~200 entries at config B): ONE wave per tile,
-//    8 KiB of LDS, the network's barriers degenerate to wave-local waits; every tile of the frame is
-//    resident at once;
-//  * long lists: one 256-thread workgroup per tile, 32 KiB of LDS, or in place in HBM beyond that.
+//    17 KiB of LDS, barriers degenerate to wave-local waits (bitonic network up to 256 keys, radix
+//    sort above);
+//  * long lists (up to kSortLds): one 1024-thread workgroup per list (a fixed grid walks the tiles), 82 KiB
+//    of LDS; beyond that the multi-workgroup kernels further down, or in place in HBM without their scratch.
 constexpr int kSortWave = 1024;
 
 // The host may know the longest list (status[2] of an earlier iteration).  The long-list kernel is skipped only when that
