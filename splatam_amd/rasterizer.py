@@ -195,6 +195,7 @@ def _alloc_state(pk: _Pack, dev, P: int, H: int, W: int, use_sh: bool):
 
 
 LONG_LIST = 4096        # per-tile lists beyond this are sorted by the multi-workgroup kernels, which need a second key buffer
+LONG_ITEM_TABLE = True   # SplatState.long_items (work-item table of those kernels); False: they binary-search long_base (tests)
 
 
 def _alloc_lists(pk: _Pack, dev, capacity: int, longest=None):
@@ -206,9 +207,12 @@ def _alloc_lists(pk: _Pack, dev, capacity: int, longest=None):
     pk.tensors.update(keys=keys, point_list=plist)
     if longest is None or longest > LONG_LIST:
         alt = torch.empty(capacity, dtype=torch.int64, device=dev)
-        items = torch.empty(capacity // 1024 + pk.num_tiles + 1, dtype=torch.int32, device=dev)      # SplatState.long_items
-        pk.st.keys_alt, pk.st.long_items = alt.data_ptr(), items.data_ptr()
-        pk.tensors.update(keys_alt=alt, long_items=items)
+        pk.st.keys_alt = alt.data_ptr()
+        pk.tensors.update(keys_alt=alt)
+        if LONG_ITEM_TABLE:
+            items = torch.empty(capacity // 1024 + pk.num_tiles + 1, dtype=torch.int32, device=dev)      # SplatState.long_items
+            pk.st.long_items = items.data_ptr()
+            pk.tensors.update(long_items=items)
 
 
 def _stream(dev) -> int:

@@ -101,13 +101,15 @@ def test_global_bitonic_sort(n):
     assert torch.equal(out.cpu(), torch.sort(keys.cpu())[0])
 
 
-@pytest.mark.parametrize("n", [70_000, 250_000, 600_000])
-def test_lists_beyond_lds_multi_workgroup_sort(n):
-    """Per-tile lists of ~7 k / ~25 k / ~60 k entries (1, 3 and 4 merge passes of the multi-workgroup sort, binning.hip L1-L4):
-    tile ranges and sorted ids must be the C oracle's, bit for bit; the render still matches."""
+@pytest.mark.parametrize("n,item_table", [(70_000, True), (250_000, True), (600_000, True), (250_000, False)])
+def test_lists_beyond_lds_multi_workgroup_sort(n, item_table, monkeypatch):
+    """Per-tile lists of ~7 k / ~25 k / ~60 k entries (0, 2 and 3 merge passes of the multi-workgroup sort on 8 192-key runs,
+    binning.hip L1-L4): tile ranges and sorted ids must be the C oracle's, bit for bit; the render still matches.  item_table = False:
+    a caller that does not pass SplatState.long_items (ABI <= 6 layouts): the kernels find an item's tile by binary search."""
     import numpy as np
     from oracle import c_ref
     from splatam_amd import rasterizer as rz
+    monkeypatch.setattr(rz, "LONG_ITEM_TABLE", item_table)
     from tests.util import scene
     from diff_gaussian_rasterization import GaussianRasterizationSettings as Camera
     W, H = 96, 64
@@ -130,6 +132,7 @@ def test_lists_beyond_lds_multi_workgroup_sort(n):
     base = cr.ranges()
     longest = int(np.diff(base).max())
     assert longest > 4096 and 'keys_alt' in pk.tensors, longest
+    assert ('long_items' in pk.tensors) == item_table
     assert pk.num_rendered == cr.num_rendered()
     assert (pk.tensors['tile_base'].cpu().numpy() == base).all()
     got, ref = pk.tensors['point_list'].cpu().numpy()[:pk.num_rendered], cr.point_list()
