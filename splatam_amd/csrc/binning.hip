@@ -49,6 +49,49 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(SplatGaussians g, Splat
     }
 }
 
+// K3 for exact lists known to be very long (dense_exact_lists, splat_device.h; the partner of preprocess_forward_dense_kernel: same
+// partition, same sub-bin): the workgroup counts its instances per tile in LDS, reserves each non-empty tile's slots with ONE returning
+// atomic on the cursor of (tile, its sub-bin) and hands them out through the same table (5 M clustered Gaussians: 860 us with one
+// returning atomic per instance).
+__global__ __launch_bounds__(kDenseThreads) void scatter_dense_kernel(SplatGaussians g, SplatState st, int gx, int T) {
+    extern __shared__ unsigned s_tile[];
+    if ((long long)st.status[0] > st.capacity) return;      // lists would not fit: host re-sizes and retries
+    const int tid = threadIdx.x;
+    for (int t = tid; t < T; t += kDenseThreads) s_tile[t] = 0u;
+    __syncthreads();
+    constexpr int K = kDenseGaussians / kDenseThreads;
+    unsigned r0[K], r1[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int i = blockIdx.x * kDenseGaussians + k * kDenseThreads + tid;
+        r0[k] = r1[k] = 0u;
+        if (i < g.P && st.radii[i] > 0) {
+            const uint2 r = reinterpret_cast<const uint2 *>(st.rect)[i];
+            r0[k] = r.x;
+            r1[k] = r.y;
+            const int x0 = r.x & 0xffff, y0 = r.x >> 16, x1 = r.y & 0xffff, y1 = r.y >> 16;
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) atomicAdd(&s_tile[y * gx + x], 1u);
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += kDenseThreads) {
+        const unsigned cnt = s_tile[t];
+        if (cnt) s_tile[t] = atomicAdd(&st.tile_cursor[sub_counter(st, t, (int)blockIdx.x)], cnt);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int i = blockIdx.x * kDenseGaussians + k * kDenseThreads + tid;
+        const int x0 = r0[k] & 0xffff, y0 = r0[k] >> 16, x1 = r1[k] & 0xffff, y1 = r1[k] >> 16;
+        if (y1 > y0 && x1 > x0) {
+            const uint64_t key = ((uint64_t)__float_as_uint(st.depth[i]) << 32) | (uint32_t)i;
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) st.keys[atomicAdd(&s_tile[y * gx + x], 1u)] = key;
+        }
+    }
+}
+
 // K4(+K5).  tile_base already holds the ranges.  Two kernels:
 //  * short lists (n <= kSortWave, the normal case: ~200 entries at config B): ONE wave per tile,
 //    17 KiB of LDS, barriers degenerate to wave-local waits (bitonic network up to 256 keys, radix
@@ -329,11 +372,17 @@ __global__ __launch_bounds__(kBlock) void long_publish_kernel(SplatState st, int
     }
 }
 
-hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s, bool sort) {
+hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s, bool sort, bool counted_per_workgroup) {
     const int gx = (cam.image_width + kTile - 1) / kTile;
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
     // bucketed lists were filled by the per-Gaussian kernel: only the per-tile sort remains
-    if (g.P > 0 && st.tile_stride == 0) hipLaunchKernelGGL(scatter_kernel, dim3((g.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, g, st, gx);
+    if (g.P > 0 && st.tile_stride == 0) {
+        if (counted_per_workgroup && dense_exact_lists(st, g.P, T))
+            hipLaunchKernelGGL(scatter_dense_kernel, dim3((g.P + kDenseGaussians - 1) / kDenseGaussians), dim3(kDenseThreads),
+                               sizeof(unsigned) * (size_t)T, s, g, st, gx, T);
+        else
+            hipLaunchKernelGGL(scatter_kernel, dim3((g.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, g, st, gx);
+    }
     if (T > 0 && sort) {
         hipLaunchKernelGGL(tile_sort_wave_kernel, dim3(T), dim3(64), 0, s, st);
         // the host may know the longest list (status[2]); only then can the long-list kernels be skipped

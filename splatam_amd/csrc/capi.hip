@@ -72,7 +72,8 @@ int splat_preprocess_forward(const SplatCamera *cam, const SplatGaussians *g, Sp
 
 int splat_bin_forward(const SplatCamera *cam, const SplatGaussians *g, SplatState *st, void *stream) {
     if (!valid_inputs(cam, g) || !valid_state(g, st, true)) return SPLAT_E_INVALID;
-    return check(launch_bin_forward(*cam, *g, *st, (hipStream_t)stream));
+    // (splat_preprocess_forward of the same state counted per workgroup under the same predicate)
+    return check(launch_bin_forward(*cam, *g, *st, (hipStream_t)stream, true, true));
 }
 
 int splat_render_forward(const SplatCamera *cam, const SplatGaussians *g, SplatState *st, float *out_color,

@@ -10,12 +10,9 @@ namespace splat {
 constexpr int kBlock = 256;
 int g_debug_skip_count = 0;     // splat_debug_option(0, v): timing experiment only
 
-// K1: Appendix A steps 1-9 + one atomicAdd per touched tile.
-__global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(SplatCamera cam, SplatGaussians g, SplatState st, int skip_count) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= g.P) return;
-    CamConst c;
-    load_cam(c, cam);
+// K1: Appendix A steps 1-9 for Gaussian i (geometry, SH colour); returns its visibility, `o` holds the tile rectangle.
+__device__ __forceinline__ bool preprocess_forward_one(const SplatCamera &cam, const CamConst &c, const SplatGaussians &g, const SplatState &st, int i,
+                                                       Projected &o) {
     const float p[3] = {g.means3D[3 * i], g.means3D[3 * i + 1], g.means3D[3 * i + 2]};
     float S6[6];
     if (g.cov3D_precomp) {
@@ -25,7 +22,6 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(SplatCamera 
         const float q[4] = {g.rotations[4 * i], g.rotations[4 * i + 1], g.rotations[4 * i + 2], g.rotations[4 * i + 3]};
         cov3d_from_scale_rot(s, c.scale_modifier, q, S6);
     }
-    Projected o;
     const bool vis = project_gaussian(c, p, S6, o);
     st.depth[i] = o.depth;
     reinterpret_cast<float2 *>(st.xy)[i] = make_float2(o.px, o.py);
@@ -49,9 +45,47 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(SplatCamera 
             st.rgb[3 * i + ch] = fmaxf(v, 0.f);
         }
     }
+    return vis;
+}
+
+// K1 + one atomicAdd per touched tile.
+__global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(SplatCamera cam, SplatGaussians g, SplatState st, int skip_count) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= g.P) return;
+    CamConst c;
+    load_cam(c, cam);
+    Projected o;
+    const bool vis = preprocess_forward_one(cam, c, g, st, i, o);
     if (vis && !skip_count) {
         for (int y = o.y0; y < o.y1; ++y)
             for (int x = o.x0; x < o.x1; ++x) atomicAdd(&st.tile_count[sub_counter(st, y * c.gx + x, i)], 1u);
+    }
+}
+
+// K1 for exact lists known to be very long (dense_exact_lists, splat_device.h): the workgroup's instances are counted per tile in LDS and
+// added to the tiles' counters (sub-bin: the workgroup's) with one atomic per non-empty tile -- 5 M clustered Gaussians on ~400 tiles took
+// 497 us of same-address atomics with one per instance.
+__global__ __launch_bounds__(kDenseThreads) void preprocess_forward_dense_kernel(SplatCamera cam, SplatGaussians g, SplatState st) {
+    extern __shared__ unsigned s_tile[];
+    const int tid = threadIdx.x;
+    CamConst c;
+    load_cam(c, cam);
+    const int T = c.gx * c.gy;
+    for (int t = tid; t < T; t += kDenseThreads) s_tile[t] = 0u;
+    __syncthreads();
+    for (int k = 0; k < kDenseGaussians / kDenseThreads; ++k) {
+        const int i = blockIdx.x * kDenseGaussians + k * kDenseThreads + tid;
+        if (i < g.P) {
+            Projected o;
+            if (preprocess_forward_one(cam, c, g, st, i, o))
+                for (int y = o.y0; y < o.y1; ++y)
+                    for (int x = o.x0; x < o.x1; ++x) atomicAdd(&s_tile[y * c.gx + x], 1u);
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += kDenseThreads) {
+        const unsigned cnt = s_tile[t];
+        if (cnt) atomicAdd(&st.tile_count[sub_counter(st, t, (int)blockIdx.x)], cnt);
     }
 }
 
@@ -271,8 +305,13 @@ hipError_t launch_preprocess_forward(const SplatCamera &cam, const SplatGaussian
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
     hipError_t e = launch_tile_count_reset(st, T, s);
     if (e != hipSuccess) return e;
-    if (g.P > 0)
-        hipLaunchKernelGGL(preprocess_forward_kernel, dim3((g.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, cam, g, st, g_debug_skip_count);
+    if (g.P > 0) {
+        if (dense_exact_lists(st, g.P, T))
+            hipLaunchKernelGGL(preprocess_forward_dense_kernel, dim3((g.P + kDenseGaussians - 1) / kDenseGaussians), dim3(kDenseThreads),
+                               sizeof(unsigned) * (size_t)T, s, cam, g, st);
+        else
+            hipLaunchKernelGGL(preprocess_forward_kernel, dim3((g.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, cam, g, st, g_debug_skip_count);
+    }
     return launch_tile_scan(st, T, s);
 }
 

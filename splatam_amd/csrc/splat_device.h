@@ -18,7 +18,19 @@ constexpr int kWave = 64;
 hipError_t launch_preprocess_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s);
 hipError_t launch_tile_count_reset(SplatState &st, int T, hipStream_t s);
 hipError_t launch_tile_scan(SplatState &st, int T, hipStream_t s);
-hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s, bool sort = true);
+// counted_per_workgroup: the instance counts came from preprocess_forward_dense_kernel (launch_preprocess_forward under dense_exact_lists):
+// the scatter must use the same (workgroup, sub-bin) partition.  The fused iteration counts per Gaussian in F1: false.
+hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s, bool sort = true,
+                              bool counted_per_workgroup = false);
+
+// Exact lists known to be very long (SplatState.sub_bins > 1: the host has seen lists beyond 2048 entries -- BASELINE config E clustered):
+// K1's count and K3's scatter take one atomic per (WORKGROUP, tile) instead of one per instance -- a 1024-thread workgroup over
+// kDenseGaussians Gaussians counts / ranks them per tile in an LDS table of the whole frame (4 bytes x tiles).  Both kernels must agree
+// on the partition (workgroup b: Gaussians [b kDenseGaussians, (b + 1) kDenseGaussians), sub-bin b mod S): one predicate for both.
+constexpr int kDenseThreads = 1024, kDenseGaussians = 4096, kDenseMaxTilesLds = 12 * 1024;
+inline bool dense_exact_lists(const SplatState &st, int P, int T) {
+    return st.tile_stride == 0 && st.sub_bins > 1 && P >= 8 * kDenseGaussians && T <= kDenseMaxTilesLds;
+}
 hipError_t launch_render_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st,
                                  float *out_color, float *out_depth, hipStream_t s);
 hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &g, const SplatState &st,
