@@ -16,6 +16,7 @@ iteration"); PyTorch only owns the memory and the stream.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 
 import torch
@@ -109,10 +110,11 @@ class FusedEngine:
         # kernel files one record per 2 x 2-tile group (slots through an LDS histogram) and the composite filters its group's
         # records: ~10x fewer global atomics in the per-Gaussian kernel.  Results do not depend on it
         self.group_bins = True
-        # the Adam step inside F6 touches moments and parameters row by row (12-byte rows: three strided accesses per line); it beats the
-        # separate, fully coalesced adam_map_kernel while the map's rows stay cache resident (F6 + Adam at 300 k rows: 29 us fused vs
-        # 19 + 16 us; at 830 k rows: 96 us fused vs 42 + 42 us, rocprofv3 of the frame loop) -- larger maps take the two-kernel form
-        self.fused_adam_max_rows = 500_000
+        # the Adam step inside F6 touches moments and parameters row by row (12-byte rows).  Round 2: it lost to the separate, fully
+        # coalesced adam_map_kernel once the rows no longer stayed cache resident (96 us fused vs 42 + 42 us at 830 k rows) and maps above
+        # 500 k rows took the two-kernel form.  Since F6 requests all its moments in one round (round 3) the fused form is ahead at every
+        # size measured (mapping at 816 k rows 1 491 -> 1 505 it/s, at 5 M 383 -> 386): no limit by default (SPLAT_FUSED_ADAM_MAX_ROWS)
+        self.fused_adam_max_rows = int(os.environ.get("SPLAT_FUSED_ADAM_MAX_ROWS", 1 << 30))
         self._tile_rows = None          # (begin, end): the band of tile rows the next iteration composites (tile-row-sharded tracking)
         self._stats_partial = False     # the last iteration's list statistics cover a band only: check_overflow() does not learn from them
         self.sub_bins = 1               # counters per tile on the exact-list path (16 once lists get very long: SplatState.sub_bins)
