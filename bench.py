@@ -276,14 +276,16 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
     k6 = pmc_kernel(pmc, "render_forward_kernel", "<6, 8, false, true, false>") or pmc_kernel(pmc, "render_forward_kernel", "<6, 8")
     dom = k7 if dominant == "render_backward" else k6
     rows = {}
+    trace = load_kernel_trace(workload)          # per-kernel average durations: the kernel TRACE of the bench command (not the counter passes)
     per_unit = {"fused_preprocess_kernel": N * (48 + 87), "ssim_forward_kernel": HW * (2 * 12 + 36 + 16), "map_loss_backward_kernel": HW * (36 + 24 + 16),
                 "fused_backward_kernel": N * (64 + 40 + 48), "adam_map_kernel": N * 12 * 4 * 6}
     for kname, abytes in per_unit.items():
-        d = pmc_kernel(pmc, kname)
-        if d and d.get("avg_us"):
-            rows[kname] = {"avg_us": round(d["avg_us"], 1), "algorithmic_bytes": abytes, "GBps": round(abytes / d["avg_us"] / 1e3, 1),
-                           "frac_of_hbm_peak": round(abytes / d["avg_us"] / 1e3 / HBM_PEAK_GBS, 4), "traffic_bytes": d.get("traffic_bytes"),
-                           "valu_issue_frac": d.get("valu_issue_frac")}
+        d = pmc_kernel(pmc, kname) or {}
+        us = trace_avg_us(trace, kname)
+        if us:
+            rows[kname] = {"avg_us": round(us, 1), "algorithmic_bytes": abytes, "GBps": round(abytes / us / 1e3, 1),
+                           "frac_of_hbm_peak": round(abytes / us / 1e3 / HBM_PEAK_GBS, 4), "traffic_bytes": d.get("traffic_bytes"),
+                           "valu_cycles_frac": d.get("valu_cycles_frac")}
     r4 = lambda v: None if v is None else round(v, 4)          # noqa: E731
     other = {"render_forward_ms": round(out["render_forward"], 4), "render_forward_GBps": round(gbs_f, 2),
              "render_backward_ms": round(out["render_backward"], 4), "render_backward_GBps": round(gbs_b, 2),
@@ -300,6 +302,7 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
              "valu_cycles_frac": dom.get("valu_cycles_frac") if dom else None,
              "valu_insts_per_launch": dom.get("SQ_INSTS_VALU") if dom else None,
              "pmc_source": (f"profiles/{pmc[0]} @ {pmc[1].get('git_head')}" if pmc else None),
+             "kernel_trace_source": (f"profiles/{trace[0]}" if trace else None),
              "kernels": rows,
              "note": "K6 / K7 times are live HIP-event measurements of this run (30 launches in a row on the iteration's stream, learnt list "
                      "state, after a mapping iteration); counters (traffic = 2 x FETCH_SIZE + WRITE_SIZE) and the "
@@ -327,6 +330,30 @@ def load_pmc(workload):
         if d.get("workload") == workload:
             best = (os.path.basename(path), d)
     return best
+
+
+def load_kernel_trace(workload):
+    """The newest committed rocprofv3 --kernel-trace --stats CSV of the bench command at `workload`
+    (profiles/<tag>_bench_kernel_stats.csv for B, profiles/<tag>_<workload>_kernel_stats.csv otherwise), or None."""
+    import csv
+    import glob
+    pat = "*_bench_kernel_stats.csv" if workload == "B" else f"*_{workload.replace('B-loop', 'Bloop')}_kernel_stats.csv"
+    paths = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", pat)) if "cluster" not in os.path.basename(p) or "cluster" in workload)
+    if not paths:
+        return None
+    try:
+        return os.path.basename(paths[-1]), list(csv.DictReader(open(paths[-1])))
+    except Exception:
+        return None
+
+
+def trace_avg_us(trace, needle):
+    if trace is None:
+        return None
+    for r in trace[1]:
+        if needle in r.get("Name", ""):
+            return float(r["AverageNs"]) / 1e3
+    return None
 
 
 def pmc_kernel(pmc, *needles):
@@ -425,28 +452,87 @@ def cpu_baseline(name, params, frames, budget_s=25.0):
                       f"at full size; C oracle (OpenMP, {os.cpu_count()} threads) + PyTorch-CPU glue; median {med:.3f} s/iter"}
 
 
-def slam_loop_figure(name, dev, frames=4):
-    """Informational: the WHOLE frame loop of scripts/splatam.py:654-905 (pose initialisation, tracking, densification,
-    keyframe selection, mapping with pruning, keyframe list; splatam_amd/pipeline.py) on a synthetic RGB-D sequence of the
-    workload's image size with the reference's Replica iteration counts.  The map is what the loop builds (one Gaussian per
-    valid first-frame pixel, then densification), not the workload's fixed 300k."""
+def slam_loop_figure(name, dev, frames=13, engine="fused", runs=2):
+    """The WHOLE frame loop of scripts/splatam.py:654-905 (pose initialisation, tracking, densification, keyframe selection, mapping
+    with pruning, keyframe list; splatam_amd/pipeline.py) on a synthetic RGB-D sequence of the workload's image size with the
+    reference's Replica iteration counts.  The map is what the loop builds (one Gaussian per valid first-frame pixel, then
+    densification), not the workload's fixed 300k.  `frames` frames, the FIRST EXCLUDED from every rate (it pays the allocations and has no
+    tracking phase); run `runs` times in this process, every run reported; per-phase milliseconds per frame (means over the counted
+    frames) from synchronised timers around the phases.  engine: "fused", or "plugin" (the reference-shaped loop -- add_new_gaussians /
+    prune_gaussians re-create every tensor -- with splatam_amd.plugin installed)."""
     from splatam_amd import pipeline
     N, W, H, fx, fy, cx, cy = WORKLOADS[name]
-    ds = pipeline.SyntheticRGBDSequence(N, W, H, fx, fy, cx, cy, num_frames=frames, seed=3, device=dev)
+    ds = pipeline.SyntheticRGBDSequence(N, W, H, fx, fy, cx, cy, num_frames=frames, seed=3, device=dev).preload()
     cfg = pipeline.replica_config()
-    torch.manual_seed(0)
-    np.random.seed(0)
-    t0 = time.perf_counter()
-    params, _, st = pipeline.rgbd_slam(ds, cfg, engine="fused")
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
-    ate = max(float((pipeline._est_w2c(params, t)[:3, 3] - ds.gt_w2c(t)[:3, 3]).norm()) for t in range(frames))
-    return {"frames": frames, "image": f"{W}x{H}", "gaussians_per_frame": st['num_gaussians'],
-            "tracking_iters": st['tracking_iters'], "mapping_iters": st['mapping_iters'],
-            "tracking_iters_per_s": round(st['tracking_iters'] / max(st['tracking_s'], 1e-9), 1),
-            "mapping_iters_per_s": round(st['mapping_iters'] / max(st['mapping_loop_s'], 1e-9), 1),      # the reference's timer: iterations (+ pruning) only
-            "mapping_iters_per_s_incl_densify_keyframes_prune": round(st['mapping_iters'] / max(st['mapping_s'], 1e-9), 1),
-            "frames_per_s": round(frames / wall, 3), "redone_frames": st['redone_frames'], "max_translation_error_m": round(ate, 5)}
+    out_runs = []
+    for _ in range(runs):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        torch.cuda.synchronize(dev)
+        params, _, st = pipeline.rgbd_slam(ds, cfg, engine=engine)
+        torch.cuda.synchronize(dev)
+        counted = st['frame_s'][1:]
+        ate = max(float((pipeline._est_w2c(params, t)[:3, 3] - ds.gt_w2c(t)[:3, 3]).norm()) for t in range(frames))
+        phases = {}
+        for fr in st['phase_ms'][1:]:
+            for k, v in fr.items():
+                phases[k] = phases.get(k, 0.0) + v
+        n_counted = max(len(counted), 1)
+        track_ms = sum(fr.get('tracking', 0.0) for fr in st['phase_ms'][1:])
+        map_ms = sum(fr.get('mapping_iterations', 0.0) for fr in st['phase_ms'][1:])
+        tcfg, mcfg = cfg['tracking'], cfg['mapping']
+        run = {"frames_per_s": round(n_counted / max(sum(counted), 1e-9), 3),
+               "tracking_iters_per_s": round(1e3 * tcfg['num_iters'] * n_counted / max(track_ms, 1e-9), 1),
+               "mapping_iters_per_s": round(1e3 * mcfg['num_iters'] * n_counted / max(map_ms, 1e-9), 1),     # the reference's timer: iterations only
+               "ms_per_frame": round(1e3 * sum(counted) / n_counted, 2),
+               "phase_ms_per_frame": {k: round(v / n_counted, 3) for k, v in sorted(phases.items())},
+               "first_frame_s": round(st['frame_s'][0], 3),
+               "gaussians_first_last": [st['num_gaussians'][0], st['num_gaussians'][-1]],
+               "redone_iterations": st['redone_iterations'], "max_translation_error_m": round(ate, 5)}
+        if 'plugin' in st:
+            run["plugin_session"] = st['plugin']
+        out_runs.append(run)
+        del params
+    fps = [r["frames_per_s"] for r in out_runs]
+    return {"frames": frames, "frames_counted": frames - 1, "image": f"{W}x{H}", "engine": engine,
+            "tracking_iters_per_frame": cfg['tracking']['num_iters'], "mapping_iters_per_frame": cfg['mapping']['num_iters'],
+            "frames_per_s": round(sum(fps) / len(fps), 3), "runs_agree_within": round(abs(max(fps) - min(fps)) / max(fps), 4),
+            "runs": out_runs}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from a bare shell (no torchrun around it): re-run this command under torch.distributed.run with one
+    rank per GPU on this node; rank 0 of the child job prints the JSON line.  With fewer GPUs than ranks (development boxes) the ranks
+    share what is there over gloo."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # torchrun pins OMP_NUM_THREADS=1 when it is unset: give every rank its share of the host cores instead (host-side legs)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    ngpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ngpu < args.gpus:
+        env.setdefault("SPLAT_DIST_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_check():
+    """`--launch-check`: the N-rank launch path without a GPU -- rendezvous, one all-reduce, rank 0 prints a JSON line (tests/test_bench_launch.py)."""
+    from splatam_amd import dist as sdist
+    rank, world, _ = sdist.init_from_env(backend="gloo" if not torch.cuda.is_available() else None)
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "world": world, "sum_of_ranks_plus_one": float(t[0]),
+                          "omp_num_threads": os.environ.get("OMP_NUM_THREADS")}), flush=True)
 
 
 def main():
@@ -465,12 +551,18 @@ def main():
                     help="N > 1 over RCCL: issue the per-iteration all-reduces on the iteration's own stream (splatam_amd.dist.InStreamRccl)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-slam-loop", action="store_true", help="skip the informational end-to-end frame-loop figure")
+    ap.add_argument("--no-slam-loop", action="store_true", help="skip the end-to-end frame-loop figures (slam_loop, slam_loop_plugin)")
+    ap.add_argument("--slam-frames", type=int, default=13, help="frames of the frame-loop figures (the first is not counted)")
+    ap.add_argument("--launch-check", action="store_true", help="only exercise the N-rank launch (no GPU needed)")
     ap.add_argument("--replicated-tracking", action="store_true",
                     help="--gpus N > 1: every rank tracks the whole frame (no exchange) instead of sharding the frame's tile rows over the ranks")
     args = ap.parse_args()
     global SHARD_TRACKING
     SHARD_TRACKING = not args.replicated_tracking
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    if args.launch_check:
+        return launch_check()
 
     from splatam_amd import dist as sdist
     from splatam_amd import rasterizer as rz
@@ -482,7 +574,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP rasterizer has no CPU path)")
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())     # several ranks may share a GPU on a development box
     torch.cuda.set_device(dev)
     rz.set_sync_mode(args.sync_mode)
@@ -576,7 +668,7 @@ def main():
         sustained_s = time.perf_counter() - t1
         sustained_ok = not eng.check_overflow(grow=False)
         # the exchange step alone (rank-local average over 20 collectives of the flat gradient bucket)
-        allreduce_ms = allreduce_small_ms = None
+        allreduce_ms = allreduce_small_ms = allreduce_small_folded_ms = None
         if world > 1:
             from splatam_amd.dist import all_reduce_sum_flat
             for _ in range(3):
@@ -598,6 +690,22 @@ def main():
             torch.cuda.synchronize(dev)
             allreduce_small_ms = 1e3 * (time.perf_counter() - t3) / 20
             eng.buf['sums'].zero_()
+            # ... and in the form the loop uses by default: the 64 copies folded on the device first (splat_iter_fold_sums), 256 bytes on the wire
+            import ctypes as C
+            from splatam_amd import _capi
+
+            def folded():
+                _capi.check(eng.L.splat_iter_fold_sums(eng.buf['sums'].data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "splat_iter_fold_sums")
+                all_reduce_sum_flat(eng.buf['sums'][:_capi.SPLAT_ITER_SUMS])
+            for _ in range(3):
+                folded()
+            barrier()
+            t4 = time.perf_counter()
+            for _ in range(20):
+                folded()
+            torch.cuda.synchronize(dev)
+            allreduce_small_folded_ms = 1e3 * (time.perf_counter() - t4) / 20
+            eng.buf['sums'].zero_()
     else:
         variables = run_steps(params_d, variables, frames, bucket, rank, world, args.warmup, opt_track, opt_map, tstate, 0)
         barrier()
@@ -606,7 +714,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
     if not fused:
-        n_sus, sustained_s, allreduce_ms, allreduce_small_ms, sustained_ok = args.steps, elapsed, None, None, True
+        n_sus, sustained_s, allreduce_ms, allreduce_small_ms, allreduce_small_folded_ms, sustained_ok = args.steps, elapsed, None, None, None, True
     if world > 1:
         t = torch.tensor([elapsed, sustained_s], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -694,6 +802,7 @@ def main():
                             ("torch.distributed " + torch.distributed.get_backend() if world > 1 else None)),
             "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4),
             "allreduce_small_ms": None if allreduce_small_ms is None else round(allreduce_small_ms, 4),
+            "allreduce_small_folded_ms": None if allreduce_small_folded_ms is None else round(allreduce_small_folded_ms, 4),
             "tracking_replicated_iters_per_s": None if not (fused and world > 1) else round(track_rate_repl, 3),
             "mapping_with_exchange_iters_per_s": None if not (fused and world > 1) else round(map_rate_exch, 3),
             "tracking_iters_per_s": round(track_rate, 3), "mapping_iters_per_s": round(map_rate, 3),
@@ -707,7 +816,8 @@ def main():
         if roof is not None:
             result["roofline"] = roof
         if world == 1 and fused and not args.no_slam_loop:
-            result["slam_loop"] = slam_loop_figure(args.workload, dev)
+            result["slam_loop"] = slam_loop_figure(args.workload, dev, frames=args.slam_frames)
+            result["slam_loop_plugin"] = slam_loop_figure(args.workload, dev, frames=args.slam_frames, engine="plugin")
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.workload, params_d, frames)
             pairs = result["cpu_baseline"].get("pairs_per_render")

@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define SPLAT_ABI_VERSION 7        /* 7: SplatState.long_items (work-item table of the multi-workgroup sort);
+#define SPLAT_ABI_VERSION 8        /* 8: SplatIterWorkspace.d_cam is SPLAT_ITER_DCAM floats (loss terms, status snapshot, gated-iteration count),
+                                      the Adam steps skip while the capacity flag is up (SplatAdamMap.gate), per-group bc2_sqrt;
+                                      7: SplatState.long_items (work-item table of the multi-workgroup sort);
                                       6: SplatState.tile_row_begin / _end, SplatLossConfig.defer_finish, splat_iter_finish (tile-row-sharded tracking);
                                       5: SplatState.group_count / group_recs / group_stride (group binning), splat_iter_mapping_step; 4: densification (splat_iter_means2d_accumulate, splat_map_densify_select / _duplicate);
                                       3: SplatState.keys_alt / long_base (multi-workgroup sort of lists beyond LDS); 2: map edits,
@@ -270,6 +272,7 @@ typedef struct SplatLossConfig {
 
 #define SPLAT_ITER_SUMS 32       /* doubles per copy of the partial sums */
 #define SPLAT_ITER_SUM_COPIES 64 /* copies: workgroups spread their atomics over them (one hot cache line otherwise) */
+#define SPLAT_ITER_DCAM 32       /* floats of SplatIterWorkspace.d_cam */
 
 /* Device scratch + outputs of one fused iteration; every array is caller-owned.  The caller ZERO-INITIALISES sums,
  * st.tile_count, accum and dL_dout6 once; each iteration leaves them zeroed again (the kernels that consume a buffer
@@ -282,7 +285,8 @@ typedef struct SplatIterWorkspace {
     float *accum;                /* [P][SPLAT_GRAD_STRIDE] */
     float *ssim_maps;            /* [9][H][W] mapping only (NULL for tracking) */
     double *sums;                /* [SPLAT_ITER_SUM_COPIES][SPLAT_ITER_SUMS]: [0] masked depth L1 sum, [1] image L1 sum,
-                                    [2] mask count, [3] SSIM map sum, [8..23] camera-pose partial sums */
+                                    [2] mask count, [3] SSIM map sum, [8..23] camera-pose partial sums, [31] != 0: a capacity flag was
+                                    raised on some band of a tile-row-sharded iteration (cfg.defer_finish) */
     float *max_2D_radius;        /* [P] variables['max_2D_radius'], updated in place, or NULL */
     /* gradients of the map (written when non-NULL; means3D / unnorm_rotations only with gaussians_grad) */
     float *d_means3D;            /* [P][3] */
@@ -290,10 +294,21 @@ typedef struct SplatIterWorkspace {
     float *d_unnorm_rotations;   /* [P][4] */
     float *d_logit_opacities;    /* [P] */
     float *d_log_scales;         /* [P][1|3] */
-    float *d_cam;                /* [16]: dL/dcam_unnorm_rots[...,t] (4), dL/dcam_trans[...,t] (3), loss (1), the raw sums
-                                    [0..3] of this iteration (4), [12] STICKY "lists overflowed / unsorted" flag (set by any
-                                    iteration whose status[1] or status[3] was set; cleared by the host), [13] the median
-                                    depth error of this iteration when ignore_outlier_depth_loss is set, 2 spare */
+    float *d_cam;                /* [SPLAT_ITER_DCAM] the iteration's report, written by its last kernel:
+                                    [0..3] dL/dcam_unnorm_rots[...,t], [4..6] dL/dcam_trans[...,t], [7] loss,
+                                    [8..11] the raw sums [0..3] of this iteration,
+                                    [12] STICKY "lists overflowed / unsorted" flag (set by any iteration whose status[1] or
+                                         status[3] was set; cleared by the host).  While it is up the Adam steps of this ABI
+                                         (inside splat_iter_tracking_step / _mapping_step / _finish, splat_iter_adam_pose, and
+                                         splat_iter_adam_map with SplatAdamMap.gate) leave parameters, moments and the
+                                         best-candidate record untouched: an iteration on truncated lists never moves the map,
+                                    [13] the median depth error of this iteration when ignore_outlier_depth_loss is set,
+                                    [14] loss_weights['depth'] * the depth term, [15] loss_weights['im'] * the image term of [7]
+                                         (weighted_losses['depth' / 'im'] of /root/reference/scripts/splatam.py:339),
+                                    [16..19] int32 bit patterns of st.status[0..3] as this iteration left them (instances,
+                                         overflow, longest list, stale hint),
+                                    [20] int32: 1 when THIS iteration was flagged, [21] int32: iterations whose Adam step was
+                                         skipped since the host last cleared it, 10 spare */
     /* only read when cfg->ignore_outlier_depth_loss (/root/reference/scripts/splatam.py:266-268), NULL otherwise */
     float *outlier_err;          /* [H*W] scratch: depth error per pixel */
     uint32_t *outlier_scratch;   /* splat_map_scratch_words(H*W) words: histograms of the radix selection of torch.median */
@@ -306,20 +321,25 @@ int splat_iter_loss_backward(const SplatCamera *cam, const SplatMap *map, const 
                              const SplatLossConfig *cfg, SplatIterWorkspace *ws, void *stream);
 
 /* torch.optim.Adam over the five Gaussian groups (mapping: /root/reference/scripts/splatam.py:160-166 with
- * eps = 1e-15, lr per group from the config).  step_size[k] = lr_k / (1 - beta1^t) and bc2_sqrt = sqrt(1 - beta2^t)
- * are formed by the caller in double, as torch does.  Group order: means3D, rgb_colors, unnorm_rotations,
- * logit_opacities, log_scales.  exp_avg / exp_avg_sq have the shapes of the parameters. */
+ * eps = 1e-15, lr per group from the config).  step_size[k] = lr_k / (1 - beta1^t_k) and bc2_sqrt[k] = sqrt(1 - beta2^t_k)
+ * are formed by the caller in double, as torch does -- per group, because torch keeps a step count per parameter and a
+ * parameter the caller re-created (pruning, opacity reset) restarts or skips its count.  Group order: means3D, rgb_colors,
+ * unnorm_rotations, logit_opacities, log_scales.  exp_avg / exp_avg_sq have the shapes of the parameters.  gate: NULL, or
+ * the d_cam of the iteration that formed the gradients -- the step is skipped while d_cam[12] (the capacity flag) is up. */
 typedef struct SplatAdamMap {
-    float beta1, beta2, eps, bc2_sqrt;
+    float beta1, beta2, eps;
+    float bc2_sqrt[5];
     float step_size[5];
     const float *grad[5];
     float *exp_avg[5];
     float *exp_avg_sq[5];
+    const float *gate;
 } SplatAdamMap;
 int splat_iter_adam_map(const SplatMap *map, const SplatAdamMap *opt, void *stream);
 
 /* Adam step of the camera pose of frame `time_idx` (tracking: default eps 1e-8) followed by the reference's
- * best-candidate bookkeeping: if loss < min_loss, remember the UPDATED pose.
+ * best-candidate bookkeeping: if loss < min_loss, remember the UPDATED pose.  d_cam: the report of the iteration
+ * (gradient [0..6], loss [7]); skipped while d_cam[12] is up.
  * state [24] floats: exp_avg q(4) t(3), exp_avg_sq q(4) t(3), min_loss, candidate q(4) t(3), 2 spare. */
 #define SPLAT_POSE_STATE 24
 int splat_iter_adam_pose(const SplatMap *map, int32_t time_idx, const float *d_cam, float *state,
@@ -342,6 +362,11 @@ int splat_iter_tracking_step(const SplatCamera *cam, const SplatMap *map, const 
  * doubles, sum) over the ranks between the two calls; every rank then holds the same sums and takes the same step. */
 int splat_iter_finish(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame, const SplatLossConfig *cfg,
                       SplatIterWorkspace *ws, const SplatPoseAdam *adam, void *stream);
+
+/* Between an iteration that ran with cfg->defer_finish and its all-reduce: folds the SPLAT_ITER_SUM_COPIES copies of ws->sums into
+ * copy 0 and zeroes the others, so that the exchange carries SPLAT_ITER_SUMS doubles (256 bytes) instead of all the copies (16 KB);
+ * splat_iter_finish totals the copies either way. */
+int splat_iter_fold_sums(double *sums, void *stream);
 
 /* One whole single-view mapping iteration (/root/reference/scripts/splatam.py:846-863: get_loss, backward, optimizer.step) in
  * one call: splat_iter_loss_backward with cfg->tracking clear, with splat_iter_adam_map folded into its last kernel (every
@@ -481,13 +506,8 @@ int splat_map_densify_select(SplatMapStore *store, const SplatDensifyArgs *args,
  * are zero.  The caller then sets map.P = counts[0]; the split originals are removed with splat_map_prune(to_remove = flags). */
 int splat_map_duplicate(SplatMapStore *store, const SplatDensifyArgs *args, void *stream);
 
-/* Developer switches used by scripts/ (never by the product path): key 0 = skip the per-tile
- * count atomics of K1 (timing experiment; results are then invalid); key 1 = generation of the composite kernels
- * (3 = current; 2 = previous, 3-channel calls only, and 4 = rejected experiment exist only in a library built with
- * `make EXPERIMENTS=1`: the product library answers -1 for them); key 3 = generation of the backward composite
- * (5 = the product's two-phase kernel; 3 = round 1's per-visit-reduction kernel, EXPERIMENTS builds only); key 2 = list
- * entries per loop trip of backward generation 3 (EXPERIMENTS builds only).  Returns the previous value, -1 for an
- * unknown key / unavailable value. */
+/* Developer switch used by scripts/ (never by the product path): key 0 = skip the per-tile count atomics of K1 (timing
+ * experiment; results are then invalid).  Returns the previous value, -1 for an unknown key. */
 int splat_debug_option(int key, int value);
 
 #ifdef __cplusplus

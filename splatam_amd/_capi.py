@@ -18,7 +18,7 @@ SPLAT_MAX_CHANNELS = 8
 SPLAT_GRAD_STRIDE = 16
 SPLAT_COUNTER_STRIDE = 32
 SPLAT_GROUP_TILES = 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -80,8 +80,8 @@ class SplatIterWorkspace(C.Structure):
 
 
 class SplatAdamMap(C.Structure):
-    _fields_ = [("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("bc2_sqrt", C.c_float),
-                ("step_size", C.c_float * 5), ("grad", _fp * 5), ("exp_avg", _fp * 5), ("exp_avg_sq", _fp * 5)]
+    _fields_ = [("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("bc2_sqrt", C.c_float * 5),
+                ("step_size", C.c_float * 5), ("grad", _fp * 5), ("exp_avg", _fp * 5), ("exp_avg_sq", _fp * 5), ("gate", _fp)]
 
 
 class SplatMapStore(C.Structure):
@@ -121,6 +121,7 @@ SPLAT_DENSIFY_SPLIT = 1
 SPLAT_ITER_SUMS = 32
 SPLAT_ITER_SUM_COPIES = 64
 SPLAT_POSE_STATE = 24
+SPLAT_ITER_DCAM = 32
 
 EXPORTS = (
     "splat_error_string", "splat_abi_version", "splat_sizeof", "splat_num_tiles",
@@ -128,7 +129,7 @@ EXPORTS = (
     "splat_render_backward", "splat_preprocess_backward", "splat_backward",
     "splat_mark_visible", "splat_time_kernel", "splat_debug_option",
     "splat_iter_loss_backward", "splat_iter_adam_map", "splat_iter_adam_pose", "splat_iter_time_kernel",
-    "splat_iter_tracking_step", "splat_iter_mapping_step", "splat_iter_finish", "splat_iter_render", "splat_map_scratch_words", "splat_map_row_floats", "splat_map_add_new_gaussians", "splat_map_prune",
+    "splat_iter_tracking_step", "splat_iter_mapping_step", "splat_iter_finish", "splat_iter_fold_sums", "splat_iter_render", "splat_map_scratch_words", "splat_map_row_floats", "splat_map_add_new_gaussians", "splat_map_prune",
     "splat_iter_means2d_accumulate", "splat_map_densify_select", "splat_map_duplicate",
 )
 
@@ -189,6 +190,8 @@ def lib():
     L.splat_iter_finish.restype = C.c_int
     L.splat_iter_finish.argtypes = [cam, C.POINTER(SplatMap), C.POINTER(SplatFrameData), C.POINTER(SplatLossConfig),
                                     C.POINTER(SplatIterWorkspace), C.POINTER(SplatPoseAdam), _fp]
+    L.splat_iter_fold_sums.restype = C.c_int
+    L.splat_iter_fold_sums.argtypes = [_fp, _fp]
     L.splat_iter_render.restype = C.c_int
     L.splat_iter_render.argtypes = [cam, C.POINTER(SplatMap), C.POINTER(SplatFrameData), C.POINTER(SplatIterWorkspace), _fp]
     L.splat_map_scratch_words.restype = C.c_size_t

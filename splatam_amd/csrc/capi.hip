@@ -196,6 +196,11 @@ int splat_iter_finish(const SplatCamera *cam, const SplatMap *map, const SplatFr
     return check(launch_iter_finish(*cam, *map, *frame, *cfg, *ws, (hipStream_t)stream, adam));
 }
 
+int splat_iter_fold_sums(double *sums, void *stream) {
+    if (!sums) return SPLAT_E_INVALID;
+    return check(launch_iter_fold_sums(sums, (hipStream_t)stream));
+}
+
 int splat_iter_mapping_step(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame,
                             const SplatLossConfig *cfg, SplatIterWorkspace *ws, const SplatAdamMap *adam, void *stream) {
     if (!cfg || cfg->tracking || !cfg->gaussians_grad || !adam || !ws) return SPLAT_E_INVALID;
@@ -353,27 +358,6 @@ int splat_map_duplicate(SplatMapStore *store, const SplatDensifyArgs *a, void *s
 
 int splat_debug_option(int key, int value) {
     if (key == 0) { const int old = g_debug_skip_count; g_debug_skip_count = value; return old; }
-    if (key == 1) {
-#if defined(SPLAT_EXPERIMENTS)
-        const int old = g_debug_composite_version; g_debug_composite_version = value; return old;
-#else
-        return value == 3 ? 3 : -1;     // the product library holds generation 3 only
-#endif
-    }
-    if (key == 2) {
-#if defined(SPLAT_EXPERIMENTS)
-        const int old = g_debug_entries_per_trip; g_debug_entries_per_trip = (value == 1 || value == 3) ? value : 2; return old;
-#else
-        return -1;
-#endif
-    }
-    if (key == 3) {
-#if defined(SPLAT_EXPERIMENTS)
-        const int old = g_debug_k7_generation; if (value == 3 || value == 5) g_debug_k7_generation = value; return old;
-#else
-        return value == 5 ? 5 : -1;     // the product library holds generation 5 only
-#endif
-    }
     return -1;
 }
 

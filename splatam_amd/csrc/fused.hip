@@ -30,6 +30,7 @@ namespace splat {
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kFlagSum = SPLAT_ITER_SUMS - 1;     // ws.sums slot that carries a rank's capacity flags through the all-reduce of sharded tracking
 
 struct FusedArgs {
     SplatCamera cam;
@@ -822,11 +823,16 @@ __global__ __launch_bounds__(256) void pose_finish_kernel(FusedArgs a, int HW, P
     // what the closing thread needs -- the pose, the Adam state, the capacity flags -- is requested here, ahead of the first store
     Pose P{};
     PoseAdamRegs adam{};
-    int flagged = 0;
+    int flagged = 0, stat[4] = {0, 0, 0, 0}, skipped = 0;
+    float sticky = 0.f;
     if (t == 0) {
         if (a.cfg.camera_grad) load_pose(a.map, a.frame.time_idx, P);
         if (pa.state) pose_adam_load(a.map, a.frame.time_idx, pa, adam);
-        flagged = a.ws.st.status[1] | a.ws.st.status[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) stat[k] = a.ws.st.status[k];
+        flagged = stat[1] | stat[3];
+        sticky = a.ws.d_cam[12];
+        skipped = reinterpret_cast<const int *>(a.ws.d_cam)[21];
     }
     // (all eight loads first, then the resets: a store between two loads makes the second wait for the first)
     double part_sum[8];
@@ -844,6 +850,9 @@ __global__ __launch_bounds__(256) void pose_finish_kernel(FusedArgs a, int HW, P
     if (part == 0) S[k] = v;
     __syncthreads();
     if (t != 0) return;
+    // tile-row-sharded tracking: a rank whose band overflowed says so through the all-reduced sums (kFlagSum), so that every rank
+    // takes the same decision about the step below
+    if (S[kFlagSum] != 0.0) flagged = 1;
     float *out = a.ws.d_cam;
     float dq[4] = {0.f, 0.f, 0.f, 0.f}, dt[3] = {0.f, 0.f, 0.f};
     if (a.cfg.camera_grad) {
@@ -853,19 +862,29 @@ __global__ __launch_bounds__(256) void pose_finish_kernel(FusedArgs a, int HW, P
     }
     for (int k = 0; k < 4; ++k) out[k] = dq[k];
     for (int k = 0; k < 3; ++k) out[4 + k] = dt[k];
-    float loss;
+    float loss, w_depth_term, w_im_term;
     const float l_depth = a.cfg.use_l1 ? (float)S[0] : 0.f;
     if (a.cfg.tracking) {
-        loss = a.cfg.w_depth * l_depth + a.cfg.w_im * (float)S[1];
+        w_depth_term = a.cfg.w_depth * l_depth;
+        w_im_term = a.cfg.w_im * (float)S[1];
     } else {
         const float n = 3.0f * (float)HW;
         const float l_im = 0.8f * ((float)S[1] / n) + 0.2f * (1.0f - (float)S[3] / n);
-        loss = a.cfg.w_depth * (a.cfg.use_l1 ? l_depth / (float)S[2] : 0.f) + a.cfg.w_im * l_im;
+        w_depth_term = a.cfg.w_depth * (a.cfg.use_l1 ? l_depth / (float)S[2] : 0.f);
+        w_im_term = a.cfg.w_im * l_im;
     }
+    loss = w_depth_term + w_im_term;
     out[7] = loss;
     for (int k = 0; k < 4; ++k) out[8 + k] = (float)S[k];       // raw sums, for inspection
+    const bool gate_up = flagged != 0 || sticky != 0.f;
     if (flagged != 0) out[12] = 1.0f;     // sticky until the host clears it
-    if (pa.state) {
+    out[14] = w_depth_term;
+    out[15] = w_im_term;
+    int *outi = reinterpret_cast<int *>(out);
+    for (int k = 0; k < 4; ++k) outi[16 + k] = stat[k];
+    outi[20] = flagged != 0 ? 1 : 0;
+    if (gate_up) outi[21] = skipped + 1;  // an iteration on truncated / unsorted lists: no Adam step moves anything (see SplatIterWorkspace.d_cam)
+    if (pa.state && !gate_up) {
         float g[7];
         for (int k = 0; k < 4; ++k) g[k] = dq[k];
         for (int k = 0; k < 3; ++k) g[4 + k] = dt[k];
@@ -914,6 +933,10 @@ __global__ __launch_bounds__(kBlock, ISO ? 5 : 4) void fused_backward_kernel(Fus
         float p[3], u[4], logit, ls[3];
         load_gaussian(a.map, i, p, u, logit, ls);
         const float4 co = reinterpret_cast<const float4 *>(ws.st.conic_opacity)[i];
+        // the Adam step is skipped while a capacity flag is up (this iteration's lists, or an earlier iteration's the host has not
+        // dealt with yet: SplatIterWorkspace.d_cam[12]); wave-uniform
+        bool gate_up = false;
+        if constexpr (ADAM) gate_up = (ws.st.status[1] | ws.st.status[3]) != 0 || ws.d_cam[12] != 0.f;
         // the row is consumed: the next iteration's K7 accumulates from zero without a memset.  (Unconditional -- rows outside the view
         // are zero already -- and AFTER every load above: a store the compiler can neither sink nor prove disjoint pins them up here,
         // ahead of the visibility test.)
@@ -982,9 +1005,9 @@ __global__ __launch_bounds__(kBlock, ISO ? 5 : 4) void fused_backward_kernel(Fus
                     if (k >= kWidth[gidx]) continue;
                     float mm = mom1[gidx][k], vv = mom2[gidx][k];
                     const float gk = grads[gidx][k];
-                    if (gk == 0.f && mm == 0.f && vv == 0.f) continue;          // (see adam_map_kernel)
+                    if ((gk == 0.f && mm == 0.f && vv == 0.f) || gate_up) continue;          // (see adam_map_kernel)
                     const size_t j = (size_t)i * kWidth[gidx] + k;
-                    params[gidx][j] = adam_update(olds[gidx][k], gk, mm, vv, opt.beta1, opt.beta2, opt.step_size[gidx], opt.bc2_sqrt, opt.eps);
+                    params[gidx][j] = adam_update(olds[gidx][k], gk, mm, vv, opt.beta1, opt.beta2, opt.step_size[gidx], opt.bc2_sqrt[gidx], opt.eps);
                     opt.exp_avg[gidx][j] = mm;
                     opt.exp_avg_sq[gidx][j] = vv;
                 }
@@ -1015,6 +1038,8 @@ __global__ __launch_bounds__(kBlock, ISO ? 5 : 4) void fused_backward_kernel(Fus
             if ((threadIdx.x & 63) == 0 && sum) { atomicAdd((unsigned *)&ws.st.status[0], sum); atomicMax((unsigned *)&ws.st.status[2], mx); }
         }
     }
+    // a band of tile rows (the other ranks hold the other bands): this rank's capacity flags travel with the partial sums
+    if (a.cfg.defer_finish && i == 0 && (ws.st.status[1] | ws.st.status[3]) != 0) atomicAdd(ws.sums + kFlagSum, 1.0);
     if (a.cfg.camera_grad) block_sum_to<kPoseSums>(sum_copy(ws.sums) + 8, pose, s_part);
 }
 
@@ -1030,6 +1055,7 @@ struct AdamArgs {
 __global__ __launch_bounds__(kBlock) void adam_map_kernel(AdamArgs a, long long total) {
     const long long e = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (e >= total) return;
+    if (a.opt.gate && a.opt.gate[12] != 0.f) return;            // the iteration that formed these gradients ran on truncated lists
     float *params[5] = {a.map.means3D, a.map.rgb_colors, a.map.unnorm_rotations, a.map.logit_opacities, a.map.log_scales};
     const int width[5] = {3, 3, 4, 1, a.map.isotropic ? 1 : 3};
     long long off = 0;
@@ -1046,7 +1072,7 @@ __global__ __launch_bounds__(kBlock) void adam_map_kernel(AdamArgs a, long long 
                 // isotropic map): the step leaves parameter and moments as they are -- nothing to write
                 if (gg == 0.f && mm == 0.f && vv == 0.f) return;
                 float *p = params[gidx];
-                p[j] = adam_update(p[j], gg, mm, vv, a.opt.beta1, a.opt.beta2, a.opt.step_size[gidx], a.opt.bc2_sqrt, a.opt.eps);
+                p[j] = adam_update(p[j], gg, mm, vv, a.opt.beta1, a.opt.beta2, a.opt.step_size[gidx], a.opt.bc2_sqrt[gidx], a.opt.eps);
                 a.opt.exp_avg[gidx][j] = mm;
                 a.opt.exp_avg_sq[gidx][j] = vv;
             }
@@ -1055,9 +1081,30 @@ __global__ __launch_bounds__(kBlock) void adam_map_kernel(AdamArgs a, long long 
     }
 }
 
+// The 64 copies of the partial sums folded into copy 0 (the others zeroed): tile-row-sharded tracking then exchanges 256 bytes
+// instead of 16 KB (pose_finish_kernel totals the copies either way)
+__global__ __launch_bounds__(256) void fold_sums_kernel(double *sums) {
+    static_assert(SPLAT_ITER_SUMS * 8 == 256 && SPLAT_ITER_SUM_COPIES == 64, "thread t: sum k = t / 8, copies (t % 8) * 8 .. + 7");
+    const int t = threadIdx.x, k = t >> 3, part = t & 7;
+    double part_sum[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) part_sum[c] = sums[(size_t)(part * 8 + c) * SPLAT_ITER_SUMS + k];
+    double v = 0.0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        v += part_sum[c];
+        if (part * 8 + c != 0) sums[(size_t)(part * 8 + c) * SPLAT_ITER_SUMS + k] = 0.0;
+    }
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    if (part == 0) sums[k] = v;
+}
+
 __global__ void adam_pose_kernel(SplatMap map, int time_idx, const float *d_cam, float *state, float beta1, float beta2,
                                  float eps, float bc2_sqrt, float ss_rot, float ss_trans) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (d_cam[12] != 0.f) return;                               // (see SplatIterWorkspace.d_cam[12])
     const PoseAdam pa{state, beta1, beta2, eps, bc2_sqrt, ss_rot, ss_trans};
     pose_adam_step(map, time_idx, d_cam, d_cam[7], pa);
 }
@@ -1256,6 +1303,11 @@ hipError_t launch_iter_means2d_accumulate(const SplatCamera &cam, const SplatMap
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(means2d_accumulate_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, ws, P, cam.image_width, cam.image_height, gaccum,
                        denom, means2D_grad);
+    return hipGetLastError();
+}
+
+hipError_t launch_iter_fold_sums(double *sums, hipStream_t s) {
+    hipLaunchKernelGGL(fold_sums_kernel, dim3(1), dim3(256), 0, s, sums);
     return hipGetLastError();
 }
 

@@ -1,6 +1,7 @@
 // render.hip -- tile-wise alpha compositing, forward (K6) and backward (K7).
 //
-// MI355X mapping (forward: third generation, backward: fifth; earlier / rejected ones live in experiments/, built only with EXPERIMENTS=1):
+// MI355X mapping (forward: third generation, backward: fifth; the earlier / rejected ones are in the git history, their measurements in
+// profiles/r0*_experiments.md):
 //   * one 256-thread workgroup per 16x16 tile, ONE WAVE64 PER 8x8 QUADRANT, one pixel per lane.  A frame of
 //     config B is 3 225 tiles = 12 900 waves = 12.6 per SIMD, so every SIMD always has several waves to
 //     interleave (the one-wave-per-tile kernels were latency bound at ~3 waves per SIMD);
@@ -39,24 +40,6 @@ constexpr int kBatchEntries = 255;  // list entries staged per buffer: record 25
 constexpr int kSegBytes = 68;       // one visit list: <= 64 one-byte entries, padded with 0xFF to a multiple of 4, + the next group's look-ahead
 constexpr int kBlockListBytes = 264; // a block's visit list over a whole batch: <= 255 entries + padding + look-ahead
 
-#if defined(SPLAT_EXPERIMENTS)
-// Superseded / rejected generations of these kernels (experiments/render_v2.hip, experiments/render_v4.hip), built only with
-// `make EXPERIMENTS=1` and selected with splat_debug_option(1, v) for A/B timing: 2 = wave per tile (3-channel calls only),
-// 4 = one 4x4 block per 16-lane row (fewer VALU instructions but twice the accumulator atomics).
-hipError_t launch_render_forward_v2(const SplatCamera &cam, const float *col, SplatState &st, float *out_color,
-                                    float *out_depth, hipStream_t s);
-hipError_t launch_render_backward_v2(const SplatCamera &cam, const float *col, const SplatState &st, const float *dL_dcolor,
-                                     float *accum, hipStream_t s);
-hipError_t launch_render_forward_v4(const SplatCamera &cam, const float *col, int channels, SplatState &st, float *out_color,
-                                    float *out_depth, hipStream_t s);
-hipError_t launch_render_backward_v4(const SplatCamera &cam, const float *col, int channels, const SplatState &st,
-                                     const float *dL_dcolor, float *accum, hipStream_t s);
-hipError_t launch_render_forward_feat8_v4(const SplatCamera &cam, const float *feat8, SplatState &st, float *out6, bool sort_in_kernel,
-                                          hipStream_t s);
-hipError_t launch_render_backward_feat8_v4(const SplatCamera &cam, const float *feat8, const SplatState &st, const float *dL_dout6,
-                                           float *accum, bool rgb_sums, hipStream_t s);
-#endif
-int g_debug_composite_version = 3;
 
 // One staged Gaussian as the gathering thread holds it in registers.
 template <int FP>
@@ -650,14 +633,11 @@ constexpr int nth_set_bit(unsigned m, int n) {      // index of the n-th (0-base
     }
 }
 
-#if defined(SPLAT_EXPERIMENTS)
-#include "experiments/render_backward_v3.h"
-#endif
 
 // ---------------------------------------------------------------------------
 // K7 backward composite, generation 5: no cross-lane reduction per Gaussian visit
 // ---------------------------------------------------------------------------
-// Generation 3 above spends ~95 VALU wave-instructions per (Gaussian, 8x8 quadrant) visit, ~40 of them on reducing the
+// Generation 3 (round 1) spent ~95 VALU wave-instructions per (Gaussian, 8x8 quadrant) visit, ~40 of them on reducing the
 // 6 + |SMASK| partial sums across the 64 pixel lanes (packed permlane / DPP trees, zero fills, publish selects) -- while only
 // ~21 % of the lanes of a visited quadrant hold a live pixel.  This generation splits the visit into two phases and turns
 // the reduction over PIXELS into a loop, not a lane tree:
@@ -1028,24 +1008,10 @@ static void launch_fwd(const SplatCamera &cam, const float *colors, SplatState &
     hipLaunchKernelGGL((render_forward_kernel<C, CS, WITH_DEPTH, SORT, false>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, oc, od, T, per,
                        TrackLossEpilogue{});
 }
-int g_debug_k7_generation = 5;         // splat_debug_option(3, v): 5 = two-phase backward composite; 3 = generation 3 (EXPERIMENTS builds only)
-int g_debug_entries_per_trip = 2;      // splat_debug_option(2, v), generation 3 only: 1 = one list entry per loop trip (A/B timing)
 template <int C, int CS, unsigned DMASK = (1u << C) - 1u, unsigned SMASK = (1u << C) - 1u, bool OPAC = true, bool BG = true>
 static void launch_bwd(const SplatCamera &cam, const float *colors, const SplatState &st, const float *dl, float *acc, int T,
                        hipStream_t s) {
     const int per = (T + 7) / 8;
-#if defined(SPLAT_EXPERIMENTS)
-    if (g_debug_k7_generation == 3) {
-        // two entries per trip pay when they save a packed reduction group (2 x 10 sums -> 5 groups instead of 6, 2 x 6 -> 3 instead of 4)
-        constexpr int NV = (OPAC ? 6 : 5) + popcount_c(SMASK);
-        constexpr bool kPairPays = (2 * NV + 3) / 4 < 2 * ((NV + 3) / 4);
-        if (kPairPays && g_debug_entries_per_trip != 1)
-            hipLaunchKernelGGL((render_backward_kernel<C, CS, DMASK, SMASK, 2, OPAC, BG>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
-        else
-            hipLaunchKernelGGL((render_backward_kernel<C, CS, DMASK, SMASK, 1, OPAC, BG>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
-        return;
-    }
-#endif
     if constexpr (popcount_c(SMASK) <= 2)
         hipLaunchKernelGGL((render_backward_kernel5_w5<C, CS, DMASK, SMASK, OPAC, BG>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
     else
@@ -1061,10 +1027,6 @@ hipError_t launch_render_forward(const SplatCamera &cam, const SplatGaussians &g
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
     const float *col = colour_source(g, st);
     if (T == 0) return hipSuccess;
-#if defined(SPLAT_EXPERIMENTS)
-    if (g_debug_composite_version == 4) return launch_render_forward_v4(cam, col, g.channels, st, out_color, out_depth, s);
-    if (g_debug_composite_version == 2 && g.channels == 3) return launch_render_forward_v2(cam, col, st, out_color, out_depth, s);
-#endif
     switch (g.channels) {
         case 1: launch_fwd<1, 1, true>(cam, col, st, out_color, out_depth, T, s); break;
         case 2: launch_fwd<2, 2, true>(cam, col, st, out_color, out_depth, T, s); break;
@@ -1086,10 +1048,6 @@ hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &
     hipError_t e = hipMemsetAsync(gr.accum, 0, sizeof(float) * SPLAT_GRAD_STRIDE * (size_t)g.P, s);
     if (e != hipSuccess) return e;
     if (T == 0 || g.P == 0) return hipSuccess;
-#if defined(SPLAT_EXPERIMENTS)
-    if (g_debug_composite_version == 4) return launch_render_backward_v4(cam, col, g.channels, st, gr.dL_dcolor, gr.accum, s);
-    if (g_debug_composite_version == 2 && g.channels == 3) return launch_render_backward_v2(cam, col, st, gr.dL_dcolor, gr.accum, s);
-#endif
     switch (g.channels) {
         case 1: launch_bwd<1, 1>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
         case 2: launch_bwd<2, 2>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
@@ -1118,9 +1076,6 @@ hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat
     const int T = launch_tiles(cam, st);
     if (ep_done) *ep_done = false;
     if (T == 0) return hipSuccess;
-#if defined(SPLAT_EXPERIMENTS)
-    if (g_debug_composite_version == 4) return launch_render_forward_feat8_v4(cam, feat8, st, out6, sort_in_kernel, s);
-#endif
     const int per = (T + 7) / 8;
     if (ep && ep_done) {
         if (sort_in_kernel)
@@ -1145,9 +1100,6 @@ hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *fea
         if (e != hipSuccess) return e;
     }
     if (T == 0 || P == 0) return hipSuccess;
-#if defined(SPLAT_EXPERIMENTS)
-    if (g_debug_composite_version == 4) return launch_render_backward_feat8_v4(cam, feat8, st, dL_dout6, accum, rgb_sums, s);
-#endif
     // channels r, g, b, z carry gradient; the silhouette and depth^2 planes never do.  dL/drgb is only summed on request
     // (tracking does not read it: LR 0 in /root/reference/configs/*/splatam.py, optimizer discarded after the frame).
     // (zero background: FusedEngine refuses anything else, as setup_camera builds it)

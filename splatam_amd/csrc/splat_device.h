@@ -60,6 +60,7 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
 hipError_t launch_iter_finish(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame, const SplatLossConfig &cfg,
                               SplatIterWorkspace &ws, hipStream_t s, const SplatPoseAdam *pose_adam);
 hipError_t launch_iter_adam_map(const SplatMap &map, const SplatAdamMap &opt, hipStream_t s);
+hipError_t launch_iter_fold_sums(double *sums, hipStream_t s);
 hipError_t launch_iter_adam_pose(const SplatMap &map, int time_idx, const float *d_cam, float *state, float beta1, float beta2,
                                  float eps, float bc2_sqrt, float ss_rot, float ss_trans, hipStream_t s);
 hipError_t launch_iter_render(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame, SplatIterWorkspace &ws,
@@ -75,9 +76,6 @@ hipError_t launch_render_backward_rgb_only(const SplatCamera &cam, const float *
 size_t map_scratch_words(long long n);
 int map_row_floats(const SplatMapStore &st);
 extern int g_debug_skip_count;
-extern int g_debug_composite_version;
-extern int g_debug_entries_per_trip;
-extern int g_debug_k7_generation;
 hipError_t launch_selftest(int which, const void *in, void *out, int n, hipStream_t s);
 
 #if defined(__HIPCC__)

@@ -224,6 +224,15 @@ def any_rank(flag: bool, device=None, group=None) -> bool:
     return bool(int(t[0]))
 
 
+def max_int(value: int, device=None, group=None) -> int:
+    """The largest ``value`` over the ranks (a no-op for a single process)."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t[0])
+
+
 def tile_row_band(tile_rows: int, rank: int, world: int):
     """Rows [begin, end) of a ``tile_rows``-row tile grid that rank ``rank`` composites in tile-row-sharded tracking: contiguous,
     disjoint, covering, sizes differing by at most one."""

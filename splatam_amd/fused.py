@@ -29,13 +29,15 @@ VARIABLE_KEYS = ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")
 
 
 class FusedEngine:
-    def __init__(self, params, cam, capacity=None, track_max_radius=None, gaussian_capacity=None, variables=None):
+    def __init__(self, params, cam, capacity=None, track_max_radius=None, gaussian_capacity=None, variables=None, row_headroom=0.0):
         """params: the reference's dict of float32 CUDA tensors / Parameters (updated in place);
         cam: a GaussianRasterizationSettings; capacity: (Gaussian, tile) instances the lists can hold;
         gaussian_capacity: rows the map may grow to.  When given, the five Gaussian tensors (and ``variables``' per-Gaussian
         entries) move into capacity-sized backing arrays owned by the engine and ``params[k]`` / ``variables[k]`` become
         views of their first P rows, re-made after every ``add_new_gaussians`` / ``prune_gaussians`` -- the reference
-        replaces the dict entries at the same places (/root/reference/scripts/splatam.py:410-411)."""
+        replaces the dict entries at the same places (/root/reference/scripts/splatam.py:410-411).
+        row_headroom (engines that do NOT own the map): the per-Gaussian scratch is allocated for (1 + row_headroom) x P rows, so
+        that ``rebind`` to a map the caller has grown (splatam_amd.plugin) need not re-allocate it."""
         self.L = _capi.lib()
         self.params = params
         self.variables = variables
@@ -52,7 +54,7 @@ class FusedEngine:
         self.P = P
         self.iso = params['log_scales'].shape[1] == 1
         self.managed = gaussian_capacity is not None
-        self.Pcap = max(int(gaussian_capacity), P) if self.managed else P
+        self.Pcap = max(int(gaussian_capacity), P) if self.managed else int(P * (1.0 + float(row_headroom)))
         self.store = None
         if self.managed:
             self._adopt(params, variables)
@@ -89,7 +91,7 @@ class FusedEngine:
         b['accum'] = torch.zeros(P_alloc, _capi.SPLAT_GRAD_STRIDE, dtype=f32, **z)
         b['ssim_maps'] = torch.empty(9, H, W, dtype=f32, **z)
         b['sums'] = torch.zeros(_capi.SPLAT_ITER_SUM_COPIES * _capi.SPLAT_ITER_SUMS, dtype=torch.float64, **z)
-        b['d_cam'] = torch.zeros(16, dtype=f32, **z)
+        b['d_cam'] = torch.zeros(_capi.SPLAT_ITER_DCAM, dtype=f32, **z)
         b['pose_state'] = torch.zeros(_capi.SPLAT_POSE_STATE, dtype=f32, **z)
         self.max_2D_radius = self.store['max_2D_radius'] if self.managed else track_max_radius
         b['counts'] = torch.zeros(8, dtype=i32, **z)
@@ -125,6 +127,9 @@ class FusedEngine:
         self._cam = self._make_cam(cam)
         self._cam_ok = {}
         self._frame_keep = None
+        self.fold_sums = os.environ.get("SPLAT_FOLD_SUMS", "1") != "0"     # tile-row-sharded tracking: exchange 256 B instead of 16 KB
+        self.skipped_iterations = 0     # of the last check_overflow() / digest_report(): iterations whose Adam step the device skipped
+        self._learnt_P = None           # rows of the map the list statistics were learnt on (rebind keeps them for a similar map)
 
     # ------------------------------------------------------------------ capacity-managed map
     def _adopt(self, params, variables):
@@ -167,6 +172,47 @@ class FusedEngine:
         self.reduce_flat = self.grad_flat[:(sum(self._widths) - 4) * P] if self.iso else self.grad_flat
         self.exp_avg = {k: self._m_store[k][:P] for k in PARAM_ORDER}
         self.exp_avg_sq = {k: self._v_store[k][:P] for k in PARAM_ORDER}
+
+    def rebind(self, params, track_max_radius=None, keep_lists_within=0.10):
+        """The caller replaced its tensors (the reference's add_new_gaussians / remove_points re-create every parameter:
+        /root/reference/scripts/splatam.py:410-411, /root/reference/utils/slam_external.py:139-162): point the engine at the new
+        ones.  The workspace (per-pixel planes, lists, records), the list statistics and the bucket stride are KEPT when the number
+        of rows moved by less than ``keep_lists_within`` of the rows they were learnt on -- an engine built from scratch starts on
+        exact lists (scan + scatter + sort launches) and re-learns them through a host read.  Engines that own their map
+        (gaussian_capacity) are edited through add_new_gaussians / remove_points instead."""
+        if self.managed:
+            raise RuntimeError("rebind is for engines on caller-owned tensors")
+        dev = self.dev
+        for k in PARAM_ORDER + ("cam_unnorm_rots", "cam_trans"):
+            t = params[k]
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+                raise RuntimeError(f"params['{k}'] must be a contiguous float32 tensor on {dev}")
+        if (params['log_scales'].shape[1] == 1) != self.iso or params['cam_unnorm_rots'].shape[-1] != self.num_frames:
+            raise RuntimeError("rebind: the map's layout (isotropy, number of frames) differs from the engine's")
+        P = int(params['means3D'].shape[0])
+        self.params = params
+        self.max_2D_radius = track_max_radius
+        if P > self.Pcap:
+            # per-Gaussian scratch for the grown map (+12.5 %: the next few edits fit); accum must be zero, the others are written
+            # by the per-Gaussian kernel before they are read
+            cap = P + P // 8 + 1024
+            f32, i32, b = torch.float32, torch.int32, self.buf
+            for k, shape, dt in (('conic', (4,), f32), ('xy', (2,), f32), ('rect', (2,), i32), ('depth', (), f32), ('radii', (), i32),
+                                 ('feat8', (8,), f32), ('accum', (_capi.SPLAT_GRAD_STRIDE,), f32)):
+                b[k] = torch.zeros((cap,) + shape, dtype=dt, device=dev)
+            self._grad_store = torch.zeros(sum(self._widths) * cap, dtype=f32, device=dev)
+            self._m_store = {k: torch.zeros(cap, w, dtype=f32, device=dev) for k, w in zip(PARAM_ORDER, self._widths)}
+            self._v_store = {k: torch.zeros(cap, w, dtype=f32, device=dev) for k, w in zip(PARAM_ORDER, self._widths)}
+            self.Pcap = cap
+        changed = P != self.P
+        self.P = P
+        self._layout_rows()
+        if changed:
+            ref = self._learnt_P
+            if ref is None or abs(P - ref) > keep_lists_within * max(ref, 1):
+                self.tile_stride = 0
+                self.max_list_hint = 0
+        return self
 
     def _grow_rows(self, new_cap):
         """Re-allocate every per-Gaussian array for ``new_cap`` rows (contents of the first P rows kept)."""
@@ -633,19 +679,24 @@ class FusedEngine:
         from .dist import tile_row_band
         return tile_row_band((self.H + 15) // 16, rank, world)
 
-    def _adam_map_args(self, lrs, beta1=0.9, beta2=0.999, eps=1e-15):
+    def _adam_map_args(self, lrs, beta1=0.9, beta2=0.999, eps=1e-15, steps=None):
         """The next step of torch.optim.Adam(param_groups, lr=0.0, eps=1e-15) over the five Gaussian groups
-        (/root/reference/scripts/splatam.py:160-166).  Bias corrections in double on the host, as torch forms them."""
-        self.map_step += 1
-        t = self.map_step
-        bc1, bc2 = 1.0 - beta1 ** t, 1.0 - beta2 ** t
+        (/root/reference/scripts/splatam.py:160-166).  Bias corrections in double on the host, as torch forms them; ``steps``:
+        the step count of each group AFTER this step (torch counts per parameter: a parameter the caller re-created restarts),
+        default: the engine's own count for all five.  The step is gated on the iteration's capacity flag (d_cam[12])."""
+        if steps is None:
+            self.map_step += 1
+            steps = (self.map_step,) * 5
         o = _capi.SplatAdamMap()
-        o.beta1, o.beta2, o.eps, o.bc2_sqrt = beta1, beta2, eps, math.sqrt(bc2)
+        o.beta1, o.beta2, o.eps = beta1, beta2, eps
         for k, name in enumerate(PARAM_ORDER):
-            o.step_size[k] = lrs[name] / bc1
+            t = max(int(steps[k]), 1)
+            o.bc2_sqrt[k] = math.sqrt(1.0 - beta2 ** t)
+            o.step_size[k] = lrs[name] / (1.0 - beta1 ** t)
             o.grad[k] = self.grads[name].data_ptr()
             o.exp_avg[k] = self.exp_avg[name].data_ptr()
             o.exp_avg_sq[k] = self.exp_avg_sq[name].data_ptr()
+        o.gate = self.buf['d_cam'].data_ptr()
         return o
 
     def adam_map(self, lrs, beta1=0.9, beta2=0.999, eps=1e-15):
@@ -713,7 +764,13 @@ class FusedEngine:
         if cfg['ignore_outlier_depth_loss']:
             raise RuntimeError("tile-row-sharded tracking needs a pixel-local loss: not with ignore_outlier_depth_loss")
         self.loss_backward(curr_data, self.track_time_idx, cfg, tracking=True, tile_rows=self.tile_row_band(*shard))
-        allreduce_sums(self.buf['sums'])
+        if self.fold_sums:
+            # the 64 copies of the partial sums folded into the first (one tiny launch): the exchange carries 256 bytes, not 16 KB
+            with torch.cuda.device(self.dev):
+                _capi.check(self.L.splat_iter_fold_sums(self.buf['sums'].data_ptr(), self._stream()), "splat_iter_fold_sums")
+            allreduce_sums(self.buf['sums'][:_capi.SPLAT_ITER_SUMS])
+        else:
+            allreduce_sums(self.buf['sums'])
         self.finish_iteration(pa)
 
     def mapping_iteration(self, iter_data, iter_time_idx, cfg, bucket_allreduce=None):
@@ -760,15 +817,29 @@ class FusedEngine:
 
     def check_overflow(self, grow=True):
         """Lists are fixed-size; an iteration whose instances did not fit rendered truncated / empty lists and flagged
-        it (stickily).  Call at frame end (one D2H read): returns True when an iteration since the last call has to
-        be repeated.  Also learns the list statistics: from then on the per-tile lists are BUCKETED at 1.5x the longest
+        it (stickily; from then on the device skips every Adam step: nothing moves on bad lists).  Call at frame end (two small
+        D2H reads): returns True when iterations since the last call were flagged -- ``self.skipped_iterations`` says how many
+        took no step.  Also learns the list statistics: from then on the per-tile lists are BUCKETED at 1.5x the longest
         list seen (the per-Gaussian kernel writes instances straight into their tile's bucket: no scan kernel, no
         scatter pass) and the long-list sort launch is skipped while lists stay short."""
         stat = self.buf['status'].tolist()
-        sticky = float(self.buf['d_cam'][12]) != 0.0
+        rep = self.buf['d_cam'].cpu()
+        return self._digest(stat, float(rep[12]) != 0.0, int(rep.view(torch.int32)[21]), grow)
+
+    def digest_report(self, report, grow=True):
+        """check_overflow() from a HOST copy of an iteration's report (``buf['d_cam']``, SPLAT_ITER_DCAM floats: the status words
+        the iteration left are in [16..19]) -- for callers that fetch the report asynchronously (splatam_amd.plugin): no
+        blocking read here.  Only valid for reports of whole iterations (their last kernel writes the snapshot)."""
+        ints = report.view(torch.int32)
+        return self._digest(ints[16:20].tolist(), float(report[12]) != 0.0, int(ints[21]), grow, hysteresis=True)
+
+    def _digest(self, stat, sticky, skipped, grow, hysteresis=False):
         bad = sticky or stat[1] != 0 or stat[3] != 0 or (self.tile_stride == 0 and stat[0] > self.capacity)
+        self.skipped_iterations = 0
         if bad:
+            self.skipped_iterations = max(int(skipped), 1)
             self.buf['d_cam'][12] = 0.0
+            self.buf['d_cam'][21] = 0.0             # (an int32 counter: the bit pattern of 0.0 is 0)
             self.buf['status'].zero_()
             self.buf['tile_count'].zero_()
             self.buf['group_count'].zero_()
@@ -785,11 +856,16 @@ class FusedEngine:
             return False
         longest = int(stat[2])
         self.max_list_hint = longest            # short lists: sorted inside the composite, no sort launch
+        self._learnt_P = self.P
         self._set_sub_bins(16 if longest > 2048 else 1)
         if grow and self.allow_buckets and longest > 0:
             stride = max(256, (int(longest * 1.5) + 63) // 64 * 64)
             # buckets cost 20 bytes per slot (keys, their merge partner, sorted ids): up to ~15 GB of the 288 GB for the clustered
             # stress scenes (337 M slots at 5 M Gaussians) -- one returning atomic per instance instead of count + scan + scatter
+            # (reports digested every iteration: the stride only moves when the margin has become thin or the buckets far too wide --
+            #  a stride that follows every fluctuation of the longest list would re-lay the buckets iteration by iteration)
+            if hysteresis and self.tile_stride > 0 and longest * 5 // 4 <= self.tile_stride <= 2 * stride:
+                stride = self.tile_stride
             if stride != self.tile_stride and stride * self.num_tiles <= 768 * 1024 * 1024:
                 if stride * self.num_tiles > self.capacity:
                     self._alloc_lists(stride * self.num_tiles)

@@ -178,6 +178,11 @@ class SyntheticRGBDSequence:
     def __len__(self):
         return self.num_frames
 
+    def preload(self):
+        """Render every frame once and keep it (a real dataset hands over loaded images; without this every ``dataset[t]`` renders)."""
+        self._cache = {t: self._item(t) for t in range(self.num_frames)}
+        return self
+
     def gt_w2c(self, t):
         q = F.normalize(self._scene['cam_unnorm_rots'][..., t].detach())
         w2c = torch.eye(4, device=self.device)
@@ -186,6 +191,10 @@ class SyntheticRGBDSequence:
         return w2c
 
     def __getitem__(self, t):
+        cache = getattr(self, "_cache", None)
+        return cache[t] if cache is not None and t in cache else self._item(t)
+
+    def _item(self, t):
         im, depth = self._render(t)
         pose = torch.inverse(self.gt_w2c(t))
         return (im.permute(1, 2, 0) * 255.0).contiguous(), depth.permute(1, 2, 0).contiguous(), self.k, pose
@@ -231,15 +240,55 @@ def initialize_first_timestep(dataset, num_frames, scene_radius_depth_ratio, mea
     return params, variables, intrinsics, w2c, cam
 
 
+class _PhaseTimer:
+    """Wall time per named phase of the frame being processed (a device synchronisation on either side: ~10 per frame)."""
+
+    def __init__(self, dev):
+        self.dev, self.frame, self._open = dev, {}, []
+
+    def _sync(self):
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+
+    def __call__(self, name):
+        self._name = name
+        return self
+
+    def __enter__(self):
+        self._sync()
+        self._open.append((self._name, time.perf_counter()))
+
+    def __exit__(self, *exc):
+        self._sync()
+        name, t0 = self._open.pop()
+        self.frame[name] = self.frame.get(name, 0.0) + 1e3 * (time.perf_counter() - t0)
+
+    def next_frame(self):
+        done, self.frame = self.frame, {}
+        return {k: round(v, 3) for k, v in done.items()}
+
+
 def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacity=None, verbose=False):
     """Runs the SplaTAM frame loop over ``dataset``; returns ``(params, variables, stats)`` with
     ``stats = {keyframe_time_indices, tracking_iters, mapping_iters, tracking_s, mapping_s, mapping_loop_s, num_gaussians,
-    redone_frames}`` (``mapping_loop_s``: the iterations alone, where the reference's own mapping timer runs, scripts/splatam.py:825-891;
-    ``mapping_s`` also holds densification, keyframe selection and list re-learning).
+    redone_iterations, phase_ms}`` (``mapping_loop_s``: the iterations alone, where the reference's own mapping timer runs,
+    scripts/splatam.py:825-891; ``mapping_s`` also holds densification, keyframe selection and list re-learning; ``phase_ms``: one
+    dict per frame -- tracking, add_new_gaussians, keyframe_selection, relearn_lists, mapping_iterations, prune, keyframe_store).
+
+    ``engine``: "fused" (FusedEngine: every iteration one C call, the map edited in place on the device), "dropin" (the
+    reference-shaped PyTorch loop of splatam_amd.slam on the drop-in rasterizer), or "plugin": the SAME reference-shaped loop -- its
+    ``add_new_gaussians`` / ``prune_gaussians`` / ``remove_points`` re-create every tensor, its statements are get_loss -> backward ->
+    prune -> step -- with ``splatam_amd.plugin`` installed into the module that holds it, i.e. what
+    /root/reference/scripts/splatam.py:654-905 executes after ``plugin.install``.
+
+    Per-tile list overflow (fused): a flagged iteration and every iteration after it take NO Adam step on the device
+    (include/splat_hip.h, d_cam[12]); at the end of a phase ``check_overflow()`` says how many, the lists are re-sized and exactly
+    that many iterations are run again -- the pose / the map never saw a bad gradient, so nothing has to be restored.
 
     With ``torch.distributed`` initialised (one process per GPU, splatam_amd.dist.init_from_env) the loop runs on every rank
     over the REPLICATED map:
-      * tracking: replicas only -- every rank tracks the frame; rank 0's pose is then broadcast (7 floats), because the float
+      * tracking: the frame's tile rows are sharded over the ranks (every rank takes the same Adam step); with the outlier-rejecting
+        loss every rank tracks the whole frame and rank 0's pose is then broadcast (7 floats), because the float
         atomics of the backward composite leave the replicas' poses different in the last bits and the densification that follows
         thresholds a render at that pose;
       * mapping: every iteration draws ``world`` keyframe views instead of one (the same random stream on every rank, the
@@ -247,10 +296,12 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
         rank r renders the r-th, ONE gradient all-reduce (mean) follows, and every rank takes the identical Adam step;
       * after every edit of the map (densification, pruning) the row counts of the replicas are compared (all-reduce of min / max)."""
     from . import dist as sdist
-    if engine not in ("fused", "dropin"):
+    if engine not in ("fused", "dropin", "plugin"):
         raise ValueError(engine)
     fused = engine == "fused"
     world, rank = sdist.world_size(), sdist.get_rank()
+    if engine == "plugin" and world > 1:
+        raise NotImplementedError("engine='plugin' runs the reference's single-process loop")
     num_frames = len(dataset) if num_frames is None else min(num_frames, len(dataset))
     tcfg, mcfg = config['tracking'], config['mapping']
     if mcfg.get('use_gaussian_splatting_densification') and not fused:
@@ -295,111 +346,110 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
         dev = params['means3D'].device
         first_frame_w2c = first_frame_w2c.to(dev).float().contiguous()
     keyframe_list, keyframe_time_indices = [], []
-    stats = dict(tracking_iters=0, mapping_iters=0, tracking_s=0.0, mapping_s=0.0, mapping_loop_s=0.0, redone_frames=0, num_gaussians=[])
+    stats = dict(tracking_iters=0, mapping_iters=0, tracking_s=0.0, mapping_s=0.0, mapping_loop_s=0.0, redone_iterations=0,
+                 num_gaussians=[], phase_ms=[], frame_s=[])
+    phase = _PhaseTimer(dev)
+    installed = None
+    if engine == "plugin":
+        from . import plugin
+        installed = plugin.install(slam)
+    try:
+        for time_idx in range(num_frames):
+            t_frame = time.perf_counter()
+            color, depth, _, gt_pose = dataset[time_idx]
+            color = (color.permute(2, 0, 1) / 255).contiguous()
+            depth = depth.permute(2, 0, 1).contiguous()
+            curr_data = {'cam': cam, 'im': color, 'depth': depth, 'id': time_idx, 'intrinsics': intrinsics, 'w2c': first_frame_w2c}
+            if time_idx > 0:
+                slam.initialize_camera_pose(params, time_idx, forward_prop=tcfg['forward_prop'])
 
-    def sync():
-        if dev.type == "cuda":
-            torch.cuda.synchronize(dev)
+            # ---------------- tracking (scripts/splatam.py:676-744)
+            with phase("tracking"):
+                t0 = time.perf_counter()
+                if time_idx > 0 and not tcfg['use_gt_poses']:
+                    if engine == "plugin":
+                        n_track, variables = _track_frame_statements(params, variables, curr_data, time_idx, tcfg)
+                    else:
+                        n_track = _track_frame(params, variables, curr_data, time_idx, tcfg, eng, stats)
+                    stats['tracking_iters'] += n_track
+                    sdist.broadcast_pose(params, time_idx)              # replicas: one pose for the map edits that follow
+                elif time_idx > 0:
+                    with torch.no_grad():
+                        rel = torch.linalg.inv(gt_pose).to(dev)
+                        params['cam_unnorm_rots'][..., time_idx] = _matrix_to_quaternion(rel[:3, :3])
+                        params['cam_trans'][..., time_idx] = rel[:3, 3]
+            stats['tracking_s'] += time.perf_counter() - t0
 
-    for time_idx in range(num_frames):
-        color, depth, _, gt_pose = dataset[time_idx]
-        color = (color.permute(2, 0, 1) / 255).contiguous()
-        depth = depth.permute(2, 0, 1).contiguous()
-        curr_data = {'cam': cam, 'im': color, 'depth': depth, 'id': time_idx, 'intrinsics': intrinsics, 'w2c': first_frame_w2c}
-        if time_idx > 0:
-            slam.initialize_camera_pose(params, time_idx, forward_prop=tcfg['forward_prop'])
-
-        # ---------------- tracking (scripts/splatam.py:676-744)
-        sync()
-        t0 = time.perf_counter()
-        if time_idx > 0 and not tcfg['use_gt_poses']:
-            pose0 = (params['cam_unnorm_rots'].detach()[..., time_idx].clone(), params['cam_trans'].detach()[..., time_idx].clone())
-            for attempt in range(3):
-                n_track = _track_frame(params, variables, curr_data, time_idx, tcfg, eng)
-                # (sharded tracking: a rank's lists cover its band only -- the decision to redo the frame is taken together)
-                if not fused or not sdist.any_rank(eng.check_overflow(), dev):
-                    break
-                if attempt == 2:
-                    raise RuntimeError(f"frame {time_idx}: the per-tile lists overflowed three times in a row")
-                # a tile list overflowed its bucket: the engine has re-sized / gone back to exact lists; redo the frame
-                stats['redone_frames'] += 1
-                with torch.no_grad():
-                    params['cam_unnorm_rots'][..., time_idx] = pose0[0]
-                    params['cam_trans'][..., time_idx] = pose0[1]
-            stats['tracking_iters'] += n_track
-            sdist.broadcast_pose(params, time_idx)              # replicas: one pose for the map edits that follow
-        elif time_idx > 0:
-            with torch.no_grad():
-                rel = torch.linalg.inv(gt_pose).to(dev)
-                params['cam_unnorm_rots'][..., time_idx] = _matrix_to_quaternion(rel[:3, :3])
-                params['cam_trans'][..., time_idx] = rel[:3, 3]
-        sync()
-        stats['tracking_s'] += time.perf_counter() - t0
-
-        # ---------------- densification + keyframe mapping (scripts/splatam.py:768-891)
-        if time_idx == 0 or (time_idx + 1) % config['map_every'] == 0:
-            t0 = time.perf_counter()
-            if mcfg['add_new_gaussians'] and time_idx > 0:
+            # ---------------- densification + keyframe mapping (scripts/splatam.py:768-891)
+            if time_idx == 0 or (time_idx + 1) % config['map_every'] == 0:
+                t0 = time.perf_counter()
+                if mcfg['add_new_gaussians'] and time_idx > 0:
+                    with phase("add_new_gaussians"):
+                        if fused:
+                            eng.add_new_gaussians(curr_data, mcfg['sil_thres'], time_idx, config['mean_sq_dist_method'], dist_kind)
+                        else:
+                            params, variables = slam.add_new_gaussians(params, variables, curr_data, mcfg['sil_thres'], time_idx,
+                                                                       config['mean_sq_dist_method'], dist_kind)
+                    sdist.assert_replicated_count(int(params['means3D'].shape[0]), f"add_new_gaussians (frame {time_idx})", dev)
+                with phase("keyframe_selection"), torch.no_grad():
+                    curr_w2c = _est_w2c(params, time_idx)
+                    selected = keyframe_selection_overlap(depth, curr_w2c, intrinsics.to(dev), keyframe_list[:-1],
+                                                          config['mapping_window_size'] - 2)
+                    if len(keyframe_list) > 0:
+                        selected.append(len(keyframe_list) - 1)
+                    selected.append(-1)
                 if fused:
-                    eng.add_new_gaussians(curr_data, mcfg['sil_thres'], time_idx, config['mean_sq_dist_method'], dist_kind)
-                else:
-                    params, variables = slam.add_new_gaussians(params, variables, curr_data, mcfg['sil_thres'], time_idx,
-                                                               config['mean_sq_dist_method'], dist_kind)
-                sdist.assert_replicated_count(int(params['means3D'].shape[0]), f"add_new_gaussians (frame {time_idx})", dev)
-            with torch.no_grad():
-                curr_w2c = _est_w2c(params, time_idx)
-                selected = keyframe_selection_overlap(depth, curr_w2c, intrinsics.to(dev), keyframe_list[:-1],
-                                                      config['mapping_window_size'] - 2)
-                if len(keyframe_list) > 0:
-                    selected.append(len(keyframe_list) - 1)
-                selected.append(-1)
-            if fused:
-                eng.relearn_lists(curr_data, time_idx)
-                snap = {k: eng.store[k][:eng.P].clone() for k in slam.GAUSSIAN_KEYS}
-                snap_vars = {k: eng.store[k][:eng.P].clone() for k in ('max_2D_radius', 'means2D_gradient_accum', 'denom', 'timestep')}
-                rng_state = np.random.get_state()
-            sync()
-            t_loop = time.perf_counter()                        # the reference's mapping timer starts here (scripts/splatam.py:825)
-            for attempt in range(3):
-                _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, mcfg, eng,
-                           scene_radius if fused else None)
-                # (ranks render different views: whether the frame's mapping is repeated is decided together)
-                if not fused or not sdist.any_rank(eng.check_overflow(), dev):
-                    break
-                if attempt == 2:
-                    raise RuntimeError(f"frame {time_idx}: the per-tile lists overflowed three times in a row")
-                stats['redone_frames'] += 1
-                np.random.set_state(rng_state)
-                eng._set_rows(snap['means3D'].shape[0])
-                with torch.no_grad():
-                    for k, v in {**snap, **snap_vars}.items():
-                        eng.store[k][:eng.P] = v
-                eng.allow_buckets = False               # exact lists for the repeat: they cannot overflow a bucket
-                eng.relearn_lists(curr_data, time_idx)
-            if fused:
-                eng.allow_buckets = True
-            stats['mapping_iters'] += mcfg['num_iters']
-            sync()
-            stats['mapping_s'] += time.perf_counter() - t0
-            stats['mapping_loop_s'] += time.perf_counter() - t_loop
+                    with phase("relearn_lists"):
+                        eng.relearn_lists(curr_data, time_idx)
+                if dev.type == "cuda":
+                    torch.cuda.synchronize(dev)
+                t_loop = time.perf_counter()                        # the reference's mapping timer starts here (scripts/splatam.py:825)
+                t_prune0 = phase.frame.get("prune", 0.0)
+                with phase("mapping_iterations"):
+                    _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, mcfg, eng,
+                               scene_radius if fused else None, stats, phase)
+                # (the prune phase is timed inside the loop: report the iterations without it)
+                phase.frame["mapping_iterations"] -= phase.frame.get("prune", 0.0) - t_prune0
+                stats['mapping_iters'] += mcfg['num_iters']
+                stats['mapping_s'] += time.perf_counter() - t0
+                stats['mapping_loop_s'] += time.perf_counter() - t_loop
 
-        # ---------------- keyframe list (scripts/splatam.py:893-905)
-        if time_idx == 0 or (time_idx + 1) % config['keyframe_every'] == 0 or time_idx == num_frames - 2:
-            with torch.no_grad():
-                keyframe_list.append({'id': time_idx, 'est_w2c': _est_w2c(params, time_idx), 'color': color, 'depth': depth})
-                keyframe_time_indices.append(time_idx)
-        stats['num_gaussians'].append(int(params['means3D'].shape[0]))
-        if verbose:
-            print(f"frame {time_idx}: {stats['num_gaussians'][-1]} Gaussians, keyframes {keyframe_time_indices}", flush=True)
+            # ---------------- keyframe list (scripts/splatam.py:893-905)
+            if time_idx == 0 or (time_idx + 1) % config['keyframe_every'] == 0 or time_idx == num_frames - 2:
+                with phase("keyframe_store"), torch.no_grad():
+                    keyframe_list.append({'id': time_idx, 'est_w2c': _est_w2c(params, time_idx), 'color': color, 'depth': depth})
+                    keyframe_time_indices.append(time_idx)
+            stats['num_gaussians'].append(int(params['means3D'].shape[0]))
+            stats['phase_ms'].append(phase.next_frame())
+            stats['frame_s'].append(time.perf_counter() - t_frame)
+            if verbose:
+                print(f"frame {time_idx}: {stats['num_gaussians'][-1]} Gaussians, keyframes {keyframe_time_indices}", flush=True)
+    finally:
+        if installed is not None:
+            from . import plugin
+            stats['plugin'] = plugin.session_stats()
+            installed.uninstall()
     stats['keyframe_time_indices'] = keyframe_time_indices
     return params, variables, stats
 
 
-def _track_frame(params, variables, curr_data, time_idx, tcfg, eng):
+def _settle_lists(eng, dev, stats, what):
+    """End of a phase on the fused engine: were iterations flagged (on any rank)?  Returns how many took no Adam step -- the lists
+    have been re-sized; the caller runs that many again."""
+    from . import dist as sdist
+    if not sdist.any_rank(eng.check_overflow(), dev):
+        return 0
+    lost = sdist.max_int(eng.skipped_iterations, dev)
+    stats['redone_iterations'] += lost
+    if stats['redone_iterations'] > 100000:
+        raise RuntimeError(f"{what}: the per-tile lists keep overflowing")
+    return max(lost, 1)
+
+
+def _track_frame(params, variables, curr_data, time_idx, tcfg, eng, stats):
     """Tracking iterations of one frame incl. the reference's doubling of the budget when the depth loss stays above
     ``depth_loss_thres`` (scripts/splatam.py:727-735).  Returns the number of iterations run."""
     num_iters = tcfg['num_iters']
-    it, doubled = 0, False
     if eng is not None:
         eng.begin_tracking(time_idx)
     else:
@@ -409,27 +459,72 @@ def _track_frame(params, variables, curr_data, time_idx, tcfg, eng):
     # takes the same Adam step on the pose (FusedEngine.tracking_iteration); the outlier-rejecting loss needs the whole render
     from . import dist as sdist
     world, rank = sdist.world_size(), sdist.get_rank()
+    dev = params['cam_trans'].device
     shard = (rank, world) if (eng is not None and world > 1 and not tcfg['ignore_outlier_depth_loss']) else None
-    while True:
+    it, todo, doubled, rounds = 0, num_iters, False, 0
+    while todo:
+        for _ in range(todo):
+            if eng is not None:
+                eng.tracking_iteration(curr_data, tcfg, shard=shard, allreduce_sums=sdist.all_reduce_sum_flat)
+            else:
+                loss, _ = slam.tracking_iteration(params, curr_data, variables, time_idx, optimizer, state, tcfg)
+        it += todo
+        todo = 0
         if eng is not None:
-            eng.tracking_iteration(curr_data, tcfg, shard=shard, allreduce_sums=sdist.all_reduce_sum_flat)
-        else:
-            loss, _ = slam.tracking_iteration(params, curr_data, variables, time_idx, optimizer, state, tcfg)
-        it += 1
-        if it == num_iters:
-            if not tcfg.get('use_depth_loss_thres', False):
-                break
-            depth_loss = (tcfg['loss_weights']['depth'] * float(eng.buf['d_cam'][8])) if eng is not None else float(_last_depth_loss(
+            lost = _settle_lists(eng, dev, stats, f"frame {time_idx} tracking")
+            if lost:
+                rounds += 1
+                if rounds > 3:
+                    raise RuntimeError(f"frame {time_idx}: the per-tile lists overflowed three times in a row")
+                eng.pose_step = max(eng.pose_step - lost, 0)     # (the skipped steps never happened: their bias corrections are taken again)
+                it -= lost
+                todo = lost
+                continue
+        if it == num_iters and tcfg.get('use_depth_loss_thres', False) and not doubled:
+            depth_loss = (float(eng.buf['d_cam'][14])) if eng is not None else float(_last_depth_loss(
                 params, curr_data, variables, time_idx, tcfg))
-            if depth_loss < tcfg['depth_loss_thres'] or doubled:
-                break
-            doubled = True
-            num_iters *= 2
+            if depth_loss >= tcfg['depth_loss_thres']:
+                doubled, todo = True, num_iters
     if eng is not None:
         eng.end_tracking()
     else:
         state.commit(params)
     return it
+
+
+def _track_frame_statements(params, variables, curr_data, time_idx, tcfg):
+    """The tracking phase in the reference's own statements (scripts/splatam.py:680-744: optimizer per frame, get_loss -> backward ->
+    step -> zero_grad, the host-side `if loss < current_min_loss`, the doubled budget) -- every name resolved in ``slam`` at call
+    time, so that ``plugin.install(slam)`` is what runs."""
+    optimizer = slam.initialize_optimizer(params, tcfg['lrs'], tracking=True)
+    candidate_rot = params['cam_unnorm_rots'][..., time_idx].detach().clone()
+    candidate_tran = params['cam_trans'][..., time_idx].detach().clone()
+    current_min_loss = float(1e20)
+    it, extended, budget = 0, False, tcfg['num_iters']
+    while True:
+        loss, variables, losses = slam.get_loss(params, curr_data, variables, time_idx, tcfg['loss_weights'], tcfg['use_sil_for_loss'],
+                                                tcfg['sil_thres'], tcfg['use_l1'], tcfg['ignore_outlier_depth_loss'], tracking=True)
+        loss.backward()
+        optimizer.step()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            if loss < current_min_loss:
+                current_min_loss = loss
+                candidate_rot = params['cam_unnorm_rots'][..., time_idx].detach().clone()
+                candidate_tran = params['cam_trans'][..., time_idx].detach().clone()
+        it += 1
+        if it == budget:
+            use_thres = tcfg.get('use_depth_loss_thres', False)
+            if use_thres and losses['depth'] < tcfg['depth_loss_thres']:
+                break
+            if use_thres and not extended:
+                extended, budget = True, 2 * budget
+            else:
+                break
+    with torch.no_grad():
+        params['cam_unnorm_rots'][..., time_idx] = candidate_rot
+        params['cam_trans'][..., time_idx] = candidate_tran
+    return it, variables
 
 
 def _last_depth_loss(params, curr_data, variables, time_idx, tcfg):
@@ -439,10 +534,12 @@ def _last_depth_loss(params, curr_data, variables, time_idx, tcfg):
     return wl['depth']
 
 
-def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, mcfg, eng, scene_radius):
+def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, mcfg, eng, scene_radius, stats, phase):
     """The mapping iterations of one frame over the selected keyframes + the current frame.  With ``world`` ranks every
     iteration draws ``world`` views from the SAME random stream on every rank; this rank renders its own one, the gradients are
-    averaged by one all-reduce, every rank takes the same Adam step and the same pruning decisions."""
+    averaged by one all-reduce, every rank takes the same Adam step and the same pruning decisions.
+    (Gradient-based densification accumulates the screen-space gradient of every iteration it sees, a flagged one included: its
+    statistic is then one truncated-list sample short -- the map itself never moves on a flagged iteration.)"""
     from . import dist as sdist
     world, rank = sdist.world_size(), sdist.get_rank()
     cam, intrinsics, w2c0 = curr_data['cam'], curr_data['intrinsics'], curr_data['w2c']
@@ -457,7 +554,9 @@ def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, 
         eng.reset_map_optimizer()
     else:
         optimizer = slam.initialize_optimizer(params, mcfg['lrs'], tracking=False)
-    for it in range(mcfg['num_iters']):
+
+    def iteration(it):
+        nonlocal bucket
         if world == 1:
             sel = selected[np.random.randint(0, len(selected))]
         else:
@@ -486,8 +585,9 @@ def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, 
                 # the colour pass' screen-space gradient is accumulated from THIS iteration's workspace (lists, radii, features
                 # indexed by the rows the render saw): before any row is removed
                 eng.accumulate_mean2d_gradient()
-            if prune:
-                edited = bool(eng.prune_gaussians(it, pd, scene_radius))
+            if prune and (on_schedule or resets):
+                with phase("prune"):
+                    edited = bool(eng.prune_gaussians(it, pd, scene_radius))
             if densifying:                                               # scripts/splatam.py:864-867
                 dd = mcfg['densify_dict']
                 dens_sched = it <= dd['stop_after'] and it >= dd['start_after'] and it % dd['densify_every'] == 0
@@ -495,7 +595,8 @@ def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, 
                 on_schedule = on_schedule or dens_sched                   # re-created parameters carry no gradient: no Adam step
             if edited:
                 sdist.assert_replicated_count(eng.P, f"map edit (frame {time_idx}, iteration {it})", dev)
-                eng.relearn_lists(curr_data, time_idx)
+                with phase("relearn_lists"):
+                    eng.relearn_lists(curr_data, time_idx)
             if not on_schedule:
                 eng.adam_map(mcfg['lrs'])
         else:
@@ -509,11 +610,29 @@ def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, 
             with torch.no_grad():
                 if prune:
                     n_before = params['means3D'].shape[0]
-                    slam.prune_gaussians(params, variables, optimizer, it, pd)
+                    if on_schedule or resets:
+                        with phase("prune"):
+                            slam.prune_gaussians(params, variables, optimizer, it, pd)
+                    else:                                       # (the reference calls it every iteration; off schedule it does nothing)
+                        slam.prune_gaussians(params, variables, optimizer, it, pd)
                     if params['means3D'].shape[0] != n_before:
                         sdist.assert_replicated_count(int(params['means3D'].shape[0]), f"prune_gaussians (frame {time_idx}, iteration {it})", dev)
                 optimizer.step()
                 optimizer.zero_grad(set_to_none=True)
+
+    it, todo, rounds = 0, mcfg['num_iters'], 0
+    while todo:
+        for _ in range(todo):
+            iteration(it)
+            it += 1
+        todo = 0
+        if eng is not None:
+            todo = _settle_lists(eng, dev, stats, f"frame {time_idx} mapping")
+            if todo:
+                rounds += 1
+                if rounds > 3:
+                    raise RuntimeError(f"frame {time_idx}: the per-tile lists overflowed three times in a row")
+                eng.map_step = max(eng.map_step - todo, 0)
 
 
 def _matrix_to_quaternion(R):

@@ -8,29 +8,43 @@
     optimizer.step()
     optimizer.zero_grad(set_to_none=True)
 
-with ``optimizer = initialize_optimizer(params, lrs, tracking=...)`` created per frame and phase (:680, :821).  Unmodified, on the
-drop-in rasterizer, one such iteration costs ~5 ms at BASELINE config B: ~100 small PyTorch launches around two rasterizer
-forwards and two backwards.  ``install(module)`` replaces the two names the loops resolve at call time in the module that holds
-them -- ``get_loss`` and ``initialize_optimizer`` -- so that the SAME statements run the fused iteration of ``FusedEngine``:
+with ``optimizer = initialize_optimizer(params, lrs, tracking=...)`` created per frame and phase (:680, :821), and around them
+``add_new_gaussians`` (:378-420) and ``prune_gaussians`` / ``remove_points`` (/root/reference/utils/slam_external.py:139-188)
+REPLACE every parameter tensor.  Unmodified, on the drop-in rasterizer, one iteration costs ~5 ms at BASELINE config B: ~100 small
+PyTorch launches around two rasterizer forwards and two backwards.  ``install(module)`` replaces the two names the loops resolve at
+call time in the module that holds them -- ``get_loss`` and ``initialize_optimizer`` -- so that the SAME statements run the fused
+iteration of ``FusedEngine``:
 
 * ``get_loss`` runs ``splat_iter_loss_backward`` (render, loss, every gradient) and returns a 0-dim loss tensor whose
   ``.backward()`` has nothing left to do, ``variables`` updated as the reference updates them (``seen``, ``max_2D_radius``), and the
-  weighted ``losses`` dict;
+  weighted ``losses`` dict (``depth``, ``im``, ``loss``: the three values the reference returns, :339-346);
 * ``initialize_optimizer`` returns a ``torch.optim.Adam`` (same ``param_groups`` / ``state`` layout, so the reference's own
   ``remove_points`` / ``cat_params_to_optimizer`` / ``update_params_and_optimizer`` keep working on it: they slice and re-attach
-  ``exp_avg`` / ``exp_avg_sq``) whose ``step()`` is one Adam kernel over the engine's gradients, on those very moment tensors.
-  A parameter the caller re-created between ``backward()`` and ``step()`` (pruning: a fresh nn.Parameter without ``.grad``) is
-  skipped by that step, as torch skips it.
+  ``exp_avg`` / ``exp_avg_sq``) whose ``step()`` is one Adam kernel over the engine's gradients, on those very moment tensors,
+  with torch's per-parameter step counts.  A parameter the caller re-created between ``backward()`` and ``step()`` (pruning: a
+  fresh nn.Parameter without ``.grad``) is skipped by that step, as torch skips it.
 
-The caller's dict of nn.Parameters stays the single copy of the map: the engine reads and updates it in place, and is rebuilt when
-the caller replaces the tensors (pruning, add_new_gaussians).  What the plug-in does NOT provide: ``variables['means2D'].grad``
-(gradient-based densification: ``use_gaussian_splatting_densification`` raises), non-zero learning rates for the Gaussians while
-tracking or for the poses while mapping (no shipped configuration has them; they raise).  Every ``get_loss`` checks the
-iteration's list capacity flags (one 16-byte read) and transparently repeats an iteration whose lists overflowed.
+The caller's dict of nn.Parameters stays the single copy of the map: the engine reads and updates it in place.  When the caller
+replaces the tensors the engine is RE-BOUND (``FusedEngine.rebind``): workspace, list statistics and bucket stride survive an edit
+that moves the row count by less than 10 %.
+
+No blocking read per iteration.  The per-tile lists have a fixed capacity; an iteration whose lists did not fit raises a flag ON THE
+DEVICE and every Adam kernel skips while it is up (include/splat_hip.h, ``SplatIterWorkspace.d_cam[12]``), so a bad iteration never
+moves the map or the pose.  The host learns of it
+  * from the iteration's 128-byte report, copied to pinned memory asynchronously after every ``get_loss`` and looked at (event
+    query, no wait) at the start of later calls: the lists are then re-sized and the loop goes on (mapping: the skipped iterations
+    are lost, ``session_stats()['skipped_iterations']``);
+  * or the moment the caller reads the loss value anyway (the tracking loop's ``if loss < current_min_loss``, :708): that ONE
+    read fetches the report too, and a flagged tracking iteration is repeated on the spot, invisibly to the caller.
+
+What the plug-in does NOT provide: ``variables['means2D'].grad`` (gradient-based densification:
+``use_gaussian_splatting_densification`` raises), non-zero learning rates for the Gaussians while tracking or for the poses while
+mapping (no shipped configuration has them; they raise).
 """
 from __future__ import annotations
 
 import ctypes as C
+import operator
 
 import torch
 
@@ -38,42 +52,181 @@ from . import _capi
 from .fused import PARAM_ORDER, FusedEngine
 
 _POSE_KEYS = ("cam_unnorm_rots", "cam_trans")
+_ALL_KEYS = PARAM_ORDER + _POSE_KEYS
+
+
+class _Report:
+    """One iteration's report (``d_cam``, SPLAT_ITER_DCAM floats) on the device, and its host copy once someone needed it."""
+    __slots__ = ("dev", "host", "args", "stepped", "digested")
+
+    def __init__(self, dev):
+        self.dev = dev              # device copy (the engine's own buffer is overwritten by the next iteration)
+        self.host = None            # list of floats, after the first read
+        self.args = None            # what get_loss was called with (a flagged tracking iteration is repeated from it)
+        self.stepped = False        # optimizer.step() ran on this iteration
+        self.digested = False
 
 
 class _FusedLoss(torch.Tensor):
-    """The loss value of an iteration whose gradients already exist: ``backward()`` is a no-op."""
+    """The loss value of an iteration whose gradients already exist: ``backward()`` is a no-op.  Reading the VALUE (comparison,
+    float(), item(), format) costs one device read, which also brings the iteration's capacity flags: see the module docstring."""
+
+    # torch functions see (and return) plain tensors: the overrides below are the whole of the subclass
+    __torch_function__ = torch._C._disabled_torch_function_impl
 
     def backward(self, *args, **kwargs):          # noqa: D401
         return None
 
+    # -- value reads: through the report, so that the flag check rides on the read the caller does anyway
+    def _value(self):
+        rep = getattr(self, "_report", None)
+        if rep is None:
+            return float(self.as_subclass(torch.Tensor))
+        return _session.value_of(rep, getattr(self, "_slot", 7))
 
-def _key(params, variables, cam):
-    ptrs = tuple(int(params[k].data_ptr()) for k in PARAM_ORDER + _POSE_KEYS)
-    shapes = tuple(tuple(params[k].shape) for k in PARAM_ORDER + _POSE_KEYS)
-    r = variables.get('max_2D_radius') if variables is not None else None
-    return ptrs, shapes, (int(r.data_ptr()) if r is not None else 0), (int(cam.image_height), int(cam.image_width))
+    def item(self):
+        return self._value()
+
+    def __float__(self):
+        return self._value()
+
+    def __format__(self, spec):
+        return format(self._value(), spec)
+
+    # comparisons with numbers and with other losses are decided on the host (the reference's `if loss < current_min_loss` reads the
+    # value there anyway); with any other tensor they stay torch operations on the device
+    def _cmp(self, o, op, name):
+        if isinstance(o, _FusedLoss):
+            return op(self._value(), o._value())
+        if torch.is_tensor(o):
+            return getattr(torch.Tensor, name)(self.as_subclass(torch.Tensor), o)
+        return op(self._value(), o)
+
+    def __lt__(self, o):
+        return self._cmp(o, operator.lt, "__lt__")
+
+    def __le__(self, o):
+        return self._cmp(o, operator.le, "__le__")
+
+    def __gt__(self, o):
+        return self._cmp(o, operator.gt, "__gt__")
+
+    def __ge__(self, o):
+        return self._cmp(o, operator.ge, "__ge__")
+
+
+def _scalar(rep, slot):
+    t = rep.dev[slot].as_subclass(_FusedLoss)
+    t._report, t._slot = rep, slot
+    return t
 
 
 class _Session:
     """Engines for the caller's current tensors (one per camera resolution), the phase the next iterations belong to."""
 
     def __init__(self):
-        self.engines = {}           # key -> FusedEngine
-        self.current = None         # (key, engine, params dict) of the last get_loss
+        self.engines = {}           # (H, W) -> FusedEngine
+        self.bound = {}             # (H, W) -> tuple of the tensor OBJECTS the engine is bound to (kept alive: ids stay unique)
+        self.current = None         # (engine, bound tensors, report) of the last get_loss
         self.pending_tracking = True
-        self.map_step = 0
-        self.stats = {"iterations": 0, "rebuilds": 0, "repeats": 0}
+        self.pending = []           # [(report, pinned host tensor, event)] reports in flight to the host
+        self.pool = []              # pinned buffers / events for re-use
+        self.stats = {"iterations": 0, "rebuilds": 0, "engines_built": 0, "repeats": 0, "skipped_iterations": 0}
 
+    # ---------------------------------------------------------------- engines
     def engine(self, params, variables, cam):
-        key = _key(params, variables, cam)
-        eng = self.engines.get(key)
+        hw = (int(cam.image_height), int(cam.image_width))
+        radius = variables.get('max_2D_radius') if variables is not None else None
+        now = tuple(params[k] for k in _ALL_KEYS) + (radius,)
+        eng = self.engines.get(hw)
+        was = self.bound.get(hw)
+        if eng is not None and was is not None and all(a is b for a, b in zip(now, was)):
+            return eng, was
+        # the caller replaced its tensors (first call, pruning, add_new_gaussians): re-bind, or build the first engine of this size
+        if eng is not None and ((params['log_scales'].shape[1] == 1) != eng.iso or params['cam_unnorm_rots'].shape[-1] != eng.num_frames
+                                or params['means3D'].device != eng.dev):
+            eng = None
         if eng is None:
-            # the caller replaced its tensors (first call, pruning, densification): engines of the old tensors are dead
-            self.engines = {k: e for k, e in self.engines.items() if k[0] == key[0] and k[1] == key[1] and k[2] == key[2]}
-            eng = FusedEngine(params, cam, track_max_radius=None if variables is None else variables.get('max_2D_radius'))
-            self.engines[key] = eng
-            self.stats["rebuilds"] += 1
-        return key, eng
+            eng = FusedEngine(params, cam, track_max_radius=radius, row_headroom=0.125)
+            self.engines[hw] = eng
+            self.stats["engines_built"] += 1
+        else:
+            self.drain(eng)                     # reports of the old tensors' iterations: learn from them before the lists are judged
+            eng.rebind(params, radius)
+        self.bound[hw] = now
+        self.stats["rebuilds"] += 1
+        return eng, now
+
+    # ---------------------------------------------------------------- reports
+    def post(self, eng, rep):
+        """Queue the asynchronous host copy of a report."""
+        if self.pool:
+            host, ev = self.pool.pop()
+        else:
+            host, ev = torch.empty(_capi.SPLAT_ITER_DCAM, dtype=torch.float32, pin_memory=True), torch.cuda.Event()
+        host.copy_(rep.dev, non_blocking=True)
+        ev.record()
+        self.pending.append((eng, rep, host, ev))
+
+    def poll(self, wait=False):
+        """Look at the reports that have arrived (``wait``: at all of them)."""
+        while self.pending:
+            eng, rep, host, ev = self.pending[0]
+            if not wait and not ev.query():
+                return
+            if wait:
+                ev.synchronize()
+            self.pending.pop(0)
+            if rep.host is None:
+                rep.host = host.tolist()
+            self.digest(eng, rep, host)
+            self.pool.append((host, ev))
+
+    def drain(self, eng=None):
+        self.poll(wait=True)
+
+    def digest(self, eng, rep, host=None):
+        """Learn the list statistics / deal with a capacity flag from one report (once)."""
+        if rep.digested:
+            return False
+        rep.digested = True
+        if host is None:
+            host = torch.tensor(rep.host, dtype=torch.float32)
+        if eng.digest_report(host):
+            self.stats["skipped_iterations"] += eng.skipped_iterations
+            # reports already in flight were written under the same flag: they carry nothing new
+            for _, r, _, _ in self.pending:
+                r.digested = True
+            return True
+        return False
+
+    def value_of(self, rep, slot):
+        """The caller reads a value of an iteration's report: ONE device read fetches the whole report, flags included."""
+        if rep.host is None:
+            rep.host = rep.dev.tolist()
+            eng = self.current[0] if self.current is not None and self.current[2] is rep else None
+            if eng is not None and self.digest(eng, rep) and rep.args is not None and rep.args[-1]:
+                self.repeat_tracking(eng, rep)
+        return rep.host[slot]
+
+    def repeat_tracking(self, eng, rep):
+        """The tracking iteration the caller is looking at ran on lists that did not fit: its Adam step was skipped on the device.
+        The lists have been re-sized (digest); run it again -- same pose, same frame -- and, when the caller has already stepped,
+        take that step now.  The caller sees the repeated iteration's values."""
+        params, curr_data, iter_time_idx, cfg, do_ba, tracking = rep.args
+        for _ in range(3):
+            eng.loss_backward(curr_data, iter_time_idx, cfg, tracking=True, do_ba=do_ba)
+            if rep.stepped is not False:
+                eng.pose_step -= 1
+                eng.adam_pose(*rep.stepped)
+            fresh = eng.buf['d_cam'].tolist()
+            self.stats["repeats"] += 1
+            if fresh[12] == 0.0:
+                rep.dev.copy_(eng.buf['d_cam'])
+                rep.host = fresh
+                return
+            eng.digest_report(torch.tensor(fresh, dtype=torch.float32))
+        raise RuntimeError("the instance lists overflowed three times in a row")
 
 
 _session = _Session()
@@ -90,25 +243,24 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
     if visualize_tracking_loss:
         raise NotImplementedError("visualize_tracking_loss needs the rendered images of the reference's get_loss; use the drop-in path")
     s = _session
-    key, eng = s.engine(params, variables, curr_data['cam'])
+    s.poll()                                        # reports that have arrived since the last call (no wait)
+    eng, bound = s.engine(params, variables, curr_data['cam'])
     cfg = dict(loss_weights=loss_weights, use_sil_for_loss=use_sil_for_loss, sil_thres=sil_thres, use_l1=use_l1,
                ignore_outlier_depth_loss=ignore_outlier_depth_loss)
+    tracking = bool(tracking)
     if tracking and (s.pending_tracking or eng.track_time_idx != int(iter_time_idx)):
         eng.begin_tracking(iter_time_idx)           # fresh pose Adam state: the caller made a new optimizer for this frame (:680)
         s.pending_tracking = False
-    for attempt in range(3):
-        eng.loss_backward(curr_data, iter_time_idx, cfg, tracking=bool(tracking), do_ba=bool(do_ba))
-        if not eng.check_overflow():                # a 16-byte read; True: the lists did not fit, they were re-sized / re-learnt
-            break
-        s.stats["repeats"] += 1
-    else:
-        raise RuntimeError("the instance lists overflowed three times in a row")
+    eng.loss_backward(curr_data, iter_time_idx, cfg, tracking=tracking, do_ba=bool(do_ba))
+    rep = _Report(eng.buf['d_cam'].clone())
+    rep.args = (params, curr_data, int(iter_time_idx), cfg, bool(do_ba), tracking)
+    s.post(eng, rep)
     s.stats["iterations"] += 1
-    s.current = (key, eng, params)
-    d = eng.buf['d_cam']
-    loss = d[7].clone().as_subclass(_FusedLoss)
-    depth_w = loss_weights['depth'] * d[8].clone()
-    losses = {'depth': depth_w, 'im': loss.as_subclass(torch.Tensor) - depth_w}
+    s.current = (eng, bound, rep)
+    loss = _scalar(rep, 7)
+    losses = {'im': _scalar(rep, 15), 'loss': loss}
+    if use_l1:
+        losses['depth'] = _scalar(rep, 14)
     if variables is not None:
         variables['seen'] = eng.seen
     return loss, variables, losses
@@ -125,15 +277,18 @@ class FusedOptimizer(torch.optim.Adam):
             super().__init__(groups, lr=0.0, eps=1e-15)
         self._tracking = bool(tracking)
         self._lrs = dict(lrs_dict)
+        s = _session
+        # a phase boundary: the reference's own statements have just synchronised (add_new_gaussians' boolean indexing, the loss
+        # comparison of the last tracking iteration); every report of the finished phase is looked at here
+        s.drain()
         if tracking:
             if any(float(lrs_dict[k]) != 0.0 for k in PARAM_ORDER):
                 raise NotImplementedError("the fused tracking iteration forms the pose gradient only: Gaussian learning rates must be 0 "
                                           "(as in every shipped configuration)")
-            _session.pending_tracking = True
+            s.pending_tracking = True
         else:
             if any(float(lrs_dict.get(k, 0.0)) != 0.0 for k in _POSE_KEYS):
                 raise NotImplementedError("pose learning rates in the mapping optimizer (bundle adjustment) are not supported by the plug-in")
-            _session.map_step = 0
             # the state the reference's map edits expect to find and re-attach (exp_avg / exp_avg_sq per parameter)
             for g in self.param_groups:
                 p = g['params'][0]
@@ -148,35 +303,35 @@ class FusedOptimizer(torch.optim.Adam):
         s = _session
         if s.current is None:
             raise RuntimeError("optimizer.step() before any get_loss()")
-        key, eng, params = s.current
+        eng, bound, rep = s.current
         if self._tracking:
-            eng.adam_pose(self._lrs['cam_unnorm_rots'], self._lrs['cam_trans'])
+            lr = (self._lrs['cam_unnorm_rots'], self._lrs['cam_trans'])
+            eng.adam_pose(*lr)
+            rep.stepped = lr
             return None
         by_name = {g['name']: g for g in self.param_groups}
-        skip = []
+        steps, live = [1] * 5, []
         for idx, k in enumerate(PARAM_ORDER):
             p = by_name[k]['params'][0]
             st = self.state.get(p)
             # a parameter re-created since the backward pass has no gradient: torch's step skips it (pruning, opacity reset).  Compared
-            # with the tensors get_loss SAW (the key): the reference's map edits update the caller's dict in place, and the engine
-            # reads that same dict
-            if int(p.data_ptr()) != key[0][idx] or tuple(p.shape) != key[1][idx] or st is None:
-                skip.append(k)
+            # with the tensors get_loss SAW: the reference's map edits update the caller's dict in place, and the engine reads that dict
+            if p is not bound[idx] or st is None:
                 continue
             eng.exp_avg[k], eng.exp_avg_sq[k] = st['exp_avg'], st['exp_avg_sq']
-        if len(skip) == len(PARAM_ORDER):
+            st['step'] += 1                         # torch counts per parameter (a CPU scalar tensor, as torch keeps it)
+            steps[idx] = int(st['step'])
+            live.append(idx)
+        if not live:
             return None
-        eng.map_step = s.map_step
-        o = eng._adam_map_args(self._lrs)
-        s.map_step = eng.map_step
-        for idx, k in enumerate(PARAM_ORDER):
-            if k in skip:
+        o = eng._adam_map_args(self._lrs, steps=steps)
+        for idx in range(5):
+            if idx not in live:
                 o.grad[idx] = None
-            else:
-                self.state[by_name[k]['params'][0]]['step'] += 1
         m = eng._map_struct()
         with torch.cuda.device(eng.dev):
             _capi.check(eng.L.splat_iter_adam_map(C.byref(m), C.byref(o), eng._stream()), "splat_iter_adam_map")
+        rep.stepped = True
         return None
 
 
@@ -191,14 +346,25 @@ class _Installed:
     def uninstall(self):
         for k, v in self.saved.items():
             setattr(self.module, k, v)
-        _session.engines.clear()
-        _session.current = None
+        _reset_session()
 
     def __enter__(self):
         return self
 
     def __exit__(self, *exc):
         self.uninstall()
+
+
+def _reset_session():
+    s = _session
+    if s.pending:
+        try:
+            s.poll(wait=True)
+        except Exception:                           # noqa: BLE001 (tear-down: the engines are going away)
+            s.pending.clear()
+    s.engines.clear()
+    s.bound.clear()
+    s.current = None
 
 
 def install(module):
@@ -209,7 +375,6 @@ def install(module):
         raise RuntimeError(f"{module!r} does not look like scripts/splatam.py: it has no get_loss / initialize_optimizer")
     module.get_loss = get_loss
     module.initialize_optimizer = initialize_optimizer
-    _session.engines.clear()
-    _session.current = None
-    _session.stats.update(iterations=0, rebuilds=0, repeats=0)
+    _reset_session()
+    _session.stats.update(iterations=0, rebuilds=0, engines_built=0, repeats=0, skipped_iterations=0)
     return _Installed(module, saved)

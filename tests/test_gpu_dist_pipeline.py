@@ -27,7 +27,7 @@ def _run(out_path):
     params, variables, st = pipeline.rgbd_slam(ds, cfg, engine="fused")
     torch.cuda.synchronize()
     err = max(float((pipeline._est_w2c(params, t)[:3, 3] - ds.gt_w2c(t)[:3, 3]).norm()) for t in range(FRAMES))
-    np.savez(out_path, err=err, n=np.array(st['num_gaussians']), redone=st['redone_frames'],
+    np.savez(out_path, err=err, n=np.array(st['num_gaussians']), redone=st['redone_iterations'],
              **{k: v.detach().cpu().numpy() for k, v in params.items()})
 
 

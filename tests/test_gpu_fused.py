@@ -664,3 +664,95 @@ def test_tile_row_sharded_tracking_equals_whole_frame_tracking(lists, world):
     assert float((ranks[0].params["cam_trans"].detach() - full.params["cam_trans"].detach()).abs().max()) <= 2e-5
     assert float((ranks[0].params["cam_unnorm_rots"].detach() - full.params["cam_unnorm_rots"].detach()).abs().max()) <= 2e-5
     assert float(ranks[0].buf['tile_count'].abs().max()) == 0.0 and float(ranks[0].buf['accum'].abs().max()) == 0.0
+
+
+def test_flagged_iterations_take_no_adam_step_and_are_counted():
+    """A capacity flag raised on the device (per-tile lists that did not fit) holds back every Adam step until the host has dealt
+    with it (include/splat_hip.h, d_cam[12]): the map, the pose, the moments and the best-candidate record stay as they were, d_cam[21]
+    counts the iterations, check_overflow() reports them (skipped_iterations) and re-sizes the lists; the loop then goes on."""
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    params, variables, frame, cam = _scene(12000, 256, 192, seed=21)
+    p = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    eng = FusedEngine(p, cam)
+    mcfg, tcfg = slam.REPLICA_MAPPING, slam.REPLICA_TRACKING
+    for _ in range(2):
+        eng.mapping_iteration(frame, 1, mcfg)
+        assert not eng.check_overflow()
+    assert eng.tile_stride > 0 and eng.skipped_iterations == 0
+    good = (eng.tile_stride, eng.max_list_hint)
+    snap = {k: v.detach().clone() for k, v in p.items()}
+    m_snap = {k: eng.exp_avg[k].clone() for k in eng.exp_avg}
+    eng.tile_stride, eng.max_list_hint = 64, 40                     # buckets far too small: every list overflows
+    for _ in range(3):
+        eng.mapping_iteration(frame, 1, mcfg)                       # Adam inside the per-Gaussian backward kernel: gated
+    eng.loss_backward(frame, 1, mcfg, tracking=False)
+    eng.adam_map(mcfg['lrs'])                                       # Adam as its own kernel: gated
+    torch.cuda.synchronize()
+    rep = eng.buf['d_cam'].cpu()
+    assert float(rep[12]) == 1.0 and int(rep.view(torch.int32)[20]) == 1 and int(rep.view(torch.int32)[21]) == 4
+    assert int(rep.view(torch.int32)[17]) == 1                      # the status snapshot: overflow
+    for k in snap:
+        assert torch.equal(p[k].detach(), snap[k]), k
+    for k in m_snap:
+        assert torch.equal(eng.exp_avg[k], m_snap[k]), k
+    assert eng.check_overflow() and eng.skipped_iterations == 4 and eng.tile_stride == 0
+    eng.map_step -= eng.skipped_iterations
+    eng.mapping_iteration(frame, 1, mcfg)                           # exact lists: valid again, steps again
+    assert not eng.check_overflow() and eng.skipped_iterations == 0 and eng.tile_stride > 0
+    assert not torch.equal(p['means3D'].detach(), snap['means3D'])
+    # tracking: the pose's step rides in the last kernel of the iteration (and as a kernel of its own)
+    eng.begin_tracking(1)
+    eng.tracking_iteration(frame, tcfg)
+    torch.cuda.synchronize()
+    pose = (p['cam_unnorm_rots'].detach().clone(), p['cam_trans'].detach().clone(), eng.buf['pose_state'].clone())
+    eng.tile_stride, eng.max_list_hint = 64, 40
+    eng.tracking_iteration(frame, tcfg)
+    eng.loss_backward(frame, 1, tcfg, tracking=True)
+    eng.adam_pose(tcfg['lrs']['cam_unnorm_rots'], tcfg['lrs']['cam_trans'])
+    torch.cuda.synchronize()
+    assert torch.equal(p['cam_unnorm_rots'].detach(), pose[0]) and torch.equal(p['cam_trans'].detach(), pose[1])
+    assert torch.equal(eng.buf['pose_state'], pose[2])
+    assert eng.check_overflow() and eng.skipped_iterations == 2
+    eng.pose_step -= 2
+    eng.tracking_iteration(frame, tcfg)
+    torch.cuda.synchronize()
+    assert not torch.equal(p['cam_trans'].detach(), pose[1]) and not eng.check_overflow()
+    assert (eng.tile_stride, eng.max_list_hint)[0] > 0 and good[0] > 0
+
+
+def test_sharded_tracking_flag_travels_with_the_sums_and_folded_sums_are_the_sums():
+    """Tile-row-sharded tracking: a rank whose band overflowed adds to sums[31] (all-reduced with the partial sums), so that EVERY
+    rank skips the Adam step of that iteration; and splat_iter_fold_sums leaves the totals of the 64 copies in copy 0."""
+    from splatam_amd import _capi, slam
+    from splatam_amd.fused import FusedEngine
+    params, variables, frame, cam = _scene(20000, 328, 248, seed=53)
+    cfg = slam.REPLICA_TRACKING
+    ranks = []
+    for r in range(2):
+        e = FusedEngine({k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}, cam)
+        e.loss_backward(frame, 1, slam.REPLICA_MAPPING, tracking=False)
+        assert not e.check_overflow() and e.tile_stride > 0
+        e.begin_tracking(1)
+        ranks.append(e)
+    bands = [e.tile_row_band(r, 2) for r, e in enumerate(ranks)]
+    ranks[1].tile_stride, ranks[1].max_list_hint = 64, 40           # rank 1's lists will not fit
+    pose0 = ranks[0].params['cam_trans'].detach().clone()
+    for r, e in enumerate(ranks):
+        e.loss_backward(frame, 1, cfg, tracking=True, tile_rows=bands[r])
+    # folded: copy 0 holds the totals, the others are zero
+    raw = ranks[0].buf['sums'].clone().view(_capi.SPLAT_ITER_SUM_COPIES, _capi.SPLAT_ITER_SUMS)
+    _capi.check(ranks[0].L.splat_iter_fold_sums(ranks[0].buf['sums'].data_ptr(), ranks[0]._stream()), "splat_iter_fold_sums")
+    folded = ranks[0].buf['sums'].view(_capi.SPLAT_ITER_SUM_COPIES, _capi.SPLAT_ITER_SUMS)
+    torch.cuda.synchronize()
+    assert float(folded[1:].abs().max()) == 0.0
+    assert float((folded[0] - raw.sum(0)).abs().max()) <= 1e-12 * float(raw.sum(0).abs().max())
+    total = sum(e.buf['sums'] for e in ranks)                          # the all-reduce
+    assert float(total[_capi.SPLAT_ITER_SUMS - 1]) == 1.0           # rank 1's flag
+    for e in ranks:
+        e.buf['sums'].copy_(total)
+        e.finish_iteration(e._pose_adam_args(cfg))
+    torch.cuda.synchronize()
+    for e in ranks:                                                 # BOTH ranks held their step back
+        assert torch.equal(e.params['cam_trans'].detach(), pose0)
+        assert float(e.buf['d_cam'][12]) == 1.0

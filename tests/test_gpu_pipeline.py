@@ -41,6 +41,33 @@ def test_frame_loop_fused_matches_reference_shaped_loop():
     assert vf['timestep'].max() == len(ds) - 1
 
 
+def test_frame_loop_through_the_plugin_matches_the_fused_loop():
+    """engine="plugin": the reference-shaped frame loop -- add_new_gaussians / prune_gaussians / remove_points RE-CREATE every
+    parameter tensor, the statements are get_loss -> backward -> prune -> step, tracking compares the loss on the host -- with
+    splatam_amd.plugin installed, i.e. what /root/reference/scripts/splatam.py:654-905 executes after plugin.install.  Against the
+    fused engine's own loop: same keyframes, same map sizes, same trajectory; one engine for the whole run, re-bound at every map edit,
+    no iteration lost to list overflow."""
+    from splatam_amd import pipeline
+    ds, pf, vf, sf = _run("fused")
+    _, pp, vp, sp = _run("plugin")
+    assert sf['keyframe_time_indices'] == sp['keyframe_time_indices'] == [0, 1, 3]
+    assert sp['tracking_iters'] == 4 * 12 and sp['mapping_iters'] == 5 * 24
+    for a, b in zip(sf['num_gaussians'], sp['num_gaussians']):
+        assert abs(a - b) <= max(3, int(2e-3 * b)), (sf['num_gaussians'], sp['num_gaussians'])
+    for t in range(len(ds)):
+        wf, wp, gt = pipeline._est_w2c(pf, t), pipeline._est_w2c(pp, t), ds.gt_w2c(t)
+        assert float((wf - wp).abs().max()) < 2e-3, (t, wf, wp)
+        assert float((wp[:3, 3] - gt[:3, 3]).norm()) < 0.02, (t, wp[:3, 3], gt[:3, 3])
+    st = sp['plugin']
+    frames = len(ds)
+    assert st['iterations'] == 4 * 12 + 5 * 24, st
+    assert st['engines_built'] == 1, st
+    # tensor replacements: prune_gaussians at iterations 0 and 20 of every frame's mapping (remove_points re-creates the parameters
+    # whether or not a row goes), add_new_gaussians on frames 1.. when it adds anything; + the first binding
+    assert 1 + 2 * frames <= st['rebuilds'] <= 1 + 2 * frames + (frames - 1), st
+    assert st['skipped_iterations'] == 0 and st['repeats'] <= 1, st
+
+
 def test_params_survive_a_checkpoint_round_trip(tmp_path):
     from splatam_amd import pipeline
     _, params, _, _ = _run("fused", frames=2)

@@ -72,7 +72,8 @@ def test_tracking_statements_run_fused_and_match_the_dropin_path():
         my_losses = _tracking_loop(slam, mine, _variables(mine), frame, 1, cfg, 6)
         stats = plugin.session_stats()
     assert slam.get_loss is not plugin.get_loss                     # uninstalled
-    assert stats["iterations"] == 6 and stats["rebuilds"] == 1, stats
+    assert stats["iterations"] == 6 and stats["rebuilds"] == 1 and stats["engines_built"] == 1, stats
+    assert stats["skipped_iterations"] == 0, stats
     for it, (a, b) in enumerate(zip(my_losses, ref_losses)):
         assert abs(a - b) <= track_loop_loss_rtol(it) * abs(b), (my_losses, ref_losses)
     assert (mine['cam_unnorm_rots'] - ref['cam_unnorm_rots']).abs().max() <= 1e-4
@@ -80,36 +81,151 @@ def test_tracking_statements_run_fused_and_match_the_dropin_path():
     assert torch.equal(mine['means3D'], ref['means3D'])
 
 
+def _prune_dict():
+    return dict(start_after=0, remove_big_after=0, stop_after=20, prune_every=20, removal_opacity_threshold=0.005,
+                final_removal_opacity_threshold=0.005, reset_opacities=False, reset_opacities_every=500)
+
+
+def _assert_adam_step_matches(name, p_mine, p_ref, p_before, m_mine, m_ref, lr):
+    """ONE Adam step with eps = 1e-15 moves an element by lr * sign(g) (m / sqrt(v) = g / |g|): where the sign of the gradient is
+    certain the two paths must land on the same value; the first moment (0.1 g) is compared at the north star's gradient tolerance."""
+    scale = float(m_ref.abs().max())
+    err = (m_mine - m_ref).abs()
+    assert float(torch.quantile(err.reshape(-1)[:4_000_000].float(), 0.9999)) <= 1e-3 * scale + 1e-20, (name, float(err.max()), scale)
+    certain = m_ref.abs() > 2e-3 * scale
+    d = (p_mine - p_ref).abs()[certain]
+    moved = (p_ref - p_before).abs()[certain]
+    assert float(moved.min()) > 0.5 * lr, (name, float(moved.min()), lr)                # every certain element took its step
+    assert float(d.max()) <= 0.02 * lr, (name, float(d.max()), lr)                      # ... to the same place (float32 rounding of p)
+    flipped = float(((p_mine - p_ref).abs() > 0.5 * lr).float().mean())
+    assert flipped <= 5e-3, (name, flipped)                                             # elements whose gradient is rounding noise
+
+
 def test_mapping_statements_with_the_references_pruning_run_fused():
-    """Three mapping iterations; the pruning schedule removes rows at iteration 0 (the reference's own remove_points slices the
-    optimizer state and re-creates every parameter: that iteration takes no Adam step), iterations 1 and 2 step the smaller map."""
+    """Mapping iterations in the reference's statements; the pruning schedule removes rows at iteration 0 (the reference's own
+    remove_points slices the optimizer state and re-creates every parameter: that iteration takes no Adam step), iteration 1 steps
+    the smaller map: parameters and moments after that ONE step element-wise against torch.optim.Adam on the drop-in path."""
     from splatam_amd import plugin, slam
     params, _, frame, cam = _scene(8000, 208, 160, aniso=False, seed=7)
     with torch.no_grad():
         params['logit_opacities'][::5] = -6.0                       # a fifth of the map is transparent: pruned at iteration 0
     cfg = slam.REPLICA_MAPPING
-    pd = dict(start_after=0, remove_big_after=0, stop_after=20, prune_every=20, removal_opacity_threshold=0.005,
-              final_removal_opacity_threshold=0.005, reset_opacities=False, reset_opacities_every=500)
     ref = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
     mine = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
-    ref, ref_vars, ref_opt = _mapping_loop(slam, ref, _variables(ref), frame, 1, cfg, 3, copy.deepcopy(pd))
+    ref, ref_vars, ref_opt = _mapping_loop(slam, ref, _variables(ref), frame, 1, cfg, 1, _prune_dict())
+    before = {k: ref[k].detach().clone() for k in ("means3D", "rgb_colors", "logit_opacities", "log_scales")}
     with plugin.install(slam):
-        mine, my_vars, my_opt = _mapping_loop(slam, mine, _variables(mine), frame, 1, cfg, 3, copy.deepcopy(pd))
-        stats = plugin.session_stats()
+        mine, my_vars, my_opt = _mapping_loop(slam, mine, _variables(mine), frame, 1, cfg, 1, _prune_dict())
     n = ref['means3D'].shape[0]
     assert n < 8000 and mine['means3D'].shape[0] == n
-    assert stats["iterations"] == 3 and stats["rebuilds"] == 2, stats          # the pruned map is a new set of tensors
+    for k in before:                                                # iteration 0 pruned and took no step: the rows are the reference's
+        assert torch.equal(mine[k].detach(), before[k]), k
+
+    def one_more(mod, p, v, opt):
+        loss, v, losses = mod.get_loss(p, frame, v, 1, cfg['loss_weights'], cfg['use_sil_for_loss'], cfg['sil_thres'], cfg['use_l1'],
+                                       cfg['ignore_outlier_depth_loss'], mapping=True)
+        loss.backward()
+        with torch.no_grad():
+            p, v = mod.prune_gaussians(p, v, opt, 1, _prune_dict())
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        return p, v, losses
+    ref, ref_vars, ref_losses = one_more(slam, ref, ref_vars, ref_opt)
+    with plugin.install(slam):
+        # (a fresh session: the optimizer of the first loop is the caller's object and keeps working across it)
+        mine, my_vars, my_losses = one_more(slam, mine, my_vars, my_opt)
+        stats = plugin.session_stats()
+    assert stats["iterations"] == 1 and stats["skipped_iterations"] == 0, stats
     assert isinstance(my_opt, torch.optim.Adam)
     for k in ("means3D", "rgb_colors", "logit_opacities", "log_scales"):
-        lr = cfg['lrs'][k]
-        diff = (mine[k].detach() - ref[k].detach()).abs()
-        # two Adam steps with eps = 1e-15 move an element by ~2 lr; elements whose gradient is rounding noise may step the other way
-        assert float((diff > 0.1 * lr).float().mean()) < 2e-2, (k, float(diff.max()), lr)
-        m_ref = ref_opt.state[ref[k]]['exp_avg']
-        m_my = my_opt.state[mine[k]]['exp_avg']
-        assert float((m_my - m_ref).abs().max()) <= 2e-3 * float(m_ref.abs().max()) + 1e-12, k
+        _assert_adam_step_matches(k, mine[k].detach(), ref[k].detach(), before[k], my_opt.state[mine[k]]['exp_avg'],
+                                  ref_opt.state[ref[k]]['exp_avg'], cfg['lrs'][k])
+        assert float(my_opt.state[mine[k]]['step']) == 1.0 == float(ref_opt.state[ref[k]]['step'])
     assert torch.equal(my_vars['seen'], ref_vars['seen'])
     assert torch.equal(my_vars['max_2D_radius'], ref_vars['max_2D_radius'])
+    # the whole losses dict of the reference (scripts/splatam.py:339-346: weighted terms + their sum)
+    assert set(my_losses) == set(ref_losses) == {'depth', 'im', 'loss'}
+    for k in ref_losses:
+        assert abs(float(my_losses[k]) - float(ref_losses[k])) <= 2e-5 * abs(float(ref_losses[k])) + 1e-7, (k, float(my_losses[k]), float(ref_losses[k]))
+
+
+@pytest.mark.parametrize("tracking", [True, False])
+@pytest.mark.parametrize("use_l1", [True, False])
+def test_losses_dict_is_the_references(tracking, use_l1):
+    """get_loss returns (loss, variables, weighted_losses) with weighted_losses = {'depth' (only with use_l1), 'im', 'loss'}
+    (scripts/splatam.py:275-346; report_loss reads losses['loss'], utils/eval_helpers.py:82): tracking sums, mapping means."""
+    from splatam_amd import plugin, slam
+    params, _, frame, cam = _scene(9000, 224, 160, aniso=False, seed=5)
+    cfg = dict(slam.REPLICA_TRACKING if tracking else slam.REPLICA_MAPPING)
+    w = {'im': 0.5, 'depth': 1.7}
+    kw = dict(tracking=True) if tracking else dict(mapping=True)
+    ref = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    mine = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    _, _, want = slam.get_loss(ref, frame, _variables(ref), 1, w, cfg['use_sil_for_loss'], cfg['sil_thres'], use_l1, False, **kw)
+    with plugin.install(slam):
+        loss, _, got = slam.get_loss(mine, frame, _variables(mine), 1, w, cfg['use_sil_for_loss'], cfg['sil_thres'], use_l1, False, **kw)
+        assert set(got) == set(want) == ({'depth', 'im', 'loss'} if use_l1 else {'im', 'loss'})
+        for k in want:
+            assert abs(float(got[k]) - float(want[k])) <= 3e-5 * abs(float(want[k])) + 1e-7, (k, float(got[k]), float(want[k]))
+        assert float(got['loss']) == float(loss) and got['loss'].item() == float(loss)
+        assert f"{loss:.3f}" == f"{float(loss):.3f}"
+        assert (loss < 1e20) is True and (loss > 1e20) is False and bool(loss < torch.tensor(1e20, device="cuda"))
+
+
+def test_a_flagged_iteration_moves_nothing_and_is_repeated_or_reported():
+    """Per-tile lists that do not fit raise a flag on the device; the Adam kernels skip while it is up.  Tracking: the caller's own
+    `loss < current_min_loss` read fetches the flag and the iteration is repeated on re-sized lists (same values as an undisturbed run).
+    Mapping: the iteration is skipped, the next ones run on re-sized lists, session_stats() reports it."""
+    from splatam_amd import plugin, slam
+    params, _, frame, cam = _scene(12000, 256, 192, aniso=False, seed=11)
+    cfg = slam.REPLICA_TRACKING
+    clean = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    mine = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    with plugin.install(slam):
+        clean_losses = _tracking_loop(slam, clean, _variables(clean), frame, 1, cfg, 5)
+    with plugin.install(slam):
+        v = _variables(mine)
+        _tracking_loop(slam, mine, v, frame, 1, cfg, 2)          # learns bucketed lists
+        with torch.no_grad():
+            for k in mine:
+                mine[k].copy_(params[k])
+        eng = next(iter(plugin._session.engines.values()))
+        plugin._session.drain()
+        assert eng.tile_stride > 0
+        eng.tile_stride = 64                                        # buckets far too small for this scene: the next iteration overflows
+        eng.max_list_hint = 40
+        losses = _tracking_loop(slam, mine, v, frame, 1, cfg, 5)
+        stats = plugin.session_stats()
+    assert stats["repeats"] >= 1, stats
+    for a, b in zip(losses, clean_losses):
+        assert abs(a - b) <= 1e-4 * abs(b), (losses, clean_losses)
+    assert (mine['cam_trans'] - clean['cam_trans']).abs().max() <= 1e-5
+    # mapping: the flagged iteration takes no step
+    mcfg = slam.REPLICA_MAPPING
+    mp = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    with plugin.install(slam):
+        mv = _variables(mp)
+        mp, mv, opt = _mapping_loop(slam, mp, mv, frame, 1, mcfg, 3, None)
+        plugin._session.drain()
+        eng = next(iter(plugin._session.engines.values()))
+        snap = {k: mp[k].detach().clone() for k in mp}
+        eng.tile_stride, eng.max_list_hint = 64, 40
+        loss, mv, _ = slam.get_loss(mp, frame, mv, 1, mcfg['loss_weights'], mcfg['use_sil_for_loss'], mcfg['sil_thres'], mcfg['use_l1'],
+                                    mcfg['ignore_outlier_depth_loss'], mapping=True)
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        for k in snap:
+            assert torch.equal(mp[k].detach(), snap[k]), k          # nothing moved
+        plugin._session.drain()
+        assert plugin.session_stats()["skipped_iterations"] >= 1
+        assert eng.tile_stride != 64                                # lists re-sized
+        loss, mv, _ = slam.get_loss(mp, frame, mv, 1, mcfg['loss_weights'], mcfg['use_sil_for_loss'], mcfg['sil_thres'], mcfg['use_l1'],
+                                    mcfg['ignore_outlier_depth_loss'], mapping=True)
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        assert not torch.equal(mp['means3D'].detach(), snap['means3D'])      # ... and the loop goes on
 
 
 def test_plugin_speed_against_the_dropin_statements():
