@@ -756,6 +756,33 @@ def main():
             opt_map.zero_grad(set_to_none=True)
     map_rate_d = phase_rate(map_once, n_drop, dev)
     dropin_rate = 5.0 / (2.0 / track_rate_d + 3.0 / map_rate_d)
+    # the rasterizer's own share of a drop-in iteration (two forwards + two backwards through the autograd surface): HIP events around
+    # its C calls on the iteration's stream, summed over a few mapping iterations -- the rest is the reference's PyTorch glue
+    # (~100 small launches, MIOpen convolutions, boolean-mask indexing, torch.optim.Adam), which the library cannot shorten
+    spans = []
+
+    def timed(fn):
+        def wrapper(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            spans.append((e0, e1))
+            return out
+        return wrapper
+    saved_f, saved_b = rz.rasterize_forward, rz.rasterize_backward
+    rz.rasterize_forward, rz.rasterize_backward = timed(saved_f), timed(saved_b)
+    try:
+        torch.cuda.synchronize(dev)
+        for _ in range(5):
+            map_once()
+        torch.cuda.synchronize(dev)
+    finally:
+        rz.rasterize_forward, rz.rasterize_backward = saved_f, saved_b
+    dropin_raster_ms = sum(a.elapsed_time(b) for a, b in spans) / 5.0
+    rz.set_geometry_cache(False)
+    map_rate_d_nocache = phase_rate(map_once, n_drop, dev)
+    rz.set_geometry_cache(True)
     # the SAME statements with splatam_amd.plugin installed (get_loss / initialize_optimizer of the module replaced at run time): what an
     # unmodified scripts/splatam.py gets from the plug-in -- the fused iteration behind the reference's own loop statements
     from splatam_amd import plugin
@@ -810,6 +837,8 @@ def main():
             "plugin_mapping_iters_per_s": round(map_rate_p, 3),
             "dropin_iters_per_s": round(dropin_rate, 3), "dropin_tracking_iters_per_s": round(track_rate_d, 3),
             "dropin_mapping_iters_per_s": round(map_rate_d, 3),
+            "dropin_mapping_iters_per_s_without_geometry_cache": round(map_rate_d_nocache, 3),
+            "dropin_mapping_ms_per_iter": round(1e3 / map_rate_d, 3), "dropin_mapping_rasterizer_ms_per_iter": round(dropin_raster_ms, 3),
             "render_fwd_bwd_mpix_per_s": round(mpix, 2), "render_fwd_bwd_ms": round(ms_call, 4),
             "host_cores": os.cpu_count(),
         }

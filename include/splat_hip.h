@@ -167,7 +167,12 @@ int splat_preprocess_forward(const SplatCamera *cam, const SplatGaussians *g, Sp
 /* Scatter (Gaussian, tile) instances into per-tile buckets and sort every
  * bucket by (depth bits, id).  Replaces duplicateWithKeys + the global radix
  * sort + identifyTileRanges of the reference.  A no-op that leaves status[1]
- * set when num_rendered > st->capacity. */
+ * set when num_rendered > st->capacity.
+ * CONTRACT: the second half of ONE forward pass -- call it on the SplatState that splat_preprocess_forward has just filled, with the
+ * same cam, the same g->P and unchanged st->sub_bins / st->tile_stride (the caller may only set keys / point_list / capacity in
+ * between, after reading status[0]).  With sub_bins > 1 the per-tile counters are split over sub-bins by (workgroup of 4 096
+ * Gaussians) and the scatter walks the SAME partition the count used; a caller that fills tile_count itself, or changes P or
+ * sub_bins between the two calls, gets ranges that do not match the scatter (undefined lists).  splat_forward() does both. */
 int splat_bin_forward(const SplatCamera *cam, const SplatGaussians *g, SplatState *st, void *stream);
 
 /* Tile-wise alpha compositing.  out_color [C][H][W], out_depth [H][W].
@@ -208,6 +213,15 @@ int splat_backward(const SplatCamera *cam, const SplatGaussians *g, const SplatS
 
 /* `_C.mark_visible` of the reference extension: present[i] = (view-space z > 0.2). */
 int splat_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, uint8_t *present, void *stream);
+
+/* Do two rasterizer calls see the same geometry?  *differ (device int32) = 0 when opacities [P], scales [P][3] and rotations [P][4]
+ * of call A and call B hold the same bits, non-zero otherwise.  The two renders of the reference's get_loss
+ * (/root/reference/scripts/splatam.py:249,253) receive equal-valued but distinct tensors (sigmoid / exp / normalize are applied
+ * twice: /root/reference/utils/slam_helpers.py:124-139, 234-249); a binding that has proven the rest equal (same means3D storage,
+ * same camera) may then hand the second call the first call's SplatState -- geometry and sorted lists -- and run only
+ * splat_render_forward for it. */
+int splat_same_geometry(int32_t P, const float *opacities_a, const float *opacities_b, const float *scales_a, const float *scales_b,
+                        const float *rotations_a, const float *rotations_b, int32_t *differ, void *stream);
 
 /* Kernel-only timing helper for bench.py: runs `fn` (0 = render forward,
  * 1 = render backward) `iters` times on `stream` between two hipEvents created
@@ -381,7 +395,8 @@ int splat_iter_mapping_step(const SplatCamera *cam, const SplatMap *map, const S
  * timed bracket, so the workspace stays usable), 2 = the forward composite in the form the iteration launches on short lists
  * (it filters its group's records / reads its bucket, sorts and publishes the tile's list itself; needs bucketed lists and a list
  * length hint <= 819, SPLAT_E_INVALID otherwise), 3 = forward (sorting form when the state allows it) and backward composite
- * alternating, `iters` pairs (time(3) - time(2 or 0) = the backward composite between other kernels), launched `iters` times on `stream` between two hipEvents; the workspace must hold
+ * alternating, `iters` pairs (time(3) - time(2 or 0) = the backward composite between other kernels), 4 = the backward composite in its
+ * tracking form (depth colour sum only, no opacity sum), launched `iters` times on `stream` between two hipEvents; the workspace must hold
  * the state of a completed splat_iter_loss_backward. */
 int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P, SplatIterWorkspace *ws, void *stream, float *ms);
 
@@ -506,9 +521,14 @@ int splat_map_densify_select(SplatMapStore *store, const SplatDensifyArgs *args,
  * are zero.  The caller then sets map.P = counts[0]; the split originals are removed with splat_map_prune(to_remove = flags). */
 int splat_map_duplicate(SplatMapStore *store, const SplatDensifyArgs *args, void *stream);
 
-/* Developer switch used by scripts/ (never by the product path): key 0 = skip the per-tile count atomics of K1 (timing
- * experiment; results are then invalid).  Returns the previous value, -1 for an unknown key. */
+/* Developer switches used by scripts/ (never by the product path): key 0 = skip the per-tile count atomics of K1 (timing
+ * experiment; results are then invalid); key 4 = measurement builds of the fused backward composite (bits: 1 = per-workgroup
+ * wall-clock stamps into the buffer of splat_debug_stamps, 2 = stage the batches but visit nothing, 4 = no accumulator atomics,
+ * 8 = phase 1 only; results are then invalid; 0 = the product kernel).  Returns the previous value, -1 for an unknown key. */
 int splat_debug_option(int key, int value);
+/* device buffer of 2 x (workgroups of the launch) int64 for splat_debug_option(4, 1): (start, end) of every workgroup in
+ * wall_clock64() ticks (100 MHz); NULL switches it off. */
+int splat_debug_stamps(void *buffer);
 
 #ifdef __cplusplus
 }

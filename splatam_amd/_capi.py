@@ -127,7 +127,7 @@ EXPORTS = (
     "splat_error_string", "splat_abi_version", "splat_sizeof", "splat_num_tiles",
     "splat_preprocess_forward", "splat_bin_forward", "splat_render_forward", "splat_forward",
     "splat_render_backward", "splat_preprocess_backward", "splat_backward",
-    "splat_mark_visible", "splat_time_kernel", "splat_debug_option",
+    "splat_mark_visible", "splat_same_geometry", "splat_time_kernel", "splat_debug_option", "splat_debug_stamps",
     "splat_iter_loss_backward", "splat_iter_adam_map", "splat_iter_adam_pose", "splat_iter_time_kernel",
     "splat_iter_tracking_step", "splat_iter_mapping_step", "splat_iter_finish", "splat_iter_fold_sums", "splat_iter_render", "splat_map_scratch_words", "splat_map_row_floats", "splat_map_add_new_gaussians", "splat_map_prune",
     "splat_iter_means2d_accumulate", "splat_map_densify_select", "splat_map_duplicate",
@@ -166,6 +166,7 @@ def lib():
         ("splat_preprocess_backward", [cam, g, st, gr, _fp]),
         ("splat_backward", [cam, g, st, gr, _fp]),
         ("splat_mark_visible", [C.c_int32, _fp, _fp, _fp, _fp]),
+        ("splat_same_geometry", [C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
         ("splat_time_kernel", [C.c_int, C.c_int, cam, g, st, gr, _fp, _fp, _fp, C.POINTER(C.c_float)]),
     ):
         f = getattr(L, name)
@@ -210,6 +211,8 @@ def lib():
         f.argtypes = [C.POINTER(SplatMapStore), C.POINTER(SplatDensifyArgs), _fp]
     L.splat_debug_option.restype = C.c_int
     L.splat_debug_option.argtypes = [C.c_int, C.c_int]
+    L.splat_debug_stamps.restype = C.c_int
+    L.splat_debug_stamps.argtypes = [_fp]
     if hasattr(L, "splat_selftest"):
         L.splat_selftest.restype = C.c_int
         L.splat_selftest.argtypes = [C.c_int, _fp, _fp, C.c_int, _fp]

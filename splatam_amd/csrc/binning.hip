@@ -152,7 +152,8 @@ __global__ __launch_bounds__(kSortBlock) void tile_sort_block_kernel(SplatState 
     __shared__ __attribute__((aligned(8))) unsigned s_scratch[400];
     if (st.tile_stride == 0 && (long long)st.status[0] > st.capacity) return;
     const int tid = threadIdx.x;
-    // (68 KB of LDS: two workgroups per CU -- a fixed grid walks the tiles, most of which have nothing for this kernel)
+    // (2 x (kSortLds + 1024) keys + scratch = ~83 KB of LDS: one workgroup per CU -- a fixed grid walks the tiles, most of which have
+    //  nothing for this kernel)
     for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
         unsigned lo;
         int n;

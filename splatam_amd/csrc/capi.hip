@@ -126,6 +126,13 @@ int splat_mark_visible(int32_t P, const float *means3D, const float *viewmatrix,
     return check(launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream));
 }
 
+int splat_same_geometry(int32_t P, const float *opacities_a, const float *opacities_b, const float *scales_a, const float *scales_b,
+                        const float *rotations_a, const float *rotations_b, int32_t *differ, void *stream) {
+    if (P < 0 || !differ) return SPLAT_E_INVALID;
+    if (P > 0 && (!opacities_a || !opacities_b || !scales_a || !scales_b || !rotations_a || !rotations_b)) return SPLAT_E_INVALID;
+    return check(launch_same_geometry(P, opacities_a, opacities_b, scales_a, scales_b, rotations_a, rotations_b, differ, (hipStream_t)stream));
+}
+
 int splat_time_kernel(int fn, int iters, const SplatCamera *cam, const SplatGaussians *g, SplatState *st, SplatGrads *gr,
                       float *out_color, float *out_depth, void *stream, float *ms) {
     if (!ms || iters <= 0 || !valid_inputs(cam, g) || !valid_state(g, st, true)) return SPLAT_E_INVALID;
@@ -227,7 +234,7 @@ int splat_iter_adam_pose(const SplatMap *map, int32_t time_idx, const float *d_c
 }
 
 int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P, SplatIterWorkspace *ws, void *stream, float *ms) {
-    if (!ms || iters <= 0 || !cam || !ws || fn < 0 || fn > 3 || P < 0) return SPLAT_E_INVALID;
+    if (!ms || iters <= 0 || !cam || !ws || fn < 0 || fn > 4 || P < 0) return SPLAT_E_INVALID;
     if (!ws->feat8 || !ws->out6 || !ws->dL_dout6 || !ws->accum || !ws->st.tile_base || !ws->st.point_list) return SPLAT_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0, e1;
@@ -254,14 +261,15 @@ int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P,
     }
     (void)hipEventRecord(e0, s);
     for (int i = 0; i < iters && err == hipSuccess; ++i) {
-        if (fn != 1) err = launch_render_forward_feat8(*cam, ws->feat8, st, ws->out6, sort_form, s);
+        if (fn != 1 && fn != 4) err = launch_render_forward_feat8(*cam, ws->feat8, st, ws->out6, sort_form, s);
         if ((fn == 1 || fn == 3) && err == hipSuccess)
             err = launch_render_backward_feat8(*cam, ws->feat8, st, ws->dL_dout6, ws->accum, P, false, true, s);
+        if (fn == 4) err = launch_render_backward_feat8(*cam, ws->feat8, st, ws->dL_dout6, ws->accum, P, false, false, s, false);     // tracking form
     }
     (void)hipEventRecord(e1, s);
     // the timed backward launches accumulated into ws->accum: restore the workspace invariant (every iteration leaves the
     // accumulator zeroed; fused_backward_kernel relies on it) outside the timed bracket
-    if ((fn == 1 || fn == 3) && err == hipSuccess && P > 0) err = hipMemsetAsync(ws->accum, 0, sizeof(float) * SPLAT_GRAD_STRIDE * (size_t)P, s);
+    if ((fn == 1 || fn == 3 || fn == 4) && err == hipSuccess && P > 0) err = hipMemsetAsync(ws->accum, 0, sizeof(float) * SPLAT_GRAD_STRIDE * (size_t)P, s);
     (void)hipEventSynchronize(e1);
     float t = 0.f;
     (void)hipEventElapsedTime(&t, e0, e1);
@@ -358,7 +366,13 @@ int splat_map_duplicate(SplatMapStore *store, const SplatDensifyArgs *a, void *s
 
 int splat_debug_option(int key, int value) {
     if (key == 0) { const int old = g_debug_skip_count; g_debug_skip_count = value; return old; }
+    if (key == 4) { const int old = g_debug_k7_bits; g_debug_k7_bits = value; return old; }
     return -1;
+}
+
+int splat_debug_stamps(void *buffer) {
+    g_debug_stamps = reinterpret_cast<long long *>(buffer);
+    return SPLAT_OK;
 }
 
 // test hook (tests/test_gpu_primitives.py): see launch_selftest in binning.hip

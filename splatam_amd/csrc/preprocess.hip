@@ -322,6 +322,31 @@ hipError_t launch_preprocess_backward(const SplatCamera &cam, const SplatGaussia
     return hipGetLastError();
 }
 
+// K11: do two rasterizer calls see the same geometry?  One lane per Gaussian compares the bits of opacity, scales (3), rotation (4)
+// of call A and call B; any difference raises *differ.  (The drop-in path's geometry cache, rasterizer.py: the two renders of the
+// reference's get_loss -- /root/reference/scripts/splatam.py:249,253 -- are given equal-valued but DISTINCT tensors.)
+__global__ __launch_bounds__(kBlock) void same_geometry_kernel(int P, const uint32_t *oa, const uint32_t *ob, const uint32_t *sa, const uint32_t *sb,
+                                                               const uint4 *ra, const uint4 *rb, int *differ) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P) return;
+    const uint4 qa = ra[i], qb = rb[i];
+    bool same = oa[i] == ob[i] && qa.x == qb.x && qa.y == qb.y && qa.z == qb.z && qa.w == qb.w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) same = same && sa[3 * (size_t)i + k] == sb[3 * (size_t)i + k];
+    if (__builtin_amdgcn_ballot_w64(!same) != 0ull && (threadIdx.x & 63) == 0) atomicOr(differ, 1);
+}
+
+hipError_t launch_same_geometry(int P, const float *oa, const float *ob, const float *sa, const float *sb, const float *ra, const float *rb,
+                                int *differ, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(differ, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    if (P > 0)
+        hipLaunchKernelGGL(same_geometry_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, P, reinterpret_cast<const uint32_t *>(oa),
+                           reinterpret_cast<const uint32_t *>(ob), reinterpret_cast<const uint32_t *>(sa), reinterpret_cast<const uint32_t *>(sb),
+                           reinterpret_cast<const uint4 *>(ra), reinterpret_cast<const uint4 *>(rb), differ);
+    return hipGetLastError();
+}
+
 hipError_t launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s) {
     if (P > 0) hipLaunchKernelGGL(mark_visible_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, P, means3D, view, present);
     return hipGetLastError();

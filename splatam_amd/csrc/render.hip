@@ -675,9 +675,18 @@ __device__ __forceinline__ float group8_allreduce_add(float v) {
     return v;
 }
 
-template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC, bool BG>
+// DBG (measurement builds of the SAME body, selected by splat_debug_option(4, bits); 0 in the product launches): 1 = every workgroup
+// leaves (start, end) wall-clock stamps in `stamps` [gridDim.x][2]; 2 = stage and commit the batches but visit nothing; 4 = everything
+// but the accumulator atomics; 8 = phase 1 only (the pairs are written, never read).  profiles/r04_k7_account.md is built from them.
+template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC, bool BG, int DBG = 0>
 __device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, const float *colors, const SplatState &st,
-                                                      const float *dL_dcolor, float *accum, int T, int per_xcd) {
+                                                      const float *dL_dcolor, float *accum, int T, int per_xcd, long long *stamps = nullptr) {
+    long long t_begin = 0;
+    if constexpr ((DBG & 1) != 0) t_begin = (long long)wall_clock64();
+    auto stamp = [&]() {
+        if constexpr ((DBG & 1) != 0)
+            if (threadIdx.x == 0 && stamps) { stamps[2 * (size_t)blockIdx.x] = t_begin; stamps[2 * (size_t)blockIdx.x + 1] = (long long)wall_clock64(); }
+    };
     constexpr int CL = highest_set_bit(DMASK) + 1;        // colour channels staged per Gaussian: only those that carry gradient
     static_assert(CL >= 1 && CL <= C, "DMASK names channels of the call");
     constexpr int FP = (CL + 3) / 4 * 4;
@@ -691,7 +700,7 @@ __device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, co
     __shared__ PairBuf PB;
     __shared__ unsigned s_wmax[4];
     const int tile_local = block_tile(per_xcd, T);
-    if (tile_local < 0) return;
+    if (tile_local < 0) { stamp(); return; }
     const int W = cam.image_width, H = cam.image_height;
     const int gx = (W + kTile - 1) / kTile;
     const int tile = tile_local + st.tile_row_begin * gx;
@@ -759,7 +768,7 @@ __device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, co
     if (lane == 0) s_wmax[wave] = wmax;
     __syncthreads();
     const unsigned tmax = (unsigned)__builtin_amdgcn_readfirstlane((int)max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])));
-    if (tmax == 0) return;                                     // uniform over the workgroup
+    if (tmax == 0) { stamp(); return; }                        // uniform over the workgroup
     const unsigned lo = st.tile_stride > 0 ? (unsigned)tile * (unsigned)st.tile_stride : st.tile_base[tile];
     const int nb = (int)((tmax + kBatchEntries - 1) / kBatchEntries);
 
@@ -843,7 +852,10 @@ __device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, co
             if (k < NV) pv = s2 == k ? val[k] : pv;
         if (s2 < 5) pv *= op;                                  // S1..S5 carry q = opacity * dL/dalpha
         const bool valid = v2 < nvis;
-        if constexpr (NX == 0) {
+        if constexpr ((DBG & 4) != 0) {
+            // (measurement: the values are formed, the atomics are not issued -- a dependent, never-true store keeps them alive)
+            if (pv == 1.2345e-33f && valid) accum[0] = pv + val[NV > 8 ? 8 : 0];
+        } else if constexpr (NX == 0) {
             if (valid && s2 < NV) atomicAdd(accum + (size_t)id * SPLAT_GRAD_STRIDE + doff_own, pv);
         } else {
             float px_ = val[8];
@@ -933,7 +945,7 @@ __device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, co
             slot_rec = lane_of(slot_m) ? rec : slot_rec;
             slot_m <<= 8;
             if (++nslot == kChunk) {
-                phase2(kChunk);
+                if constexpr ((DBG & 8) == 0) phase2(kChunk);
                 nslot = 0;
                 slot_m = 0xFFull;
                 wr_ptr = my_vw + wr_lane;
@@ -945,6 +957,7 @@ __device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, co
         // padding (the inert record) -- is visited without effect, as is whatever the look-ahead below the list's start names
 #pragma unroll 1
         for (int g = 3; g >= 0; --g) {
+            if constexpr ((DBG & 2) != 0) break;
             const int kk = lim - 64 * g;
             if (kk <= 0) continue;
             unsigned long long bits = mask_word(B, wave, g);
@@ -976,12 +989,13 @@ __device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, co
         }
         // the records of the waiting visits live in this batch: publish them before it is replaced
         if (nslot > 0) {
-            phase2(nslot);
+            if constexpr ((DBG & 8) == 0) phase2(nslot);
             nslot = 0;
             slot_m = 0xFFull;
             wr_ptr = my_vw + wr_lane;
         }
     }
+    stamp();
 }
 
 // Two launch shapes of the same body.  With at most two colour sums (the tracking form) the phase-2 gradient rows live in registers: the
@@ -999,6 +1013,21 @@ __global__ __launch_bounds__(256, 5) void render_backward_kernel5_w5(SplatCamera
     render_backward_body5<C, CS, DMASK, SMASK, OPAC, BG>(cam, colors, st, dL_dcolor, accum, T, per_xcd);
 }
 
+// measurement builds (splat_debug_option(4, bits)): the fused iteration's two forms only
+template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC, bool BG, int DBG>
+__global__ __launch_bounds__(256) void render_backward_kernel5_dbg(SplatCamera cam, const float *colors, SplatState st, const float *dL_dcolor,
+                                                                   float *accum, int T, int per_xcd, long long *stamps) {
+    render_backward_body5<C, CS, DMASK, SMASK, OPAC, BG, DBG>(cam, colors, st, dL_dcolor, accum, T, per_xcd, stamps);
+}
+template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC, bool BG, int DBG>
+__global__ __launch_bounds__(256, 5) void render_backward_kernel5_w5_dbg(SplatCamera cam, const float *colors, SplatState st,
+                                                                         const float *dL_dcolor, float *accum, int T, int per_xcd, long long *stamps) {
+    render_backward_body5<C, CS, DMASK, SMASK, OPAC, BG, DBG>(cam, colors, st, dL_dcolor, accum, T, per_xcd, stamps);
+}
+
+int g_debug_k7_bits = 0;                // splat_debug_option(4, bits)
+long long *g_debug_stamps = nullptr;    // splat_debug_stamps(buffer)
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
@@ -1012,6 +1041,30 @@ template <int C, int CS, unsigned DMASK = (1u << C) - 1u, unsigned SMASK = (1u <
 static void launch_bwd(const SplatCamera &cam, const float *colors, const SplatState &st, const float *dl, float *acc, int T,
                        hipStream_t s) {
     const int per = (T + 7) / 8;
+    if constexpr (C == 6 && CS == 8 && DMASK == 0xFu && !BG && (SMASK == 0xFu || (SMASK == 0x8u && !OPAC))) {
+        if (g_debug_k7_bits != 0) {
+            constexpr bool W5 = popcount_c(SMASK) <= 2;
+            auto go = [&](auto D) {
+                constexpr int DBG = decltype(D)::value;
+                if constexpr (W5)
+                    hipLaunchKernelGGL((render_backward_kernel5_w5_dbg<C, CS, DMASK, SMASK, OPAC, BG, DBG>), dim3(8 * per), dim3(256), 0, s, cam, colors,
+                                       st, dl, acc, T, per, g_debug_stamps);
+                else
+                    hipLaunchKernelGGL((render_backward_kernel5_dbg<C, CS, DMASK, SMASK, OPAC, BG, DBG>), dim3(8 * per), dim3(256), 0, s, cam, colors, st,
+                                       dl, acc, T, per, g_debug_stamps);
+            };
+            switch (g_debug_k7_bits) {
+                case 1: go(std::integral_constant<int, 1>{}); return;
+                case 2: go(std::integral_constant<int, 2>{}); return;
+                case 3: go(std::integral_constant<int, 3>{}); return;
+                case 4: go(std::integral_constant<int, 4>{}); return;
+                case 5: go(std::integral_constant<int, 5>{}); return;
+                case 8: go(std::integral_constant<int, 8>{}); return;
+                case 9: go(std::integral_constant<int, 9>{}); return;
+                default: break;
+            }
+        }
+    }
     if constexpr (popcount_c(SMASK) <= 2)
         hipLaunchKernelGGL((render_backward_kernel5_w5<C, CS, DMASK, SMASK, OPAC, BG>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
     else

@@ -38,6 +38,8 @@ hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &
 hipError_t launch_preprocess_backward(const SplatCamera &cam, const SplatGaussians &g, const SplatState &st,
                                       SplatGrads &gr, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
+hipError_t launch_same_geometry(int P, const float *oa, const float *ob, const float *sa, const float *sb, const float *ra, const float *rb,
+                                int *differ, hipStream_t s);
 // Optional epilogue of the 6-channel forward composite for the fused TRACKING iteration: the masked L1 losses of get_loss
 // (/root/reference/scripts/splatam.py:256-286, tracking=True, no outlier rejection) and their gradient planes, formed from
 // the pixel's six channels while they are still in registers (saves the separate loss kernel and its re-read of six planes).
@@ -76,6 +78,8 @@ hipError_t launch_render_backward_rgb_only(const SplatCamera &cam, const float *
 size_t map_scratch_words(long long n);
 int map_row_floats(const SplatMapStore &st);
 extern int g_debug_skip_count;
+extern int g_debug_k7_bits;
+extern long long *g_debug_stamps;
 hipError_t launch_selftest(int which, const void *in, void *out, int n, hipStream_t s);
 
 #if defined(__HIPCC__)

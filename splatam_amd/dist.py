@@ -158,36 +158,77 @@ class InStreamRccl:
             self.comm = None
 
 
-_instream: Optional[InStreamRccl] = None
-_instream_failed = False
+_instream: Optional[InStreamRccl] = None         # the communicator of the DEFAULT group (bench.py reports it)
+_instream_by_group: Dict[object, Optional[InStreamRccl]] = {}
 
 
 def instream(group=None) -> Optional[InStreamRccl]:
-    """The in-stream communicator when it is switched on (SPLAT_INSTREAM_RCCL=1) and the job runs over RCCL, else None."""
-    global _instream, _instream_failed
-    if _instream is not None or _instream_failed:
-        return _instream
-    if os.environ.get("SPLAT_INSTREAM_RCCL", "0") != "1" or not dist.is_initialized() or dist.get_backend(group) != "nccl":
+    """The in-stream communicator of ``group`` when it is switched on (SPLAT_INSTREAM_RCCL=1) and the job runs over RCCL, else None.
+    Every step that could differ between the ranks -- the environment switch, loading librccl, drawing the id, creating the
+    communicator, the self-check -- is followed by ONE all-reduce(MIN) of its outcome over the process group before anything
+    depends on it, so that all ranks issue the same sequence of collectives and take the same path (a rank whose library fails to
+    load cannot leave the others waiting in a broadcast)."""
+    global _instream
+    key = group
+    if key in _instream_by_group:
+        return _instream_by_group[key]
+    if not dist.is_initialized() or dist.get_backend(group) != "nccl":
         return None
-    comm, err, good = None, None, 0
     dev = torch.device("cuda", torch.cuda.current_device())
-    try:
-        comm = InStreamRccl(dist.get_rank(group), dist.get_world_size(group), group=group)
-        # self-check before anything depends on it: sum of (rank + 1)
-        probe = torch.full((8,), float(comm.rank + 1), device=dev)
-        comm.all_reduce(probe, InStreamRccl.SUM)
-        good = 1 if bool((probe == comm.world * (comm.world + 1) / 2).all()) else 0
-    except Exception as e:                                 # noqa: BLE001  (fall back to the process group, loudly)
-        err = e
-    ok = torch.tensor([good], dtype=torch.int32, device=dev)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)   # every rank takes the same path
-    if int(ok[0]) == 1:
-        _instream = comm
-    else:
-        _instream_failed = True
+
+    def all_agree(ok: bool) -> bool:
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return int(t[0]) == 1
+
+    comm, err = None, None
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    # 1. switched on everywhere, and the library loads everywhere
+    L = None
+    want = os.environ.get("SPLAT_INSTREAM_RCCL", "0") == "1"
+    if want:
+        try:
+            L = _load_rccl()
+        except Exception as e:                             # noqa: BLE001
+            err = e
+    if not all_agree(want and L is not None):
+        _instream_by_group[key] = None
+        if want:
+            import warnings
+            warnings.warn(f"SPLAT_INSTREAM_RCCL=1 but not every rank can use the in-stream communicator ({err!r}); using torch.distributed")
+        return None
+    # 2. rank 0 draws the id (a local call); whether it could is agreed BEFORE the broadcast that ships it
+    uid = None
+    if rank == 0:
+        try:
+            u = _NcclUniqueId()
+            rc = L.ncclGetUniqueId(C.byref(u))
+            uid = C.string_at(C.byref(u), 128) if rc == 0 else None
+        except Exception as e:                             # noqa: BLE001
+            err = e
+    ok = all_agree(rank != 0 or uid is not None)
+    if ok:
+        box = [uid]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        # 3. communicator + self-check (sum of rank + 1), agreed again
+        good = False
+        try:
+            comm = InStreamRccl(rank, world, uid=box[0], group=group)
+            probe = torch.full((8,), float(rank + 1), device=dev)
+            comm.all_reduce(probe, InStreamRccl.SUM)
+            good = bool((probe == world * (world + 1) / 2).all())
+        except Exception as e:                             # noqa: BLE001  (fall back to the process group, loudly)
+            err = e
+        ok = all_agree(good)
+    if not ok:
+        comm = None
         import warnings
         warnings.warn(f"SPLAT_INSTREAM_RCCL=1 but the in-stream communicator is unavailable on some rank ({err!r}); using torch.distributed")
-    return _instream
+    _instream_by_group[key] = comm
+    if group is None:
+        _instream = comm
+    return comm
 
 
 def all_reduce_mean_flat(flat: torch.Tensor, group=None) -> None:

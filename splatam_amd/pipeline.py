@@ -39,12 +39,11 @@ from . import slam
 # keyframe selection
 # --------------------------------------------------------------------------
 
-def _sampled_cloud(depth, intrinsics, w2c, sampled_indices):
-    """World-frame points of the sampled pixels; points that coincide after rounding to 1e-4 (duplicated samples, or
-    the camera origin) are dropped, all copies of them, as the reference's unique/isin construction does."""
+def _sampled_cloud(z, intrinsics, w2c, sampled_indices):
+    """World-frame points of the sampled pixels (``z``: their depths); points that coincide after rounding to 1e-4 (duplicated
+    samples, or the camera origin) are dropped, all copies of them, as the reference's unique/isin construction does."""
     fx, fy, cx, cy = intrinsics[0][0], intrinsics[1][1], intrinsics[0][2], intrinsics[1][2]
     v, u = sampled_indices[:, 0], sampled_indices[:, 1]
-    z = depth[0, v, u]
     pts_cam = torch.stack(((u - cx) / fx * z, (v - cy) / fy * z, z), dim=-1)
     c2w = torch.inverse(w2c)
     pts = pts_cam @ c2w[:3, :3].t() + c2w[:3, 3]
@@ -58,13 +57,18 @@ def keyframe_selection_overlap(gt_depth, w2c, intrinsics, keyframe_list, k, pixe
     """Indices (into ``keyframe_list``) of up to ``k`` keyframes that see part of the current frame: 1600 valid-depth
     pixels are back-projected and re-projected into every keyframe (one batched product over all keyframes); keyframes with
     a non-zero share of points inside the image (20 px border) are kept, ordered by that share, then shuffled."""
-    # a few thousand points against a few dozen keyframes: host-side work (on the GPU the nonzero / unique(dim=0) / tolist chain
-    # of this function cost 86 ms per frame in synchronisations and tiny launches -- more than the 60 mapping iterations)
-    gt_depth, w2c, intrinsics = gt_depth.cpu(), w2c.cpu(), intrinsics.cpu()
+    # The frame stays where it is: the valid-pixel list (one nonzero: row-major order, as torch.where gives it) and the gather of the
+    # 1600 sampled depths run on the depth image's device, and only those samples travel to the host -- copying the frame and scanning
+    # it there cost ~5 ms per 1200x680 frame.  The few thousand points against a few dozen keyframes that follow are host-side work
+    # (on the GPU the unique(dim=0) / tolist chain cost 86 ms per frame in synchronisations and tiny launches).  Random numbers are
+    # drawn where the reference draws them: torch.randint on the CPU generator, then numpy's permutation.
     H, W = gt_depth.shape[1], gt_depth.shape[2]
-    valid = torch.stack(torch.where(gt_depth[0] > 0), dim=1)
-    sampled = valid[torch.randint(valid.shape[0], (pixels,))]
-    pts = _sampled_cloud(gt_depth, intrinsics, w2c, sampled)
+    valid = torch.nonzero(gt_depth[0] > 0)
+    pick = torch.randint(valid.shape[0], (pixels,))
+    sampled = valid[pick.to(valid.device)]
+    z = gt_depth[0, sampled[:, 0], sampled[:, 1]].cpu()
+    sampled, w2c, intrinsics = sampled.cpu(), w2c.cpu(), intrinsics.cpu()
+    pts = _sampled_cloud(z, intrinsics, w2c, sampled)
     if len(keyframe_list) == 0:
         return []
     est = torch.stack([kf['est_w2c'] for kf in keyframe_list]).cpu()               # [K,4,4]

@@ -223,6 +223,97 @@ class LazyOverflow(RuntimeError):
     """Lazy sync mode: the (Gaussian, tile) instances did not fit the lists sized from the high-water mark."""
 
 
+# ---------------------------------------------------------------------------
+# Shared geometry between consecutive calls (SURVEY.md 7 step 5).
+# The reference's get_loss renders the SAME Gaussians twice per iteration -- colours, then depth / silhouette / depth^2
+# (/root/reference/scripts/splatam.py:249,253) -- and so do add_new_gaussians + the first mapping iteration, the evaluation code
+# (/root/reference/utils/eval_helpers.py:219,225) ...  K1-K5 (projection, tile lists, sort) depend on the camera, means3D,
+# opacities, scales and rotations only, not on the colours: the second call re-uses the first call's SplatState and runs K6 alone.
+# Proof of equality, all of it on what the caller handed over (any doubt falls back to the full pass):
+#   * camera: same image size / tanfov / scale_modifier, viewmatrix and projmatrix in the same storage at the same version;
+#   * means3D: same storage, same version, while the cache keeps the first call's tensor alive (the two render-variable dicts
+#     share one means3D tensor: /root/reference/utils/slam_helpers.py:131,241);
+#   * opacities / scales / rotations: the same tensors, or -- the reference applies sigmoid / exp / normalize twice, so they are
+#     distinct tensors with equal values -- compared bit for bit on the device (splat_same_geometry: one kernel + the one status
+#     read that an "exact"-mode forward makes anyway).
+# Only in "exact" sync mode, with scales + rotations (no cov3D_precomp), without SHs.
+# ---------------------------------------------------------------------------
+_GEOM_CACHE = True
+_geom_last: dict = {}
+geometry_cache_stats = {"shared": 0, "verified_on_device": 0, "mismatch": 0}
+
+
+def set_geometry_cache(on: bool) -> None:
+    global _GEOM_CACHE
+    _GEOM_CACHE = bool(on)
+    _geom_last.clear()
+
+
+def clear_geometry_cache() -> None:
+    """Drops the cached state (it keeps one call's geometry and lists alive per device)."""
+    _geom_last.clear()
+
+
+def _cam_key(settings, view, proj):
+    return (int(settings.image_height), int(settings.image_width), float(settings.tanfovx), float(settings.tanfovy),
+            float(settings.scale_modifier), bool(settings.prefiltered), view.data_ptr(), view._version, proj.data_ptr(), proj._version)
+
+
+class _GeomEntry:
+    __slots__ = ("pk", "key", "tensors", "versions")
+
+
+def _remember_geometry(pk, settings, means3D, opac, scales, rots):
+    e = _GeomEntry()
+    e.pk = pk
+    view, proj = _cached_contiguous(settings.viewmatrix), _cached_contiguous(settings.projmatrix)
+    e.key = _cam_key(settings, view, proj)
+    e.tensors = (means3D, opac, scales, rots, view, proj)          # alive: their storage cannot be handed to another tensor
+    e.versions = (means3D._version, opac._version, scales._version, rots._version)
+    _geom_last[means3D.device.index] = e
+
+
+def _shared_geometry(settings, means3D, colors, opac, scales, rots, cov3D, shs):
+    """The pack of a call that re-uses the cached call's geometry and lists, or None."""
+    dev = means3D.device
+    e = _geom_last.get(dev.index)
+    if e is None:
+        return None
+    m1, o1, s1, r1, _, _ = e.tensors
+    P = means3D.shape[0]
+    if P == 0 or m1.shape != means3D.shape or m1.data_ptr() != means3D.data_ptr() or means3D._version != e.versions[0] \
+            or m1._version != e.versions[0]:
+        return None
+    if e.key != _cam_key(settings, _cached_contiguous(settings.viewmatrix), _cached_contiguous(settings.projmatrix)):
+        return None
+    if o1.shape != opac.shape or s1.shape != scales.shape or r1.shape != rots.shape:
+        return None
+    if (o1._version, s1._version, r1._version) != e.versions[1:]:
+        return None                                                 # the first call's inputs were modified in place since
+    same_objects = o1.data_ptr() == opac.data_ptr() and s1.data_ptr() == scales.data_ptr() and r1.data_ptr() == rots.data_ptr()
+    if not same_objects:
+        flag = torch.empty(1, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _capi.check(_capi.lib().splat_same_geometry(P, o1.data_ptr(), opac.data_ptr(), s1.data_ptr(), scales.data_ptr(),
+                                                        r1.data_ptr(), rots.data_ptr(), flag.data_ptr(), _stream(dev)), "splat_same_geometry")
+        geometry_cache_stats["verified_on_device"] += 1
+        if flag.tolist()[0] != 0:                                   # (the host read an exact-mode forward makes anyway)
+            geometry_cache_stats["mismatch"] += 1
+            return None
+    pk1 = e.pk
+    pk = _build_pack(settings, means3D, colors, opac, scales, rots, cov3D, shs)
+    C.memmove(C.byref(pk.st), C.byref(pk1.st), C.sizeof(_capi.SplatState))
+    H, W = int(settings.image_height), int(settings.image_width)
+    final_T = torch.empty(H, W, dtype=torch.float32, device=dev)
+    n_contrib = torch.empty(H, W, dtype=torch.int32, device=dev)
+    pk.st.final_T, pk.st.n_contrib = final_T.data_ptr(), n_contrib.data_ptr()
+    pk.tensors = dict(pk1.tensors, final_T=final_T, n_contrib=n_contrib)       # shares the first call's geometry + lists (ref-counted)
+    pk.num_tiles, pk.num_rendered = pk1.num_tiles, pk1.num_rendered
+    pk.shared_geometry = True
+    geometry_cache_stats["shared"] += 1
+    return pk
+
+
 def rasterize_forward(settings, means3D, colors, opacities, scales, rotations, cov3D, shs, will_backward=True):
     """One forward through the C ABI.  Returns (color, radii, depth, pack).
 
@@ -247,8 +338,18 @@ def _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotati
     dev = means3D.device
     H, W = int(settings.image_height), int(settings.image_width)
     P = means3D.shape[0]
-    pk = _build_pack(settings, means3D, colors, opacities, scales, rotations, cov3D, shs)
     use_sh = shs.numel() > 0
+    cacheable = _GEOM_CACHE and _SYNC_MODE == "exact" and not use_sh and cov3D.numel() == 0 and scales.numel() > 0 and rotations.numel() > 0
+    if cacheable:
+        pk = _shared_geometry(settings, means3D, colors, opacities, scales, rotations, cov3D, shs)
+        if pk is not None:                  # K6 alone, on the cached call's geometry and sorted lists
+            out_color = torch.empty(pk.g.channels, H, W, dtype=torch.float32, device=dev)
+            out_depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _capi.check(L.splat_render_forward(C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), out_color.data_ptr(),
+                                                   out_depth.data_ptr(), _stream(dev)), "splat_render_forward")
+            return out_color, pk.tensors['radii'], out_depth, pk
+    pk = _build_pack(settings, means3D, colors, opacities, scales, rotations, cov3D, shs)
     radii, status = _alloc_state(pk, dev, P, H, W, use_sh)
     Cn = pk.g.channels
     out_color = torch.empty(Cn, H, W, dtype=torch.float32, device=dev)
@@ -283,6 +384,8 @@ def _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotati
         if _SYNC_MODE == "lazy" and pk.num_rendered is None:
             pk.pending_status = _async_status(status, dev)
             pk.hint_key = hint_key
+    if cacheable:
+        _remember_geometry(pk, settings, means3D, opacities, scales, rotations)
     return out_color, radii, out_depth, pk
 
 

@@ -28,9 +28,20 @@ def _camera():
                   sh_degree=0, campos=t("campos"), prefiltered=False)
 
 
+@pytest.fixture(params=["geometry cache on", "geometry cache off"])
+def geometry_cache(request):
+    from splatam_amd import rasterizer as rz
+    on = request.param.endswith("on")
+    rz.set_geometry_cache(on)
+    before = dict(rz.geometry_cache_stats)
+    yield on, before
+    rz.set_geometry_cache(True)
+
+
 @pytest.mark.parametrize("mode", ["tracking", "mapping"])
-def test_reference_call_sequence_replayed_on_hip(mode):
+def test_reference_call_sequence_replayed_on_hip(mode, geometry_cache):
     from diff_gaussian_rasterization import GaussianRasterizer as Renderer
+    from splatam_amd import rasterizer as rz
     cam = _camera()
     calls = []
     shared = {}
@@ -60,6 +71,10 @@ def test_reference_call_sequence_replayed_on_hip(mode):
         res = Renderer(raster_settings=cam)(**kw)
         assert isinstance(res, tuple) and len(res) == 3
         outs.append(res)
+    # the second render re-used the first one's geometry and sorted lists (proven equal on the device: its opacities / scales /
+    # rotations are distinct tensors, as in the caller) -- or, with the cache off, ran the whole pass
+    on, before = geometry_cache
+    assert rz.geometry_cache_stats["shared"] - before["shared"] == (1 if on else 0)
     for ci, (color, radii, depth) in enumerate(outs):
         assert radii.dtype == torch.int32 and tuple(depth.shape) == (1,) + tuple(color.shape[1:])
         assert (radii.cpu().numpy() != GOLD[f"call{ci}/out/radii"]).sum() <= 1
@@ -106,3 +121,53 @@ def test_reference_call_sequence_replayed_on_hip(mode):
     max_r[seen] = torch.max(radius[seen], max_r[seen])          # /root/reference/scripts/splatam.py:341-343
     assert (seen.cpu().numpy() != GOLD[f"{mode}/seen"]).sum() <= 1
     assert (max_r.cpu().numpy() != GOLD[f"{mode}/max_2D_radius"]).sum() <= 1
+
+
+def test_geometry_cache_shares_only_what_is_proven_equal():
+    """K1-K5 of a call are re-used by the next one only when camera, means3D (same storage, same version), opacities, scales and
+    rotations (same tensors, or bitwise equal on the device) are the same; anything else runs the full pass.  Shared or not, the
+    render is the same function."""
+    from diff_gaussian_rasterization import GaussianRasterizer as Renderer
+    from splatam_amd import rasterizer as rz
+    cam = _camera()
+    g = lambda k: torch.tensor(GOLD[f"call0/in/{k}"]).cuda()      # noqa: E731
+    base = {k: g(k) for k in ('means3D', 'colors_precomp', 'rotations', 'opacities', 'scales', 'means2D')}
+    rz.set_geometry_cache(True)
+    try:
+        def render(**over):
+            kw = dict(base)
+            kw.update(over)
+            n = rz.geometry_cache_stats["shared"]
+            out = Renderer(raster_settings=cam)(**kw)
+            return out, rz.geometry_cache_stats["shared"] - n
+        (c0, r0, d0), s = render()
+        assert s == 0                                               # nothing cached yet
+        other_colors = base['colors_precomp'].flip(0).contiguous()
+        (c1, r1, d1), s = render(colors_precomp=other_colors, scales=base['scales'].clone(), rotations=base['rotations'].clone(),
+                                 opacities=base['opacities'].clone())
+        assert s == 1                                               # equal values in distinct tensors: verified on the device
+        rz.set_geometry_cache(False)
+        (c1_ref, r1_ref, d1_ref), _ = render(colors_precomp=other_colors)
+        rz.set_geometry_cache(True)
+        assert torch.equal(c1, c1_ref) and torch.equal(d1, d1_ref) and torch.equal(r1, r1_ref)
+        render()                                                    # (fills the cache again)
+        sc = base['scales'].clone()
+        sc[123, 1] *= 1.5
+        (_, _, _), s = render(scales=sc)
+        assert s == 0                                               # one scale differs: full pass
+        render()
+        (_, _, _), s = render(means3D=base['means3D'].clone())
+        assert s == 0                                               # another means3D tensor: no proof, full pass
+        render()
+        base['means3D'][7, 0] += 0.01                               # modified in place: the version moved
+        (_, _, _), s = render()
+        assert s == 0
+        (_, _, _), s = render()
+        assert s == 1                                               # ... and the unchanged map shares again
+        from diff_gaussian_rasterization import GaussianRasterizationSettings as Camera
+        cam2 = Camera(**{**cam._asdict(), 'viewmatrix': cam.viewmatrix.clone()})
+        n = rz.geometry_cache_stats["shared"]
+        Renderer(raster_settings=cam2)(**base)
+        assert rz.geometry_cache_stats["shared"] == n                # another view matrix tensor: full pass
+    finally:
+        rz.set_geometry_cache(True)
