@@ -139,6 +139,15 @@ typedef struct SplatState {
      * iteration shards over GPUs: every quantity the pose gradient needs is a SUM over pixels, so the ranks' copies of
      * SplatIterWorkspace.sums add up to the whole frame's (one all-reduce of 16 KB per iteration; splat_iter_finish) */
     int32_t tile_row_begin, tile_row_end;
+    /* launch order of the composites' workgroups (fused iteration, whole frames; NULL / NULL = the natural order).  A launch of
+     * 3 225 tile workgroups of very different length on 1 024 resident slots leaves a long tail (time-weighted occupancy 67-76 %,
+     * profiles/r04_k7_account.md): the forward composite leaves a work estimate per tile in tile_work ([T]: the sum over the
+     * tile's four 8x8 quadrants of the deepest list entry any pixel blended -- what the backward composite will walk), a small
+     * kernel turns it into tile_order ([8 * ceil(T / 8)]: the tiles of every XCD band, heaviest first, 0xFFFFFFFF = no tile),
+     * and both composites start their workgroups in that order (the forward one in the previous iteration's).  Only a
+     * schedule: any permutation of each band gives the same results. */
+    uint32_t *tile_work;
+    uint32_t *tile_order;
     /* per-pixel */
     float *final_T;              /* [H][W] */
     int32_t *n_contrib;          /* [H][W] 1-based list position of the last contributor */

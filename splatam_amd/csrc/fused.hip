@@ -1181,6 +1181,8 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
     if (ws.st.tile_row_end > ws.st.tile_row_begin && !fuse_loss) return hipErrorInvalidValue;
     e = launch_render_forward_feat8(cam, ws.feat8, ws.st, ws.out6, sort_in_k6, s, fuse_loss ? &ep : nullptr, fuse_loss ? &loss_done : nullptr);
     if (e != hipSuccess) return e;
+    e = launch_tile_order(cam, ws.st, s);           // the backward composite (and the next forward one) start their heaviest tiles first
+    if (e != hipSuccess) return e;
     if (cfg.ignore_outlier_depth_loss) {
         // torch.median of the depth error (exact radix selection, mapedit.hip) -> d_cam[13] (its bits through counts[4])
         e = launch_depth_error_median(ws.out6, frame.depth, ws.outlier_err, ws.outlier_scratch, HW,

@@ -266,10 +266,16 @@ __device__ __forceinline__ unsigned long long mask_word(const Batch<FP, NL> &b, 
 }
 
 // blockIdx -> tile: XCD x (blocks with b % 8 == x) owns tiles [x*per, (x+1)*per)
-__device__ __forceinline__ int block_tile(int per_xcd, int T) {
+// `order` (SplatState.tile_order): the band's tiles in the order they should START (heaviest first), or NULL for the natural order
+__device__ __forceinline__ int block_tile(int per_xcd, int T, const uint32_t *order = nullptr) {
     const int b = blockIdx.x, slot = b >> 3;
-    const int tile = (b & 7) * per_xcd + slot;
-    return (slot < per_xcd && tile < T) ? tile : -1;
+    const int pos = (b & 7) * per_xcd + slot;
+    if (slot >= per_xcd) return -1;
+    if (order) {
+        const unsigned t = order[pos];
+        return t < (unsigned)T ? (int)t : -1;
+    }
+    return pos < T ? pos : -1;
 }
 
 // Per-lane predicates of the inner loops are kept as wave-uniform 64-bit masks in SGPRs (ballot in, inverse
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(256, 5) void render_forward_kernel(SplatCamera cam,
     constexpr int NL = 16;
     __shared__ Batch<FP, NL> B;
     __shared__ __attribute__((aligned(16))) uint64_t s_keys[SORT ? kFusedSortMax + 2 : 2];
-    const int tile_local = block_tile(per_xcd, T);              // T: tiles of this launch (SplatState.tile_row_begin: a band of tile rows)
+    const int tile_local = block_tile(per_xcd, T, st.tile_row_end > st.tile_row_begin ? nullptr : st.tile_order);      // T: tiles of this launch (SplatState.tile_row_begin: a band of tile rows)
     if (tile_local < 0) return;
     const int W = cam.image_width, H = cam.image_height;
     const int gx = (W + kTile - 1) / kTile;
@@ -567,6 +573,16 @@ __global__ __launch_bounds__(256, 5) void render_forward_kernel(SplatCamera cam,
             wdone = done_m == ~0ull;
         }
     }
+    if (st.tile_work) {
+        // what the backward composite will walk in this tile: per quadrant, the deepest list entry a pixel blended (SplatState.tile_work)
+        __shared__ unsigned s_work;
+        const unsigned wmax = wave_max_u32(inside ? last : 0u);
+        if (tid == 0) s_work = 0u;
+        __syncthreads();
+        if (lane == 0) atomicAdd(&s_work, wmax);
+        __syncthreads();
+        if (tid == 0) st.tile_work[tile] = s_work;
+    }
     float acc_depth = 0.f, acc_im = 0.f;
     if (inside) {
         const size_t HW = (size_t)H * W;
@@ -699,7 +715,7 @@ __device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, co
     __shared__ Batch<FP> B;
     __shared__ PairBuf PB;
     __shared__ unsigned s_wmax[4];
-    const int tile_local = block_tile(per_xcd, T);
+    const int tile_local = block_tile(per_xcd, T, st.tile_row_end > st.tile_row_begin ? nullptr : st.tile_order);
     if (tile_local < 0) { stamp(); return; }
     const int W = cam.image_width, H = cam.image_height;
     const int gx = (W + kTile - 1) / kTile;
@@ -1112,6 +1128,53 @@ hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &
         case 8: launch_bwd<8, 8>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+// SplatState.tile_order from SplatState.tile_work: one workgroup per XCD band; the band's tiles by descending work through a
+// 256-bin counting sort (the order inside a bin is whatever the atomics give: it is a schedule, not a result).
+__global__ __launch_bounds__(256) void tile_order_kernel(const uint32_t *work, uint32_t *order, int T, int per_xcd) {
+    __shared__ unsigned s_max, s_hist[256], s_off[256];
+    const int band = blockIdx.x, tid = threadIdx.x;
+    const int t0 = band * per_xcd, t1 = min(T, t0 + per_xcd);
+    if (tid == 0) s_max = 1u;
+    s_hist[tid] = 0u;
+    __syncthreads();
+    unsigned mx = 0u;
+    for (int t = t0 + tid; t < t1; t += 256) mx = max(mx, work[t]);
+    mx = wave_max_u32(mx);
+    if ((tid & 63) == 0) atomicMax(&s_max, mx);
+    __syncthreads();
+    const float scale = 255.0f / (float)s_max;
+    for (int t = t0 + tid; t < t1; t += 256) atomicAdd(&s_hist[255 - (int)((float)work[t] * scale)], 1u);
+    __syncthreads();
+    if (tid < 64) {                         // exclusive scan of the 256 bins by one wave (four bins per lane)
+        unsigned c[4], sum = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c[k] = s_hist[4 * tid + k]; sum += c[k]; }
+        unsigned incl = sum;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = (unsigned)__shfl_up((int)incl, d, 64);
+            if (tid >= d) incl += o;
+        }
+        unsigned run = incl - sum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s_off[4 * tid + k] = run; run += c[k]; }
+    }
+    __syncthreads();
+    for (int t = t0 + tid; t < t1; t += 256) {
+        const unsigned pos = atomicAdd(&s_off[255 - (int)((float)work[t] * scale)], 1u);
+        order[t0 + pos] = (uint32_t)t;
+    }
+    for (int t = max(t1, t0) + tid; t < t0 + per_xcd; t += 256) order[t] = 0xFFFFFFFFu;       // (the last band may be short)
+}
+
+hipError_t launch_tile_order(const SplatCamera &cam, SplatState &st, hipStream_t s) {
+    if (!st.tile_work || !st.tile_order || st.tile_row_end > st.tile_row_begin) return hipSuccess;
+    const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
+    if (T == 0) return hipSuccess;
+    const int per = (T + 7) / 8;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(256), 0, s, st.tile_work, st.tile_order, T, per);
     return hipGetLastError();
 }
 

@@ -83,6 +83,13 @@ class FusedEngine:
         self.num_groups = (((W + 15) // 16 + GT - 1) // GT) * (((H + 15) // 16 + GT - 1) // GT)
         b['group_count'] = torch.zeros(self.num_groups * CS, dtype=i32, **z)
         b['status'] = torch.zeros(4, dtype=i32, **z)
+        # launch order of the composites' workgroups (SplatState.tile_work / tile_order): heaviest tiles of every XCD band first
+        per = (T + 7) // 8
+        nat = torch.arange(8 * per, dtype=torch.int64)
+        b['tile_order'] = torch.where(nat < T, nat, torch.full_like(nat, 0xFFFFFFFF)).to(torch.uint32).view(i32).to(dev) \
+            if hasattr(torch, "uint32") else None
+        b['tile_work'] = torch.zeros(T, dtype=i32, **z)
+        self.tile_order_on = os.environ.get("SPLAT_TILE_ORDER", "1") != "0" and b['tile_order'] is not None
         b['final_T'] = torch.empty(H, W, dtype=f32, **z)
         b['n_contrib'] = torch.empty(H, W, dtype=i32, **z)
         b['feat8'] = torch.empty(P_alloc, 8, dtype=f32, **z)
@@ -593,6 +600,8 @@ class FusedEngine:
                     b['group_recs'] = torch.empty(need, dtype=torch.int32, device=self.dev)
                 st.group_recs, st.group_stride = b['group_recs'].data_ptr(), gs
         st.order_hint = int(self.creation_order)
+        if self.tile_order_on:
+            st.tile_work, st.tile_order = b['tile_work'].data_ptr(), b['tile_order'].data_ptr()
         st.sub_bins = self.sub_bins if self.tile_stride == 0 else 1
         st.final_T, st.n_contrib, st.status = b['final_T'].data_ptr(), b['n_contrib'].data_ptr(), b['status'].data_ptr()
         ws.feat8, ws.out6, ws.dL_dout6, ws.accum = b['feat8'].data_ptr(), b['out6'].data_ptr(), b['dL_dout6'].data_ptr(), b['accum'].data_ptr()

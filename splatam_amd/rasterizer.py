@@ -240,7 +240,8 @@ class LazyOverflow(RuntimeError):
 # ---------------------------------------------------------------------------
 _GEOM_CACHE = True
 _geom_last: dict = {}
-geometry_cache_stats = {"shared": 0, "verified_on_device": 0, "mismatch": 0}
+geometry_cache_stats = {"shared": 0, "verified_on_device": 0, "mismatch": 0, "other_means3D": 0, "other_camera": 0, "other_shapes": 0,
+                        "inputs_modified": 0}
 
 
 def set_geometry_cache(on: bool) -> None:
@@ -281,14 +282,19 @@ def _shared_geometry(settings, means3D, colors, opac, scales, rots, cov3D, shs):
         return None
     m1, o1, s1, r1, _, _ = e.tensors
     P = means3D.shape[0]
+    st = geometry_cache_stats
     if P == 0 or m1.shape != means3D.shape or m1.data_ptr() != means3D.data_ptr() or means3D._version != e.versions[0] \
             or m1._version != e.versions[0]:
+        st["other_means3D"] += 1
         return None
     if e.key != _cam_key(settings, _cached_contiguous(settings.viewmatrix), _cached_contiguous(settings.projmatrix)):
+        st["other_camera"] += 1
         return None
     if o1.shape != opac.shape or s1.shape != scales.shape or r1.shape != rots.shape:
+        st["other_shapes"] += 1
         return None
-    if (o1._version, s1._version, r1._version) != e.versions[1:]:
+    if (o1._version, s1._version, r1._version) != tuple(e.versions[1:]):
+        st["inputs_modified"] += 1
         return None                                                 # the first call's inputs were modified in place since
     same_objects = o1.data_ptr() == opac.data_ptr() and s1.data_ptr() == scales.data_ptr() and r1.data_ptr() == rots.data_ptr()
     if not same_objects:

@@ -74,7 +74,7 @@ def test_reference_call_sequence_replayed_on_hip(mode, geometry_cache):
     # the second render re-used the first one's geometry and sorted lists (proven equal on the device: its opacities / scales /
     # rotations are distinct tensors, as in the caller) -- or, with the cache off, ran the whole pass
     on, before = geometry_cache
-    assert rz.geometry_cache_stats["shared"] - before["shared"] == (1 if on else 0)
+    assert rz.geometry_cache_stats["shared"] - before["shared"] == (1 if on else 0), (rz.geometry_cache_stats, before)
     for ci, (color, radii, depth) in enumerate(outs):
         assert radii.dtype == torch.int32 and tuple(depth.shape) == (1,) + tuple(color.shape[1:])
         assert (radii.cpu().numpy() != GOLD[f"call{ci}/out/radii"]).sum() <= 1

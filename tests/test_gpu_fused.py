@@ -756,3 +756,41 @@ def test_sharded_tracking_flag_travels_with_the_sums_and_folded_sums_are_the_sum
     for e in ranks:                                                 # BOTH ranks held their step back
         assert torch.equal(e.params['cam_trans'].detach(), pose0)
         assert float(e.buf['d_cam'][12]) == 1.0
+
+
+def test_tile_launch_order_changes_nothing_but_speed():
+    """SplatState.tile_work / tile_order: the composites start the heaviest tiles of every XCD band first.  The order is a permutation
+    of each band's tiles (the forward composite's own work estimates, descending), and a schedule only: the rendered planes are
+    bit-identical with and without it, the gradients equal to float-atomic summation order."""
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    params, variables, frame, cam = _scene(30000, 424, 312, seed=77)       # 27 x 20 = 540 tiles: bands of 68, the last one short
+    cfg = slam.REPLICA_MAPPING
+    res = {}
+    for on in (True, False):
+        eng = FusedEngine({k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}, cam)
+        eng.tile_order_on = on
+        for _ in range(3):                                          # exact lists, then learnt lists in the learnt order
+            eng.loss_backward(frame, 1, cfg, tracking=False)
+            assert not eng.check_overflow()
+        torch.cuda.synchronize()
+        res[on] = (eng.buf['out6'].clone(), {k: v.clone() for k, v in eng.grads.items()}, eng.loss(),
+                   eng.buf['tile_order'].cpu().numpy().astype(np.int64) & 0xFFFFFFFF, eng.buf['tile_work'].cpu().numpy())
+    T, per = 540, 68
+    order, work = res[True][3], res[True][4]
+    assert work.max() > 0
+    for band in range(8):
+        seg = order[band * per:(band + 1) * per]
+        tiles = seg[seg != 0xFFFFFFFF]
+        lo, hi = band * per, min(T, (band + 1) * per)
+        assert sorted(tiles.tolist()) == list(range(lo, hi)), band             # a permutation of the band's tiles
+        assert (seg[len(tiles):] == 0xFFFFFFFF).all()
+        w = work[tiles].astype(np.float64)
+        bins = np.floor(w * 255.0 / max(work[lo:hi].max(), 1)).astype(int)
+        assert (np.diff(bins) <= 0).all(), band                                 # heaviest first (to the sort's 256 bins)
+    assert (res[False][3] == np.where(np.arange(8 * per) < T, np.arange(8 * per), 0xFFFFFFFF)).all()      # off: never touched
+    assert torch.equal(res[True][0], res[False][0])
+    assert abs(res[True][2] - res[False][2]) <= 1e-6 * abs(res[False][2])
+    for k in res[True][1]:
+        a, b = res[True][1][k], res[False][1][k]
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, k
