@@ -70,7 +70,7 @@ class SplatLossConfig(C.Structure):
     _fields_ = [("tracking", C.c_int32), ("camera_grad", C.c_int32), ("gaussians_grad", C.c_int32),
                 ("use_sil_for_loss", C.c_int32), ("sil_thres", C.c_float), ("use_l1", C.c_int32),
                 ("ignore_outlier_depth_loss", C.c_int32), ("w_im", C.c_float), ("w_depth", C.c_float),
-                ("defer_finish", C.c_int32)]
+                ("defer_finish", C.c_int32), ("fused_composite", C.c_int32)]
 
 
 class SplatIterWorkspace(C.Structure):

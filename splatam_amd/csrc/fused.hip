@@ -1179,35 +1179,44 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
     const bool fuse_loss = cfg.tracking && !cfg.ignore_outlier_depth_loss;
     // a band of tile rows (SplatState.tile_row_begin): only the loss that is formed per tile in the composite's epilogue is defined
     if (ws.st.tile_row_end > ws.st.tile_row_begin && !fuse_loss) return hipErrorInvalidValue;
-    e = launch_render_forward_feat8(cam, ws.feat8, ws.st, ws.out6, sort_in_k6, s, fuse_loss ? &ep : nullptr, fuse_loss ? &loss_done : nullptr);
-    if (e != hipSuccess) return e;
-    e = launch_tile_order(cam, ws.st, s);           // the backward composite (and the next forward one) start their heaviest tiles first
-    if (e != hipSuccess) return e;
-    if (cfg.ignore_outlier_depth_loss) {
-        // torch.median of the depth error (exact radix selection, mapedit.hip) -> d_cam[13] (its bits through counts[4])
-        e = launch_depth_error_median(ws.out6, frame.depth, ws.outlier_err, ws.outlier_scratch, HW,
-                                      reinterpret_cast<int32_t *>(ws.d_cam) + 9, s);
+    // ... and with short lists and nothing but the pose gradient wanted, the backward composite rides in the same kernel
+    const bool one_kernel = fuse_loss && sort_in_k6 && cfg.fused_composite != 0 && !ws.d_rgb_colors && !ws.d_logit_opacities;
+    if (one_kernel) {
+        e = launch_render_track_fused(cam, ws.feat8, ws.st, ws.out6, ws.accum, ep, cfg.fused_composite == 2, s);
+        if (e != hipSuccess) return e;
+        e = launch_tile_order(cam, ws.st, s);
+        if (e != hipSuccess) return e;
+    } else {
+        e = launch_render_forward_feat8(cam, ws.feat8, ws.st, ws.out6, sort_in_k6, s, fuse_loss ? &ep : nullptr, fuse_loss ? &loss_done : nullptr);
+        if (e != hipSuccess) return e;
+        e = launch_tile_order(cam, ws.st, s);           // the backward composite (and the next forward one) start their heaviest tiles first
+        if (e != hipSuccess) return e;
+        if (cfg.ignore_outlier_depth_loss) {
+            // torch.median of the depth error (exact radix selection, mapedit.hip) -> d_cam[13] (its bits through counts[4])
+            e = launch_depth_error_median(ws.out6, frame.depth, ws.outlier_err, ws.outlier_scratch, HW,
+                                          reinterpret_cast<int32_t *>(ws.d_cam) + 9, s);
+            if (e != hipSuccess) return e;
+        }
+        if (cfg.tracking && loss_done) {
+            // nothing: see the epilogue above
+        } else if (cfg.tracking) {
+            if (HW % 4 == 0) {
+                const int blocks = min((HW / 4 + kBlock - 1) / kBlock, 2048);
+                hipLaunchKernelGGL(track_loss_kernel<4>, dim3(blocks), dim3(kBlock), 0, s, a, HW);
+            } else {
+                const int blocks = min((HW + kBlock - 1) / kBlock, 2048);
+                hipLaunchKernelGGL(track_loss_kernel<1>, dim3(blocks), dim3(kBlock), 0, s, a, HW);
+            }
+        } else {
+            const int tiles = 3 * ((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH);
+            const dim3 grid(8 * ((tiles + 7) / 8));                 // (ssim_tile: XCD x owns a contiguous run of tiles)
+            hipLaunchKernelGGL(ssim_forward_kernel, grid, dim3(kBlock), 0, s, a, W, H);
+            hipLaunchKernelGGL(map_loss_backward_kernel, grid, dim3(kBlock), 0, s, a, W, H);
+        }
+        e = launch_render_backward_feat8(cam, ws.feat8, ws.st, ws.dL_dout6, ws.accum, P, false, ws.d_rgb_colors != nullptr, s,
+                                         ws.d_logit_opacities != nullptr);
         if (e != hipSuccess) return e;
     }
-    if (cfg.tracking && loss_done) {
-        // nothing: see the epilogue above
-    } else if (cfg.tracking) {
-        if (HW % 4 == 0) {
-            const int blocks = min((HW / 4 + kBlock - 1) / kBlock, 2048);
-            hipLaunchKernelGGL(track_loss_kernel<4>, dim3(blocks), dim3(kBlock), 0, s, a, HW);
-        } else {
-            const int blocks = min((HW + kBlock - 1) / kBlock, 2048);
-            hipLaunchKernelGGL(track_loss_kernel<1>, dim3(blocks), dim3(kBlock), 0, s, a, HW);
-        }
-    } else {
-        const int tiles = 3 * ((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH);
-        const dim3 grid(8 * ((tiles + 7) / 8));                 // (ssim_tile: XCD x owns a contiguous run of tiles)
-        hipLaunchKernelGGL(ssim_forward_kernel, grid, dim3(kBlock), 0, s, a, W, H);
-        hipLaunchKernelGGL(map_loss_backward_kernel, grid, dim3(kBlock), 0, s, a, W, H);
-    }
-    e = launch_render_backward_feat8(cam, ws.feat8, ws.st, ws.dL_dout6, ws.accum, P, false, ws.d_rgb_colors != nullptr, s,
-                                     ws.d_logit_opacities != nullptr);
-    if (e != hipSuccess) return e;
     PoseAdam pa{};
     if (pose_adam)
         pa = PoseAdam{pose_adam->state, pose_adam->beta1, pose_adam->beta2, pose_adam->eps, pose_adam->bc2_sqrt, pose_adam->step_size_rot,

@@ -145,7 +145,7 @@ __device__ __forceinline__ void gather(Staged<FP> &s, const SplatState &st, cons
 //   [0] A, B, Cq, opacity   [1 .. FP/4] features   [FP/4 + 1] mu_x, mu_y, id (bits), 0
 // so that the compositing wave needs ONE address register and reads the record with FP/4 + 2 broadcast
 // ds_read_b128 (the 48 / 64-byte record stride keeps the staging ds_write_b128 conflict free).
-template <int FP, int NL = 4>
+template <int FP, int NL = 4, bool BOTH = false>
 struct Batch {
     static constexpr int R4 = FP / 4 + 2;
     float4 rec[kBatch * R4];
@@ -165,21 +165,25 @@ struct Batch {
     unsigned char vcnt[NL == 4 ? 1 : 2][NL][4];     // entries per list and gathering wave
     unsigned char vtot[NL];         // NL == 16: entries per list
     unsigned flag[4];               // forward: wave w had no pixel left when this batch was committed
+    // BOTH (the fused forward + backward composite, NL == 16): the quadrant visit lists of the NL == 4 layout BESIDE the block lists --
+    // the backward pass walks the batch the forward pass has just composited
+    unsigned qlist[BOTH ? 1 + 16 * (kSegBytes / 4) + 1 : 1];
 };
 
-template <int FP, int NL>
-__device__ __forceinline__ const unsigned char *visit_list(const Batch<FP, NL> &b, int list, int gwave) {
-    return reinterpret_cast<const unsigned char *>(b.vlist + 1) + (list * 4 + gwave) * kSegBytes;
+template <int FP, int NL, bool BOTH>
+__device__ __forceinline__ const unsigned char *visit_list(const Batch<FP, NL, BOTH> &b, int list, int gwave) {
+    static_assert(NL == 4 || BOTH, "quadrant lists: the NL == 4 layout, or the second set of a BOTH batch");
+    return reinterpret_cast<const unsigned char *>((BOTH ? b.qlist : b.vlist) + 1) + (list * 4 + gwave) * kSegBytes;
 }
 
-template <int FP>
-__device__ __forceinline__ const unsigned char *block_list(const Batch<FP, 16> &b, int list) {
+template <int FP, bool BOTH>
+__device__ __forceinline__ const unsigned char *block_list(const Batch<FP, 16, BOTH> &b, int list) {
     return reinterpret_cast<const unsigned char *>(b.vlist) + list * kBlockListBytes;
 }
 
 // NL == 16, step 1 (before the barrier that ends the previous batch): this gathering wave's entry count per block list
-template <int FP>
-__device__ __forceinline__ void commit_counts(Batch<FP, 16> &b, const Staged<FP> &s, int tid, int parity) {
+template <int FP, bool BOTH>
+__device__ __forceinline__ void commit_counts(Batch<FP, 16, BOTH> &b, const Staged<FP> &s, int tid, int parity) {
     const int wave = tid >> 6, lane = tid & 63;
     unsigned mine = 0;
 #pragma unroll
@@ -190,9 +194,9 @@ __device__ __forceinline__ void commit_counts(Batch<FP, 16> &b, const Staged<FP>
     if (lane < 16) b.vcnt[parity][lane][wave] = (unsigned char)mine;
 }
 
-template <int FP, int NL>
-__device__ __forceinline__ void commit(Batch<FP, NL> &b, const Staged<FP> &s, int tid, unsigned flag, int parity = 0) {
-    constexpr int R4 = Batch<FP, NL>::R4;
+template <int FP, int NL, bool BOTH>
+__device__ __forceinline__ void commit(Batch<FP, NL, BOTH> &b, const Staged<FP> &s, int tid, unsigned flag, int parity = 0) {
+    constexpr int R4 = Batch<FP, NL, BOTH>::R4;
     b.rec[tid * R4] = s.ga;
 #pragma unroll
     for (int v = 0; v < FP / 4; ++v)
@@ -227,6 +231,24 @@ __device__ __forceinline__ void commit(Batch<FP, NL> &b, const Staged<FP> &s, in
             for (int j = tot[r] + lane; j < pad_end; j += 64) lists[(wave * 4 + r) * kBlockListBytes + j] = 0xFFu;
             if (lane == 0) b.vtot[wave * 4 + r] = (unsigned char)tot[r];
         }
+        if constexpr (BOTH) {
+            // the quadrant lists of the backward pass: a Gaussian is on quadrant q's list when it is on the list of any of q's four blocks
+            // (a subset of the NL == 4 quadrant test: a pixel with alpha >= 1/255 lies in a block whose box test passed)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool hit = ((s.mask >> (4 * q)) & 0xFu) != 0u;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                const int cnt = __builtin_popcountll(m);
+                unsigned char *seg = const_cast<unsigned char *>(visit_list(b, q, wave));
+                if (hit) seg[rank] = (unsigned char)tid;
+                if (lane < 4) seg[cnt + lane] = 0xFFu;
+                if (lane == 0) {
+                    b.qmask[q][wave][0] = (unsigned)m;
+                    b.qmask[q][wave][1] = (unsigned)(m >> 32);
+                }
+            }
+        }
     } else {
 #pragma unroll
         for (int q = 0; q < NL; ++q) {
@@ -247,6 +269,37 @@ __device__ __forceinline__ void commit(Batch<FP, NL> &b, const Staged<FP> &s, in
     if (lane == 0) b.flag[wave] = flag;
 }
 
+// What the backward pass needs of a batch: the records and the QUADRANT lists.  An NL == 4 batch: commit(); a BOTH batch re-staged by
+// the backward pass of the fused composite (s.mask holds the 4-bit quadrant mask of gather<.., NL = 4>)
+template <int FP, int NL, bool BOTH>
+__device__ __forceinline__ void commit_quadrants(Batch<FP, NL, BOTH> &b, const Staged<FP> &s, int tid) {
+    if constexpr (!BOTH) {
+        commit(b, s, tid, 0u);
+    } else {
+        constexpr int R4 = Batch<FP, NL, BOTH>::R4;
+        b.rec[tid * R4] = s.ga;
+#pragma unroll
+        for (int v = 0; v < FP / 4; ++v)
+            b.rec[tid * R4 + 1 + v] = make_float4(s.feat[4 * v], s.feat[4 * v + 1], s.feat[4 * v + 2], s.feat[4 * v + 3]);
+        b.rec[tid * R4 + R4 - 1] = make_float4(s.mu.x, s.mu.y, __uint_as_float(s.id), 0.f);
+        const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool hit = (s.mask >> q) & 1u;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            const int cnt = __builtin_popcountll(m);
+            unsigned char *seg = const_cast<unsigned char *>(visit_list(b, q, wave));
+            if (hit) seg[rank] = (unsigned char)tid;
+            if (lane < 4) seg[cnt + lane] = 0xFFu;
+            if (lane == 0) {
+                b.qmask[q][wave][0] = (unsigned)m;
+                b.qmask[q][wave][1] = (unsigned)(m >> 32);
+            }
+        }
+    }
+}
+
 // One staged Gaussian as a compositing wave holds it: the whole LDS record, fetched ONE VISIT AHEAD (the wave's critical path
 // per visit is then instruction issue alone; with the record read inside the visit the dependent LDS round trips were
 // exposed and the SIMDs sat ~40 % idle at the 4-5 waves each that the register / LDS budget allows).
@@ -258,8 +311,8 @@ struct Rec {
 };
 
 // wave-uniform 64-bit word of this wave's quadrant mask
-template <int FP, int NL>
-__device__ __forceinline__ unsigned long long mask_word(const Batch<FP, NL> &b, int quadrant, int w) {
+template <int FP, int NL, bool BOTH>
+__device__ __forceinline__ unsigned long long mask_word(const Batch<FP, NL, BOTH> &b, int quadrant, int w) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)b.qmask[quadrant][w][0]);
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)b.qmask[quadrant][w][1]);
     return ((unsigned long long)hi << 32) | lo;
@@ -376,40 +429,22 @@ __device__ __forceinline__ void sort_keys_two_level(uint64_t *A, uint64_t *S, co
 // SORT: the workgroup first collects its tile's (depth, id) keys in LDS (from its bucket, or by filtering its group's records:
 // SplatState.group_count), sorts them there (sort_keys_two_level) and publishes ids and count for the backward pass: no scan,
 // scatter or sort launch, and the gathers take their ids from LDS instead of a dependent global load.
-template <int C, int CS, bool WITH_DEPTH, bool SORT, bool TRACK = false>
-__global__ __launch_bounds__(256, 5) void render_forward_kernel(SplatCamera cam, const float *colors, SplatState st,
-                                                             float *out_color, float *out_depth, int T, int per_xcd,
-                                                             TrackLossEpilogue ep = TrackLossEpilogue{}) {
-    static_assert(!TRACK || (C == 6 && !WITH_DEPTH), "the tracking-loss epilogue reads the six fused channels");
+// The forward composite of ONE tile up to its per-pixel results (the kernels below add their epilogues): builds / reads the tile's list,
+// stages it batch by batch into B and composites front to back.  Returns the index of the LAST batch it staged (the one B still holds;
+// -1: empty list).  Lane l of wave w = pixel (l & 3, (l >> 2) & 3) of block (l >> 4) of quadrant w (one 4x4 block per 16-lane row).
+template <int C, int CS, bool WITH_DEPTH, bool SORT, class BatchT>
+__device__ __forceinline__ int forward_tile(const float *colors, SplatState &st, BatchT &B, uint64_t *s_keys, const int tile, const int tx, const int ty,
+                                            const int gx, const int tid, const float fpx, const float fpy, const bool inside, float &Tr, float &D,
+                                            float (&Cc)[C], unsigned &last) {
     constexpr int F = C + (WITH_DEPTH ? 1 : 0);
     constexpr int FP = (F + 3) / 4 * 4;
-    // ONE 4x4-PIXEL BLOCK PER 16-LANE ROW: row r of wave w composites block r of quadrant w (gather(): NL = 16) from the block's OWN
-    // visit lists -- the four rows of a wave process four different Gaussians per trip (each lane reads the record of its row's
-    // entry; the vector instructions are shared).  SplaTAM's splats are small ({alpha >= 1/255} radius ~3.8 px at workload B): a
-    // Gaussian that touches an 8x8 quadrant touches ~2 of its four blocks, so a wave takes ~0.6 trips per quadrant visit and ~36 %
-    // of its lanes hold a live pixel instead of ~21 % -- on a kernel bound by the vector pipe (DESIGN.md 5).
     constexpr int NL = 16;
-    __shared__ Batch<FP, NL> B;
-    __shared__ __attribute__((aligned(16))) uint64_t s_keys[SORT ? kFusedSortMax + 2 : 2];
-    const int tile_local = block_tile(per_xcd, T, st.tile_row_end > st.tile_row_begin ? nullptr : st.tile_order);      // T: tiles of this launch (SplatState.tile_row_begin: a band of tile rows)
-    if (tile_local < 0) return;
-    const int W = cam.image_width, H = cam.image_height;
-    const int gx = (W + kTile - 1) / kTile;
-    const int tile = tile_local + st.tile_row_begin * gx;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tx = tile % gx, ty = tile / gx;
+    const int lane = tid & 63, wave = tid >> 6;
     const int row = lane >> 4;                                  // this lane's block of the quadrant
-    const int px = tx * kTile + (wave & 1) * 8 + (row & 1) * 4 + (lane & 3), py = ty * kTile + (wave >> 1) * 8 + (row >> 1) * 4 + ((lane >> 2) & 3);
-    const float fpx = (float)px, fpy = (float)py;
     const float tile_x0 = (float)(tx * kTile), tile_y0 = (float)(ty * kTile);
-    const bool inside = px < W && py < H;
-    float Tr = 1.f, D = 0.f, Cc[C];
-    unsigned last = 0;
-#pragma unroll
-    for (int ch = 0; ch < C; ++ch) Cc[ch] = 0.f;
     unsigned long long done_m = __builtin_amdgcn_ballot_w64(!inside);      // wave-uniform: pixels with nothing left to composite
     bool wdone = done_m == ~0ull;
-
+    int staged = -1;
     unsigned lo;
     int n;
     tile_range(st, tile, lo, n);
@@ -494,6 +529,7 @@ __global__ __launch_bounds__(256, 5) void render_forward_kernel(SplatCamera cam,
         for (int bi = 0; bi < nb; ++bi) {
             __syncthreads();                        // every wave has finished reading the previous batch; this batch's list counts are in
             commit(B, pre, tid, wdone ? 1u : 0u, bi & 1);
+            staged = bi;
             __syncthreads();
             // every wave was finished when this batch was committed: the rest of the list cannot contribute
             const unsigned alldone = B.flag[0] & B.flag[1] & B.flag[2] & B.flag[3];
@@ -508,7 +544,7 @@ __global__ __launch_bounds__(256, 5) void render_forward_kernel(SplatCamera cam,
             unsigned last_loc = ~0u;            // record (byte offset in B.rec) of the pixel's last contributor in this batch (none yet)
             // a list entry -> its record's byte offset in B.rec: a wave-uniform value in a vector register (one byte-select shift per
             // visit, no scalar bookkeeping); the visit identifies its entry by that offset
-            constexpr int R4 = Batch<FP, NL>::R4;
+            constexpr int R4 = BatchT::R4;
             auto rec_of = [&](unsigned e) { return e * (unsigned)(R4 * sizeof(float4)); };
             // one visit of this quadrant: `cur` was fetched from LDS during the previous visit (see Rec)
             auto visit = [&](unsigned rec, const Rec<FP> &cur) {
@@ -573,6 +609,40 @@ __global__ __launch_bounds__(256, 5) void render_forward_kernel(SplatCamera cam,
             wdone = done_m == ~0ull;
         }
     }
+    return staged;
+}
+
+template <int C, int CS, bool WITH_DEPTH, bool SORT, bool TRACK = false>
+__global__ __launch_bounds__(256, 5) void render_forward_kernel(SplatCamera cam, const float *colors, SplatState st,
+                                                             float *out_color, float *out_depth, int T, int per_xcd,
+                                                             TrackLossEpilogue ep = TrackLossEpilogue{}) {
+    static_assert(!TRACK || (C == 6 && !WITH_DEPTH), "the tracking-loss epilogue reads the six fused channels");
+    constexpr int F = C + (WITH_DEPTH ? 1 : 0);
+    constexpr int FP = (F + 3) / 4 * 4;
+    // ONE 4x4-PIXEL BLOCK PER 16-LANE ROW: row r of wave w composites block r of quadrant w (gather(): NL = 16) from the block's OWN
+    // visit lists -- the four rows of a wave process four different Gaussians per trip (each lane reads the record of its row's
+    // entry; the vector instructions are shared).  SplaTAM's splats are small ({alpha >= 1/255} radius ~3.8 px at workload B): a
+    // Gaussian that touches an 8x8 quadrant touches ~2 of its four blocks, so a wave takes ~0.6 trips per quadrant visit and ~36 %
+    // of its lanes hold a live pixel instead of ~21 % -- on a kernel bound by the vector pipe (DESIGN.md 5).
+    constexpr int NL = 16;
+    __shared__ Batch<FP, NL> B;
+    __shared__ __attribute__((aligned(16))) uint64_t s_keys[SORT ? kFusedSortMax + 2 : 2];
+    const int tile_local = block_tile(per_xcd, T, st.tile_row_end > st.tile_row_begin ? nullptr : st.tile_order);      // T: tiles of this launch (SplatState.tile_row_begin: a band of tile rows)
+    if (tile_local < 0) return;
+    const int W = cam.image_width, H = cam.image_height;
+    const int gx = (W + kTile - 1) / kTile;
+    const int tile = tile_local + st.tile_row_begin * gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tx = tile % gx, ty = tile / gx;
+    const int row = lane >> 4;                                  // this lane's block of the quadrant
+    const int px = tx * kTile + (wave & 1) * 8 + (row & 1) * 4 + (lane & 3), py = ty * kTile + (wave >> 1) * 8 + (row >> 1) * 4 + ((lane >> 2) & 3);
+    const float fpx = (float)px, fpy = (float)py;
+    const bool inside = px < W && py < H;
+    float Tr = 1.f, D = 0.f, Cc[C];
+    unsigned last = 0;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) Cc[ch] = 0.f;
+    forward_tile<C, CS, WITH_DEPTH, SORT>(colors, st, B, s_keys, tile, tx, ty, gx, tid, fpx, fpy, inside, Tr, D, Cc, last);
     if (st.tile_work) {
         // what the backward composite will walk in this tile: per quadrant, the deepest list entry a pixel blended (SplatState.tile_work)
         __shared__ unsigned s_work;
@@ -691,58 +761,31 @@ __device__ __forceinline__ float group8_allreduce_add(float v) {
     return v;
 }
 
-// DBG (measurement builds of the SAME body, selected by splat_debug_option(4, bits); 0 in the product launches): 1 = every workgroup
-// leaves (start, end) wall-clock stamps in `stamps` [gridDim.x][2]; 2 = stage and commit the batches but visit nothing; 4 = everything
-// but the accumulator atomics; 8 = phase 1 only (the pairs are written, never read).  profiles/r04_k7_account.md is built from them.
-template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC, bool BG, int DBG = 0>
-__device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, const float *colors, const SplatState &st,
-                                                      const float *dL_dcolor, float *accum, int T, int per_xcd, long long *stamps = nullptr) {
-    long long t_begin = 0;
-    if constexpr ((DBG & 1) != 0) t_begin = (long long)wall_clock64();
-    auto stamp = [&]() {
-        if constexpr ((DBG & 1) != 0)
-            if (threadIdx.x == 0 && stamps) { stamps[2 * (size_t)blockIdx.x] = t_begin; stamps[2 * (size_t)blockIdx.x + 1] = (long long)wall_clock64(); }
-    };
+// The backward composite of ONE tile from the pixel state on (generation 5, see above): everything after the loads of final_T / n_contrib /
+// dL/dC.  `staged`: index of the batch that is ALREADY in B -- records, quadrant masks and quadrant visit lists committed by the
+// caller (the fused forward + backward composite hands over the batch its forward pass ended on) -- or -1.  B: a Batch with the
+// quadrant lists (NL == 4, or a BOTH batch); PB, s_wmax: the caller's LDS.
+template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC, int DBG, class BatchT>
+__device__ __forceinline__ void backward_core(const float *colors, const SplatState &st, float *accum, BatchT &B, PairBuf &PB, unsigned *s_wmax,
+                                              const int tile, const int tx, const int ty, const int tid, const bool inside, const float Tfin,
+                                              const unsigned last, const float (&dpix)[C], float R, const int staged) {
     constexpr int CL = highest_set_bit(DMASK) + 1;        // colour channels staged per Gaussian: only those that carry gradient
     static_assert(CL >= 1 && CL <= C, "DMASK names channels of the call");
-    constexpr int FP = (CL + 3) / 4 * 4;
-    constexpr int R4 = Batch<FP>::R4;
+    constexpr int R4 = BatchT::R4;
+    constexpr int FP = (R4 - 2) * 4;
+    static_assert(FP >= CL, "the batch records hold the channels that carry gradient");
     constexpr int NS = popcount_c(SMASK);
     constexpr int NB = OPAC ? 6 : 5;          // published geometric sums: S1..S5 (+ S6)
     constexpr int NV = NB + NS;               // published values per visit
     static_assert(NV <= 16, "two publish instructions carry at most 16 values");
     constexpr int NX = NV > 8 ? NV - 8 : 0;   // values 8.. travel in the row partner's lanes
-    __shared__ Batch<FP> B;
-    __shared__ PairBuf PB;
-    __shared__ unsigned s_wmax[4];
-    const int tile_local = block_tile(per_xcd, T, st.tile_row_end > st.tile_row_begin ? nullptr : st.tile_order);
-    if (tile_local < 0) { stamp(); return; }
-    const int W = cam.image_width, H = cam.image_height;
-    const int gx = (W + kTile - 1) / kTile;
-    const int tile = tile_local + st.tile_row_begin * gx;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tx = tile % gx, ty = tile / gx;
+    const int lane = tid & 63, wave = tid >> 6;
     const int qx0 = tx * kTile + (wave & 1) * 8, qy0 = ty * kTile + (wave >> 1) * 8;      // this wave's quadrant
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const float fpx = (float)px, fpy = (float)py;
     const float tile_x0 = (float)(tx * kTile), tile_y0 = (float)(ty * kTile);
-    const bool inside = px < W && py < H;
-    const size_t HW = (size_t)H * W;
-    const size_t pix = (size_t)py * W + px;
-
-    // ---- phase-1 state of this lane's pixel
-    const float Tfin = inside ? st.final_T[pix] : 0.f;
     float Tr = Tfin;
-    const unsigned last = inside ? (unsigned)st.n_contrib[pix] : 0u;
-    float dpix[C], R = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < C; ++ch) {
-        dpix[ch] = 0.f;
-        if ((DMASK >> ch) & 1u) {
-            dpix[ch] = inside ? dL_dcolor[ch * HW + pix] : 0.f;
-            if constexpr (BG) R += Tfin * cam.bg[ch] * dpix[ch];      // the background term of dL/dalpha: -T_final bg.dL/dC / (1 - alpha)
-        }
-    }
+    (void)inside;
     // ---- phase-2 constants: the incoming gradient of the 8 pixels of row s2 = lane & 7 (channels in SMASK), from a per-wave
     // LDS table [row][column] filled by the pixel lanes (row stride 8 records + 1: eight rows -> eight distinct bank groups).
     // Few channels (tracking: the depth plane only): held in registers; more: one broadcast ds_read_b128 per pixel in phase 2.
@@ -784,7 +827,7 @@ __device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, co
     if (lane == 0) s_wmax[wave] = wmax;
     __syncthreads();
     const unsigned tmax = (unsigned)__builtin_amdgcn_readfirstlane((int)max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])));
-    if (tmax == 0) { stamp(); return; }                        // uniform over the workgroup
+    if (tmax == 0) return;                                     // uniform over the workgroup
     const unsigned lo = st.tile_stride > 0 ? (unsigned)tile * (unsigned)st.tile_stride : st.tile_base[tile];
     const int nb = (int)((tmax + kBatchEntries - 1) / kBatchEntries);
 
@@ -899,14 +942,17 @@ __device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, co
 
     int nslot = 0;                                              // wave-uniform
     Staged<FP> pre;
-    {
+    const bool handed_over = staged == nb - 1;                  // (uniform) the first batch of this pass is the one already in B
+    if (!handed_over) {
         const unsigned e = (unsigned)((nb - 1) * kBatchEntries + tid);
         gather<CL, CS, false, FP>(pre, st, colors, lo + e, tid < kBatchEntries && e < tmax, tile_x0, tile_y0);
     }
     for (int bi = nb - 1; bi >= 0; --bi) {
-        if (bi < nb - 1) __syncthreads();           // every wave has finished reading the previous batch
-        commit(B, pre, tid, 0u);
-        __syncthreads();
+        if (!(handed_over && bi == nb - 1)) {
+            if (bi < nb - 1 || staged >= 0) __syncthreads();   // every wave has finished reading the previous batch
+            commit_quadrants(B, pre, tid);
+            __syncthreads();
+        }
         const bool more = bi > 0;
         if (more) gather<CL, CS, false, FP>(pre, st, colors, lo + (unsigned)((bi - 1) * kBatchEntries + tid), tid < kBatchEntries, tile_x0, tile_y0);
         const int base = bi * kBatchEntries;
@@ -1011,6 +1057,51 @@ __device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, co
             wr_ptr = my_vw + wr_lane;
         }
     }
+}
+
+// DBG (measurement builds of the SAME body, selected by splat_debug_option(4, bits); 0 in the product launches): 1 = every workgroup
+// leaves (start, end) wall-clock stamps in `stamps` [gridDim.x][2]; 2 = stage and commit the batches but visit nothing; 4 = everything
+// but the accumulator atomics; 8 = phase 1 only (the pairs are written, never read).  profiles/r04_k7_account.md is built from them.
+template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC, bool BG, int DBG = 0>
+__device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, const float *colors, const SplatState &st,
+                                                      const float *dL_dcolor, float *accum, int T, int per_xcd, long long *stamps = nullptr) {
+    long long t_begin = 0;
+    if constexpr ((DBG & 1) != 0) t_begin = (long long)wall_clock64();
+    auto stamp = [&]() {
+        if constexpr ((DBG & 1) != 0)
+            if (threadIdx.x == 0 && stamps) { stamps[2 * (size_t)blockIdx.x] = t_begin; stamps[2 * (size_t)blockIdx.x + 1] = (long long)wall_clock64(); }
+    };
+    constexpr int CL = highest_set_bit(DMASK) + 1;        // colour channels staged per Gaussian: only those that carry gradient
+    static_assert(CL >= 1 && CL <= C, "DMASK names channels of the call");
+    constexpr int FP = (CL + 3) / 4 * 4;
+    __shared__ Batch<FP> B;
+    __shared__ PairBuf PB;
+    __shared__ unsigned s_wmax[4];
+    const int tile_local = block_tile(per_xcd, T, st.tile_row_end > st.tile_row_begin ? nullptr : st.tile_order);
+    if (tile_local < 0) { stamp(); return; }
+    const int W = cam.image_width, H = cam.image_height;
+    const int gx = (W + kTile - 1) / kTile;
+    const int tile = tile_local + st.tile_row_begin * gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tx = tile % gx, ty = tile / gx;
+    const int px = tx * kTile + (wave & 1) * 8 + (lane & 7), py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const size_t HW = (size_t)H * W;
+    const size_t pix = (size_t)py * W + px;
+
+    // ---- phase-1 state of this lane's pixel
+    const float Tfin = inside ? st.final_T[pix] : 0.f;
+    const unsigned last = inside ? (unsigned)st.n_contrib[pix] : 0u;
+    float dpix[C], R = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+        dpix[ch] = 0.f;
+        if ((DMASK >> ch) & 1u) {
+            dpix[ch] = inside ? dL_dcolor[ch * HW + pix] : 0.f;
+            if constexpr (BG) R += Tfin * cam.bg[ch] * dpix[ch];      // the background term of dL/dalpha: -T_final bg.dL/dC / (1 - alpha)
+        }
+    }
+    backward_core<C, CS, DMASK, SMASK, OPAC, DBG>(colors, st, accum, B, PB, s_wmax, tile, tx, ty, tid, inside, Tfin, last, dpix, R, -1);
     stamp();
 }
 
@@ -1027,6 +1118,108 @@ __global__ __launch_bounds__(256, 5) void render_backward_kernel5_w5(SplatCamera
                                                                      const float *dL_dcolor, float *accum, int T, int per_xcd) {
     static_assert(popcount_c(SMASK) <= 2, "the five-wave shape is for the forms whose gradient rows live in registers");
     render_backward_body5<C, CS, DMASK, SMASK, OPAC, BG>(cam, colors, st, dL_dcolor, accum, T, per_xcd);
+}
+
+// ---------------------------------------------------------------------------
+// K6 + K7 in ONE kernel: the tracking iteration's forward composite, loss and backward composite
+// ---------------------------------------------------------------------------
+// The tracking loss is pixel-local (/root/reference/scripts/splatam.py:256-288 with ignore_outlier_depth_loss = False, as every shipped
+// configuration has it): a tile's gradient planes exist the moment its forward composite ends.  This kernel keeps going: the loss terms
+// and dL/d(render) of a pixel are formed in its registers (TrackLossEpilogue, above), moved from the forward pass' lane layout (one 4x4
+// block per 16-lane row) to the backward pass' (8x8 quadrant, row-major) by one ds_bpermute per value, and the backward composite
+// (backward_core) walks the batch the forward pass has just composited -- its records are still in LDS, and commit() left the quadrant
+// visit lists beside the block lists (Batch<.., BOTH>).  Against the two-kernel form a tile with a one-batch list (workload B: ~220
+// entries) saves the whole second staging (point list -> conic / centre / feature gathers, culling tests, ballots: 16-20 % of the
+// backward composite, profiles/r04_k7_account.md), the round trip of ten per-pixel planes (six rendered, four gradient; final_T and
+// n_contrib) and a launch; a tile with more batches re-stages all but its last one.  KEEP: the planes are written as well (what
+// FusedEngine.rendered() / the tests read); the tracking step of the product loop has no reader for them.
+// LDS: one batch of 64-byte records + block lists + quadrant lists + the pair buffer (the sort's key array, dead once the forward
+// pass has gathered its last batch, shares it): ~39.6 KB -> four workgroups per CU.
+template <bool KEEP>
+__global__ __launch_bounds__(256, 4) void render_track_fused_kernel(SplatCamera cam, const float *feat8, SplatState st, float *out6, float *accum,
+                                                                    int T, int per_xcd, TrackLossEpilogue ep) {
+    constexpr int C = 6, CS = 8, FP = 8;
+    using BatchT = Batch<FP, 16, true>;
+    constexpr size_t kRaw = sizeof(PairBuf) > sizeof(uint64_t) * (kFusedSortMax + 2) ? sizeof(PairBuf) : sizeof(uint64_t) * (kFusedSortMax + 2);
+    __shared__ BatchT B;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kRaw];
+    __shared__ unsigned s_wmax[4];
+    __shared__ double s_loss[2][4];
+    uint64_t *const s_keys = reinterpret_cast<uint64_t *>(s_raw);
+    PairBuf &PB = *reinterpret_cast<PairBuf *>(s_raw);
+    const int tile_local = block_tile(per_xcd, T, st.tile_row_end > st.tile_row_begin ? nullptr : st.tile_order);
+    if (tile_local < 0) return;
+    const int W = cam.image_width, H = cam.image_height;
+    const int gx = (W + kTile - 1) / kTile;
+    const int tile = tile_local + st.tile_row_begin * gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tx = tile % gx, ty = tile / gx;
+    const size_t HW = (size_t)H * W;
+    // ---- forward pass: lane = pixel of block (lane >> 4) of quadrant `wave`
+    const int row = lane >> 4;
+    const int fx_ = tx * kTile + (wave & 1) * 8 + (row & 1) * 4 + (lane & 3), fy_ = ty * kTile + (wave >> 1) * 8 + (row >> 1) * 4 + ((lane >> 2) & 3);
+    const bool finside = fx_ < W && fy_ < H;
+    float Tr = 1.f, D = 0.f, Cc[C];
+    unsigned flast = 0;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) Cc[ch] = 0.f;
+    const int staged = forward_tile<C, CS, false, true>(feat8, st, B, s_keys, tile, tx, ty, gx, tid, (float)fx_, (float)fy_, finside, Tr, D, Cc, flast);
+    (void)D;
+    // ---- the loss of this pixel and its gradient planes, in registers (the arithmetic of render_forward_kernel's TRACK epilogue)
+    float acc_depth = 0.f, acc_im = 0.f, g[4] = {0.f, 0.f, 0.f, 0.f};
+    if (finside) {
+        const size_t pix = (size_t)fy_ * W + fx_;
+        const float gt = ep.depth[pix];
+        const float im3[3] = {ep.im[pix], ep.im[HW + pix], ep.im[2 * HW + pix]};
+        float o[C];
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) o[ch] = Cc[ch] + Tr * cam.bg[ch];
+        const float unc = o[5] - o[3] * o[3];
+        bool m = gt > 0.f && !(o[3] != o[3]) && !(unc != unc);
+        if (ep.use_sil_for_loss) m = m && (o[4] > ep.sil_thres);
+        const float dd = gt - o[3];
+        acc_depth = m ? fabsf(dd) : 0.f;
+        const float dsign = m ? ((dd > 0.f) ? -1.f : ((dd < 0.f) ? 1.f : 0.f)) : 0.f;
+        g[3] = ep.use_l1 ? ep.w_depth * dsign : 0.f;
+        const bool cm = ep.use_sil_for_loss ? m : true;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float di = im3[ch] - o[ch];
+            acc_im += cm ? fabsf(di) : 0.f;
+            g[ch] = cm ? -ep.w_im * ((di > 0.f) ? 1.f : ((di < 0.f) ? -1.f : 0.f)) : 0.f;
+        }
+        if constexpr (KEEP) {
+            st.final_T[pix] = Tr;
+            st.n_contrib[pix] = (int)flast;
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) out6[ch * HW + pix] = o[ch];
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) ep.dL_dout6[ch * HW + pix] = g[ch];
+        }
+    }
+    {
+        float a0 = acc_depth, a1 = acc_im;
+        for (int msk = 32; msk >= 1; msk >>= 1) { a0 += __shfl_xor(a0, msk, 64); a1 += __shfl_xor(a1, msk, 64); }
+        if (lane == 0) { s_loss[0][wave] = (double)a0; s_loss[1][wave] = (double)a1; }
+        __syncthreads();                    // (also: every wave has left the forward pass -- the key array may become the pair buffer)
+        if (tid < 2) {
+            const double t = s_loss[tid][0] + s_loss[tid][1] + s_loss[tid][2] + s_loss[tid][3];
+            if (t != 0.0) atomicAdd(ep.sums + (size_t)(blockIdx.x % SPLAT_ITER_SUM_COPIES) * SPLAT_ITER_SUMS + tid, t);
+        }
+    }
+    // ---- to the backward pass' layout: lane = pixel (lane & 7, lane >> 3) of the quadrant; its values sit in lane `src` of the forward layout
+    const int qx = lane & 7, qy = lane >> 3;
+    const int src = 16 * ((qx >> 2) + 2 * (qy >> 2)) + 4 * (qy & 3) + (qx & 3);
+    const bool inside = tx * kTile + (wave & 1) * 8 + qx < W && ty * kTile + (wave >> 1) * 8 + qy < H;
+    const float Tfin = inside ? __shfl(Tr, src, 64) : 0.f;
+    const unsigned last = inside ? (unsigned)__shfl((int)flast, src, 64) : 0u;
+    float dpix[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) dpix[ch] = ch < 4 ? __shfl(g[ch < 4 ? ch : 0], src, 64) : 0.f;      // (outside the image g is zero)
+    // ---- backward pass over the same lists, starting on the batch that is still staged
+    backward_core<C, CS, 0xFu, 0x8u, false, 0>(feat8, st, accum, B, PB, s_wmax, tile, tx, ty, tid, inside, Tfin, last, dpix, 0.f, staged);
+    // what the next launch's order is built from (SplatState.tile_work): the quadrants' deepest contributors, as the core left them
+    if (st.tile_work && tid == 0) st.tile_work[tile] = s_wmax[0] + s_wmax[1] + s_wmax[2] + s_wmax[3];
 }
 
 // measurement builds (splat_debug_option(4, bits)): the fused iteration's two forms only
@@ -1205,6 +1398,18 @@ hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat
     }
     if (sort_in_kernel) launch_fwd<6, 8, false, true>(cam, feat8, st, out6, nullptr, T, s);
     else launch_fwd<6, 8, false, false>(cam, feat8, st, out6, nullptr, T, s);
+    return hipGetLastError();
+}
+
+// The tracking iteration's composites as ONE launch (render_track_fused_kernel): lists short enough for the composite's own sort, a
+// pixel-local loss (no outlier rejection).  keep_planes: also write out6 / final_T / n_contrib / dL_dout6.
+hipError_t launch_render_track_fused(const SplatCamera &cam, const float *feat8, SplatState &st, float *out6, float *accum,
+                                     const TrackLossEpilogue &ep, bool keep_planes, hipStream_t s) {
+    const int T = launch_tiles(cam, st);
+    if (T == 0) return hipSuccess;
+    const int per = (T + 7) / 8;
+    if (keep_planes) hipLaunchKernelGGL((render_track_fused_kernel<true>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6, accum, T, per, ep);
+    else hipLaunchKernelGGL((render_track_fused_kernel<false>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6, accum, T, per, ep);
     return hipGetLastError();
 }
 

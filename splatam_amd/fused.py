@@ -134,6 +134,7 @@ class FusedEngine:
         self._cam = self._make_cam(cam)
         self._cam_ok = {}
         self._frame_keep = None
+        self.track_fused = os.environ.get("SPLAT_TRACK_FUSED", "1") != "0"    # tracking: forward + loss + backward composite in one kernel
         self.fold_sums = os.environ.get("SPLAT_FOLD_SUMS", "1") != "0"     # tile-row-sharded tracking: exchange 256 B instead of 16 KB
         self.skipped_iterations = 0     # of the last check_overflow() / digest_report(): iterations whose Adam step the device skipped
         self._learnt_P = None           # rows of the map the list statistics were learnt on (rebind keeps them for a similar map)
@@ -622,9 +623,10 @@ class FusedEngine:
         return torch.cuda.current_stream(self.dev).cuda_stream
 
     @staticmethod
-    def loss_config(cfg, tracking, do_ba=False, defer_finish=False):
+    def loss_config(cfg, tracking, do_ba=False, defer_finish=False, fused_composite=0):
         c = _capi.SplatLossConfig()
         c.defer_finish = int(defer_finish)
+        c.fused_composite = int(fused_composite)
         c.tracking = int(tracking)
         c.camera_grad = int(tracking or do_ba)
         c.gaussians_grad = int(not tracking)
@@ -635,11 +637,13 @@ class FusedEngine:
 
     # ------------------------------------------------------------------ one iteration
     def loss_backward(self, curr_data, time_idx, cfg, tracking, map_grads=None, do_ba=False, pose_adam=None, map_adam=None,
-                      tile_rows=None):
+                      tile_rows=None, keep_planes=None):
         """get_loss + backward.  Afterwards (stream order): ``self.grads`` (mapping) and
         ``self.buf['d_cam']`` = [dL/dq_raw(4), dL/dt_raw(3), loss].  ``pose_adam`` (a SplatPoseAdam): the pose's Adam step
         rides in the last kernel (splat_iter_tracking_step); ``map_adam`` (a SplatAdamMap): likewise the map's
-        (splat_iter_mapping_step)."""
+        (splat_iter_mapping_step).  ``keep_planes`` (tracking): the rendered planes / gradient planes (``rendered()``,
+        ``buf['dL_dout6']``) are wanted -- default: yes, unless the pose's Adam step rides along (the loop's own iterations); without
+        them the tracking iteration's composites run as ONE kernel that keeps its planes in registers (SplatLossConfig.fused_composite)."""
         if map_grads is None:
             map_grads = not tracking
         self._check_cam(curr_data)
@@ -650,7 +654,10 @@ class FusedEngine:
             im, depth, w2c = im.contiguous(), depth.contiguous(), w2c.contiguous()
         fr.im, fr.depth, fr.w2c, fr.time_idx = im.data_ptr(), depth.data_ptr(), w2c.data_ptr(), int(time_idx)
         self._frame_keep = (im, depth, w2c)
-        lc = self.loss_config(cfg, tracking, do_ba, defer_finish=tile_rows is not None)
+        if keep_planes is None:
+            keep_planes = pose_adam is None
+        one_kernel = (2 if keep_planes else 1) if (tracking and self.track_fused and not map_grads) else 0
+        lc = self.loss_config(cfg, tracking, do_ba, defer_finish=tile_rows is not None, fused_composite=one_kernel)
         self._tile_rows = tile_rows         # a band: the iteration stops before its last kernel (finish_iteration completes it)
         self._stats_partial = tile_rows is not None
         self._lc_keep = lc
@@ -772,7 +779,7 @@ class FusedEngine:
             return
         if cfg['ignore_outlier_depth_loss']:
             raise RuntimeError("tile-row-sharded tracking needs a pixel-local loss: not with ignore_outlier_depth_loss")
-        self.loss_backward(curr_data, self.track_time_idx, cfg, tracking=True, tile_rows=self.tile_row_band(*shard))
+        self.loss_backward(curr_data, self.track_time_idx, cfg, tracking=True, tile_rows=self.tile_row_band(*shard), keep_planes=False)
         if self.fold_sums:
             # the 64 copies of the partial sums folded into the first (one tiny launch): the exchange carries 256 bytes, not 16 KB
             with torch.cuda.device(self.dev):

@@ -215,7 +215,7 @@ class _Session:
         take that step now.  The caller sees the repeated iteration's values."""
         params, curr_data, iter_time_idx, cfg, do_ba, tracking = rep.args
         for _ in range(3):
-            eng.loss_backward(curr_data, iter_time_idx, cfg, tracking=True, do_ba=do_ba)
+            eng.loss_backward(curr_data, iter_time_idx, cfg, tracking=True, do_ba=do_ba, keep_planes=False)
             if rep.stepped is not False:
                 eng.pose_step -= 1
                 eng.adam_pose(*rep.stepped)
@@ -251,7 +251,7 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
     if tracking and (s.pending_tracking or eng.track_time_idx != int(iter_time_idx)):
         eng.begin_tracking(iter_time_idx)           # fresh pose Adam state: the caller made a new optimizer for this frame (:680)
         s.pending_tracking = False
-    eng.loss_backward(curr_data, iter_time_idx, cfg, tracking=tracking, do_ba=bool(do_ba))
+    eng.loss_backward(curr_data, iter_time_idx, cfg, tracking=tracking, do_ba=bool(do_ba), keep_planes=False)
     rep = _Report(eng.buf['d_cam'].clone())
     rep.args = (params, curr_data, int(iter_time_idx), cfg, bool(do_ba), tracking)
     s.post(eng, rep)

@@ -34,9 +34,9 @@ CONFIGS = {
 CLUSTER = (0.40, 0.40, 0.40 + 0.2236, 0.40 + 0.2236)        # 5 % of the image area
 
 
-def _scene(cfg, seed=0, aniso=False, region=None):
+def _scene(cfg, seed=0, aniso=False, region=None, bg=(0.0, 0.0, 0.0), scale_modifier=1.0):
     c = CONFIGS[cfg]
-    cam = R.make_camera(c['W'], c['H'], c['fx'], c['fy'], c['cx'], c['cy'])
+    cam = R.make_camera(c['W'], c['H'], c['fx'], c['fy'], c['cx'], c['cy'], bg=bg)._replace(scale_modifier=scale_modifier)
     p = R.synthetic_cloud(c['n'], c['W'], c['H'], c['fx'], c['fy'], c['cx'], c['cy'], seed=seed, anisotropic=aniso, region=region)
     return cam, R.cloud_to_rendervar(p)
 
@@ -96,6 +96,20 @@ def test_dropin_full_size(cfg, aniso):
     _check_images(gc, gr, gd, oc, orad, od)
     og64 = _oracle(cam, rv, gout, "f64")[3]
     _check_dropin_grads(gg, og, og64, f"{cfg}{'-aniso' if aniso else ''}", aniso)
+
+
+@pytest.mark.parametrize("cfg,aniso,bg,mod", [('D', True, (1.0, 1.0, 1.0), 1.0), ('B', False, (0.2, 0.6, 1.0), 1.0), ('D', True, (0.0, 0.0, 0.0), 1.6)])
+def test_dropin_full_size_viewer_settings(cfg, aniso, bg, mod):
+    """The settings the reference's viewers render with -- a white background (/root/reference/viz_scripts/final_recon.py:110-122: bg
+    enters the forward as C + T bg and the backward through dL/dalpha) -- and a scale modifier other than 1 (the settings tuple's
+    sixth field, /root/reference/utils/recon_helpers.py:20), at full size: forward and all six gradients vs the C oracle."""
+    cam, rv = _scene(cfg, seed=11, aniso=aniso, bg=bg, scale_modifier=mod)
+    gout = torch.randn(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(3))
+    gc, gr, gd, gg = _dropin(cam, rv, gout)
+    oc, orad, od, og, _ = _oracle(cam, rv, gout)
+    _check_images(gc, gr, gd, oc, orad, od)
+    og64 = _oracle(cam, rv, gout, "f64")[3]
+    _check_dropin_grads(gg, og, og64, f"{cfg}{'-aniso' if aniso else ''} bg {bg} modifier {mod}", aniso)
 
 
 def test_dropin_clustered_lists_beyond_lds():
@@ -263,8 +277,9 @@ def _fused_case(cfg_name, aniso, tracking, monkeypatch, seed=0, region=None):
     planes = eng.buf['dL_dout6'].detach().cpu()
     ref_planes = torch.cat([plane_grads[0], plane_grads[1][0:1]])
     pmax = float(ref_planes.abs().max())
-    # (round 3: the printed reports show at most 1.0e-4 of the plane elements at a kink -- D mapping -- hence 1.5e-4, was 1e-3)
-    assert_close_outliers(planes[0:4].numpy(), ref_planes.numpy(), 1e-4 * pmax, rtol=1e-3, max_outlier_frac=1.5e-4, outlier_atol=2.5 * pmax,
+    # (round 3: the printed reports show at most 1.0e-4 of the plane elements at a kink -- D mapping -- hence 1.5e-4, was 1e-3; a kink
+    #  flips the sign of one L1 term: the element moves by exactly twice its magnitude, 2 pmax at most -- round 4: 2.05, was 2.5)
+    assert_close_outliers(planes[0:4].numpy(), ref_planes.numpy(), 1e-4 * pmax, rtol=1e-3, max_outlier_frac=1.5e-4, outlier_atol=2.05 * pmax,
                           what=f"{what} dL/d(render) planes")
     assert float(planes[4:6].abs().max()) == 0.0 and float(plane_grads[1][1:3].abs().max()) == 0.0
     # (D) parameter / pose gradients for the SAME gradient planes, float32 and float64 oracle
@@ -279,7 +294,8 @@ def test_fused_mapping_vs_oracle(cfg_name, aniso, monkeypatch):
     keys = ["means3D", "rgb_colors", "logit_opacities", "log_scales"] + (["unnorm_rotations"] if aniso else [])
     # a depth tie (two list neighbours swapped, verified above) moves the gradients of the Gaussians under it: the 99.99 % quantile
     # of a 150 k-row tensor is 15 elements, so that one swap IS the tail there (D-anisotropic: log_scales 2.3x the oracle's own tail)
-    tail = 2.0 if eng.depth_tie_pixels == 0 else 4.0
+    # (round 4: the worst case measured under a verified tie is 2.3x -- D-anisotropic log_scales -- + 30 % = 3.0, was 4.0)
+    tail = 2.0 if eng.depth_tie_pixels == 0 else 3.0
     for k in keys:
         assert_grad_calibrated(eng.grads[k].cpu().numpy(), g32[k], g64[k], what=f"{what} grad {k}", tail_factor=tail)
     if not aniso:

@@ -794,3 +794,42 @@ def test_tile_launch_order_changes_nothing_but_speed():
     for k in res[True][1]:
         a, b = res[True][1][k], res[False][1][k]
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, k
+
+
+@pytest.mark.parametrize("n,W,H,label", [(20000, 328, 248, "one batch per tile"), (90000, 328, 248, "two to three batches per tile"),
+                                         (4000, 200, 120, "sparse: empty tiles, pixels outside the image")])
+def test_tracking_composites_in_one_kernel_equal_the_two_kernels(n, W, H, label):
+    """SplatLossConfig.fused_composite: the tracking iteration's forward composite, loss and backward composite as ONE kernel (the
+    backward pass walks the batch the forward pass left in LDS; planes in registers) against the two-kernel form: rendered planes,
+    gradient planes, final_T / n_contrib bit for bit (the forward pass is the same code), loss and pose gradient to float-atomic
+    summation order; and, without the planes, the same tracking LOOP."""
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    params, variables, frame, cam = _scene(n, W, H, seed=91)
+    cfg = slam.REPLICA_TRACKING
+    out = {}
+    for fused in (True, False):
+        eng = FusedEngine({k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}, cam)
+        eng.track_fused = fused
+        eng.loss_backward(frame, 1, slam.REPLICA_MAPPING, tracking=False)       # learn the lists (the composite sorts them itself)
+        assert not eng.check_overflow() and eng.tile_stride > 0 and eng.max_list_hint * 5 // 4 <= 1024
+        eng.begin_tracking(1)
+        eng.loss_backward(frame, 1, cfg, tracking=True)                         # planes kept
+        torch.cuda.synchronize()
+        assert not eng.check_overflow(grow=False)
+        out[fused] = dict(out6=eng.buf['out6'].clone(), dplanes=eng.buf['dL_dout6'].clone(), T=eng.buf['final_T'].clone(),
+                          nc=eng.buf['n_contrib'].clone(), d=eng.buf['d_cam'].clone(), longest=eng.max_list_hint)
+        for _ in range(4):                                                      # the loop's own iterations: no planes
+            eng.tracking_iteration(frame, cfg)
+        torch.cuda.synchronize()
+        assert not eng.check_overflow(grow=False)
+        out[fused].update(rot=eng.params['cam_unnorm_rots'].detach().clone(), trans=eng.params['cam_trans'].detach().clone(), loss=eng.loss())
+    a, b = out[True], out[False]
+    print(label, "longest list", a['longest'])
+    for k in ('out6', 'dplanes', 'T', 'nc'):
+        assert torch.equal(a[k], b[k]), (label, k)
+    assert abs(float(a['d'][7]) - float(b['d'][7])) <= 1e-6 * abs(float(b['d'][7]))
+    assert float((a['d'][:7] - b['d'][:7]).abs().max()) <= 2e-5 * float(b['d'][:7].abs().max()), (a['d'][:7], b['d'][:7])
+    assert float((a['d'][8:12] - b['d'][8:12]).abs().max()) <= 1e-5 * float(b['d'][8:12].abs().max())
+    assert float((a['trans'] - b['trans']).abs().max()) <= 2e-5 and float((a['rot'] - b['rot']).abs().max()) <= 2e-5
+    assert abs(a['loss'] - b['loss']) <= 1e-3 * abs(b['loss'])
