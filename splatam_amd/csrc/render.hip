@@ -49,6 +49,7 @@ struct Staged {
     float feat[FP];     // colours (then depth in the forward of the reference API), zero padded
     unsigned mask;      // 4-bit quadrant mask
     unsigned id;        // Gaussian index
+    float aux;          // travels in the spare word of the record's last float4 (COMPACT6 forward records: depth^2)
 };
 
 // colours of Gaussian `id`: C floats at colors + id*CS (CS = record stride in floats; CS % 4 == 0 records are
@@ -73,7 +74,9 @@ __device__ __forceinline__ void load_colors(const float *colors, unsigned id, fl
 
 // NL: visit lists per tile the staged mask addresses -- 4: one per 8x8 quadrant (bit q);  16: one per 4x4-PIXEL BLOCK, bit
 // 4 * quadrant + block-in-quadrant (block r of quadrant w: columns 4 (2 (w & 1) + (r & 1)) .., rows 4 (2 (w >> 1) + (r >> 1)) ..)
-template <int C, int CS, bool WITH_DEPTH, int FP, int NL = 4>
+// AUXZ2: s.aux = feat[3]^2 (the six channels of the fused iteration -- r, g, b, z, 1, z^2 -- from the FIRST float4 of the 8-float record:
+// the silhouette colour is the constant 1, and z^2 is the product the per-Gaussian kernel stored, formed again from the same float)
+template <int C, int CS, bool WITH_DEPTH, int FP, int NL = 4, bool AUXZ2 = false>
 __device__ __forceinline__ void gather(Staged<FP> &s, const SplatState &st, const float *colors, unsigned idx, bool valid,
                                        float tile_x0, float tile_y0, const uint64_t *lds_keys = nullptr, int lds_idx = 0) {
     s.ga = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -82,6 +85,7 @@ __device__ __forceinline__ void gather(Staged<FP> &s, const SplatState &st, cons
     for (int f = 0; f < FP; ++f) s.feat[f] = 0.f;
     s.mask = 0;
     s.id = 0;
+    s.aux = 0.f;
     if (valid) {
         // sorted id: from the tile's keys sorted in LDS by this workgroup (low 32 bits), or from the global list
         const unsigned id = lds_keys ? (unsigned)lds_keys[lds_idx] : st.point_list[idx];
@@ -138,6 +142,7 @@ __device__ __forceinline__ void gather(Staged<FP> &s, const SplatState &st, cons
         s.mu = mu;
         s.mask = mask;
         s.id = id;
+        if constexpr (AUXZ2) s.aux = s.feat[3] * s.feat[3];
     }
 }
 
@@ -161,13 +166,14 @@ struct Batch {
     // over the gathering waves, kBlockListBytes each) -- per gathering wave the maximum of four ~15-entry pieces sat 30 % above
     // their mean.  The gathering waves exchange their per-list counts (vcnt, double buffered over the batches) one barrier
     // before they write: commit_counts() / commit()
-    unsigned vlist[NL == 4 ? 1 + 16 * (kSegBytes / 4) + 1 : NL * (kBlockListBytes / 4)];
     unsigned char vcnt[NL == 4 ? 1 : 2][NL][4];     // entries per list and gathering wave
     unsigned char vtot[NL];         // NL == 16: entries per list
     unsigned flag[4];               // forward: wave w had no pixel left when this batch was committed
     // BOTH (the fused forward + backward composite, NL == 16): the quadrant visit lists of the NL == 4 layout BESIDE the block lists --
     // the backward pass walks the batch the forward pass has just composited
     unsigned qlist[BOTH ? 1 + 16 * (kSegBytes / 4) + 1 : 1];
+    // (last member: the fused composite lets its backward pass' pair buffer start HERE -- the block lists are dead by then)
+    unsigned vlist[NL == 4 ? 1 + 16 * (kSegBytes / 4) + 1 : NL * (kBlockListBytes / 4)];
 };
 
 template <int FP, int NL, bool BOTH>
@@ -201,7 +207,7 @@ __device__ __forceinline__ void commit(Batch<FP, NL, BOTH> &b, const Staged<FP> 
 #pragma unroll
     for (int v = 0; v < FP / 4; ++v)
         b.rec[tid * R4 + 1 + v] = make_float4(s.feat[4 * v], s.feat[4 * v + 1], s.feat[4 * v + 2], s.feat[4 * v + 3]);
-    b.rec[tid * R4 + R4 - 1] = make_float4(s.mu.x, s.mu.y, __uint_as_float(s.id), 0.f);
+    b.rec[tid * R4 + R4 - 1] = make_float4(s.mu.x, s.mu.y, __uint_as_float(s.id), s.aux);
     const int wave = tid >> 6, lane = tid & 63;
     if constexpr (NL == 16) {
         // step 2 (after that barrier): entries at the offset the lower gathering waves leave; the lists of quadrant `wave` get
@@ -281,7 +287,7 @@ __device__ __forceinline__ void commit_quadrants(Batch<FP, NL, BOTH> &b, const S
 #pragma unroll
         for (int v = 0; v < FP / 4; ++v)
             b.rec[tid * R4 + 1 + v] = make_float4(s.feat[4 * v], s.feat[4 * v + 1], s.feat[4 * v + 2], s.feat[4 * v + 3]);
-        b.rec[tid * R4 + R4 - 1] = make_float4(s.mu.x, s.mu.y, __uint_as_float(s.id), 0.f);
+        b.rec[tid * R4 + R4 - 1] = make_float4(s.mu.x, s.mu.y, __uint_as_float(s.id), s.aux);
         const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -429,6 +435,14 @@ __device__ __forceinline__ void sort_keys_two_level(uint64_t *A, uint64_t *S, co
 // SORT: the workgroup first collects its tile's (depth, id) keys in LDS (from its bucket, or by filtering its group's records:
 // SplatState.group_count), sorts them there (sort_keys_two_level) and publishes ids and count for the backward pass: no scan,
 // scatter or sort launch, and the gathers take their ids from LDS instead of a dependent global load.
+// The fused iteration's six channels (r, g, b, z, 1, z^2 read from 8-float records) travel as 48-byte LDS records -- r, g, b, z in the
+// colour word, z^2 in the spare word of the centre word, the silhouette colour as the constant it is -- instead of 64-byte ones:
+// three ds_read_b128 per visit instead of four, a quarter less LDS per workgroup, and half the colour gather.  Same sums, same order.
+template <int C, int CS, bool WITH_DEPTH>
+constexpr bool forward_compact6() { return C == 6 && CS == 8 && !WITH_DEPTH; }
+template <int C, int CS, bool WITH_DEPTH>
+constexpr int forward_fp() { return forward_compact6<C, CS, WITH_DEPTH>() ? 4 : (C + (WITH_DEPTH ? 1 : 0) + 3) / 4 * 4; }
+
 // The forward composite of ONE tile up to its per-pixel results (the kernels below add their epilogues): builds / reads the tile's list,
 // stages it batch by batch into B and composites front to back.  Returns the index of the LAST batch it staged (the one B still holds;
 // -1: empty list).  Lane l of wave w = pixel (l & 3, (l >> 2) & 3) of block (l >> 4) of quadrant w (one 4x4 block per 16-lane row).
@@ -437,7 +451,10 @@ __device__ __forceinline__ int forward_tile(const float *colors, SplatState &st,
                                             const int gx, const int tid, const float fpx, const float fpy, const bool inside, float &Tr, float &D,
                                             float (&Cc)[C], unsigned &last) {
     constexpr int F = C + (WITH_DEPTH ? 1 : 0);
-    constexpr int FP = (F + 3) / 4 * 4;
+    constexpr bool COMPACT6 = forward_compact6<C, CS, WITH_DEPTH>();
+    constexpr int FP = forward_fp<C, CS, WITH_DEPTH>();
+    static_assert(BatchT::R4 == FP / 4 + 2, "the batch holds this pass' records");
+    constexpr int CG = COMPACT6 ? 4 : C;                        // channels the gather loads
     constexpr int NL = 16;
     const int lane = tid & 63, wave = tid >> 6;
     const int row = lane >> 4;                                  // this lane's block of the quadrant
@@ -524,7 +541,7 @@ __device__ __forceinline__ int forward_tile(const float *colors, SplatState &st,
         // One LDS buffer (a tile's list is usually ONE batch; a second buffer would halve the resident workgroups):
         // the next batch's gather is in flight in registers while this one is composited, then barrier - commit - barrier.
         Staged<FP> pre;
-        gather<C, CS, WITH_DEPTH, FP, NL>(pre, st, colors, lo + tid, tid < kBatchEntries && tid < n, tile_x0, tile_y0, lk, tid);
+        gather<CG, CS, WITH_DEPTH, FP, NL, COMPACT6>(pre, st, colors, lo + tid, tid < kBatchEntries && tid < n, tile_x0, tile_y0, lk, tid);
         commit_counts(B, pre, tid, 0);
         for (int bi = 0; bi < nb; ++bi) {
             __syncthreads();                        // every wave has finished reading the previous batch; this batch's list counts are in
@@ -537,7 +554,7 @@ __device__ __forceinline__ int forward_tile(const float *colors, SplatState &st,
             const bool more = bi + 1 < nb;
             if (more) {                         // next batch's gather stays in flight while this one is composited
                 const int e = (bi + 1) * kBatchEntries + tid;
-                gather<C, CS, WITH_DEPTH, FP, NL>(pre, st, colors, lo + e, tid < kBatchEntries && e < n, tile_x0, tile_y0, lk, e);
+                gather<CG, CS, WITH_DEPTH, FP, NL, COMPACT6>(pre, st, colors, lo + e, tid < kBatchEntries && e < n, tile_x0, tile_y0, lk, e);
                 commit_counts(B, pre, tid, (bi + 1) & 1);
             }
             const unsigned base1 = (unsigned)(bi * kBatchEntries + 1);
@@ -557,12 +574,19 @@ __device__ __forceinline__ int forward_tile(const float *colors, SplatState &st,
                 const unsigned long long stop_m = __builtin_amdgcn_ballot_w64(test_T < kTStop) & live_m;
                 const bool upd = lane_of(live_m & ~stop_m);
                 const float wgt = upd ? alpha * Tr : 0.f;
+                if constexpr (COMPACT6) {
+                    // r, g, b, z from the record's colour word; the silhouette colour is 1; z^2 rides in the centre word
+                    Cc[0] += cur.f[0].x * wgt; Cc[1] += cur.f[0].y * wgt; Cc[2] += cur.f[0].z * wgt; Cc[3] += cur.f[0].w * wgt;
+                    Cc[4] += wgt;
+                    Cc[5] += cur.m.w * wgt;
+                } else {
 #pragma unroll
-                for (int ch = 0; ch < F; ++ch) {
-                    const float4 &fv = cur.f[ch >> 2];
-                    const float c = (ch & 3) == 0 ? fv.x : ((ch & 3) == 1 ? fv.y : ((ch & 3) == 2 ? fv.z : fv.w));
-                    if (ch < C) Cc[ch] += c * wgt;
-                    else D += c * wgt;
+                    for (int ch = 0; ch < F; ++ch) {
+                        const float4 &fv = cur.f[ch >> 2];
+                        const float c = (ch & 3) == 0 ? fv.x : ((ch & 3) == 1 ? fv.y : ((ch & 3) == 2 ? fv.z : fv.w));
+                        if (ch < C) Cc[ch] += c * wgt;
+                        else D += c * wgt;
+                    }
                 }
                 Tr = upd ? test_T : Tr;
                 last_loc = upd ? rec : last_loc;
@@ -617,8 +641,7 @@ __global__ __launch_bounds__(256, 5) void render_forward_kernel(SplatCamera cam,
                                                              float *out_color, float *out_depth, int T, int per_xcd,
                                                              TrackLossEpilogue ep = TrackLossEpilogue{}) {
     static_assert(!TRACK || (C == 6 && !WITH_DEPTH), "the tracking-loss epilogue reads the six fused channels");
-    constexpr int F = C + (WITH_DEPTH ? 1 : 0);
-    constexpr int FP = (F + 3) / 4 * 4;
+    constexpr int FP = forward_fp<C, CS, WITH_DEPTH>();
     // ONE 4x4-PIXEL BLOCK PER 16-LANE ROW: row r of wave w composites block r of quadrant w (gather(): NL = 16) from the block's OWN
     // visit lists -- the four rows of a wave process four different Gaussians per trip (each lane reads the record of its row's
     // entry; the vector instructions are shared).  SplaTAM's splats are small ({alpha >= 1/255} radius ~3.8 px at workload B): a
@@ -1133,20 +1156,23 @@ __global__ __launch_bounds__(256, 5) void render_backward_kernel5_w5(SplatCamera
 // backward composite, profiles/r04_k7_account.md), the round trip of ten per-pixel planes (six rendered, four gradient; final_T and
 // n_contrib) and a launch; a tile with more batches re-stages all but its last one.  KEEP: the planes are written as well (what
 // FusedEngine.rendered() / the tests read); the tracking step of the product loop has no reader for them.
-// LDS: one batch of 64-byte records + block lists + quadrant lists + the pair buffer (the sort's key array, dead once the forward
-// pass has gathered its last batch, shares it): ~39.6 KB -> four workgroups per CU.
 template <bool KEEP>
-__global__ __launch_bounds__(256, 4) void render_track_fused_kernel(SplatCamera cam, const float *feat8, SplatState st, float *out6, float *accum,
+__global__ __launch_bounds__(256, 5) void render_track_fused_kernel(SplatCamera cam, const float *feat8, SplatState st, float *out6, float *accum,
                                                                     int T, int per_xcd, TrackLossEpilogue ep) {
-    constexpr int C = 6, CS = 8, FP = 8;
+    constexpr int C = 6, CS = 8, FP = forward_fp<C, CS, false>();
     using BatchT = Batch<FP, 16, true>;
-    constexpr size_t kRaw = sizeof(PairBuf) > sizeof(uint64_t) * (kFusedSortMax + 2) ? sizeof(PairBuf) : sizeof(uint64_t) * (kFusedSortMax + 2);
-    __shared__ BatchT B;
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kRaw];
+    // LDS, 31.4 KB (five workgroups per CU): [records | quadrant masks + lists | counts] live through both passes; behind them ONE region
+    // that holds the forward pass' block lists and the sort's key array, then the backward pass' pair buffer
+    constexpr size_t kHead = offsetof(BatchT, vlist);
+    constexpr size_t kKeysAt = (kHead + sizeof(BatchT::vlist) + 15) / 16 * 16;
+    constexpr size_t kFwd = kKeysAt + sizeof(uint64_t) * (kFusedSortMax + 2);
+    constexpr size_t kBwd = (kHead + 15) / 16 * 16 + sizeof(PairBuf);
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kFwd > kBwd ? kFwd : kBwd];
     __shared__ unsigned s_wmax[4];
     __shared__ double s_loss[2][4];
-    uint64_t *const s_keys = reinterpret_cast<uint64_t *>(s_raw);
-    PairBuf &PB = *reinterpret_cast<PairBuf *>(s_raw);
+    BatchT &B = *reinterpret_cast<BatchT *>(s_raw);
+    uint64_t *const s_keys = reinterpret_cast<uint64_t *>(s_raw + kKeysAt);
+    PairBuf &PB = *reinterpret_cast<PairBuf *>(s_raw + (kHead + 15) / 16 * 16);
     const int tile_local = block_tile(per_xcd, T, st.tile_row_end > st.tile_row_begin ? nullptr : st.tile_order);
     if (tile_local < 0) return;
     const int W = cam.image_width, H = cam.image_height;

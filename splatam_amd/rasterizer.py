@@ -231,8 +231,9 @@ class LazyOverflow(RuntimeError):
 # opacities, scales and rotations only, not on the colours: the second call re-uses the first call's SplatState and runs K6 alone.
 # Proof of equality, all of it on what the caller handed over (any doubt falls back to the full pass):
 #   * camera: same image size / tanfov / scale_modifier, viewmatrix and projmatrix in the same storage at the same version;
-#   * means3D: same storage, same version, while the cache keeps the first call's tensor alive (the two render-variable dicts
-#     share one means3D tensor: /root/reference/utils/slam_helpers.py:131,241);
+#   * means3D: the tensor THE CALLER PASSED (before any .contiguous(): the reference's transformed_pts is a transposed, non-contiguous
+#     view, /root/reference/utils/slam_helpers.py:294-295, and every call copies it) -- same storage, offset, strides and version,
+#     while the cache keeps the first call's tensor alive (the two render-variable dicts share one means3D tensor: :131,241);
 #   * opacities / scales / rotations: the same tensors, or -- the reference applies sigmoid / exp / normalize twice, so they are
 #     distinct tensors with equal values -- compared bit for bit on the device (splat_same_geometry: one kernel + the one status
 #     read that an "exact"-mode forward makes anyway).
@@ -264,18 +265,18 @@ class _GeomEntry:
     __slots__ = ("pk", "key", "tensors", "versions")
 
 
-def _remember_geometry(pk, settings, means3D, opac, scales, rots):
+def _remember_geometry(pk, settings, means3D_src, opac, scales, rots):
     e = _GeomEntry()
     e.pk = pk
     view, proj = _cached_contiguous(settings.viewmatrix), _cached_contiguous(settings.projmatrix)
     e.key = _cam_key(settings, view, proj)
-    e.tensors = (means3D, opac, scales, rots, view, proj)          # alive: their storage cannot be handed to another tensor
-    e.versions = (means3D._version, opac._version, scales._version, rots._version)
-    _geom_last[means3D.device.index] = e
+    e.tensors = (means3D_src, opac, scales, rots, view, proj)      # alive: their storage cannot be handed to another tensor
+    e.versions = (means3D_src._version, opac._version, scales._version, rots._version)
+    _geom_last[means3D_src.device.index] = e
 
 
-def _shared_geometry(settings, means3D, colors, opac, scales, rots, cov3D, shs):
-    """The pack of a call that re-uses the cached call's geometry and lists, or None."""
+def _shared_geometry(settings, means3D, colors, opac, scales, rots, cov3D, shs, means3D_src):
+    """The pack of a call that re-uses the cached call's geometry and lists, or None.  ``means3D_src``: the tensor the caller passed."""
     dev = means3D.device
     e = _geom_last.get(dev.index)
     if e is None:
@@ -283,8 +284,8 @@ def _shared_geometry(settings, means3D, colors, opac, scales, rots, cov3D, shs):
     m1, o1, s1, r1, _, _ = e.tensors
     P = means3D.shape[0]
     st = geometry_cache_stats
-    if P == 0 or m1.shape != means3D.shape or m1.data_ptr() != means3D.data_ptr() or means3D._version != e.versions[0] \
-            or m1._version != e.versions[0]:
+    if P == 0 or m1.shape != means3D_src.shape or m1.stride() != means3D_src.stride() or m1.data_ptr() != means3D_src.data_ptr() \
+            or means3D_src._version != e.versions[0] or m1._version != e.versions[0]:
         st["other_means3D"] += 1
         return None
     if e.key != _cam_key(settings, _cached_contiguous(settings.viewmatrix), _cached_contiguous(settings.projmatrix)):
@@ -320,7 +321,7 @@ def _shared_geometry(settings, means3D, colors, opac, scales, rots, cov3D, shs):
     return pk
 
 
-def rasterize_forward(settings, means3D, colors, opacities, scales, rotations, cov3D, shs, will_backward=True):
+def rasterize_forward(settings, means3D, colors, opacities, scales, rotations, cov3D, shs, will_backward=True, means3D_src=None):
     """One forward through the C ABI.  Returns (color, radii, depth, pack).
 
     ``will_backward=False`` (no input requires grad: torch.no_grad renders such as add_new_gaussians, evaluation,
@@ -328,7 +329,8 @@ def rasterize_forward(settings, means3D, colors, opacities, scales, rotations, c
     overflow publishes EMPTY lists (a background-only image).  The status is therefore resolved here (one D2H read, as
     the exact mode does) and the render is repeated with the raised capacity."""
     for _ in range(4):
-        out = _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotations, cov3D, shs)
+        out = _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotations, cov3D, shs,
+                                      means3D if means3D_src is None else means3D_src)
         if will_backward or getattr(out[3], "pending_status", None) is None:
             return out
         try:
@@ -339,7 +341,7 @@ def rasterize_forward(settings, means3D, colors, opacities, scales, rotations, c
     raise RuntimeError("lazy sync mode: the instance lists could not be sized")
 
 
-def _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotations, cov3D, shs):
+def _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotations, cov3D, shs, means3D_src):
     L = _capi.lib()
     dev = means3D.device
     H, W = int(settings.image_height), int(settings.image_width)
@@ -347,7 +349,7 @@ def _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotati
     use_sh = shs.numel() > 0
     cacheable = _GEOM_CACHE and _SYNC_MODE == "exact" and not use_sh and cov3D.numel() == 0 and scales.numel() > 0 and rotations.numel() > 0
     if cacheable:
-        pk = _shared_geometry(settings, means3D, colors, opacities, scales, rotations, cov3D, shs)
+        pk = _shared_geometry(settings, means3D, colors, opacities, scales, rotations, cov3D, shs, means3D_src)
         if pk is not None:                  # K6 alone, on the cached call's geometry and sorted lists
             out_color = torch.empty(pk.g.channels, H, W, dtype=torch.float32, device=dev)
             out_depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
@@ -391,7 +393,7 @@ def _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotati
             pk.pending_status = _async_status(status, dev)
             pk.hint_key = hint_key
     if cacheable:
-        _remember_geometry(pk, settings, means3D, opacities, scales, rotations)
+        _remember_geometry(pk, settings, means3D_src, opacities, scales, rotations)
     return out_color, radii, out_depth, pk
 
 
@@ -456,6 +458,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # ctx.needs_input_grad reflects the inputs' requires_grad whatever the grad mode: nn.Parameters rendered under
         # torch.no_grad -- evaluation, add_new_gaussians -- would otherwise count as "a backward will follow")
         dev = means3D.device
+        means3D_src = means3D                   # what the caller passed (the geometry cache proves identity on it)
         means3D = _check_input("means3D", means3D, dev)
         P = means3D.shape[0]
         sh = _check_input("shs", sh, dev) if sh.numel() else sh
@@ -474,7 +477,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if sh.numel() and (sh.dim() != 3 or sh.shape[0] != P or sh.shape[2] != 3):
             raise RuntimeError(f"shs must be [{P}, M, 3], got {tuple(sh.shape)}")
         color, radii, depth, pk = rasterize_forward(raster_settings, means3D, colors, opac, scales_c, rots_c, cov_c, sh,
-                                                    will_backward=bool(grad_enabled) and any(ctx.needs_input_grad))
+                                                    will_backward=bool(grad_enabled) and any(ctx.needs_input_grad), means3D_src=means3D_src)
         ctx.pack = pk
         ctx.use_sh = sh.numel() > 0
         ctx.sh_shape = tuple(sh.shape)

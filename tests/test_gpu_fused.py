@@ -796,7 +796,7 @@ def test_tile_launch_order_changes_nothing_but_speed():
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, k
 
 
-@pytest.mark.parametrize("n,W,H,label", [(20000, 328, 248, "one batch per tile"), (90000, 328, 248, "two to three batches per tile"),
+@pytest.mark.parametrize("n,W,H,label", [(20000, 328, 248, "one batch per tile"), (64000, 328, 248, "two to three batches per tile"),
                                          (4000, 200, 120, "sparse: empty tiles, pixels outside the image")])
 def test_tracking_composites_in_one_kernel_equal_the_two_kernels(n, W, H, label):
     """SplatLossConfig.fused_composite: the tracking iteration's forward composite, loss and backward composite as ONE kernel (the

@@ -121,6 +121,7 @@ def test_lists_beyond_lds_multi_workgroup_sort(n, item_table, monkeypatch):
     args = (cs, rv['means3D'].cuda(), rv['colors_precomp'].cuda(), rv['opacities'].cuda().reshape(-1), rv['scales'].cuda(), rv['rotations'].cuda(),
             empty, empty)
     col1, radii1, dep1, pk1 = rz.rasterize_forward(*args)           # one counter per tile (nothing known about this shape yet)
+    rz.clear_geometry_cache()                                       # (the same inputs again: a full pass is wanted here, not the first call's lists)
     col, radii, dep, pk = rz.rasterize_forward(*args)               # the first call saw very long lists: 16 counters per tile now
     torch.cuda.synchronize()
     assert pk1.st.sub_bins == 1 and pk.st.sub_bins == rz.SUB_BINS_LONG
