@@ -142,9 +142,9 @@ typedef struct SplatState {
     /* launch order of the composites' workgroups (fused iteration, whole frames; NULL / NULL = the natural order).  A launch of
      * 3 225 tile workgroups of very different length on 1 024 resident slots leaves a long tail (time-weighted occupancy 67-76 %,
      * profiles/r04_k7_account.md): the forward composite leaves a work estimate per tile in tile_work ([T]: the sum over the
-     * tile's four 8x8 quadrants of the deepest list entry any pixel blended -- what the backward composite will walk), a small
-     * kernel turns it into tile_order ([8 * ceil(T / 8)]: the tiles of every XCD band, heaviest first, 0xFFFFFFFF = no tile),
-     * and both composites start their workgroups in that order (the forward one in the previous iteration's).  Only a
+     * tile's four 8x8 quadrants of the deepest list entry any pixel blended -- what the backward composite will walk), eight extra
+     * workgroups of the iteration's last kernel turn it into tile_order ([8 * ceil(T / 8)]: the tiles of every XCD band, heaviest first, 0xFFFFFFFF = no tile),
+     * and the NEXT iteration's composites start their workgroups in that order.  Only a
      * schedule: any permutation of each band gives the same results. */
     uint32_t *tile_work;
     uint32_t *tile_order;

@@ -816,8 +816,17 @@ __device__ __forceinline__ void pose_adam_step(const SplatMap &map, int time_idx
 
 // F7: one thread: pose partial sums -> gradients of the raw camera parameters; loss value (+ the pose's Adam step when the
 // caller asked for the whole tracking step in one call: one launch less per iteration)
+// Workgroups 1..8 (launched when the state carries SplatState.tile_work / tile_order) have nothing to do with the pose: each turns the
+// forward composite's per-tile work estimates of ITS XCD band into the band's launch order for the next iteration's composites -- a
+// 5 us kernel of its own on the iteration's critical path otherwise, here it runs beside the single workgroup that closes the iteration.
 __global__ __launch_bounds__(256) void pose_finish_kernel(FusedArgs a, int HW, PoseAdam pa) {
     static_assert(SPLAT_ITER_SUMS * 8 == 256 && SPLAT_ITER_SUM_COPIES == 64, "thread t: sum k = t / 8, copies (t % 8) * 8 .. + 7");
+    if (blockIdx.x > 0) {
+        __shared__ unsigned s_order[513];
+        const int T = c_num_tiles(a.cam.image_width, a.cam.image_height);
+        tile_order_band(a.ws.st.tile_work, a.ws.st.tile_order, T, (T + 7) / 8, (int)blockIdx.x - 1, s_order);
+        return;
+    }
     __shared__ double S[SPLAT_ITER_SUMS];
     const int t = threadIdx.x, k = t >> 3, part = t & 7;
     // what the closing thread needs -- the pose, the Adam state, the capacity flags -- is requested here, ahead of the first store
@@ -1128,6 +1137,12 @@ static bool group_binning(const SplatState &st, const SplatCamera &cam) {
            num_tile_groups(cam) <= 8192;
 }
 
+// workgroups of the iteration's last kernel: the one that closes the iteration + one per XCD band when the composites' launch order is kept
+// (whole frames only: a band of tile rows is composited in the natural order)
+static int finish_blocks(const SplatState &st) {
+    return (st.tile_work && st.tile_order && st.tile_row_end <= st.tile_row_begin) ? 9 : 1;
+}
+
 // F1 in the mode the state asks for
 static void launch_fused_preprocess(const FusedArgs &a, hipStream_t s) {
     const int P = a.map.P;
@@ -1184,12 +1199,8 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
     if (one_kernel) {
         e = launch_render_track_fused(cam, ws.feat8, ws.st, ws.out6, ws.accum, ep, cfg.fused_composite == 2, s);
         if (e != hipSuccess) return e;
-        e = launch_tile_order(cam, ws.st, s);
-        if (e != hipSuccess) return e;
     } else {
         e = launch_render_forward_feat8(cam, ws.feat8, ws.st, ws.out6, sort_in_k6, s, fuse_loss ? &ep : nullptr, fuse_loss ? &loss_done : nullptr);
-        if (e != hipSuccess) return e;
-        e = launch_tile_order(cam, ws.st, s);           // the backward composite (and the next forward one) start their heaviest tiles first
         if (e != hipSuccess) return e;
         if (cfg.ignore_outlier_depth_loss) {
             // torch.median of the depth error (exact radix selection, mapedit.hip) -> d_cam[13] (its bits through counts[4])
@@ -1233,7 +1244,7 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
         else if (iso) hipLaunchKernelGGL((fused_backward_kernel<false, false, true>), grid, block, 0, s, a, opt);
         else hipLaunchKernelGGL((fused_backward_kernel<false, false, false>), grid, block, 0, s, a, opt);
     }
-    if (!cfg.defer_finish) hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(256), 0, s, a, HW, pa);
+    if (!cfg.defer_finish) hipLaunchKernelGGL(pose_finish_kernel, dim3(finish_blocks(ws.st)), dim3(256), 0, s, a, HW, pa);
     return hipGetLastError();
 }
 
@@ -1245,7 +1256,7 @@ hipError_t launch_iter_finish(const SplatCamera &cam, const SplatMap &map, const
     if (pose_adam)
         pa = PoseAdam{pose_adam->state, pose_adam->beta1, pose_adam->beta2, pose_adam->eps, pose_adam->bc2_sqrt, pose_adam->step_size_rot,
                       pose_adam->step_size_trans};
-    hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(256), 0, s, a, cam.image_width * cam.image_height, pa);
+    hipLaunchKernelGGL(pose_finish_kernel, dim3(finish_blocks(ws.st)), dim3(256), 0, s, a, cam.image_width * cam.image_height, pa);
     return hipGetLastError();
 }
 

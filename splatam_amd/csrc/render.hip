@@ -1350,53 +1350,6 @@ hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &
     return hipGetLastError();
 }
 
-// SplatState.tile_order from SplatState.tile_work: one workgroup per XCD band; the band's tiles by descending work through a
-// 256-bin counting sort (the order inside a bin is whatever the atomics give: it is a schedule, not a result).
-__global__ __launch_bounds__(256) void tile_order_kernel(const uint32_t *work, uint32_t *order, int T, int per_xcd) {
-    __shared__ unsigned s_max, s_hist[256], s_off[256];
-    const int band = blockIdx.x, tid = threadIdx.x;
-    const int t0 = band * per_xcd, t1 = min(T, t0 + per_xcd);
-    if (tid == 0) s_max = 1u;
-    s_hist[tid] = 0u;
-    __syncthreads();
-    unsigned mx = 0u;
-    for (int t = t0 + tid; t < t1; t += 256) mx = max(mx, work[t]);
-    mx = wave_max_u32(mx);
-    if ((tid & 63) == 0) atomicMax(&s_max, mx);
-    __syncthreads();
-    const float scale = 255.0f / (float)s_max;
-    for (int t = t0 + tid; t < t1; t += 256) atomicAdd(&s_hist[255 - (int)((float)work[t] * scale)], 1u);
-    __syncthreads();
-    if (tid < 64) {                         // exclusive scan of the 256 bins by one wave (four bins per lane)
-        unsigned c[4], sum = 0u;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { c[k] = s_hist[4 * tid + k]; sum += c[k]; }
-        unsigned incl = sum;
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned o = (unsigned)__shfl_up((int)incl, d, 64);
-            if (tid >= d) incl += o;
-        }
-        unsigned run = incl - sum;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { s_off[4 * tid + k] = run; run += c[k]; }
-    }
-    __syncthreads();
-    for (int t = t0 + tid; t < t1; t += 256) {
-        const unsigned pos = atomicAdd(&s_off[255 - (int)((float)work[t] * scale)], 1u);
-        order[t0 + pos] = (uint32_t)t;
-    }
-    for (int t = max(t1, t0) + tid; t < t0 + per_xcd; t += 256) order[t] = 0xFFFFFFFFu;       // (the last band may be short)
-}
-
-hipError_t launch_tile_order(const SplatCamera &cam, SplatState &st, hipStream_t s) {
-    if (!st.tile_work || !st.tile_order || st.tile_row_end > st.tile_row_begin) return hipSuccess;
-    const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
-    if (T == 0) return hipSuccess;
-    const int per = (T + 7) / 8;
-    hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(256), 0, s, st.tile_work, st.tile_order, T, per);
-    return hipGetLastError();
-}
-
 // Fused-iteration path (fused.hip): 6 channels (r, g, b, z, 1, z^2) read from 8-float records, no separate depth plane.
 // tiles a fused composite launch covers: the whole frame, or the band of tile rows SplatState.tile_row_begin / _end name
 static int launch_tiles(const SplatCamera &cam, const SplatState &st) {

@@ -54,7 +54,6 @@ struct TrackLossEpilogue {
 // *ep_done tells the caller whether the epilogue ran (generation-3 kernels) or the separate loss kernel is still needed.
 hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat8, SplatState &st, float *out6, bool sort_in_kernel,
                                        hipStream_t s, const TrackLossEpilogue *ep = nullptr, bool *ep_done = nullptr);
-hipError_t launch_tile_order(const SplatCamera &cam, SplatState &st, hipStream_t s);
 hipError_t launch_render_track_fused(const SplatCamera &cam, const float *feat8, SplatState &st, float *out6, float *accum,
                                      const TrackLossEpilogue &ep, bool keep_planes, hipStream_t s);
 hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *feat8, const SplatState &st, const float *dL_dout6,
@@ -545,6 +544,45 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// SplatState.tile_order from SplatState.tile_work for ONE XCD band (a 256-thread workgroup): the band's tiles by descending work
+// through a 256-bin counting sort (the order inside a bin is whatever the atomics give: it is a schedule, not a result).
+// `scratch`: 513 words of LDS.
+__device__ __forceinline__ void tile_order_band(const uint32_t *work, uint32_t *order, int T, int per_xcd, int band, unsigned *scratch) {
+    unsigned *s_hist = scratch, *s_off = scratch + 256, *s_max = scratch + 512;
+    const int tid = threadIdx.x;
+    const int t0 = band * per_xcd, t1 = min(T, t0 + per_xcd);
+    if (tid == 0) *s_max = 1u;
+    s_hist[tid] = 0u;
+    __syncthreads();
+    unsigned mx = 0u;
+    for (int t = t0 + tid; t < t1; t += 256) mx = max(mx, work[t]);
+    mx = wave_max_u32(mx);
+    if ((tid & 63) == 0) atomicMax(s_max, mx);
+    __syncthreads();
+    const float scale = 255.0f / (float)*s_max;
+    for (int t = t0 + tid; t < t1; t += 256) atomicAdd(&s_hist[255 - (int)((float)work[t] * scale)], 1u);
+    __syncthreads();
+    if (tid < 64) {                         // exclusive scan of the 256 bins by one wave (four bins per lane)
+        unsigned c[4], sum = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c[k] = s_hist[4 * tid + k]; sum += c[k]; }
+        unsigned incl = sum;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = (unsigned)__shfl_up((int)incl, d, 64);
+            if (tid >= d) incl += o;
+        }
+        unsigned run = incl - sum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s_off[4 * tid + k] = run; run += c[k]; }
+    }
+    __syncthreads();
+    for (int t = t0 + tid; t < t1; t += 256) {
+        const unsigned pos = atomicAdd(&s_off[255 - (int)((float)work[t] * scale)], 1u);
+        order[t0 + pos] = (uint32_t)t;
+    }
+    for (int t = max(t1, t0) + tid; t < t0 + per_xcd; t += 256) order[t] = 0xFFFFFFFFu;       // (the last band may be short)
+}
 
 #endif  // __HIPCC__
 
