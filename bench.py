@@ -277,7 +277,9 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
     dom = k7 if dominant == "render_backward" else k6
     rows = {}
     trace = load_kernel_trace(workload)          # per-kernel average durations: the kernel TRACE of the bench command (not the counter passes)
-    per_unit = {"fused_preprocess_kernel": N * (48 + 87), "ssim_forward_kernel": HW * (2 * 12 + 36 + 16), "map_loss_backward_kernel": HW * (36 + 24 + 16),
+    # (the tracking iteration's composites are ONE kernel: the list is gathered once -- R x 52 --, the frame is read -- 16 B per pixel --, the
+    #  planes stay in registers, six partial sums per Gaussian leave it)
+    per_unit = {"render_track_fused_kernel": R * 52 + HW * 16 + N * 24, "fused_preprocess_kernel": N * (48 + 87), "ssim_forward_kernel": HW * (2 * 12 + 36 + 16), "map_loss_backward_kernel": HW * (36 + 24 + 16),
                 "fused_backward_kernel": N * (64 + 40 + 48), "adam_map_kernel": N * 12 * 4 * 6}
     for kname, abytes in per_unit.items():
         d = pmc_kernel(pmc, kname) or {}

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_summary.md from a bench log (gpurun_out/bench_<tag>.log) and the rocprofv3 kernel stats of the same command
-(gpurun_out/<tag>_bench_kernel_stats.csv).  usage: scripts/make_profile_summary.py r01_v7 [pmc-file-name]"""
+"""profiles/<tag>_summary.md (+ the copies of the raw files it is built from) out of one scripts/r04_profile.sh call:
+gpurun_out/bench_<tag>.log (the un-profiled bench line), gpurun_out/<tag>_bench_kernel_stats.csv and <tag>_Bloop_kernel_stats.csv
+(rocprofv3 --kernel-trace --stats of the bench command at B / B-loop), gpurun_out/<tag>_k7_account_*.md.
+usage: scripts/make_profile_summary.py <tag>"""
 import csv
 import json
 import os
@@ -9,61 +11,64 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-pmc = sys.argv[2] if len(sys.argv) > 2 else None
-src_csv = os.path.join(ROOT, "gpurun_out", f"{tag}_bench_kernel_stats.csv")
-src_log = os.path.join(ROOT, "gpurun_out", f"bench_{tag}.log")
-shutil.copy(src_csv, os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats.csv"))
-line = [l for l in open(src_log) if l.startswith("{")][-1]
-open(os.path.join(ROOT, "profiles", f"{tag}_bench.json.log"), "w").write(line)
-d = json.loads(line)
-rows = list(csv.DictReader(open(src_csv)))
-tot = sum(float(r["TotalDurationNs"]) for r in rows)
+G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 
 
-def avg(sub):
+def stats(name):
+    src = os.path.join(G, name)
+    if not os.path.exists(src):
+        return []
+    shutil.copy(src, os.path.join(P, name))
+    return list(csv.DictReader(open(src)))
+
+
+def avg(rows, *needles):
     for r in rows:
-        if sub in r["Name"]:
+        if all(n in r["Name"] for n in needles):
             return float(r["AverageNs"]) / 1e3
     return 0.0
 
 
-k7m = avg("render_backward_kernel5<6, 8, 15u, 15u") or avg("render_backward_kernel<6, 8, 15u, 15u")
-k7t = avg("render_backward_kernel5_w5<6, 8, 15u, 8u") or avg("render_backward_kernel5<6, 8, 15u, 8u") or avg("render_backward_kernel<6, 8, 15u, 8u")
-k6s = avg("render_forward_kernel<6, 8, false, true, false>") or avg("render_forward_kernel<6, 8, false, true>")
-k6t = avg("render_forward_kernel<6, 8, false, true, true>")
-f1, f4, f5 = avg("fused_preprocess_kernel<2") or avg("fused_preprocess"), avg("ssim_forward"), avg("map_loss_backward")
-f6 = avg("fused_backward_kernel<false, false") or avg("fused_backward_kernel<false>") or avg("fused_backward_kernel")   # tracking form
-f6m = avg("fused_backward_kernel<true") or f6                                     # single-view mapping step: Adam inside
-f7, ap, am = avg("pose_finish"), avg("adam_pose"), avg("adam_map")
-out = [f"# `{tag}`: composites on compact visit lists (one-byte entries, four per trip), forward composite with one 4x4-pixel block per 16-lane row",
-       "(four Gaussians per trip), group binning, generation-5 backward composite, Adam of the map inside F6 for the single-view mapping step\n",
-       "`rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-slam-loop` on MI355X (gfx950), workload B",
-       "(300k Gaussians, 1200x680), engine = fused.  The run also times the drop-in path (reference-shaped PyTorch glue around the drop-in",
-       f"rasterizer), hence the MIOpen / rocBLAS rows and the 3-channel kernels.  Full CSV: `{tag}_bench_kernel_stats.csv`; bench line of the",
-       f"un-profiled run (with `cpu_baseline` and `slam_loop`): `{tag}_bench.json.log` (**{d['value']} iters/s**; tracking {d['tracking_iters_per_s']}/s, mapping",
-       f"{d['mapping_iters_per_s']}/s; the reference's loop statements through splatam_amd.plugin {d.get('plugin_iters_per_s')} iters/s, on the drop-in path {d['dropin_iters_per_s']} iters/s; CPU oracle {d['cpu_baseline']['value']} iters/s on {d['cpu_baseline']['cores']} threads)."]
-if pmc:
-    out.append(f"PMC passes of the fused path: `{pmc}` (`scripts/pmc.sh`).")
-out += ["", f"Total kernel time {tot / 1e6:.1f} ms.\n", "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
-for r in rows[:28]:
-    if "at::native" in r["Name"]:
+line = [l for l in open(os.path.join(G, f"bench_{tag}.log")) if l.startswith("{")][-1]
+open(os.path.join(P, f"{tag}_bench.json.log"), "w").write(line)
+d = json.loads(line)
+out = [f"# `{tag}`", "",
+       "`rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-slam-loop --sustain-s 1` on one MI355X",
+       f"(gfx950); the bench line of the un-profiled default run of the same call is `{tag}_bench.json.log`:",
+       f"**{d['value']} iters/s** (sustained {d['sustained'].get('iters_per_s')}), tracking {d['tracking_iters_per_s']}/s, mapping {d['mapping_iters_per_s']}/s; the reference's loop",
+       f"statements through `splatam_amd.plugin` {d.get('plugin_iters_per_s')} /s; on the drop-in rasterizer {d['dropin_iters_per_s']} /s (rasterizer",
+       f"{d.get('dropin_mapping_rasterizer_ms_per_iter')} ms of a {d.get('dropin_mapping_ms_per_iter')} ms mapping iteration); CPU oracle {d['cpu_baseline']['value']} /s on {d['cpu_baseline']['cores']} threads.", ""]
+for wl, fname in (("B (300 000 Gaussians, 1200x680)", f"{tag}_bench_kernel_stats.csv"), ("B-loop (816 000 Gaussians: the map the frame loop builds)", f"{tag}_Bloop_kernel_stats.csv")):
+    rows = stats(fname)
+    if not rows:
         continue
-    out.append(f"| `{r['Name'][:92]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {r['Percentage']} |")
-ro = d["roofline"]
-out += ["",
-        f"Reading: the dominant kernel of the fused iteration is `render_backward_kernel5<6,8,15,15>` (mapping form, {k7m:.1f} us;",
-        f"tracking form `<6,8,15,8,false>` {k7t:.1f} us); bench.py's live HIP-event figure for it is {ro['kernel_ms'] * 1e3:.1f} us (`roofline.kernel_ms`, {ro['achieved']} GB/s",
-        f"algorithmic = {100 * ro['frac']:.2f} % of HBM peak; K6 {ro['other']['render_forward_ms'] * 1e3:.1f} us = {ro['other']['render_forward_GBps']} GB/s).",
-        f"Per fused tracking iteration (us): fused_preprocess {f1:.1f} + render_forward<6,8,sort,+tracking loss> {k6t:.1f} + render_backward<6,8,15,8> {k7t:.1f} +",
-        f"fused_backward {f6:.1f} + pose_finish {f7:.1f} + adam_pose {ap:.1f} = {f1 + k6t + k7t + f6 + f7 + ap:.0f} -> {d['tracking_iters_per_s']:.0f} iterations/s measured; mapping: {f1:.1f} +",
-        f"render_forward<6,8,sort> {k6s:.1f} + ssim {f4:.1f} + map_loss_backward {f5:.1f} + render_backward {k7m:.1f} + fused_backward<Adam> {f6m:.1f} + {f7:.1f} = "
-        f"{f1 + k6s + f4 + f5 + k7m + f6m + f7:.0f} -> {d['mapping_iters_per_s']:.0f} iterations/s (adam_map as a kernel of its own, {am:.1f} us, only in the exchanged / batched step).",
-        "GPU-bound, no host gaps, no memset launches.\n"]
-sl = d.get("slam_loop")
-if sl:
-    out += [f"`slam_loop` (the whole frame loop of scripts/splatam.py:654-905 on a synthetic {sl['image']} RGB-D sequence of a smooth textured surface, Replica",
-            f"iteration counts): {sl['frames']} frames, map {sl['gaussians_per_frame'][0]} -> {sl['gaussians_per_frame'][-1]} Gaussians, tracking {sl['tracking_iters_per_s']} it/s, mapping incl.",
-            f"densification / keyframe selection / pruning / list re-learning {sl['mapping_iters_per_s_incl_densify_keyframes_prune']} it/s, {sl['frames_per_s']} frames/s, max translation error",
-            f"{sl['max_translation_error_m'] * 1e3:.2f} mm."]
-open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w").write("\n".join(out) + "\n")
-print("\n".join(out[-16:]))
+    f1 = avg(rows, "fused_preprocess_kernel<2") or avg(rows, "fused_preprocess_kernel<1") or avg(rows, "fused_preprocess")
+    trk = avg(rows, "render_track_fused_kernel<false>")
+    k6 = avg(rows, "render_forward_kernel<6, 8, false, true, false>")
+    k7 = avg(rows, "render_backward_kernel5<6, 8, 15u, 15u")
+    f4, f5 = avg(rows, "ssim_forward"), avg(rows, "map_loss_backward")
+    f6t, f6m, f7 = avg(rows, "fused_backward_kernel<false, false"), avg(rows, "fused_backward_kernel<true"), avg(rows, "pose_finish")
+    out += [f"## workload {wl}: `{fname}`", "",
+            "| kernel | avg us |", "|---|---|",
+            f"| F1 `fused_preprocess_kernel` (group binning) | {f1:.1f} |",
+            f"| tracking: `render_track_fused_kernel` (forward composite + loss + backward composite) | {trk:.1f} |",
+            f"| mapping: K6 `render_forward_kernel<6,8,sort>` | {k6:.1f} |",
+            f"| mapping: F4 `ssim_forward_kernel` / F5 `map_loss_backward_kernel` | {f4:.1f} / {f5:.1f} |",
+            f"| mapping: K7 `render_backward_kernel5<6,8,15,15>` | {k7:.1f} |",
+            f"| F6 `fused_backward_kernel` tracking / mapping (+ Adam of the map) | {f6t:.1f} / {f6m:.1f} |",
+            f"| F7 `pose_finish_kernel` (+ pose Adam, + tile launch order in its spare workgroups) | {f7:.1f} |",
+            "",
+            f"Per tracking iteration {f1 + trk + f6t + f7:.0f} us of kernels, per mapping iteration {f1 + k6 + f4 + f5 + k7 + f6m + f7:.0f} us.", ""]
+for wl in ("B", "B-loop"):
+    src = os.path.join(G, f"{tag}_k7_account_{wl}.md")
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(P, f"{tag}_k7_account_{wl}.md"))
+for key in ("slam_loop", "slam_loop_plugin"):
+    sl = d.get(key)
+    if sl:
+        r0 = sl["runs"][0]
+        out += [f"`{key}` ({sl['frames_counted']} counted frames of {sl['image']}, {sl['tracking_iters_per_frame']} + {sl['mapping_iters_per_frame']} iterations per frame, map "
+                f"{r0['gaussians_first_last'][0]} -> {r0['gaussians_first_last'][1]} Gaussians): **{sl['frames_per_s']} frames/s** (two runs within {100 * sl['runs_agree_within']:.1f} %), "
+                f"per frame {r0['phase_ms_per_frame']}, max translation error {1e3 * r0['max_translation_error_m']:.2f} mm.", ""]
+open(os.path.join(P, f"{tag}_summary.md"), "w").write("\n".join(out) + "\n")
+print("\n".join(out))

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 run() {
   tag=$1; shift
-  env "$@" timeout 600 python bench.py --no-cpu-baseline --no-slam-loop --sustain-s 2 > gpurun_out/ab_$tag.log 2> gpurun_out/ab_$tag.err
+  env "$@" timeout 600 python bench.py $BENCH_ARGS --no-cpu-baseline --no-slam-loop --sustain-s 2 > gpurun_out/ab_$tag.log 2> gpurun_out/ab_$tag.err
   python - "$tag" <<'PY'
 import json, sys
 d = json.loads([l for l in open(f"gpurun_out/ab_{sys.argv[1]}.log") if l.startswith("{")][-1])

@@ -47,8 +47,16 @@ def _sampled_cloud(z, intrinsics, w2c, sampled_indices):
     pts_cam = torch.stack(((u - cx) / fx * z, (v - cy) / fy * z, z), dim=-1)
     c2w = torch.inverse(w2c)
     pts = pts_cam @ c2w[:3, :3].t() + c2w[:3, 3]
-    key = torch.cat((torch.abs(torch.round(pts, decimals=4)), torch.zeros(1, 3, device=pts.device, dtype=pts.dtype)), dim=0)
-    _, inverse, counts = key.unique(dim=0, return_inverse=True, return_counts=True)
+    # |round(p, 4)| as integers: round(p, 4) is round(p * 1e4) / 1e4, and distinct integers below 2^24 give distinct float32 quotients, so
+    # two points coincide after rounding exactly when their integer triples do.  Three 21-bit fields make ONE int64 key per point:
+    # a 1-d unique instead of unique(dim=0) (3 ms -> 0.1 ms for the 1600 samples on the host)
+    q = torch.abs(torch.round(pts * 1e4)).to(torch.int64)
+    if pts.dtype == torch.float32 and int(q.max()) < (1 << 21):
+        key = torch.cat(((q[:, 0] << 42) | (q[:, 1] << 21) | q[:, 2], torch.zeros(1, dtype=torch.int64, device=pts.device)))
+        _, inverse, counts = key.unique(return_inverse=True, return_counts=True)
+    else:
+        key = torch.cat((torch.abs(torch.round(pts, decimals=4)), torch.zeros(1, 3, device=pts.device, dtype=pts.dtype)), dim=0)
+        _, inverse, counts = key.unique(dim=0, return_inverse=True, return_counts=True)
     keep = (counts[inverse] == 1)[:pts.shape[0]]
     return pts[keep]
 
@@ -68,6 +76,16 @@ def keyframe_selection_overlap(gt_depth, w2c, intrinsics, keyframe_list, k, pixe
     sampled = valid[pick.to(valid.device)]
     z = gt_depth[0, sampled[:, 0], sampled[:, 1]].cpu()
     sampled, w2c, intrinsics = sampled.cpu(), w2c.cpu(), intrinsics.cpu()
+    # (a few thousand floats per operation: on a 256-core host every one of these CPU operators otherwise wakes the whole thread pool)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        return _select_from_samples(z, sampled, w2c, intrinsics, keyframe_list, k, H, W)
+    finally:
+        torch.set_num_threads(threads)
+
+
+def _select_from_samples(z, sampled, w2c, intrinsics, keyframe_list, k, H, W):
     pts = _sampled_cloud(z, intrinsics, w2c, sampled)
     if len(keyframe_list) == 0:
         return []
