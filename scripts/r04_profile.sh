@@ -27,3 +27,11 @@ timeout 900 python bench.py > gpurun_out/bench_$tag.log 2> gpurun_out/bench_$tag
 echo "bench rc $?"
 tail -1 gpurun_out/bench_$tag.log | cut -c1-300
 head -12 gpurun_out/${tag}_bench_kernel_stats.csv | cut -c1-160
+if [ -z "$quick" ]; then
+  for wl in E-clustered E-clustered-5M; do
+    timeout 600 python bench.py --workload $wl --steps 10 --warmup 5 --no-cpu-baseline --no-slam-loop --sustain-s 1 > gpurun_out/bench_${tag}_$wl.log 2>&1
+    tail -1 gpurun_out/bench_${tag}_$wl.log | cut -c1-160
+  done
+  timeout 600 python bench.py --gpus 2 --steps 20 --warmup 10 --no-roofline --sustain-s 1 > gpurun_out/bench_${tag}_mix2_gloo.log 2>&1
+  tail -1 gpurun_out/bench_${tag}_mix2_gloo.log | cut -c1-200
+fi
