@@ -636,8 +636,12 @@ __device__ __forceinline__ int forward_tile(const float *colors, SplatState &st,
     return staged;
 }
 
+// (the six fused channels on 48-byte records: 25 KB of LDS and 80 VGPRs -> six workgroups per CU; the reference API's forms stay at five)
+#ifndef SPLAT_K6_WAVES
+#define SPLAT_K6_WAVES 6
+#endif
 template <int C, int CS, bool WITH_DEPTH, bool SORT, bool TRACK = false>
-__global__ __launch_bounds__(256, 5) void render_forward_kernel(SplatCamera cam, const float *colors, SplatState st,
+__global__ __launch_bounds__(256, (forward_compact6<C, CS, WITH_DEPTH>() ? SPLAT_K6_WAVES : 5)) void render_forward_kernel(SplatCamera cam, const float *colors, SplatState st,
                                                              float *out_color, float *out_depth, int T, int per_xcd,
                                                              TrackLossEpilogue ep = TrackLossEpilogue{}) {
     static_assert(!TRACK || (C == 6 && !WITH_DEPTH), "the tracking-loss epilogue reads the six fused channels");
