@@ -37,9 +37,12 @@ moves the map or the pose.  The host learns of it
   * or the moment the caller reads the loss value anyway (the tracking loop's ``if loss < current_min_loss``, :708): that ONE
     read fetches the report too, and a flagged tracking iteration is repeated on the spot, invisibly to the caller.
 
-What the plug-in does NOT provide: ``variables['means2D'].grad`` (gradient-based densification:
-``use_gaussian_splatting_densification`` raises), non-zero learning rates for the Gaussians while tracking or for the poses while
-mapping (no shipped configuration has them; they raise).
+Learning rates the shipped configurations leave at zero are honoured too: pose learning rates in the mapping optimizer (bundle
+adjustment, ``get_loss(..., do_ba=True)``: the pose gradient of the iteration's report goes through torch's own Adam on the two small
+camera tensors) and Gaussian learning rates in the tracking optimizer (rgb / opacity / scale gradients are then formed -- centres and
+rotations are detached while tracking, /root/reference/utils/slam_helpers.py:266-271 -- and stepped by the Adam kernel with the
+tracking optimizer's eps).  What the plug-in does NOT provide: ``variables['means2D'].grad`` (gradient-based densification:
+``use_gaussian_splatting_densification`` raises) and ``visualize_tracking_loss``.
 """
 from __future__ import annotations
 
@@ -129,6 +132,7 @@ class _Session:
         self.bound = {}             # (H, W) -> tuple of the tensor OBJECTS the engine is bound to (kept alive: ids stay unique)
         self.current = None         # (engine, bound tensors, report) of the last get_loss
         self.pending_tracking = True
+        self.track_steps_gaussians = False      # the live tracking optimizer has non-zero Gaussian learning rates
         self.pending = []           # [(report, pinned host tensor, event)] reports in flight to the host
         self.pool = []              # pinned buffers / events for re-use
         self.stats = {"iterations": 0, "rebuilds": 0, "engines_built": 0, "repeats": 0, "skipped_iterations": 0}
@@ -215,10 +219,17 @@ class _Session:
         take that step now.  The caller sees the repeated iteration's values."""
         params, curr_data, iter_time_idx, cfg, do_ba, tracking = rep.args
         for _ in range(3):
-            eng.loss_backward(curr_data, iter_time_idx, cfg, tracking=True, do_ba=do_ba, keep_planes=False)
+            eng.loss_backward(curr_data, iter_time_idx, cfg, tracking=True, do_ba=do_ba, keep_planes=False, map_grads=bool(self.track_steps_gaussians))
             if rep.stepped is not False:
+                lr, opt, bound = rep.stepped
                 eng.pose_step -= 1
-                eng.adam_pose(*rep.stepped)
+                eng.adam_pose(*lr)
+                if opt is not None:                 # (the skipped step counted: take it back, then step)
+                    for g in opt.param_groups:
+                        st = opt.state.get(g['params'][0]) if g['name'] in ("rgb_colors", "logit_opacities", "log_scales") else None
+                        if st is not None:
+                            st['step'] -= 1
+                    opt._step_gaussians(eng, bound, eps=1e-8, tracking=True)
             fresh = eng.buf['d_cam'].tolist()
             self.stats["repeats"] += 1
             if fresh[12] == 0.0:
@@ -251,7 +262,9 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
     if tracking and (s.pending_tracking or eng.track_time_idx != int(iter_time_idx)):
         eng.begin_tracking(iter_time_idx)           # fresh pose Adam state: the caller made a new optimizer for this frame (:680)
         s.pending_tracking = False
-    eng.loss_backward(curr_data, iter_time_idx, cfg, tracking=tracking, do_ba=bool(do_ba), keep_planes=False)
+    # (a tracking optimizer with non-zero Gaussian learning rates: the gradients torch would step -- rgb, opacity, scale -- are wanted)
+    want_map = True if not tracking else bool(s.track_steps_gaussians)
+    eng.loss_backward(curr_data, iter_time_idx, cfg, tracking=tracking, do_ba=bool(do_ba), keep_planes=False, map_grads=want_map)
     rep = _Report(eng.buf['d_cam'].clone())
     rep.args = (params, curr_data, int(iter_time_idx), cfg, bool(do_ba), tracking)
     s.post(eng, rep)
@@ -281,14 +294,13 @@ class FusedOptimizer(torch.optim.Adam):
         # a phase boundary: the reference's own statements have just synchronised (add_new_gaussians' boolean indexing, the loss
         # comparison of the last tracking iteration); every report of the finished phase is looked at here
         s.drain()
+        # groups of the OTHER kind with a non-zero learning rate (no shipped configuration): Gaussians while tracking, poses while mapping
+        self._steps_gaussians = (not tracking) or any(float(lrs_dict.get(k, 0.0)) != 0.0 for k in PARAM_ORDER)
+        self._steps_poses = tracking or any(float(lrs_dict.get(k, 0.0)) != 0.0 for k in _POSE_KEYS)
         if tracking:
-            if any(float(lrs_dict[k]) != 0.0 for k in PARAM_ORDER):
-                raise NotImplementedError("the fused tracking iteration forms the pose gradient only: Gaussian learning rates must be 0 "
-                                          "(as in every shipped configuration)")
             s.pending_tracking = True
-        else:
-            if any(float(lrs_dict.get(k, 0.0)) != 0.0 for k in _POSE_KEYS):
-                raise NotImplementedError("pose learning rates in the mapping optimizer (bundle adjustment) are not supported by the plug-in")
+            s.track_steps_gaussians = self._steps_gaussians
+        if self._steps_gaussians:
             # the state the reference's map edits expect to find and re-attach (exp_avg / exp_avg_sq per parameter)
             for g in self.param_groups:
                 p = g['params'][0]
@@ -307,32 +319,66 @@ class FusedOptimizer(torch.optim.Adam):
         if self._tracking:
             lr = (self._lrs['cam_unnorm_rots'], self._lrs['cam_trans'])
             eng.adam_pose(*lr)
-            rep.stepped = lr
+            rep.stepped = (lr, self if self._steps_gaussians else None, bound)
+            if self._steps_gaussians:
+                self._step_gaussians(eng, bound, eps=1e-8, tracking=True)       # torch.optim.Adam(param_groups): default eps
             return None
+        self._step_gaussians(eng, bound, eps=1e-15, tracking=False)
+        if self._steps_poses and rep.args is not None and rep.args[4]:
+            self._step_poses_with_torch(rep)
+        rep.stepped = True
+        return None
+
+    def _step_gaussians(self, eng, bound, eps, tracking):
         by_name = {g['name']: g for g in self.param_groups}
         steps, live = [1] * 5, []
         for idx, k in enumerate(PARAM_ORDER):
             p = by_name[k]['params'][0]
             st = self.state.get(p)
             # a parameter re-created since the backward pass has no gradient: torch's step skips it (pruning, opacity reset).  Compared
-            # with the tensors get_loss SAW: the reference's map edits update the caller's dict in place, and the engine reads that dict
-            if p is not bound[idx] or st is None:
+            # with the tensors get_loss SAW: the reference's map edits update the caller's dict in place, and the engine reads that dict.
+            # While tracking the centres and rotations are detached (no gradient: skipped as torch skips them)
+            if p is not bound[idx] or st is None or (tracking and k in ("means3D", "unnorm_rotations")):
                 continue
             eng.exp_avg[k], eng.exp_avg_sq[k] = st['exp_avg'], st['exp_avg_sq']
             st['step'] += 1                         # torch counts per parameter (a CPU scalar tensor, as torch keeps it)
             steps[idx] = int(st['step'])
             live.append(idx)
         if not live:
-            return None
-        o = eng._adam_map_args(self._lrs, steps=steps)
+            return
+        o = eng._adam_map_args(self._lrs, eps=eps, steps=steps)
         for idx in range(5):
             if idx not in live:
                 o.grad[idx] = None
         m = eng._map_struct()
         with torch.cuda.device(eng.dev):
             _capi.check(eng.L.splat_iter_adam_map(C.byref(m), C.byref(o), eng._stream()), "splat_iter_adam_map")
-        rep.stepped = True
-        return None
+
+    def _step_poses_with_torch(self, rep):
+        """Bundle adjustment (pose learning rates in the mapping optimizer, get_loss(do_ba=True)): the iteration's pose gradient -- one
+        column of the two camera tensors -- through torch's own Adam step for those two parameters (every column moves with its
+        moments, as torch moves it).  A flagged iteration contributes a zero gradient."""
+        by_name = {g['name']: g for g in self.param_groups}
+        t = rep.args[2]
+        ok = (rep.dev[12] == 0).to(rep.dev.dtype)
+        pose = []
+        for name, lo, hi in (('cam_unnorm_rots', 0, 4), ('cam_trans', 4, 7)):
+            p = by_name[name]['params'][0]
+            g = torch.zeros_like(p)
+            g[0, :, t] = rep.dev[lo:hi] * ok
+            p.grad = g
+            pose.append(p)
+        saved = [(g, g['params']) for g in self.param_groups]
+        try:
+            for g in self.param_groups:             # torch steps the parameters that carry a .grad: only the two camera tensors here
+                if g['name'] not in _POSE_KEYS:
+                    g['params'] = []
+            torch.optim.Adam.step(self)
+        finally:
+            for g, params in saved:
+                g['params'] = params
+            for p in pose:
+                p.grad = None
 
 
 def initialize_optimizer(params, lrs_dict, tracking):

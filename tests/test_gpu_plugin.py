@@ -247,3 +247,62 @@ def test_plugin_speed_against_the_dropin_statements():
         r_plug = rate(mine, 40)
     print(f"tracking statements, 100 k Gaussians 640x480: drop-in {r_drop:.0f} it/s, plug-in {r_plug:.0f} it/s")
     assert r_plug > 3.0 * r_drop
+
+
+def test_learning_rates_the_shipped_configs_leave_at_zero():
+    """Pose learning rates in the mapping optimizer (bundle adjustment: get_loss(..., do_ba=True), /root/reference/scripts/splatam.py:226-233)
+    and Gaussian learning rates in the tracking optimizer: the reference's statements through the plug-in against the same statements
+    on the drop-in path, after ONE step (Adam's first step is lr * sign(g) wherever the gradient's sign is certain)."""
+    from splatam_amd import plugin, slam
+    params, _, frame, cam = _scene(9000, 224, 160, aniso=False, seed=13)
+
+    def run(mod, p, cfg, lrs, tracking):
+        v = _variables(p)
+        opt = mod.initialize_optimizer(p, lrs, tracking=tracking)
+        kw = dict(tracking=True) if tracking else dict(mapping=True, do_ba=True)
+        loss, v, _ = mod.get_loss(p, frame, v, 1, cfg['loss_weights'], cfg['use_sil_for_loss'], cfg['sil_thres'], cfg['use_l1'],
+                                  cfg['ignore_outlier_depth_loss'], **kw)
+        loss.backward()
+        with torch.no_grad():
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        return float(loss)
+
+    def check(mine, ref, before, lrs, keys):
+        for k in keys:
+            lr = lrs[k]
+            moved = (ref[k].detach() - before[k]).abs()
+            d = (mine[k].detach() - ref[k].detach()).abs()
+            certain = moved > 0.5 * lr                          # the reference stepped this element by ~lr: its gradient is not noise
+            assert float(certain.float().mean()) > 0.02, (k, float(certain.float().mean()))
+            flipped = float((d[certain] > 0.5 * lr).float().mean())
+            assert flipped <= 5e-3, (k, flipped)
+            assert float(d[certain & (d <= 0.5 * lr)].max()) <= 0.02 * lr, (k, float(d[certain & (d <= 0.5 * lr)].max()), lr)
+    # (1) mapping with bundle adjustment
+    lrs = dict(slam.REPLICA_MAPPING['lrs'], cam_unnorm_rots=0.0004, cam_trans=0.002)
+    before = {k: v.detach().clone() for k, v in params.items()}
+    ref = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    mine = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    l_ref = run(slam, ref, slam.REPLICA_MAPPING, lrs, tracking=False)
+    with plugin.install(slam):
+        l_mine = run(slam, mine, slam.REPLICA_MAPPING, lrs, tracking=False)
+    assert abs(l_mine - l_ref) <= 1e-4 * abs(l_ref)
+    check(mine, ref, before, lrs, ("means3D", "rgb_colors", "logit_opacities", "log_scales"))
+    for k in ("cam_unnorm_rots", "cam_trans"):                      # frame 1's pose stepped by lr * sign(g); every other column untouched
+        d = (mine[k].detach() - ref[k].detach()).abs()
+        assert float(d.max()) <= 0.02 * lrs[k], (k, float(d.max()))
+        assert float((ref[k].detach() - before[k])[0, :, 1].abs().min()) > 0.5 * lrs[k]
+        assert torch.equal(mine[k].detach()[0, :, 0], before[k][0, :, 0]) and torch.equal(mine[k].detach()[0, :, 2], before[k][0, :, 2])
+    # (2) tracking with Gaussian learning rates: rgb / opacity / scale move (centres and rotations are detached while tracking)
+    lrs = dict(slam.REPLICA_TRACKING['lrs'], rgb_colors=0.0025, logit_opacities=0.05, log_scales=0.001, means3D=0.0001)
+    ref = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    mine = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    l_ref = run(slam, ref, slam.REPLICA_TRACKING, lrs, tracking=True)
+    with plugin.install(slam):
+        l_mine = run(slam, mine, slam.REPLICA_TRACKING, lrs, tracking=True)
+    assert abs(l_mine - l_ref) <= 1e-4 * abs(l_ref)
+    check(mine, ref, before, lrs, ("rgb_colors", "logit_opacities", "log_scales"))
+    assert torch.equal(mine['means3D'].detach(), before['means3D']) and torch.equal(ref['means3D'].detach(), before['means3D'])
+    for k in ("cam_unnorm_rots", "cam_trans"):
+        assert float((mine[k].detach() - ref[k].detach()).abs().max()) <= 0.02 * lrs[k], k

@@ -52,3 +52,25 @@ def test_restated_loop_statements_follow_the_reference_source():
                                          r"loss\.backward\(\)", r"params, variables = prune_gaussians\(params, variables, optimizer, iter",
                                          r"optimizer\.step\(\)", r"optimizer\.zero_grad\(set_to_none=True\)")]
     assert m == sorted(m), m
+
+
+def test_loss_scalars_read_through_their_report():
+    """The loss / losses['depth' | 'im'] values the adapters return are views of a copy of the iteration's report; comparisons with
+    numbers and with each other, float(), item() and format() are decided from ONE host copy of that report (the read the reference's
+    `if loss < current_min_loss` makes anyway), torch operations see plain tensors, backward() has nothing left to do."""
+    import torch
+    from splatam_amd import plugin
+    rep = plugin._Report(torch.arange(32, dtype=torch.float32))
+    loss, depth = plugin._scalar(rep, 7), plugin._scalar(rep, 14)
+    assert rep.host is None
+    assert (loss < 1e20) is True and (1e20 > loss) is True and (loss > 1e20) is False
+    assert rep.host is not None and rep.host[7] == 7.0              # one read fetched the whole report
+    assert float(loss) == 7.0 and loss.item() == 7.0 and f"{loss:.1f}" == "7.0"
+    assert (loss < depth) is True and (depth <= loss) is False
+    current_min = loss                                               # the reference keeps the tensor: `current_min_loss = loss`
+    later = plugin._scalar(plugin._Report(torch.full((32,), 3.0)), 7)
+    assert (later < current_min) is True
+    assert loss.backward() is None
+    assert type(loss + 1) is torch.Tensor and type(loss.detach()) is torch.Tensor
+    other = torch.tensor(8.0)
+    assert isinstance(loss < other, torch.Tensor) and bool(loss < other)
