@@ -148,15 +148,6 @@ typedef struct SplatState {
      * schedule: any permutation of each band gives the same results. */
     uint32_t *tile_work;
     uint32_t *tile_order;
-    /* Backward composite of long lists in independent SEGMENTS (fused iteration, lists the composite sorts itself, NULL / 0 = one
-     * workgroup walks a tile's whole list): the forward composite leaves, at the end of every 255-entry batch but the last, a
-     * checkpoint per pixel -- transmittance and the four colour sums that carry gradient (r, g, b, z) -- in
-     * ckpt [ckpt_segments - 1][5][H][W]; the backward composite then runs one workgroup per (tile, batch): a batch's recursion
-     * starts from its checkpoint (T at its far end; the running sum of everything behind it is dL/dC . (C_final - C_checkpoint)), so a
-     * tile of three batches is three work units a third as long -- the under-filled last round of the launch shrinks with them
-     * (profiles/r04_k7_account.md 2).  A tile with more batches than ckpt_segments raises status[3] (stale hint: re-run). */
-    float *ckpt;
-    int32_t ckpt_segments;
     /* per-pixel */
     float *final_T;              /* [H][W] */
     int32_t *n_contrib;          /* [H][W] 1-based list position of the last contributor */

@@ -46,7 +46,7 @@ class SplatState(C.Structure):
                 ("group_count", _fp), ("group_recs", _fp),
                 ("max_list_hint", C.c_int32), ("order_hint", C.c_int32), ("sub_bins", C.c_int32), ("tile_stride", C.c_int32),
                 ("group_stride", C.c_int32), ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),
-                ("tile_work", _fp), ("tile_order", _fp), ("ckpt", _fp), ("ckpt_segments", C.c_int32),
+                ("tile_work", _fp), ("tile_order", _fp),
                 ("final_T", _fp), ("n_contrib", _fp), ("status", _fp)]
 
 

@@ -263,8 +263,8 @@ int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P,
     for (int i = 0; i < iters && err == hipSuccess; ++i) {
         if (fn != 1 && fn != 4) err = launch_render_forward_feat8(*cam, ws->feat8, st, ws->out6, sort_form, s);
         if ((fn == 1 || fn == 3) && err == hipSuccess)
-            err = launch_render_backward_feat8(*cam, ws->feat8, st, ws->dL_dout6, ws->accum, P, false, true, s, true, ws->out6);
-        if (fn == 4) err = launch_render_backward_feat8(*cam, ws->feat8, st, ws->dL_dout6, ws->accum, P, false, false, s, false, ws->out6);     // tracking form
+            err = launch_render_backward_feat8(*cam, ws->feat8, st, ws->dL_dout6, ws->accum, P, false, true, s);
+        if (fn == 4) err = launch_render_backward_feat8(*cam, ws->feat8, st, ws->dL_dout6, ws->accum, P, false, false, s, false);     // tracking form
     }
     (void)hipEventRecord(e1, s);
     // the timed backward launches accumulated into ws->accum: restore the workspace invariant (every iteration leaves the

@@ -1225,7 +1225,7 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
             hipLaunchKernelGGL(map_loss_backward_kernel, grid, dim3(kBlock), 0, s, a, W, H);
         }
         e = launch_render_backward_feat8(cam, ws.feat8, ws.st, ws.dL_dout6, ws.accum, P, false, ws.d_rgb_colors != nullptr, s,
-                                         ws.d_logit_opacities != nullptr, ws.out6);
+                                         ws.d_logit_opacities != nullptr);
         if (e != hipSuccess) return e;
     }
     PoseAdam pa{};

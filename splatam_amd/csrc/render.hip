@@ -449,7 +449,7 @@ constexpr int forward_fp() { return forward_compact6<C, CS, WITH_DEPTH>() ? 4 : 
 template <int C, int CS, bool WITH_DEPTH, bool SORT, class BatchT>
 __device__ __forceinline__ int forward_tile(const float *colors, SplatState &st, BatchT &B, uint64_t *s_keys, const int tile, const int tx, const int ty,
                                             const int gx, const int tid, const float fpx, const float fpy, const bool inside, float &Tr, float &D,
-                                            float (&Cc)[C], unsigned &last, const size_t pix = 0, const size_t HW = 0) {
+                                            float (&Cc)[C], unsigned &last) {
     constexpr int F = C + (WITH_DEPTH ? 1 : 0);
     constexpr bool COMPACT6 = forward_compact6<C, CS, WITH_DEPTH>();
     constexpr int FP = forward_fp<C, CS, WITH_DEPTH>();
@@ -631,16 +631,7 @@ __device__ __forceinline__ int forward_tile(const float *colors, SplatState &st,
             }
             last = last_loc != ~0u ? base1 + last_loc / (unsigned)(R4 * sizeof(float4)) : last;
             wdone = done_m == ~0ull;
-            if constexpr (COMPACT6) {
-                // the state at the end of this batch, for the backward composite's independent segments (SplatState.ckpt)
-                if (st.ckpt && more && inside && bi + 1 < st.ckpt_segments) {
-                    float *ck = st.ckpt + (size_t)bi * 5 * HW + pix;
-                    ck[0] = Tr; ck[HW] = Cc[0]; ck[2 * HW] = Cc[1]; ck[3 * HW] = Cc[2]; ck[4 * HW] = Cc[3];
-                }
-            }
         }
-        if constexpr (COMPACT6)
-            if (st.ckpt && nb > st.ckpt_segments && tid == 0) st.status[3] = 1;       // more batches than the host sized the checkpoints for: stale hint
     }
     return staged;
 }
@@ -678,8 +669,7 @@ __global__ __launch_bounds__(256, (forward_compact6<C, CS, WITH_DEPTH>() ? SPLAT
     unsigned last = 0;
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) Cc[ch] = 0.f;
-    forward_tile<C, CS, WITH_DEPTH, SORT>(colors, st, B, s_keys, tile, tx, ty, gx, tid, fpx, fpy, inside, Tr, D, Cc, last, (size_t)py * W + px,
-                                          (size_t)H * W);
+    forward_tile<C, CS, WITH_DEPTH, SORT>(colors, st, B, s_keys, tile, tx, ty, gx, tid, fpx, fpy, inside, Tr, D, Cc, last);
     if (st.tile_work) {
         // what the backward composite will walk in this tile: per quadrant, the deepest list entry a pixel blended (SplatState.tile_work)
         __shared__ unsigned s_work;
@@ -805,8 +795,7 @@ __device__ __forceinline__ float group8_allreduce_add(float v) {
 template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC, int DBG, class BatchT>
 __device__ __forceinline__ void backward_core(const float *colors, const SplatState &st, float *accum, BatchT &B, PairBuf &PB, unsigned *s_wmax,
                                               const int tile, const int tx, const int ty, const int tid, const bool inside, const float Tfin,
-                                              const unsigned last, const float (&dpix)[C], float R, const int staged, const int seg = -1,
-                                              const float T_seg = 0.f, const float R_seg = 0.f) {
+                                              const unsigned last, const float (&dpix)[C], float R, const int staged) {
     constexpr int CL = highest_set_bit(DMASK) + 1;        // colour channels staged per Gaussian: only those that carry gradient
     static_assert(CL >= 1 && CL <= C, "DMASK names channels of the call");
     constexpr int R4 = BatchT::R4;
@@ -868,11 +857,6 @@ __device__ __forceinline__ void backward_core(const float *colors, const SplatSt
     if (tmax == 0) return;                                     // uniform over the workgroup
     const unsigned lo = st.tile_stride > 0 ? (unsigned)tile * (unsigned)st.tile_stride : st.tile_base[tile];
     const int nb = (int)((tmax + kBatchEntries - 1) / kBatchEntries);
-    // seg >= 0: this workgroup walks batch `seg` of the tile only (SplatState.ckpt).  The tile's last batch starts from the final state;
-    // an earlier one from the forward pass' checkpoint at its far end: T there, and the running sum of everything behind it
-    if (seg >= nb) return;
-    if (seg >= 0 && seg < nb - 1) { Tr = T_seg; R = R_seg; }
-    const int bi_first = seg >= 0 ? seg : nb - 1, bi_last = seg >= 0 ? seg : 0;
 
     // accumulator slot of published value k: S1..S5 (S6) -> 0..5, colour sums -> 6 + channel
     auto slot_of = [](int k) { return k < NB ? k : 6 + nth_set_bit(SMASK, k - NB); };
@@ -985,18 +969,18 @@ __device__ __forceinline__ void backward_core(const float *colors, const SplatSt
 
     int nslot = 0;                                              // wave-uniform
     Staged<FP> pre;
-    const bool handed_over = staged == nb - 1 && seg < 0;       // (uniform) the first batch of this pass is the one already in B
+    const bool handed_over = staged == nb - 1;                  // (uniform) the first batch of this pass is the one already in B
     if (!handed_over) {
-        const unsigned e = (unsigned)(bi_first * kBatchEntries + tid);
+        const unsigned e = (unsigned)((nb - 1) * kBatchEntries + tid);
         gather<CL, CS, false, FP>(pre, st, colors, lo + e, tid < kBatchEntries && e < tmax, tile_x0, tile_y0);
     }
-    for (int bi = bi_first; bi >= bi_last; --bi) {
-        if (!(handed_over && bi == bi_first)) {
-            if (bi < bi_first || staged >= 0) __syncthreads();   // every wave has finished reading the previous batch
+    for (int bi = nb - 1; bi >= 0; --bi) {
+        if (!(handed_over && bi == nb - 1)) {
+            if (bi < nb - 1 || staged >= 0) __syncthreads();   // every wave has finished reading the previous batch
             commit_quadrants(B, pre, tid);
             __syncthreads();
         }
-        const bool more = bi > bi_last;
+        const bool more = bi > 0;
         if (more) gather<CL, CS, false, FP>(pre, st, colors, lo + (unsigned)((bi - 1) * kBatchEntries + tid), tid < kBatchEntries, tile_x0, tile_y0);
         const int base = bi * kBatchEntries;
         const int lim = (int)wmax - base;                      // entries [0, lim) of this batch can matter to this wave
@@ -1146,59 +1130,6 @@ __device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, co
     }
     backward_core<C, CS, DMASK, SMASK, OPAC, DBG>(colors, st, accum, B, PB, s_wmax, tile, tx, ty, tid, inside, Tfin, last, dpix, R, -1);
     stamp();
-}
-
-// The backward composite in independent SEGMENTS (SplatState.ckpt): one workgroup per (tile, 255-entry batch).  Workgroup b: XCD band
-// b & 7, slot b >> 3 -> tile slot / S in the band's launch order, batch slot % S.  Everything a segment needs besides the tile's lists
-// is per-pixel state the forward composite left: the final state for the tile's last batch, the checkpoint at its far end otherwise
-// (requested up front whatever the tile's batch count turns out to be: an unused checkpoint is just not looked at).
-template <unsigned SMASK, bool OPAC>
-__device__ __forceinline__ void render_backward_seg_body(const SplatCamera &cam, const float *colors, const SplatState &st, const float *dL_dcolor,
-                                                         const float *out6, float *accum, int T, int per_xcd, int S) {
-    constexpr int C = 6, CS = 8, FP = 4;
-    constexpr unsigned DMASK = 0xFu;
-    __shared__ Batch<FP> B;
-    __shared__ PairBuf PB;
-    __shared__ unsigned s_wmax[4];
-    const int b = blockIdx.x, slot = b >> 3;
-    const int tslot = slot / S, seg = slot - tslot * S;
-    if (tslot >= per_xcd) return;
-    const int pos = (b & 7) * per_xcd + tslot;
-    const unsigned ot = st.tile_order ? st.tile_order[pos] : (unsigned)pos;
-    if (ot >= (unsigned)T) return;
-    const int tile = (int)ot;
-    const int W = cam.image_width, H = cam.image_height;
-    const int gx = (W + kTile - 1) / kTile;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tx = tile % gx, ty = tile / gx;
-    const int px = tx * kTile + (wave & 1) * 8 + (lane & 7), py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const size_t HW = (size_t)H * W;
-    const size_t pix = (size_t)py * W + px;
-    const float Tfin = inside ? st.final_T[pix] : 0.f;
-    const unsigned last = inside ? (unsigned)st.n_contrib[pix] : 0u;
-    float dpix[C], T_seg = 0.f, R_seg = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < C; ++ch) dpix[ch] = (ch < 4 && inside) ? dL_dcolor[ch * HW + pix] : 0.f;
-    if (seg < S - 1 && inside) {
-        const float *ck = st.ckpt + (size_t)seg * 5 * HW + pix;
-        T_seg = ck[0];
-        // everything behind this batch: sum_j (c_j . dL/dC) alpha_j T_j = dL/dC . (C_final - C_checkpoint)   (zero background)
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) R_seg = fmaf(dpix[ch], out6[ch * HW + pix] - ck[(ch + 1) * HW], R_seg);
-    }
-    backward_core<C, CS, DMASK, SMASK, OPAC, 0>(colors, st, accum, B, PB, s_wmax, tile, tx, ty, tid, inside, Tfin, last, dpix, 0.f, -1, seg, T_seg, R_seg);
-}
-
-template <unsigned SMASK, bool OPAC>
-__global__ __launch_bounds__(256) void render_backward_seg_kernel(SplatCamera cam, const float *colors, SplatState st, const float *dL_dcolor,
-                                                                  const float *out6, float *accum, int T, int per_xcd, int S) {
-    render_backward_seg_body<SMASK, OPAC>(cam, colors, st, dL_dcolor, out6, accum, T, per_xcd, S);
-}
-template <unsigned SMASK, bool OPAC>
-__global__ __launch_bounds__(256, 5) void render_backward_seg_kernel_w5(SplatCamera cam, const float *colors, SplatState st, const float *dL_dcolor,
-                                                                        const float *out6, float *accum, int T, int per_xcd, int S) {
-    render_backward_seg_body<SMASK, OPAC>(cam, colors, st, dL_dcolor, out6, accum, T, per_xcd, S);
 }
 
 // Two launch shapes of the same body.  With at most two colour sums (the tracking form) the phase-2 gradient rows live in registers: the
@@ -1460,31 +1391,19 @@ hipError_t launch_render_track_fused(const SplatCamera &cam, const float *feat8,
     const int T = launch_tiles(cam, st);
     if (T == 0) return hipSuccess;
     const int per = (T + 7) / 8;
-    SplatState st1 = st;                    // (one kernel walks a tile front to back and back to front: no checkpoints, no segments)
-    st1.ckpt = nullptr;
-    st1.ckpt_segments = 0;
-    if (keep_planes) hipLaunchKernelGGL((render_track_fused_kernel<true>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st1, out6, accum, T, per, ep);
-    else hipLaunchKernelGGL((render_track_fused_kernel<false>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st1, out6, accum, T, per, ep);
+    if (keep_planes) hipLaunchKernelGGL((render_track_fused_kernel<true>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6, accum, T, per, ep);
+    else hipLaunchKernelGGL((render_track_fused_kernel<false>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6, accum, T, per, ep);
     return hipGetLastError();
 }
 
 hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *feat8, const SplatState &st, const float *dL_dout6,
-                                        float *accum, int P, bool zero_accum, bool rgb_sums, hipStream_t s, bool opacity_sum, const float *out6) {
+                                        float *accum, int P, bool zero_accum, bool rgb_sums, hipStream_t s, bool opacity_sum) {
     const int T = launch_tiles(cam, st);
     if (zero_accum) {
         hipError_t e = hipMemsetAsync(accum, 0, sizeof(float) * SPLAT_GRAD_STRIDE * (size_t)P, s);
         if (e != hipSuccess) return e;
     }
     if (T == 0 || P == 0) return hipSuccess;
-    // long lists the forward composite left checkpoints for: one workgroup per (tile, batch) (render_backward_seg_kernel)
-    if (st.ckpt && st.ckpt_segments > 1 && out6 && g_debug_k7_bits == 0 && st.tile_row_end <= st.tile_row_begin) {
-        const int per = (T + 7) / 8, S = st.ckpt_segments;
-        const dim3 grid(8 * per * S), block(256);
-        if (rgb_sums) hipLaunchKernelGGL((render_backward_seg_kernel<0xFu, true>), grid, block, 0, s, cam, feat8, st, dL_dout6, out6, accum, T, per, S);
-        else if (opacity_sum) hipLaunchKernelGGL((render_backward_seg_kernel_w5<0x8u, true>), grid, block, 0, s, cam, feat8, st, dL_dout6, out6, accum, T, per, S);
-        else hipLaunchKernelGGL((render_backward_seg_kernel_w5<0x8u, false>), grid, block, 0, s, cam, feat8, st, dL_dout6, out6, accum, T, per, S);
-        return hipGetLastError();
-    }
     // channels r, g, b, z carry gradient; the silhouette and depth^2 planes never do.  dL/drgb is only summed on request
     // (tracking does not read it: LR 0 in /root/reference/configs/*/splatam.py, optimizer discarded after the frame).
     // (zero background: FusedEngine refuses anything else, as setup_camera builds it)

@@ -135,11 +135,6 @@ class FusedEngine:
         self._cam_ok = {}
         self._frame_keep = None
         self.track_fused = os.environ.get("SPLAT_TRACK_FUSED", "1") != "0"    # tracking: forward + loss + backward composite in one kernel
-        # ... while a tile is (mostly) one batch; longer lists take two kernels with the backward composite in segments (below)
-        self.track_fused_max_list = int(os.environ.get("SPLAT_TRACK_FUSED_MAX_LIST", 400))
-        # backward composite of lists beyond one 255-entry batch: one workgroup per (tile, batch), from the forward composite's checkpoints
-        # (SplatState.ckpt)
-        self.segmented_backward = os.environ.get("SPLAT_K7_SEGMENTS", "1") != "0"
         self.fold_sums = os.environ.get("SPLAT_FOLD_SUMS", "1") != "0"     # tile-row-sharded tracking: exchange 256 B instead of 16 KB
         self.skipped_iterations = 0     # of the last check_overflow() / digest_report(): iterations whose Adam step the device skipped
         self._learnt_P = None           # rows of the map the list statistics were learnt on (rebind keeps them for a similar map)
@@ -608,12 +603,6 @@ class FusedEngine:
         st.order_hint = int(self.creation_order)
         if self.tile_order_on:
             st.tile_work, st.tile_order = b['tile_work'].data_ptr(), b['tile_order'].data_ptr()
-        seg = self._segments()
-        if seg > 1 and not self._tile_rows:
-            need = (seg - 1) * 5 * self.H * self.W
-            if b.get('ckpt') is None or b['ckpt'].numel() < need:
-                b['ckpt'] = torch.empty(need, dtype=torch.float32, device=self.dev)
-            st.ckpt, st.ckpt_segments = b['ckpt'].data_ptr(), seg
         st.sub_bins = self.sub_bins if self.tile_stride == 0 else 1
         st.final_T, st.n_contrib, st.status = b['final_T'].data_ptr(), b['n_contrib'].data_ptr(), b['status'].data_ptr()
         ws.feat8, ws.out6, ws.dL_dout6, ws.accum = b['feat8'].data_ptr(), b['out6'].data_ptr(), b['dL_dout6'].data_ptr(), b['accum'].data_ptr()
@@ -629,14 +618,6 @@ class FusedEngine:
         if 'outlier_err' in b:
             ws.outlier_err, ws.outlier_scratch = b['outlier_err'].data_ptr(), b['outlier_scratch'].data_ptr()
         return ws
-
-    def _segments(self):
-        """255-entry batches a tile's list may hold (with the 25 % margin of the list-length hint) when the backward composite runs
-        in segments: lists the forward composite sorts itself, longer than one batch; 1 otherwise."""
-        h = self.max_list_hint
-        if not self.segmented_backward or h <= 0 or self.tile_stride <= 0 or h * 5 // 4 > 1024:
-            return 1
-        return max(1, -(-(h * 5 // 4) // 255))
 
     def _stream(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
@@ -675,8 +656,7 @@ class FusedEngine:
         self._frame_keep = (im, depth, w2c)
         if keep_planes is None:
             keep_planes = pose_adam is None
-        one_kernel = (2 if keep_planes else 1) if (tracking and self.track_fused and not map_grads and
-                                                   (self._segments() == 1 or self.max_list_hint <= self.track_fused_max_list)) else 0
+        one_kernel = (2 if keep_planes else 1) if (tracking and self.track_fused and not map_grads) else 0
         lc = self.loss_config(cfg, tracking, do_ba, defer_finish=tile_rows is not None, fused_composite=one_kernel)
         self._tile_rows = tile_rows         # a band: the iteration stops before its last kernel (finish_iteration completes it)
         self._stats_partial = tile_rows is not None

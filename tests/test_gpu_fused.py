@@ -833,63 +833,3 @@ def test_tracking_composites_in_one_kernel_equal_the_two_kernels(n, W, H, label)
     assert float((a['d'][8:12] - b['d'][8:12]).abs().max()) <= 1e-5 * float(b['d'][8:12].abs().max())
     assert float((a['trans'] - b['trans']).abs().max()) <= 2e-5 and float((a['rot'] - b['rot']).abs().max()) <= 2e-5
     assert abs(a['loss'] - b['loss']) <= 1e-3 * abs(b['loss'])
-
-
-@pytest.mark.parametrize("tracking", [False, True])
-def test_backward_composite_in_segments_equals_the_whole_list_walk(tracking):
-    """SplatState.ckpt: lists of several 255-entry batches -- the forward composite leaves a checkpoint per pixel at every batch
-    boundary, the backward composite runs one workgroup per (tile, batch), each starting from its checkpoint (T at the batch's far end,
-    running sum = dL/dC . (C_final - C_checkpoint)).  Against one workgroup walking the whole list: the forward planes are the same
-    kernel's (bit-identical), every gradient agrees to float32 evaluation order (the running sum is formed from forward sums instead of
-    being accumulated back to front)."""
-    from splatam_amd import slam
-    from splatam_amd.fused import FusedEngine
-    params, variables, frame, cam = _scene(64000, 328, 248, seed=17)        # ~640 entries per tile: three batches
-    cfg = slam.REPLICA_TRACKING if tracking else slam.REPLICA_MAPPING
-    out = {}
-    for seg in (True, False):
-        eng = FusedEngine({k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}, cam)
-        eng.segmented_backward = seg
-        eng.track_fused = False                                             # (two kernels: the segmented form is the backward composite's)
-        for _ in range(2):
-            eng.loss_backward(frame, 1, slam.REPLICA_MAPPING, tracking=False)
-            assert not eng.check_overflow()
-        assert eng.tile_stride > 0 and (eng._segments() >= 3) == seg, (eng.max_list_hint, eng._segments())
-        if tracking:
-            eng.begin_tracking(1)
-        eng.loss_backward(frame, 1, cfg, tracking=tracking)
-        torch.cuda.synchronize()
-        assert not eng.check_overflow(grow=False)
-        out[seg] = dict(out6=eng.buf['out6'].clone(), d=eng.buf['d_cam'].clone(), grads={k: v.clone() for k, v in eng.grads.items()})
-    a, b = out[True], out[False]
-    assert torch.equal(a['out6'], b['out6'])
-    assert abs(float(a['d'][7]) - float(b['d'][7])) <= 1e-6 * abs(float(b['d'][7]))
-    if tracking:
-        assert float((a['d'][:7] - b['d'][:7]).abs().max()) <= 1e-4 * float(b['d'][:7].abs().max()), (a['d'][:7], b['d'][:7])
-    else:
-        for k in ("means3D", "rgb_colors", "logit_opacities", "log_scales"):
-            ga, gb = a['grads'][k], b['grads'][k]
-            scale = float(gb.abs().max())
-            err = (ga - gb).abs()
-            assert float(torch.quantile(err.reshape(-1)[:4_000_000], 0.9999)) <= 1e-4 * scale, (k, float(err.max()), scale)
-            assert float(err.max()) <= 2e-3 * scale, (k, float(err.max()), scale)
-
-
-def test_more_batches_than_checkpoints_is_flagged():
-    """A tile with more batches than the host sized the checkpoints for (a stale list-length hint) raises the iteration's flag: no Adam
-    step, the host re-learns."""
-    from splatam_amd import slam
-    from splatam_amd.fused import FusedEngine
-    params, variables, frame, cam = _scene(64000, 328, 248, seed=17)
-    eng = FusedEngine({k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}, cam)
-    for _ in range(2):
-        eng.loss_backward(frame, 1, slam.REPLICA_MAPPING, tracking=False)
-        assert not eng.check_overflow()
-    assert eng._segments() >= 3
-    eng.max_list_hint = 300                                                  # stale: the lists hold ~640 entries
-    assert eng._segments() == 2
-    snap = eng.params['means3D'].detach().clone()
-    eng.mapping_iteration(frame, 1, slam.REPLICA_MAPPING)
-    torch.cuda.synchronize()
-    assert torch.equal(eng.params['means3D'].detach(), snap)
-    assert eng.check_overflow() and eng.skipped_iterations == 1
