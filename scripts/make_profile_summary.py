@@ -59,6 +59,17 @@ for wl, fname in (("B (300 000 Gaussians, 1200x680)", f"{tag}_bench_kernel_stats
             f"| F7 `pose_finish_kernel` (+ pose Adam, + tile launch order in its spare workgroups) | {f7:.1f} |",
             "",
             f"Per tracking iteration {f1 + trk + f6t + f7:.0f} us of kernels, per mapping iteration {f1 + k6 + f4 + f5 + k7 + f6m + f7:.0f} us.", ""]
+src = os.path.join(G, f"bench_{tag}_Bloop.log")
+if os.path.exists(src):
+    lines = [l for l in open(src) if l.startswith("{")]
+    if lines:
+        open(os.path.join(P, f"{tag}_bench_Bloop.json.log"), "w").write(lines[-1])
+        dl = json.loads(lines[-1])
+        rl = dl.get("roofline", {})
+        out += [f"Workload B-loop, un-profiled bench line `{tag}_bench_Bloop.json.log`: **{dl['value']} iters/s** (tracking {dl['tracking_iters_per_s']}, mapping "
+                f"{dl['mapping_iters_per_s']}); K7 {rl.get('kernel_ms')} ms live = {rl.get('achieved')} GB/s algorithmic = {100 * (rl.get('frac') or 0):.2f} % of HBM peak, "
+                f"PMC traffic {rl.get('traffic')} B, live pairs per launch {rl.get('other', {}).get('pairs_per_launch')}, lane-operations per live pair "
+                f"{rl.get('other', {}).get('lane_ops_per_live_pair')}.", ""]
 for wl in ("B", "B-loop"):
     src = os.path.join(G, f"{tag}_k7_account_{wl}.md")
     if os.path.exists(src):

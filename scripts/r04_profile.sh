@@ -25,6 +25,8 @@ rm -rf /tmp/prof_${tag}L
 f=$(find /tmp/prof_${tag}L -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f gpurun_out/${tag}_Bloop_kernel_stats.csv
 timeout 900 python bench.py > gpurun_out/bench_$tag.log 2> gpurun_out/bench_$tag.err
 echo "bench rc $?"
+timeout 900 python bench.py --workload B-loop --no-slam-loop > gpurun_out/bench_${tag}_Bloop.log 2> gpurun_out/bench_${tag}_Bloop.err
+echo "bench B-loop rc $?"
 tail -1 gpurun_out/bench_$tag.log | cut -c1-300
 head -12 gpurun_out/${tag}_bench_kernel_stats.csv | cut -c1-160
 if [ -z "$quick" ]; then

@@ -133,7 +133,7 @@ class _Session:
         self.current = None         # (engine, bound tensors, report) of the last get_loss
         self.pending_tracking = True
         self.track_steps_gaussians = False      # the live tracking optimizer has non-zero Gaussian learning rates
-        self.pending = []           # [(report, pinned host tensor, event)] reports in flight to the host
+        self.pending = []           # [(engine, report, pinned host tensor, event)] reports in flight to the host
         self.pool = []              # pinned buffers / events for re-use
         self.stats = {"iterations": 0, "rebuilds": 0, "engines_built": 0, "repeats": 0, "skipped_iterations": 0}
 
