@@ -7,17 +7,23 @@ A *step* is one optimisation iteration of the reference's per-frame loops
 -> Adam step, at BASELINE.json config B: 300 000 Gaussians, 1200x680, Replica
 intrinsics, synthetic data.  Steps follow the reference's 40:60 tracking:mapping
 mix (2 tracking + 3 mapping per 5 steps).  With N > 1 ranks every rank runs the
-same schedule on its own frame / keyframe view (weak scaling); mapping steps
-exchange Gaussian gradients with one RCCL all-reduce, tracking steps are replicas.
+same schedule (weak scaling in the mapping views): mapping steps render one view per
+rank and exchange Gaussian gradients with one RCCL all-reduce; a tracking step is ONE
+iteration on one frame whose tile rows are sharded over the ranks (counted once).
 
-Two engines run the same iteration (same loss, same gradients, same Adam update: tests/test_gpu_fused.py):
-  * ``fused``  (default, the headline ``value``): splatam_amd.fused.FusedEngine -- the whole iteration as ~10 kernel
-    launches of libsplat_hip.so (shared geometry, ONE 6-channel composite for the RGB and depth/silhouette renders,
-    fused loss / SSIM / pose-gradient / Adam kernels, no host synchronisation);
+Three ways through the same iteration (same loss, same gradients, same Adam update: tests/test_gpu_fused.py, tests/test_gpu_plugin.py):
+  * ``fused``  (default, the headline ``value``): splatam_amd.fused.FusedEngine -- the whole iteration as 4 (tracking) / 7 (mapping)
+    kernel launches of libsplat_hip.so (shared geometry, ONE 6-channel composite for the RGB and depth/silhouette renders, the
+    tracking iteration's forward composite + loss + backward composite as one kernel, fused SSIM / pose-gradient / Adam kernels, no host
+    synchronisation);
+  * ``plugin_iters_per_s``: the reference's own loop statements with ``splatam_amd.plugin.install()`` (get_loss / initialize_optimizer
+    of the caller's module replaced at run time by adapters over the fused engine; no host read per iteration);
   * ``dropin``: the reference's own Python glue (splatam_amd.slam, PyTorch autograd + torch.optim.Adam) around the
-    drop-in ``GaussianRasterizer`` -- what an unmodified scripts/splatam.py gets; reported as ``dropin_iters_per_s``;
-  * ``plugin_iters_per_s``: the same loop statements with ``splatam_amd.plugin.install()`` (get_loss / initialize_optimizer of the
-    caller's module replaced at run time by adapters over the fused engine).
+    drop-in ``GaussianRasterizer`` -- what an unmodified scripts/splatam.py gets; reported as ``dropin_iters_per_s`` with the
+    rasterizer's own share of the iteration beside it.
+Beside them: ``slam_loop`` / ``slam_loop_plugin`` (the whole frame loop, 13 frames, two runs, per-phase milliseconds), ``roofline`` (the
+dominant kernel live + counters of the committed profile set), ``cpu_baseline`` (the C oracle + PyTorch-CPU glue on the host cores).
+``python bench.py --gpus N`` started without a launcher starts its own N ranks (torch.distributed.run, 127.0.0.1).
 
 Prints ONE JSON line on rank 0.
 """
