@@ -470,8 +470,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // L2: with a plain 3-d grid the eight neighbours of a tile run on eight OTHER XCDs, and every halo pixel (2.1x the tile) comes from
 // memory again (F5: 167 MB of traffic for 75 MB of planes).  Here XCD x owns a contiguous run of the (channel, row, column) order, so a
 // tile's halo was read by the workgroup before it or one tile row earlier, through the SAME L2.
+template <int TW = kTW, int TH = kTH>
 __device__ __forceinline__ bool ssim_tile(int W, int H, int &bx, int &by, int &ch) {
-    const int ntx = (W + kTW - 1) / kTW, nty = (H + kTH - 1) / kTH, total = 3 * ntx * nty, per = (total + 7) / 8;
+    const int ntx = (W + TW - 1) / TW, nty = (H + TH - 1) / TH, total = 3 * ntx * nty, per = (total + 7) / 8;
     const int b = blockIdx.x, slot = b >> 3, t = (b & 7) * per + slot;
     if (slot >= per || t >= total) return false;
     ch = t / (ntx * nty);
@@ -506,7 +507,7 @@ __device__ __forceinline__ float ssim_pixel_dev(float mu1, float mu2, float e11,
 // F4: grid (tiles_x, tiles_y, 3 channels).  The five window statistics travel as two float pairs + one float, so that the
 // 11-tap sums are v_pk_fma_f32 (two statistics per instruction).  Also accumulates the L1 image sum; the z == 0 slice handles
 // the depth plane.
-__global__ __launch_bounds__(kBlock) void ssim_forward_kernel(FusedArgs a, int W, int H) {
+__global__ __launch_bounds__(kBlock) void ssim_forward_rows_kernel(FusedArgs a, int W, int H) {
     __shared__ float sx[kHH_][kHW_ + 1], sy[kHH_][kHW_ + 1];
     __shared__ f2 shA[kHH_][kTW + 1], shB[kHH_][kTW + 1];      // horizontal sums of (x, y) and (x x, y y)
     __shared__ float shC[kHH_][kTW + 1];                       // ... of x y
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(kBlock) void ssim_forward_kernel(FusedArgs a, int W
 
 // F5: dL/d(rgb) = w_im * (0.8 sign(x - y) / (3HW) - 0.2 / (3HW) * [blur(dmu1) + 2 x blur(de11) + y blur(de12)]),
 //     depth plane: w_depth * mask * sign(d - gt) / count.
-__global__ __launch_bounds__(kBlock) void map_loss_backward_kernel(FusedArgs a, int W, int H) {
+__global__ __launch_bounds__(kBlock) void map_loss_backward_rows_kernel(FusedArgs a, int W, int H) {
     __shared__ f2 smA[kHH_][kHW_ + 1];          // (d/dmu1, d/dE11) maps with halo
     __shared__ float smC[kHH_][kHW_ + 1];       // d/dE12
     __shared__ f2 shA[kHH_][kTW + 1];
@@ -760,6 +761,281 @@ __global__ __launch_bounds__(kBlock) void map_loss_backward_kernel(FusedArgs a, 
                 }
             }
         }
+    }
+}
+
+// ---- F4 / F5, column-first form ------------------------------------------------------------------------------------------------
+// The row-first kernels above stage the window (tile + halo, two planes) in LDS, run the horizontal pass over 26 halo rows for 16
+// output rows and read 12 rows of five sums back for every two output pixels: 29 LDS reads and 87 multiply-adds per pixel, 26 KB of
+// LDS.  Here the VERTICAL pass comes first and needs no LDS at all: a thread owns one column of the window (lanes = consecutive
+// columns: the loads coalesce), holds kCR + 10 input rows in registers and forms kCR output rows of vertical sums; only those go
+// through LDS (24 rows x 42 columns, no halo rows), and the horizontal pass reads 14 columns for 4 output pixels: 10.5 LDS reads and
+// 76 multiply-adds per pixel, 21 KB (F4) / 13 KB (F5) of LDS, one barrier instead of two, float4 stores.
+constexpr int kCW = 32, kCR = 4, kCG = 6;   // tile width; output rows per thread of the vertical pass; row groups per workgroup
+constexpr int kCH = kCR * kCG;              // tile height 24
+constexpr int kCCols = kCW + 2 * kSsimR;    // 42 columns with halo
+constexpr int kCStride = 45;                // LDS row stride in elements: 1 mod 4, the 64-bit reads of the horizontal pass fall on distinct banks
+constexpr int kCItems = kCH * (kCW / 4);    // horizontal work items: (row, group of 4 columns)
+static_assert(kCCols * kCG <= kBlock && kCItems <= kBlock, "one trip per pass");
+
+// four consecutive pixels of a plane row (clamped addresses; the caller discards what lies outside the image)
+template <bool VEC>
+__device__ __forceinline__ void load_px4(const float *plane, int yy, int xx, int W, int H, float *dst) {
+    const size_t row = (size_t)min(yy, H - 1) * W;
+    if constexpr (VEC) {
+        const float4 t = *reinterpret_cast<const float4 *>(plane + row + min(xx, W - 4));
+        dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = plane[row + min(xx + j, W - 1)];
+    }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void store_px4(float *plane, int yy, int xx, int W, int H, const float *v) {
+    if (yy >= H) return;
+    float *p = plane + (size_t)yy * W + xx;
+    if constexpr (VEC) {
+        if (xx < W) *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (xx + j < W) p[j] = v[j];
+    }
+}
+
+// plane[byte_off / 4] with a uniform base and a 32-bit byte offset: one address register per load instead of two
+__device__ __forceinline__ float ld_off(const float *plane, unsigned byte_off) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(plane) + byte_off);
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// VEC: W % 4 == 0 and every plane 16-byte aligned (the launcher checks): whole float4 loads / stores of a thread's four pixels
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void ssim_forward_kernel(FusedArgs a, int W, int H) {
+    __shared__ f2 svA[kCH][kCStride], svB[kCH][kCStride];      // vertical sums of (x, y) and (x x, y y)
+    __shared__ float svC[kCH][kCStride];                       // ... of x y
+    __shared__ double s_part[4 * (kBlock / 64)];
+    float g[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) g[k] = a.win[k];
+    int bx, by, ch;
+    if (!ssim_tile<kCW, kCH>(W, H, bx, by, ch)) return;
+    const int tid = threadIdx.x;
+    const int x0 = bx * kCW, y0 = by * kCH;
+    const size_t HW = (size_t)H * W;
+    const float *X = a.ws.out6 + ch * HW, *Y = a.frame.im + ch * HW;
+    float *M = a.ws.ssim_maps + (size_t)(3 * ch) * HW;
+    // the horizontal pass' work item and its own pixels (image L1 term; z == 0 slice: the depth-loss inputs)
+    const int hr = tid / (kCW / 4), hc = (tid & (kCW / 4 - 1)) * 4;
+    float own_x[4], own_y[4];
+    {   // vertical pass: thread = (column of the window, group of kCR output rows); every load in flight before the first sum
+        const int grp = tid / kCCols, col = tid - grp * kCCols;
+        if (grp < kCG) {
+            const int xx = x0 - kSsimR + col;
+            const bool cin = xx >= 0 && xx < W;
+            const int xc = min(max(xx, 0), W - 1);
+            float vx[kCR + 10], vy[kCR + 10];
+#pragma unroll
+            for (int t = 0; t < kCR + 10; ++t) {
+                const int yy = y0 + grp * kCR - kSsimR + t;
+                const bool in = cin && yy >= 0 && yy < H;
+                // (any address inside the plane will do for a row outside the image: its value is discarded)
+                const unsigned off = (unsigned)min(max(yy * (4 * W) + 4 * xc, 0), 4 * (H * W - 1));
+                const float tx = ld_off(X, off), ty = ld_off(Y, off);
+                vx[t] = in ? tx : 0.f;
+                vy[t] = in ? ty : 0.f;
+            }
+            f2 vA[kCR], vB[kCR];
+            float vC[kCR];
+#pragma unroll
+            for (int j = 0; j < kCR; ++j) { vA[j] = (f2)(0.f); vB[j] = (f2)(0.f); vC[j] = 0.f; }
+#pragma unroll
+            for (int t = 0; t < kCR + 10; ++t) {
+                const f2 p = {vx[t], vy[t]};
+                const f2 q = p * p;
+                const float xy = p.x * p.y;
+#pragma unroll
+                for (int j = 0; j < kCR; ++j) {
+                    const int tap = t - j;
+                    if (tap >= 0 && tap < 11) {
+                        const f2 w = (f2)(g[tap]);
+                        vA[j] = __builtin_elementwise_fma(w, p, vA[j]);
+                        vB[j] = __builtin_elementwise_fma(w, q, vB[j]);
+                        vC[j] = fmaf(g[tap], xy, vC[j]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kCR; ++j) { svA[grp * kCR + j][col] = vA[j]; svB[grp * kCR + j][col] = vB[j]; svC[grp * kCR + j][col] = vC[j]; }
+        }
+    }
+    // (requested here, when the window's registers are free again; they are used at the very end of the horizontal pass)
+    if (tid < kCItems) {
+        load_px4<VEC>(X, y0 + hr, x0 + hc, W, H, own_x);
+        load_px4<VEC>(Y, y0 + hr, x0 + hc, W, H, own_y);
+    }
+    __syncthreads();
+    const float median = a.cfg.ignore_outlier_depth_loss ? a.ws.d_cam[13] : 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};        // depth L1 (masked), image L1, mask count, SSIM map sum
+    if (tid < kCItems) {                        // horizontal pass: 14 columns of sums feed 4 output pixels
+        f2 oA[4], oB[4];
+        float oC[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { oA[j] = (f2)(0.f); oB[j] = (f2)(0.f); oC[j] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 14; ++t) {
+            const f2 pa = svA[hr][hc + t], pb = svB[hr][hc + t];
+            const float pc = svC[hr][hc + t];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tap = t - j;
+                if (tap >= 0 && tap < 11) {
+                    const f2 w = (f2)(g[tap]);
+                    oA[j] = __builtin_elementwise_fma(w, pa, oA[j]);
+                    oB[j] = __builtin_elementwise_fma(w, pb, oB[j]);
+                    oC[j] = fmaf(g[tap], pc, oC[j]);
+                }
+            }
+        }
+        const int yy = y0 + hr;
+        float d0[4], d1[4], d2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float map = ssim_pixel_dev(oA[j].x, oA[j].y, oB[j].x, oB[j].y, oC[j], &d0[j], &d1[j], &d2[j]);
+            // (selects, not branches: the compiler sinks a pixel's sums into its conditional block and keeps all 70 inputs alive)
+            const bool ok = yy < H && x0 + hc + j < W;
+            acc[3] += ok ? map : 0.f;
+            acc[1] += ok ? fabsf(own_x[j] - own_y[j]) : 0.f;
+        }
+        store_px4<VEC>(M, yy, x0 + hc, W, H, d0);
+        store_px4<VEC>(M + HW, yy, x0 + hc, W, H, d1);
+        store_px4<VEC>(M + 2 * HW, yy, x0 + hc, W, H, d2);
+    }
+    if (ch == 0 && tid < kCItems) {
+        // the depth loss of the z == 0 slice (a third of the workgroups), behind everything else: its sixteen input registers held
+        // through the passes would cost the kernel a wave per SIMD; the planes come through L2 (the forward composite wrote them)
+        const int yy = y0 + hr;
+        float pre[4][4];
+        load_px4<VEC>(a.ws.out6 + 3 * HW, yy, x0 + hc, W, H, pre[0]);
+        load_px4<VEC>(a.ws.out6 + 4 * HW, yy, x0 + hc, W, H, pre[1]);
+        load_px4<VEC>(a.ws.out6 + 5 * HW, yy, x0 + hc, W, H, pre[2]);
+        load_px4<VEC>(a.frame.depth, yy, x0 + hc, W, H, pre[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = yy < H && x0 + hc + j < W;
+            const Pixel px = depth_pixel(a.cfg, pre[0][j], pre[1][j], pre[2][j], pre[3][j], median);
+            acc[0] += ok ? px.d_err : 0.f;
+            acc[2] += ok && px.mask ? 1.f : 0.f;
+        }
+    }
+    block_sum_to<4>(sum_copy(a.ws.sums), acc, s_part);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void map_loss_backward_kernel(FusedArgs a, int W, int H) {
+    __shared__ f2 svA[kCH][kCStride];           // vertical sums of (d/dmu1, d/dE11)
+    __shared__ float svC[kCH][kCStride];        // ... of d/dE12
+    __shared__ float s_count;
+    float g[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) g[k] = a.win[k];
+    int bx, by, ch;
+    if (!ssim_tile<kCW, kCH>(W, H, bx, by, ch)) return;
+    const int tid = threadIdx.x;
+    const int x0 = bx * kCW, y0 = by * kCH;
+    const size_t HW = (size_t)H * W;
+    const float *M = a.ws.ssim_maps + (size_t)(3 * ch) * HW;
+    if (tid < 64) {
+        const double c = sum_total(a.ws.sums, 2);
+        if (tid == 0) s_count = (float)c;
+    }
+    const int hr = tid / (kCW / 4), hc = (tid & (kCW / 4 - 1)) * 4;
+    float own_x[4], own_y[4];
+    {   // vertical pass (see ssim_forward_kernel)
+        const int grp = tid / kCCols, col = tid - grp * kCCols;
+        if (grp < kCG) {
+            const int xx = x0 - kSsimR + col;
+            const bool cin = xx >= 0 && xx < W;
+            const int xc = min(max(xx, 0), W - 1);
+            float v0[kCR + 10], v1[kCR + 10], v2[kCR + 10];
+#pragma unroll
+            for (int t = 0; t < kCR + 10; ++t) {
+                const int yy = y0 + grp * kCR - kSsimR + t;
+                const bool in = cin && yy >= 0 && yy < H;
+                const unsigned off = (unsigned)min(max(yy * (4 * W) + 4 * xc, 0), 4 * (H * W - 1));
+                const float t0 = ld_off(M, off), t1 = ld_off(M + HW, off), t2 = ld_off(M + 2 * HW, off);
+                v0[t] = in ? t0 : 0.f;
+                v1[t] = in ? t1 : 0.f;
+                v2[t] = in ? t2 : 0.f;
+            }
+            f2 vA[kCR];
+            float vC[kCR];
+#pragma unroll
+            for (int j = 0; j < kCR; ++j) { vA[j] = (f2)(0.f); vC[j] = 0.f; }
+#pragma unroll
+            for (int t = 0; t < kCR + 10; ++t) {
+                const f2 p = {v0[t], v1[t]};
+#pragma unroll
+                for (int j = 0; j < kCR; ++j) {
+                    const int tap = t - j;
+                    if (tap >= 0 && tap < 11) {
+                        vA[j] = __builtin_elementwise_fma((f2)(g[tap]), p, vA[j]);
+                        vC[j] = fmaf(g[tap], v2[t], vC[j]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kCR; ++j) { svA[grp * kCR + j][col] = vA[j]; svC[grp * kCR + j][col] = vC[j]; }
+        }
+    }
+    if (tid < kCItems) {
+        load_px4<VEC>(a.ws.out6 + ch * HW, y0 + hr, x0 + hc, W, H, own_x);
+        load_px4<VEC>(a.frame.im + ch * HW, y0 + hr, x0 + hc, W, H, own_y);
+    }
+    __syncthreads();
+    if (tid >= kCItems) return;
+    const float inv_n = 1.0f / (3.0f * (float)HW);
+    const float median = a.cfg.ignore_outlier_depth_loss ? a.ws.d_cam[13] : 0.f;
+    const float count = s_count;
+    f2 oA[4];
+    float oC[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { oA[j] = (f2)(0.f); oC[j] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < 14; ++t) {
+        const f2 pa = svA[hr][hc + t];
+        const float pc = svC[hr][hc + t];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int tap = t - j;
+            if (tap >= 0 && tap < 11) {
+                oA[j] = __builtin_elementwise_fma((f2)(g[tap]), pa, oA[j]);
+                oC[j] = fmaf(g[tap], pc, oC[j]);
+            }
+        }
+    }
+    float out[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float xv = own_x[j], yv = own_y[j];
+        const float dssim = oA[j].x + 2.f * xv * oA[j].y + yv * oC[j];
+        out[j] = a.cfg.w_im * (0.8f * sgn(xv - yv) * inv_n - 0.2f * inv_n * dssim);
+    }
+    store_px4<VEC>(a.ws.dL_dout6 + ch * HW, y0 + hr, x0 + hc, W, H, out);
+    if (ch == 0) {      // the depth plane's gradient (see the end of ssim_forward_kernel)
+        float pre[4][4], dout[4];
+        load_px4<VEC>(a.ws.out6 + 3 * HW, y0 + hr, x0 + hc, W, H, pre[0]);
+        load_px4<VEC>(a.ws.out6 + 4 * HW, y0 + hr, x0 + hc, W, H, pre[1]);
+        load_px4<VEC>(a.ws.out6 + 5 * HW, y0 + hr, x0 + hc, W, H, pre[2]);
+        load_px4<VEC>(a.frame.depth, y0 + hr, x0 + hc, W, H, pre[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const Pixel px = depth_pixel(a.cfg, pre[0][j], pre[1][j], pre[2][j], pre[3][j], median);
+            dout[j] = a.cfg.use_l1 ? a.cfg.w_depth * px.d_sign / count : 0.f;
+        }
+        store_px4<VEC>(a.ws.dL_dout6 + 3 * HW, y0 + hr, x0 + hc, W, H, dout);
     }
 }
 
@@ -1219,10 +1495,23 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
                 hipLaunchKernelGGL(track_loss_kernel<1>, dim3(blocks), dim3(kBlock), 0, s, a, HW);
             }
         } else {
-            const int tiles = 3 * ((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH);
-            const dim3 grid(8 * ((tiles + 7) / 8));                 // (ssim_tile: XCD x owns a contiguous run of tiles)
-            hipLaunchKernelGGL(ssim_forward_kernel, grid, dim3(kBlock), 0, s, a, W, H);
-            hipLaunchKernelGGL(map_loss_backward_kernel, grid, dim3(kBlock), 0, s, a, W, H);
+            static const bool rows_first = getenv("SPLAT_SSIM_ROWS") && atoi(getenv("SPLAT_SSIM_ROWS")) != 0;
+            if (rows_first) {
+                const int tiles = 3 * ((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH);
+                const dim3 grid(8 * ((tiles + 7) / 8));                 // (ssim_tile: XCD x owns a contiguous run of tiles)
+                hipLaunchKernelGGL(ssim_forward_rows_kernel, grid, dim3(kBlock), 0, s, a, W, H);
+                hipLaunchKernelGGL(map_loss_backward_rows_kernel, grid, dim3(kBlock), 0, s, a, W, H);
+            } else {
+                const int tiles = 3 * ((W + kCW - 1) / kCW) * ((H + kCH - 1) / kCH);
+                const dim3 grid(8 * ((tiles + 7) / 8));                 // (ssim_tile: XCD x owns a contiguous run of tiles)
+                if ((W & 3) == 0 && aligned16(ws.out6) && aligned16(frame.im) && aligned16(frame.depth) && aligned16(ws.ssim_maps) && aligned16(ws.dL_dout6)) {
+                    hipLaunchKernelGGL(ssim_forward_kernel<true>, grid, dim3(kBlock), 0, s, a, W, H);
+                    hipLaunchKernelGGL(map_loss_backward_kernel<true>, grid, dim3(kBlock), 0, s, a, W, H);
+                } else {
+                    hipLaunchKernelGGL(ssim_forward_kernel<false>, grid, dim3(kBlock), 0, s, a, W, H);
+                    hipLaunchKernelGGL(map_loss_backward_kernel<false>, grid, dim3(kBlock), 0, s, a, W, H);
+                }
+            }
         }
         e = launch_render_backward_feat8(cam, ws.feat8, ws.st, ws.dL_dout6, ws.accum, P, false, ws.d_rgb_colors != nullptr, s,
                                          ws.d_logit_opacities != nullptr);
