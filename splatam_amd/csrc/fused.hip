@@ -459,18 +459,13 @@ __global__ __launch_bounds__(kBlock) void track_loss_kernel(FusedArgs a, int HW)
 // F4 / F5: SSIM (11x11, sigma 1.5, zero padding; /root/reference/utils/slam_external.py:54-97)
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kSsimR = 5;                   // window radius
-constexpr int kTW = 32, kTH = 16;           // output tile of one 256-thread workgroup
-constexpr int kRPT = kTH * kTW / kBlock;    // output rows per thread in the vertical passes
-constexpr int kHW_ = kTW + 2 * kSsimR;      // halo width 42
-constexpr int kHH_ = kTH + 2 * kSsimR;      // halo height 42
-constexpr int kHItems = kHH_ * (kTW / 4);   // horizontal-pass work items: (halo row, group of 4 columns)
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 // blockIdx -> (tile column, tile row, channel) of F4 / F5.  Workgroups are dealt to the 8 XCDs round robin and each XCD has its own
 // L2: with a plain 3-d grid the eight neighbours of a tile run on eight OTHER XCDs, and every halo pixel (2.1x the tile) comes from
 // memory again (F5: 167 MB of traffic for 75 MB of planes).  Here XCD x owns a contiguous run of the (channel, row, column) order, so a
 // tile's halo was read by the workgroup before it or one tile row earlier, through the SAME L2.
-template <int TW = kTW, int TH = kTH>
+template <int TW, int TH>
 __device__ __forceinline__ bool ssim_tile(int W, int H, int &bx, int &by, int &ch) {
     const int ntx = (W + TW - 1) / TW, nty = (H + TH - 1) / TH, total = 3 * ntx * nty, per = (total + 7) / 8;
     const int b = blockIdx.x, slot = b >> 3, t = (b & 7) * per + slot;
@@ -504,273 +499,14 @@ __device__ __forceinline__ float ssim_pixel_dev(float mu1, float mu2, float e11,
     return map;
 }
 
-// F4: grid (tiles_x, tiles_y, 3 channels).  The five window statistics travel as two float pairs + one float, so that the
-// 11-tap sums are v_pk_fma_f32 (two statistics per instruction).  Also accumulates the L1 image sum; the z == 0 slice handles
-// the depth plane.
-__global__ __launch_bounds__(kBlock) void ssim_forward_rows_kernel(FusedArgs a, int W, int H) {
-    __shared__ float sx[kHH_][kHW_ + 1], sy[kHH_][kHW_ + 1];
-    __shared__ f2 shA[kHH_][kTW + 1], shB[kHH_][kTW + 1];      // horizontal sums of (x, y) and (x x, y y)
-    __shared__ float shC[kHH_][kTW + 1];                       // ... of x y
-    __shared__ double s_part[4 * (kBlock / 64)];
-    float g[11];
-#pragma unroll
-    for (int k = 0; k < 11; ++k) g[k] = a.win[k];
-    int bx, by, ch;
-    if (!ssim_tile(W, H, bx, by, ch)) return;
-    const int tid = threadIdx.x;
-    const int x0 = bx * kTW, y0 = by * kTH;
-    const size_t HW = (size_t)H * W;
-    const float *X = a.ws.out6 + ch * HW, *Y = a.frame.im + ch * HW;
-    // (the z == 0 slice's depth-loss inputs: requested here with the halo, not one round trip per output row at the very end)
-    float pre[kRPT][4];
-#pragma unroll
-    for (int j = 0; j < kRPT; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pre[j][q] = 0.f;
-    if (ch == 0) {
-        const int c = tid & (kTW - 1), r0 = (tid / kTW) * kRPT;
-#pragma unroll
-        for (int j = 0; j < kRPT; ++j) {
-            const size_t pix = (size_t)min(y0 + r0 + j, H - 1) * W + min(x0 + c, W - 1);
-            const float *o = a.ws.out6;
-            pre[j][0] = o[3 * HW + pix]; pre[j][1] = o[4 * HW + pix]; pre[j][2] = o[5 * HW + pix]; pre[j][3] = a.frame.depth[pix];
-        }
-    }
-    // The halo: every load of the workgroup's window in flight at once (clamped address + select; round 2's loop took its five trips
-    // one after the other, and the y load of a trip behind the x load: ten dependent round trips at the head of every workgroup)
-    {
-        constexpr int kTrips = (kHH_ * kHW_ + kBlock - 1) / kBlock;
-        float vx[kTrips], vy[kTrips];
-#pragma unroll
-        for (int q = 0; q < kTrips; ++q) {
-            const int k = min(tid + q * kBlock, kHH_ * kHW_ - 1);
-            const int r = k / kHW_, c = k - r * kHW_;
-            const int yy = y0 + r - kSsimR, xx = x0 + c - kSsimR;
-            const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const size_t pix = (size_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1);
-            const float tx = X[pix], ty = Y[pix];
-            vx[q] = in ? tx : 0.f;
-            vy[q] = in ? ty : 0.f;
-        }
-#pragma unroll
-        for (int q = 0; q < kTrips; ++q) {
-            const int k = tid + q * kBlock;
-            if (k < kHH_ * kHW_) {
-                const int r = k / kHW_, c = k - r * kHW_;
-                sx[r][c] = vx[q];
-                sy[r][c] = vy[q];
-            }
-        }
-    }
-    __syncthreads();
-    // horizontal pass: one work item per (halo row, group of 4 columns): 14 + 14 LDS reads feed 4 outputs x 5 statistics
-    for (int item = tid; item < kHItems; item += kBlock) {
-        const int r = item / (kTW / 4), c0 = (item - r * (kTW / 4)) * 4;
-        f2 oA[4], oB[4];
-        float oC[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { oA[j] = (f2)(0.f); oB[j] = (f2)(0.f); oC[j] = 0.f; }
-#pragma unroll
-        for (int t = 0; t < 14; ++t) {
-            const f2 p = {sx[r][c0 + t], sy[r][c0 + t]};
-            const f2 q = p * p;
-            const float xy = p.x * p.y;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int tap = t - j;
-                if (tap >= 0 && tap < 11) {
-                    const f2 w = (f2)(g[tap]);
-                    oA[j] = __builtin_elementwise_fma(w, p, oA[j]);
-                    oB[j] = __builtin_elementwise_fma(w, q, oB[j]);
-                    oC[j] = fmaf(g[tap], xy, oC[j]);
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { shA[r][c0 + j] = oA[j]; shB[r][c0 + j] = oB[j]; shC[r][c0 + j] = oC[j]; }
-    }
-    __syncthreads();
-    const float median = a.cfg.ignore_outlier_depth_loss ? a.ws.d_cam[13] : 0.f;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};        // depth L1 (masked), image L1, mask count, SSIM map sum
-    float *M = a.ws.ssim_maps + (size_t)(3 * ch) * HW;
-    // vertical pass: one thread per (column, group of kRPT rows): kRPT + 10 rows of sums feed kRPT outputs
-    {
-        const int c = tid & (kTW - 1), r0 = (tid / kTW) * kRPT;
-        f2 vA[kRPT], vB[kRPT];
-        float vC[kRPT];
-#pragma unroll
-        for (int j = 0; j < kRPT; ++j) { vA[j] = (f2)(0.f); vB[j] = (f2)(0.f); vC[j] = 0.f; }
-#pragma unroll
-        for (int t = 0; t < kRPT + 10; ++t) {
-            const f2 pa = shA[r0 + t][c], pb = shB[r0 + t][c];
-            const float pc = shC[r0 + t][c];
-#pragma unroll
-            for (int j = 0; j < kRPT; ++j) {
-                const int tap = t - j;
-                if (tap >= 0 && tap < 11) {
-                    const f2 w = (f2)(g[tap]);
-                    vA[j] = __builtin_elementwise_fma(w, pa, vA[j]);
-                    vB[j] = __builtin_elementwise_fma(w, pb, vB[j]);
-                    vC[j] = fmaf(g[tap], pc, vC[j]);
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < kRPT; ++j) {
-            const int r = r0 + j;
-            const int yy = y0 + r, xx = x0 + c;
-            if (yy < H && xx < W) {
-                float dmu1, de11, de12;
-                acc[3] += ssim_pixel_dev(vA[j].x, vA[j].y, vB[j].x, vB[j].y, vC[j], &dmu1, &de11, &de12);
-                const size_t pix = (size_t)yy * W + xx;
-                M[pix] = dmu1; M[HW + pix] = de11; M[2 * HW + pix] = de12;
-                acc[1] += fabsf(sx[r + kSsimR][c + kSsimR] - sy[r + kSsimR][c + kSsimR]);
-                if (ch == 0) {
-                    const Pixel px = depth_pixel(a.cfg, pre[j][0], pre[j][1], pre[j][2], pre[j][3], median);
-                    acc[0] += px.d_err;
-                    acc[2] += px.mask ? 1.f : 0.f;
-                }
-            }
-        }
-    }
-    block_sum_to<4>(sum_copy(a.ws.sums), acc, s_part);
-}
-
-// F5: dL/d(rgb) = w_im * (0.8 sign(x - y) / (3HW) - 0.2 / (3HW) * [blur(dmu1) + 2 x blur(de11) + y blur(de12)]),
-//     depth plane: w_depth * mask * sign(d - gt) / count.
-__global__ __launch_bounds__(kBlock) void map_loss_backward_rows_kernel(FusedArgs a, int W, int H) {
-    __shared__ f2 smA[kHH_][kHW_ + 1];          // (d/dmu1, d/dE11) maps with halo
-    __shared__ float smC[kHH_][kHW_ + 1];       // d/dE12
-    __shared__ f2 shA[kHH_][kTW + 1];
-    __shared__ float shC[kHH_][kTW + 1];
-    __shared__ float s_count;
-    float g[11];
-#pragma unroll
-    for (int k = 0; k < 11; ++k) g[k] = a.win[k];
-    int bx, by, ch;
-    if (!ssim_tile(W, H, bx, by, ch)) return;
-    const int tid = threadIdx.x;
-    const int x0 = bx * kTW, y0 = by * kTH;
-    const size_t HW = (size_t)H * W;
-    const float *M = a.ws.ssim_maps + (size_t)(3 * ch) * HW;
-    if (tid < 64) {
-        const double c = sum_total(a.ws.sums, 2);
-        if (tid == 0) s_count = (float)c;
-    }
-    // (the output pixels' own inputs -- x, y and, in the z == 0 slice, the depth-loss inputs -- requested here with the window)
-    float px_x[kRPT], px_y[kRPT], pre[kRPT][4];
-    {
-        const int c = tid & (kTW - 1), r0 = (tid / kTW) * kRPT;
-        const float *Xp = a.ws.out6 + ch * HW, *Yp = a.frame.im + ch * HW;
-#pragma unroll
-        for (int j = 0; j < kRPT; ++j) {
-            const size_t pix = (size_t)min(y0 + r0 + j, H - 1) * W + min(x0 + c, W - 1);
-            px_x[j] = Xp[pix];
-            px_y[j] = Yp[pix];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) pre[j][q] = 0.f;
-            if (ch == 0) {
-                const float *o = a.ws.out6;
-                pre[j][0] = o[3 * HW + pix]; pre[j][1] = o[4 * HW + pix]; pre[j][2] = o[5 * HW + pix]; pre[j][3] = a.frame.depth[pix];
-            }
-        }
-    }
-    {   // (every load of the window in flight at once: see ssim_forward_kernel)
-        constexpr int kTrips = (kHH_ * kHW_ + kBlock - 1) / kBlock;
-        float v0[kTrips], v1[kTrips], v2[kTrips];
-#pragma unroll
-        for (int q = 0; q < kTrips; ++q) {
-            const int k = min(tid + q * kBlock, kHH_ * kHW_ - 1);
-            const int r = k / kHW_, c = k - r * kHW_;
-            const int yy = y0 + r - kSsimR, xx = x0 + c - kSsimR;
-            const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const size_t pix = (size_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1);
-            const float t0 = M[pix], t1 = M[HW + pix], t2 = M[2 * HW + pix];
-            v0[q] = in ? t0 : 0.f;
-            v1[q] = in ? t1 : 0.f;
-            v2[q] = in ? t2 : 0.f;
-        }
-#pragma unroll
-        for (int q = 0; q < kTrips; ++q) {
-            const int k = tid + q * kBlock;
-            if (k < kHH_ * kHW_) {
-                const int r = k / kHW_, c = k - r * kHW_;
-                smA[r][c] = (f2){v0[q], v1[q]};
-                smC[r][c] = v2[q];
-            }
-        }
-    }
-    __syncthreads();
-    for (int item = tid; item < kHItems; item += kBlock) {       // horizontal pass: (halo row, group of 4 columns)
-        const int r = item / (kTW / 4), c0 = (item - r * (kTW / 4)) * 4;
-        f2 oA[4];
-        float oC[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { oA[j] = (f2)(0.f); oC[j] = 0.f; }
-#pragma unroll
-        for (int t = 0; t < 14; ++t) {
-            const f2 p = smA[r][c0 + t];
-            const float q = smC[r][c0 + t];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int tap = t - j;
-                if (tap >= 0 && tap < 11) {
-                    oA[j] = __builtin_elementwise_fma((f2)(g[tap]), p, oA[j]);
-                    oC[j] = fmaf(g[tap], q, oC[j]);
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { shA[r][c0 + j] = oA[j]; shC[r][c0 + j] = oC[j]; }
-    }
-    __syncthreads();
-    const float inv_n = 1.0f / (3.0f * (float)HW);
-    const float median = a.cfg.ignore_outlier_depth_loss ? a.ws.d_cam[13] : 0.f;
-    const float count = s_count;            // written before the first __syncthreads above
-    float *Gout = a.ws.dL_dout6;
-    {                                        // vertical pass: (column, group of kRPT rows) per thread
-        const int c = tid & (kTW - 1), r0 = (tid / kTW) * kRPT;
-        f2 vA[kRPT];
-        float vC[kRPT];
-#pragma unroll
-        for (int j = 0; j < kRPT; ++j) { vA[j] = (f2)(0.f); vC[j] = 0.f; }
-#pragma unroll
-        for (int t = 0; t < kRPT + 10; ++t) {
-            const f2 pa = shA[r0 + t][c];
-            const float pc = shC[r0 + t][c];
-#pragma unroll
-            for (int j = 0; j < kRPT; ++j) {
-                const int tap = t - j;
-                if (tap >= 0 && tap < 11) {
-                    vA[j] = __builtin_elementwise_fma((f2)(g[tap]), pa, vA[j]);
-                    vC[j] = fmaf(g[tap], pc, vC[j]);
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < kRPT; ++j) {
-            const int yy = y0 + r0 + j, xx = x0 + c;
-            if (yy < H && xx < W) {
-                const size_t pix = (size_t)yy * W + xx;
-                const float xv = px_x[j], yv = px_y[j];
-                const float dssim = vA[j].x + 2.f * xv * vA[j].y + yv * vC[j];
-                Gout[ch * HW + pix] = a.cfg.w_im * (0.8f * sgn(xv - yv) * inv_n - 0.2f * inv_n * dssim);
-                if (ch == 0) {
-                    const Pixel px = depth_pixel(a.cfg, pre[j][0], pre[j][1], pre[j][2], pre[j][3], median);
-                    Gout[3 * HW + pix] = a.cfg.use_l1 ? a.cfg.w_depth * px.d_sign / count : 0.f;
-                }
-            }
-        }
-    }
-}
-
-// ---- F4 / F5, column-first form ------------------------------------------------------------------------------------------------
-// The row-first kernels above stage the window (tile + halo, two planes) in LDS, run the horizontal pass over 26 halo rows for 16
-// output rows and read 12 rows of five sums back for every two output pixels: 29 LDS reads and 87 multiply-adds per pixel, 26 KB of
-// LDS.  Here the VERTICAL pass comes first and needs no LDS at all: a thread owns one column of the window (lanes = consecutive
-// columns: the loads coalesce), holds kCR + 10 input rows in registers and forms kCR output rows of vertical sums; only those go
-// through LDS (24 rows x 42 columns, no halo rows), and the horizontal pass reads 14 columns for 4 output pixels: 10.5 LDS reads and
-// 76 multiply-adds per pixel, 21 KB (F4) / 13 KB (F5) of LDS, one barrier instead of two, float4 stores.
+// F4 / F5 are separable 11-tap passes, VERTICAL pass first and without LDS: a thread owns one column of the window (lanes =
+// consecutive columns: the loads coalesce), holds kCR + 10 input rows in registers and forms kCR output rows of vertical sums; only
+// those go through LDS (24 rows x 42 columns, no halo rows), and the horizontal pass reads 14 columns for 4 output pixels, which it
+// finishes and stores as one float4 per plane: 10.5 LDS reads and 76 multiply-adds per pixel, 21 KB (F4) / 13 KB (F5) of LDS, one
+// barrier.  (Rounds 2-4 ran the passes the other way round -- window staged in LDS, horizontal pass over 26 halo rows for 16 output
+// rows, 12 rows of five sums read back per two output pixels: 29 LDS reads and 87 multiply-adds per pixel, 26 KB, two barriers:
+// F4 31.2 -> 25.0 us, F5 22.2 -> 21.0 us at 1200x680, profiles/r04_experiments.md 10.)  The five window statistics travel as two
+// float pairs + one float, so that the 11-tap sums are v_pk_fma_f32 (two statistics per instruction).
 constexpr int kCW = 32, kCR = 4, kCG = 6;   // tile width; output rows per thread of the vertical pass; row groups per workgroup
 constexpr int kCH = kCR * kCG;              // tile height 24
 constexpr int kCCols = kCW + 2 * kSsimR;    // 42 columns with halo
@@ -1495,22 +1231,14 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
                 hipLaunchKernelGGL(track_loss_kernel<1>, dim3(blocks), dim3(kBlock), 0, s, a, HW);
             }
         } else {
-            static const bool rows_first = getenv("SPLAT_SSIM_ROWS") && atoi(getenv("SPLAT_SSIM_ROWS")) != 0;
-            if (rows_first) {
-                const int tiles = 3 * ((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH);
-                const dim3 grid(8 * ((tiles + 7) / 8));                 // (ssim_tile: XCD x owns a contiguous run of tiles)
-                hipLaunchKernelGGL(ssim_forward_rows_kernel, grid, dim3(kBlock), 0, s, a, W, H);
-                hipLaunchKernelGGL(map_loss_backward_rows_kernel, grid, dim3(kBlock), 0, s, a, W, H);
+            const int tiles = 3 * ((W + kCW - 1) / kCW) * ((H + kCH - 1) / kCH);
+            const dim3 grid(8 * ((tiles + 7) / 8));                 // (ssim_tile: XCD x owns a contiguous run of tiles)
+            if ((W & 3) == 0 && aligned16(ws.out6) && aligned16(frame.im) && aligned16(frame.depth) && aligned16(ws.ssim_maps) && aligned16(ws.dL_dout6)) {
+                hipLaunchKernelGGL(ssim_forward_kernel<true>, grid, dim3(kBlock), 0, s, a, W, H);
+                hipLaunchKernelGGL(map_loss_backward_kernel<true>, grid, dim3(kBlock), 0, s, a, W, H);
             } else {
-                const int tiles = 3 * ((W + kCW - 1) / kCW) * ((H + kCH - 1) / kCH);
-                const dim3 grid(8 * ((tiles + 7) / 8));                 // (ssim_tile: XCD x owns a contiguous run of tiles)
-                if ((W & 3) == 0 && aligned16(ws.out6) && aligned16(frame.im) && aligned16(frame.depth) && aligned16(ws.ssim_maps) && aligned16(ws.dL_dout6)) {
-                    hipLaunchKernelGGL(ssim_forward_kernel<true>, grid, dim3(kBlock), 0, s, a, W, H);
-                    hipLaunchKernelGGL(map_loss_backward_kernel<true>, grid, dim3(kBlock), 0, s, a, W, H);
-                } else {
-                    hipLaunchKernelGGL(ssim_forward_kernel<false>, grid, dim3(kBlock), 0, s, a, W, H);
-                    hipLaunchKernelGGL(map_loss_backward_kernel<false>, grid, dim3(kBlock), 0, s, a, W, H);
-                }
+                hipLaunchKernelGGL(ssim_forward_kernel<false>, grid, dim3(kBlock), 0, s, a, W, H);
+                hipLaunchKernelGGL(map_loss_backward_kernel<false>, grid, dim3(kBlock), 0, s, a, W, H);
             }
         }
         e = launch_render_backward_feat8(cam, ws.feat8, ws.st, ws.dL_dout6, ws.accum, P, false, ws.d_rgb_colors != nullptr, s,
