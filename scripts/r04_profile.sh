@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 4: the profile set of one state of the code (tag $1): [tests named in $2], K7 account (B, B-loop), PMC passes (B, B-loop), kernel stats of the
-# bench command (B, B-loop), the bench line.   usage (on the GPU box): scripts/r04_profile.sh <tag> ["<pytest args>"] [quick]
+# bench command (B, B-loop), the bench line.   usage (on the GPU box): scripts/r04_profile.sh <tag> ["<pytest args>"] [quick|mid]
+# (quick: no counter passes, no stress workloads; mid: counter passes at B only -- a pass takes ~2 minutes)
 tag=${1:-r04_v1}; tests=$2; quick=$3
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -13,9 +14,9 @@ for wl in B B-loop; do
   timeout 300 python scripts/k7_account.py $wl > gpurun_out/${tag}_k7_account_$wl.md 2> gpurun_out/${tag}_k7_account_$wl.err || tail -3 gpurun_out/${tag}_k7_account_$wl.err
 done
 cat gpurun_out/${tag}_k7_account_B.md
-if [ -z "$quick" ]; then
+if [ "$quick" != "quick" ]; then
   bash scripts/pmc.sh ${tag} B fused > /dev/null 2>&1
-  bash scripts/pmc.sh ${tag}_Bloop B-loop fused > /dev/null 2>&1
+  [ -z "$quick" ] && bash scripts/pmc.sh ${tag}_Bloop B-loop fused > /dev/null 2>&1
 fi
 rm -rf /tmp/prof_$tag
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-slam-loop --sustain-s 1 > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1)
