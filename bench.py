@@ -285,11 +285,13 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
     trace = load_kernel_trace(workload)          # per-kernel average durations: the kernel TRACE of the bench command (not the counter passes)
     # (the tracking iteration's composites are ONE kernel: the list is gathered once -- R x 52 --, the frame is read -- 16 B per pixel --, the
     #  planes stay in registers, six partial sums per Gaussian leave it)
-    per_unit = {"render_track_fused_kernel": R * 52 + HW * 16 + N * 24, "fused_preprocess_kernel": N * (48 + 87), "ssim_forward_kernel": HW * (2 * 12 + 36 + 16), "map_loss_backward_kernel": HW * (36 + 24 + 16),
+    # (the SSIM kernels are templates since the column-first form: a counter file taken on the row-first kernels does not describe them)
+    per_unit = {"render_track_fused_kernel": R * 52 + HW * 16 + N * 24, "fused_preprocess_kernel": N * (48 + 87), "ssim_forward_kernel<": HW * (2 * 12 + 36 + 16), "map_loss_backward_kernel<": HW * (36 + 24 + 16),
                 "fused_backward_kernel": N * (64 + 40 + 48), "adam_map_kernel": N * 12 * 4 * 6}
     for kname, abytes in per_unit.items():
         d = pmc_kernel(pmc, kname) or {}
         us = trace_avg_us(trace, kname)
+        kname = kname.rstrip("<")
         if us:
             rows[kname] = {"avg_us": round(us, 1), "algorithmic_bytes": abytes, "GBps": round(abytes / us / 1e3, 1),
                            "frac_of_hbm_peak": round(abytes / us / 1e3 / HBM_PEAK_GBS, 4), "traffic_bytes": d.get("traffic_bytes"),

@@ -1,6 +1,7 @@
 #!/bin/bash
 # what the driver runs at round end: the GPU suite, smoke(), the default bench line (timed)
 mkdir -p gpurun_out
+bash "$(dirname "$0")/gpu_probe.sh" || exit 3
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > gpurun_out/check_tests.log 2>&1
 echo "pytest rc $?" >> gpurun_out/check_tests.log

@@ -4,6 +4,7 @@
 tag=${1:-r1}; wl=${2:-B}; drv=${3:-kernel}
 if [ "$drv" = "fused" ]; then driver="scripts/fused_driver.py $wl 3"; else driver="scripts/kernel_driver.py --workload $wl --reps 3"; fi
 mkdir -p gpurun_out
+bash "$(dirname "$0")/gpu_probe.sh" || exit 3
 export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.txt
 : > $out

@@ -2,6 +2,7 @@
 # ad-hoc counter passes over scripts/fused_driver.py: usage scripts/pmc_custom.sh <tag> <workload> "<kernel regex>" "<counters of pass 1>" ["<counters of pass 2>" ...]
 tag=$1; wl=$2; pat=$3; shift 3
 mkdir -p gpurun_out
+bash "$(dirname "$0")/gpu_probe.sh" || exit 3
 export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/pmcc_$tag.txt
 : > $out

@@ -2,6 +2,7 @@
 # same-call A/B of process-level switches over the bench line (no profiler): usage scripts/r04_ab_env.sh "VAR=0" ["VAR2=0" ...]
 export TMPDIR=/tmp
 mkdir -p gpurun_out
+bash "$(dirname "$0")/gpu_probe.sh" || exit 3
 run() {
   tag=$1; shift
   env "$@" timeout 600 python bench.py $BENCH_ARGS --no-cpu-baseline --no-slam-loop --sustain-s 2 > gpurun_out/ab_$tag.log 2> gpurun_out/ab_$tag.err

@@ -3,6 +3,7 @@
 #   usage: scripts/r04_ab_prof.sh "<kernel name regex>" "VAR=1" ["VAR2=1" ...]      (base / each setting / base again)
 export TMPDIR=/tmp
 mkdir -p gpurun_out
+bash "$(dirname "$0")/gpu_probe.sh" || exit 3
 pat=$1; shift
 run() {
   tag=$1; shift

@@ -4,11 +4,14 @@
 # (quick: no counter passes, no stress workloads; mid: counter passes at B only -- a pass takes ~2 minutes)
 tag=${1:-r04_v1}; tests=$2; quick=$3
 mkdir -p gpurun_out
+bash "$(dirname "$0")/gpu_probe.sh" || exit 3
 export TMPDIR=/tmp
 if [ -n "$tests" ]; then
   timeout 1200 python -m pytest $tests -m gpu -q -x --timeout 900 -p no:cacheprovider > gpurun_out/${tag}_tests.log 2>&1
-  echo "pytest rc $?" >> gpurun_out/${tag}_tests.log
+  rc=$?
+  echo "pytest rc $rc" >> gpurun_out/${tag}_tests.log
   tail -6 gpurun_out/${tag}_tests.log
+  [ $rc -ne 0 ] && { echo "tests failed: no profile of a broken tree"; exit 1; }
 fi
 for wl in B B-loop; do
   timeout 300 python scripts/k7_account.py $wl > gpurun_out/${tag}_k7_account_$wl.md 2> gpurun_out/${tag}_k7_account_$wl.err || tail -3 gpurun_out/${tag}_k7_account_$wl.err
