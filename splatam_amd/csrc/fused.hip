@@ -462,7 +462,7 @@ constexpr int kSsimR = 5;                   // window radius
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 // blockIdx -> (tile column, tile row, channel) of F4 / F5.  Workgroups are dealt to the 8 XCDs round robin and each XCD has its own
-// L2: with a plain 3-d grid the eight neighbours of a tile run on eight OTHER XCDs, and every halo pixel (2.1x the tile) comes from
+// L2: with a plain 3-d grid the eight neighbours of a tile run on eight OTHER XCDs, and every halo pixel (the window is 1.9x the tile) comes from
 // memory again (F5: 167 MB of traffic for 75 MB of planes).  Here XCD x owns a contiguous run of the (channel, row, column) order, so a
 // tile's halo was read by the workgroup before it or one tile row earlier, through the SAME L2.
 template <int TW, int TH>
