@@ -33,3 +33,25 @@ def test_single_rank_launch_check_needs_no_launcher():
                        stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert _last_json(r.stdout)["world"] == 1
+
+
+def test_roofline_rows_find_their_kernels_in_the_committed_profiles():
+    """bench.py fills `roofline.other.kernels` from the newest committed kernel-stats CSV of the bench command and the newest
+    committed counter file: every kernel it prices must be present in the trace under the name it looks for (a renamed or
+    re-templated kernel would silently drop its row), and counters are only paired with a kernel of the same name."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for workload in ("B", "B-loop"):
+        trace = bench.load_kernel_trace(workload)
+        assert trace is not None, workload
+        for needle in ("render_track_fused_kernel", "fused_preprocess_kernel", "ssim_forward_kernel<", "map_loss_backward_kernel<",
+                       "fused_backward_kernel", "render_backward_kernel5<6, 8, 15u, 15u", "render_forward_kernel<6, 8, false, true, false>"):
+            us = bench.trace_avg_us(trace, needle)
+            assert us is not None and 1.0 < us < 2000.0, (workload, needle, us)
+        pmc = bench.load_pmc(workload)
+        assert pmc is not None and pmc[1].get("workload") == workload
+        k7 = bench.pmc_kernel(pmc, "render_backward_kernel", "<6, 8, 15u, 15u")
+        assert k7 is not None and k7.get("traffic_bytes", 0) > 0
+        for needle in ("ssim_forward_kernel<", "map_loss_backward_kernel<"):
+            d = bench.pmc_kernel(pmc, needle)
+            assert d is None or needle in d["name"]
