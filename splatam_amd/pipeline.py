@@ -369,7 +369,7 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
         first_frame_w2c = first_frame_w2c.to(dev).float().contiguous()
     keyframe_list, keyframe_time_indices = [], []
     stats = dict(tracking_iters=0, mapping_iters=0, tracking_s=0.0, mapping_s=0.0, mapping_loop_s=0.0, redone_iterations=0,
-                 num_gaussians=[], phase_ms=[], frame_s=[])
+                 num_gaussians=[], phase_ms=[], frame_s=[], decisions=[])
     phase = _PhaseTimer(dev)
     installed = None
     if engine == "plugin":
@@ -382,6 +382,11 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
             color = (color.permute(2, 0, 1) / 255).contiguous()
             depth = depth.permute(2, 0, 1).contiguous()
             curr_data = {'cam': cam, 'im': color, 'depth': depth, 'id': time_idx, 'intrinsics': intrinsics, 'w2c': first_frame_w2c}
+            # what the loop DECIDED on this frame, engine independent (host integers only; tests/loop_trace.py derives the same table
+            # from a recording of the reference's own rgbd_slam)
+            decided = dict(time_idx=time_idx, tracking_iters=0, rows_after_add=None, selected=None, views=[], prunes=[], rows_end=None,
+                           keyframe=False)
+            stats['decisions'].append(decided)
             if time_idx > 0:
                 slam.initialize_camera_pose(params, time_idx, forward_prop=tcfg['forward_prop'])
 
@@ -394,6 +399,7 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
                     else:
                         n_track = _track_frame(params, variables, curr_data, time_idx, tcfg, eng, stats)
                     stats['tracking_iters'] += n_track
+                    decided['tracking_iters'] = n_track
                     sdist.broadcast_pose(params, time_idx)              # replicas: one pose for the map edits that follow
                 elif time_idx > 0:
                     with torch.no_grad():
@@ -412,6 +418,7 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
                         else:
                             params, variables = slam.add_new_gaussians(params, variables, curr_data, mcfg['sil_thres'], time_idx,
                                                                        config['mean_sq_dist_method'], dist_kind)
+                    decided['rows_after_add'] = int(params['means3D'].shape[0])
                     sdist.assert_replicated_count(int(params['means3D'].shape[0]), f"add_new_gaussians (frame {time_idx})", dev)
                 with phase("keyframe_selection"), torch.no_grad():
                     curr_w2c = _est_w2c(params, time_idx)
@@ -420,6 +427,7 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
                     if len(keyframe_list) > 0:
                         selected.append(len(keyframe_list) - 1)
                     selected.append(-1)
+                    decided['selected'] = [int(x) for x in selected[:-1 - (1 if len(keyframe_list) > 0 else 0)]]
                 if fused:
                     with phase("relearn_lists"):
                         eng.relearn_lists(curr_data, time_idx)
@@ -429,7 +437,7 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
                 t_prune0 = phase.frame.get("prune", 0.0)
                 with phase("mapping_iterations"):
                     _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, mcfg, eng,
-                               scene_radius if fused else None, stats, phase)
+                               scene_radius if fused else None, stats, phase, decided)
                 # (the prune phase is timed inside the loop: report the iterations without it)
                 phase.frame["mapping_iterations"] -= phase.frame.get("prune", 0.0) - t_prune0
                 stats['mapping_iters'] += mcfg['num_iters']
@@ -441,6 +449,8 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
                 with phase("keyframe_store"), torch.no_grad():
                     keyframe_list.append({'id': time_idx, 'est_w2c': _est_w2c(params, time_idx), 'color': color, 'depth': depth})
                     keyframe_time_indices.append(time_idx)
+                    decided['keyframe'] = True
+            decided['rows_end'] = int(params['means3D'].shape[0])
             stats['num_gaussians'].append(int(params['means3D'].shape[0]))
             stats['phase_ms'].append(phase.next_frame())
             stats['frame_s'].append(time.perf_counter() - t_frame)
@@ -503,8 +513,8 @@ def _track_frame(params, variables, curr_data, time_idx, tcfg, eng, stats):
                 todo = lost
                 continue
         if it == num_iters and tcfg.get('use_depth_loss_thres', False) and not doubled:
-            depth_loss = (float(eng.buf['d_cam'][14])) if eng is not None else float(_last_depth_loss(
-                params, curr_data, variables, time_idx, tcfg))
+            # the value the reference compares is the LAST iteration's weighted depth loss (scripts/splatam.py:728): no extra evaluation
+            depth_loss = float(eng.buf['d_cam'][14]) if eng is not None else float(state.last_losses['depth'])
             if depth_loss >= tcfg['depth_loss_thres']:
                 doubled, todo = True, num_iters
     if eng is not None:
@@ -549,14 +559,7 @@ def _track_frame_statements(params, variables, curr_data, time_idx, tcfg):
     return it, variables
 
 
-def _last_depth_loss(params, curr_data, variables, time_idx, tcfg):
-    with torch.no_grad():
-        _, _, wl = slam.get_loss(params, curr_data, dict(variables), time_idx, tcfg['loss_weights'], tcfg['use_sil_for_loss'],
-                                 tcfg['sil_thres'], tcfg['use_l1'], tcfg['ignore_outlier_depth_loss'], tracking=True)
-    return wl['depth']
-
-
-def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, mcfg, eng, scene_radius, stats, phase):
+def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, mcfg, eng, scene_radius, stats, phase, decided):
     """The mapping iterations of one frame over the selected keyframes + the current frame.  With ``world`` ranks every
     iteration draws ``world`` views from the SAME random stream on every rank; this rank renders its own one, the gradients are
     averaged by one all-reduce, every rank takes the same Adam step and the same pruning decisions.
@@ -589,6 +592,7 @@ def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, 
             kf = keyframe_list[sel]
             iter_time_idx, iter_color, iter_depth = kf['id'], kf['color'], kf['depth']
         iter_data = {'cam': cam, 'im': iter_color, 'depth': iter_depth, 'id': iter_time_idx, 'intrinsics': intrinsics, 'w2c': w2c0}
+        decided['views'].append(int(iter_time_idx))
         # the reference prunes between backward() and step(); remove_points re-creates the parameters without their
         # gradients, so an iteration on the pruning schedule takes no Adam step
         on_schedule = prune and it <= pd['stop_after'] and it >= pd['start_after'] and it % pd['prune_every'] == 0
@@ -608,8 +612,11 @@ def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, 
                 # indexed by the rows the render saw): before any row is removed
                 eng.accumulate_mean2d_gradient()
             if prune and (on_schedule or resets):
+                rows = eng.P
                 with phase("prune"):
                     edited = bool(eng.prune_gaussians(it, pd, scene_radius))
+                if on_schedule:
+                    decided['prunes'].append((it, rows, eng.P))
             if densifying:                                               # scripts/splatam.py:864-867
                 dd = mcfg['densify_dict']
                 dens_sched = it <= dd['stop_after'] and it >= dd['start_after'] and it % dd['densify_every'] == 0
@@ -637,6 +644,8 @@ def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, 
                             slam.prune_gaussians(params, variables, optimizer, it, pd)
                     else:                                       # (the reference calls it every iteration; off schedule it does nothing)
                         slam.prune_gaussians(params, variables, optimizer, it, pd)
+                    if on_schedule:
+                        decided['prunes'].append((it, n_before, int(params['means3D'].shape[0])))
                     if params['means3D'].shape[0] != n_before:
                         sdist.assert_replicated_count(int(params['means3D'].shape[0]), f"prune_gaussians (frame {time_idx}, iteration {it})", dev)
                 optimizer.step()

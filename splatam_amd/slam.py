@@ -280,6 +280,7 @@ class TrackingState:
         self.min_loss = torch.full((), 1e20, device=params['cam_trans'].device)
         self.best_rot = params['cam_unnorm_rots'][..., time_idx].detach().clone()
         self.best_tran = params['cam_trans'][..., time_idx].detach().clone()
+        self.last_losses = None       # the weighted losses of the last iteration, as the loop reads them (scripts/splatam.py:728)
 
     def update(self, params, loss):
         with torch.no_grad():
@@ -302,6 +303,7 @@ def tracking_iteration(params, curr_data, variables, time_idx, optimizer, state:
     optimizer.step()
     optimizer.zero_grad(set_to_none=True)
     state.update(params, loss)
+    state.last_losses = losses
     return loss, variables
 
 
