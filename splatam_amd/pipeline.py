@@ -514,7 +514,7 @@ def _track_frame(params, variables, curr_data, time_idx, tcfg, eng, stats):
                 continue
         if it == num_iters and tcfg.get('use_depth_loss_thres', False) and not doubled:
             # the value the reference compares is the LAST iteration's weighted depth loss (scripts/splatam.py:728): no extra evaluation
-            depth_loss = float(eng.buf['d_cam'][14]) if eng is not None else float(state.last_losses['depth'])
+            depth_loss = float(eng.buf['d_cam'][14]) if eng is not None else float(state.last_losses['depth'].detach())
             if depth_loss >= tcfg['depth_loss_thres']:
                 doubled, todo = True, num_iters
     if eng is not None:

@@ -23,7 +23,7 @@ from test_loop_golden import GOLD, seed_everything
 
 pytestmark = pytest.mark.gpu
 
-ROW_TOL = 0.004          # relative bound on a row-count difference (measured: <= 0.15 %, printed by every test)
+ROW_TOL = 0.002          # relative bound on a row-count difference (measured: 0.021 %, 1 row of 4 7xx; profiles/r05_loop_golden_gpu.log)
 
 
 def run_engine(case, engine):
@@ -70,7 +70,7 @@ def check_decisions(case, cfg, stats, what):
 
 
 def check_trajectory(case, params, what):
-    for k, tol in (('cam_unnorm_rots', 2e-3), ('cam_trans', 2e-3)):
+    for k, tol in (('cam_unnorm_rots', 2e-4), ('cam_trans', 2e-4)):
         d = np.abs(GOLD[f"{case}/final/{k}"] - params[k].detach().cpu().numpy())
         print(f"{what}: {k}: max |difference| to the reference loop {d.max():.1e}")
         assert d.max() < tol, (what, k, d.max())

@@ -74,3 +74,47 @@ def test_loss_scalars_read_through_their_report():
     assert type(loss + 1) is torch.Tensor and type(loss.detach()) is torch.Tensor
     other = torch.tensor(8.0)
     assert isinstance(loss < other, torch.Tensor) and bool(loss < other)
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference tree is not on this machine")
+def test_install_patches_what_the_reference_loop_resolves():
+    """``plugin.install`` on the REAL module (/root/reference/scripts/splatam.py imported as tests/golden/make_golden_loop.py imports
+    it; in a subprocess -- the import shims are process wide): the two names are replaced; the loop looks both of them up as module
+    globals at call time (so the replacement is what runs); every ``get_loss`` / ``initialize_optimizer`` call of ``rgbd_slam`` binds to
+    the adapters' signatures; ``uninstall`` puts the reference's functions back.  No machine available to this repository has both the
+    reference tree and a GPU, so the loop itself runs with the plug-in on the restated statements (tests/test_gpu_loop_golden.py),
+    which tests/test_loop_golden.py pins call by call to a recording of this very module."""
+    import subprocess
+    import sys
+    code = r'''
+import ast, inspect, sys, types
+sys.path.insert(0, "tests/golden")
+import make_golden_loop as G
+G.install_device_shim()
+dummy = types.ModuleType("diff_gaussian_rasterization")
+dummy.GaussianRasterizer = object
+from splatam_amd.rasterizer import GaussianRasterizationSettings
+dummy.GaussianRasterizationSettings = GaussianRasterizationSettings
+S = G.load_reference_module(dummy)
+from splatam_amd import plugin
+ref_get_loss, ref_init = S.get_loss, S.initialize_optimizer
+for name in ("get_loss", "initialize_optimizer"):
+    assert name in S.rgbd_slam.__code__.co_names and name not in S.rgbd_slam.__code__.co_varnames and name not in S.rgbd_slam.__code__.co_freevars, name
+    assert S.rgbd_slam.__globals__ is vars(S)
+handle = plugin.install(S)
+assert S.get_loss is plugin.get_loss and S.initialize_optimizer is plugin.initialize_optimizer
+tree = ast.parse(inspect.getsource(S.rgbd_slam))
+calls = [n for n in ast.walk(tree) if isinstance(n, ast.Call) and isinstance(n.func, ast.Name) and n.func.id in ("get_loss", "initialize_optimizer")]
+seen = {"get_loss": 0, "initialize_optimizer": 0}
+for c in calls:
+    sig = inspect.signature(getattr(plugin, c.func.id))
+    sig.bind(*[None] * len(c.args), **{k.arg: None for k in c.keywords})
+    seen[c.func.id] += 1
+assert seen == {"get_loss": 2, "initialize_optimizer": 2}, seen
+handle.uninstall()
+assert S.get_loss is ref_get_loss and S.initialize_optimizer is ref_init
+print("OK", seen)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
