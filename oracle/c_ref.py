@@ -48,6 +48,7 @@ def lib(precision: str = "f32"):
             f.restype = C.POINTER(rt)
             f.argtypes = [C.c_void_p]
         L.ref_forward.restype = C.c_int
+        L.ref_flip_bounds.restype = None
         L.ref_backward.restype = C.c_int
         _libs[precision] = L
     return _libs[precision]
@@ -132,6 +133,15 @@ class CRef:
         return dict(xy=self._arr("ref_geom_xy", 2 * self.P, self.dt).reshape(-1, 2),
                     conic_op=self._arr("ref_geom_conic_op", 4 * self.P, self.dt).reshape(-1, 4),
                     depth=self._arr("ref_geom_depth", self.P, self.dt))
+
+    def flip_bounds(self, tol=2e-3, tie_tol=1e-6):
+        """Per pixel and output channel (the C colour channels, then depth): how much ONE float32 decision flip can move the pixel --
+        summed over the decisions of the last forward that were within ``tol`` (relative) of their threshold, or depth ties within
+        ``tie_tol`` -- and the smallest margin of any decision of the pixel.  See ref_flip_bounds in raster_ref.c."""
+        bound = np.zeros((self.C + 1, self.H, self.W), self.dt)
+        margin = np.zeros((self.H, self.W), self.dt)
+        self.L.ref_flip_bounds(self.ctx, self._p(self.a['colors']), self.ct(tol), self.ct(tie_tol), self._p(bound), self._p(margin))
+        return bound, margin
 
     def backward(self, dL_dcolor):
         a = self.a

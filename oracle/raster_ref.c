@@ -239,6 +239,136 @@ int ref_forward(ref_ctx *c, int P, int C, int W, int H,
     return 0;
 }
 
+/* Classifier of float32 decision flips (tests/util.py: explain_outliers).  Replays the composite of the last forward and, for every
+ * pixel, looks at each DECISION the loop takes -- `power > 0`, `alpha < 1/255`, `T (1 - alpha) < 1e-4`, and the order of two
+ * consecutive contributors whose depths agree to `tie_tol` (relative) -- and asks how close it was: |lhs - rhs| / rhs (for `power`:
+ * relative to the magnitude of its terms).  A decision within `tol` may fall on the other side in another correct float32
+ * evaluation (projected centres of ~1e3 px carry ~1e-4 px of float32 rounding, which moves `power` by ~1e-4 absolute, i.e. alpha and T
+ * by ~1e-4 relative).  For every such decision the function adds, per output channel, a bound on what taking it the other way can
+ * change in the pixel:
+ *     alpha threshold / power sign:  alpha T (|c_k| + cmax)       (the contribution itself + the (1 - alpha) factor on all later ones)
+ *     termination:                   T cmax                       (everything that could still be added)
+ *     depth tie (j before k):        alpha_j alpha_k T_j |c_j - c_k|
+ * with cmax the largest |colour| of the tile's list.  bound: [(C + 1), H, W] (channel C is the depth output); margin: [H, W], the
+ * smallest relative margin of any decision of the pixel (reported, to show how close the flipped decisions were).  Meant for the
+ * float64 build: margins measured there hold for every float32 evaluation. */
+void ref_flip_bounds(const ref_ctx *c, const real *colors, real tol, real tie_tol, real *bound, real *margin)
+{
+    const int C = c->C, W = c->W, H = c->H, gx = c->gx, tiles = c->gx * c->gy;
+    const size_t HW = (size_t)W * H;
+    #pragma omp parallel for schedule(dynamic, 4)
+    for (int t = 0; t < tiles; t++) {
+        int tx = t % gx, ty = t / gx, s = c->range[t], e = c->range[t + 1];
+        real cmax[MAXC + 1] = {0};
+        for (int k = s; k < e; k++) {
+            int id = c->list[k];
+            for (int ch = 0; ch < C; ch++) { real v = colors[(size_t)id * C + ch]; v = v < 0 ? -v : v; if (v > cmax[ch]) cmax[ch] = v; }
+            if (c->depth[id] > cmax[C]) cmax[C] = c->depth[id];
+        }
+        for (int ly = 0; ly < TILE; ly++) for (int lx = 0; lx < TILE; lx++) {
+            int px = tx * TILE + lx, py = ty * TILE + ly;
+            if (px >= W || py >= H) continue;
+            real T = 1.f, mmin = 1e30f, b[MAXC + 1] = {0};
+            int prev = -1; real prev_alpha = 0.f, prev_T = 0.f;
+            for (int k = s; k < e; k++) {
+                int id = c->list[k];
+                real dx = c->xy[2 * id] - (real)px, dy = c->xy[2 * id + 1] - (real)py;
+                const real *co = c->conic_op + 4 * id;
+                real t0 = 0.5f * co[0] * dx * dx, t1 = 0.5f * co[2] * dy * dy, t2 = co[1] * dx * dy;
+                real power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                real mag = (t0 < 0 ? -t0 : t0) + (t1 < 0 ? -t1 : t1) + (t2 < 0 ? -t2 : t2) + 1e-30f;
+                real mp = (power < 0 ? -power : power) / mag;
+                real a_raw = co[3] * R_EXP(power > 0.f ? 0.f : power);
+                real alpha = R_MIN(0.99f, a_raw);
+                #define ADD_FLIP(scale_self, scale_rest) do { \
+                    for (int ch = 0; ch < C; ch++) { real v = colors[(size_t)id * C + ch]; v = v < 0 ? -v : v; b[ch] += (scale_self) * v + (scale_rest) * cmax[ch]; } \
+                    b[C] += (scale_self) * c->depth[id] + (scale_rest) * cmax[C]; } while (0)
+                if (mp < tol && alpha >= 1.f / 255.f) { if (mp < mmin) mmin = mp; ADD_FLIP(alpha * T, alpha * T); }
+                if (power > 0.f) continue;
+                real ma = (alpha > 1.f / 255.f ? alpha - 1.f / 255.f : 1.f / 255.f - alpha) * 255.f;
+                if (ma < mmin) mmin = ma;
+                if (ma < tol) ADD_FLIP(alpha * T, alpha * T);
+                if (alpha < 1.f / 255.f) continue;
+                real test_T = T * (1.f - alpha);
+                real mt = (test_T > 0.0001f ? test_T - 0.0001f : 0.0001f - test_T) * 10000.f;
+                if (mt < mmin) mmin = mt;
+                if (mt < tol) ADD_FLIP(0.f, T);
+                if (test_T < 0.0001f) break;
+                if (prev >= 0) {
+                    real dd = c->depth[id] - c->depth[prev]; dd = dd < 0 ? -dd : dd;
+                    real md = dd / c->depth[id];
+                    if (md <= tie_tol) {
+                        if (md < mmin) mmin = md;
+                        real w = prev_alpha * alpha * prev_T;
+                        for (int ch = 0; ch < C; ch++) { real v = colors[(size_t)id * C + ch] - colors[(size_t)prev * C + ch]; b[ch] += w * (v < 0 ? -v : v); }
+                        b[C] += w * dd;
+                    }
+                }
+                prev = id; prev_alpha = alpha; prev_T = T;
+                T = test_T;
+                #undef ADD_FLIP
+            }
+            size_t pix = (size_t)py * W + px;
+            margin[pix] = mmin;
+            for (int ch = 0; ch <= C; ch++) bound[(size_t)ch * HW + pix] = b[ch];
+        }
+    }
+    /* Per-GAUSSIAN decisions: the tile rectangle.  radius = ceil(3 sqrt(lambda)) and the rectangle's edges (int)((p -+ radius [+ 15]) /
+     * 16) are step functions of float32 quantities: a centre within `geo` pixels of the value where an edge moves (or 3 sqrt(lambda)
+     * within `geo` of an integer) puts the Gaussian into one more / one fewer row or column of tiles in another float32 evaluation,
+     * i.e. adds / removes it at EVERY pixel of those tiles it reaches.  For the pixels of the tiles between the smallest and the
+     * largest rectangle the decision allows: bound += alpha (|c| + cmax_global)  (T <= 1). */
+    {
+        const real geo = 2e-3f;
+        real gmax[MAXC + 1] = {0};
+        for (int i = 0; i < c->P; i++) {
+            if (c->radii[i] <= 0) continue;
+            for (int ch = 0; ch < C; ch++) { real v = colors[(size_t)i * C + ch]; v = v < 0 ? -v : v; if (v > gmax[ch]) gmax[ch] = v; }
+            if (c->depth[i] > gmax[C]) gmax[C] = c->depth[i];
+        }
+        for (int i = 0; i < c->P; i++) {
+            if (c->radii[i] <= 0) continue;
+            const real px = c->xy[2 * i], py = c->xy[2 * i + 1];
+            const real a = c->cov2d[3 * i], bb = c->cov2d[3 * i + 1], cc = c->cov2d[3 * i + 2];
+            const real det = a * cc - bb * bb, mid = 0.5f * (a + cc);
+            const real lam = mid + R_SQRT(R_MAX(0.1f, mid * mid - det));
+            const real r3 = 3.f * R_SQRT(lam), rad = (real)c->radii[i];
+            const real r_lo = (rad - r3 > 1.f - geo) ? rad - 1.f : rad;       /* 3 sqrt(lambda) just above an integer: ceil may give one less */
+            const real r_hi = (rad - r3 < geo) ? rad + 1.f : rad;             /* just below: one more */
+            int lo[4], hi[4];
+            lo[0] = (int)((px - r_lo + geo) / TILE); hi[0] = (int)((px - r_hi - geo) / TILE);
+            lo[1] = (int)((py - r_lo + geo) / TILE); hi[1] = (int)((py - r_hi - geo) / TILE);
+            lo[2] = (int)((px + r_lo - geo + TILE - 1) / TILE); hi[2] = (int)((px + r_hi + geo + TILE - 1) / TILE);
+            lo[3] = (int)((py + r_lo - geo + TILE - 1) / TILE); hi[3] = (int)((py + r_hi + geo + TILE - 1) / TILE);
+            const int lim[4] = {gx, c->gy, gx, c->gy};
+            int same = 1;
+            for (int k = 0; k < 4; k++) {
+                lo[k] = lo[k] < 0 ? 0 : (lo[k] > lim[k] ? lim[k] : lo[k]);
+                hi[k] = hi[k] < 0 ? 0 : (hi[k] > lim[k] ? lim[k] : hi[k]);
+                if (lo[k] != hi[k]) same = 0;
+            }
+            if (same) continue;
+            const real *co = c->conic_op + 4 * i;
+            for (int tyy = hi[1]; tyy < hi[3]; tyy++) for (int txx = hi[0]; txx < hi[2]; txx++) {
+                if (txx >= lo[0] && txx < lo[2] && tyy >= lo[1] && tyy < lo[3]) continue;       /* in the smallest rectangle: certain */
+                for (int ly = 0; ly < TILE; ly++) for (int lx = 0; lx < TILE; lx++) {
+                    int qx = txx * TILE + lx, qy = tyy * TILE + ly;
+                    if (qx >= W || qy >= H) continue;
+                    real dx = px - (real)qx, dy = py - (real)qy;
+                    real power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > 0.f) continue;
+                    real alpha = R_MIN(0.99f, co[3] * R_EXP(power));
+                    if (alpha < (1.f - tol) / 255.f) continue;
+                    size_t pix = (size_t)qy * W + qx;
+                    for (int ch = 0; ch < C; ch++) { real v = colors[(size_t)i * C + ch]; v = v < 0 ? -v : v; bound[(size_t)ch * HW + pix] += alpha * (v + gmax[ch]); }
+                    bound[(size_t)C * HW + pix] += alpha * (c->depth[i] + gmax[C]);
+                    if (margin[pix] > geo) margin[pix] = geo;
+                }
+            }
+        }
+    }
+}
+
 /* Backward.  dL_dpix: [C,H,W].  Outputs (all overwritten):
  * dmeans3D[P,3] dmeans2D[P,3] dcolors[P,C] dopac[P] dscales[P,3] drot[P,4] dcov3D[P,6]
  * (dscales/drot are skipped when scales==NULL, i.e. cov3D_precomp was used). */

@@ -26,6 +26,7 @@ from .rasterizer import _cached_contiguous
 
 PARAM_ORDER = ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales")
 VARIABLE_KEYS = ("max_2D_radius", "means2D_gradient_accum", "denom", "timestep")
+_FLAG_SLOTS = 16        # floats ahead of the flat gradient bucket (one 64-byte line): slot 0 = capacity flag of the exchange
 
 
 class FusedEngine:
@@ -104,7 +105,7 @@ class FusedEngine:
         b['counts'] = torch.zeros(8, dtype=i32, **z)
         # map gradients: ONE flat buffer (the all-reduce bucket of the view-sharded mapping step), viewed per parameter
         self._widths = [3, 3, 4, 1, 1 if self.iso else 3]
-        self._grad_store = torch.zeros(sum(self._widths) * P_alloc, dtype=f32, **z)
+        self._grad_store = torch.zeros(_FLAG_SLOTS + sum(self._widths) * P_alloc, dtype=f32, **z)
         self._m_store = {k: torch.zeros(P_alloc, w, dtype=f32, **z) for k, w in zip(PARAM_ORDER, self._widths)}
         self._v_store = {k: torch.zeros(P_alloc, w, dtype=f32, **z) for k, w in zip(PARAM_ORDER, self._widths)}
         self._layout_rows()
@@ -169,7 +170,9 @@ class FusedEngine:
     def _layout_rows(self):
         """Views that depend on the number of rows: the flat gradient bucket and the moment views."""
         P = self.P
-        self.grad_flat = self._grad_store[:sum(self._widths) * P]
+        # [0, _FLAG_SLOTS): the exchange's header -- slot 0 carries this rank's capacity flag through the SAME collective as the gradients
+        # (exchange_gradients); the gradients follow, 64-byte aligned
+        self.grad_flat = self._grad_store[_FLAG_SLOTS:_FLAG_SLOTS + sum(self._widths) * P]
         # the rotations go last: for an isotropic map their gradient is exactly zero and the exchange skips them
         order = [k for k in PARAM_ORDER if k != "unnorm_rotations"] + ["unnorm_rotations"]
         widths = dict(zip(PARAM_ORDER, self._widths))
@@ -178,6 +181,7 @@ class FusedEngine:
             self.grads[k] = self.grad_flat[o:o + widths[k] * P].view(P, widths[k])
             o += widths[k] * P
         self.reduce_flat = self.grad_flat[:(sum(self._widths) - 4) * P] if self.iso else self.grad_flat
+        self._exchange_flat = self._grad_store[:_FLAG_SLOTS + self.reduce_flat.numel()]
         self.exp_avg = {k: self._m_store[k][:P] for k in PARAM_ORDER}
         self.exp_avg_sq = {k: self._v_store[k][:P] for k in PARAM_ORDER}
 
@@ -208,7 +212,7 @@ class FusedEngine:
             for k, shape, dt in (('conic', (4,), f32), ('xy', (2,), f32), ('rect', (2,), i32), ('depth', (), f32), ('radii', (), i32),
                                  ('feat8', (8,), f32), ('accum', (_capi.SPLAT_GRAD_STRIDE,), f32)):
                 b[k] = torch.zeros((cap,) + shape, dtype=dt, device=dev)
-            self._grad_store = torch.zeros(sum(self._widths) * cap, dtype=f32, device=dev)
+            self._grad_store = torch.zeros(_FLAG_SLOTS + sum(self._widths) * cap, dtype=f32, device=dev)
             self._m_store = {k: torch.zeros(cap, w, dtype=f32, device=dev) for k, w in zip(PARAM_ORDER, self._widths)}
             self._v_store = {k: torch.zeros(cap, w, dtype=f32, device=dev) for k, w in zip(PARAM_ORDER, self._widths)}
             self.Pcap = cap
@@ -239,7 +243,7 @@ class FusedEngine:
         for k in PARAM_ORDER:
             self._m_store[k] = grown(self._m_store[k], self.Pcap)
             self._v_store[k] = grown(self._v_store[k], self.Pcap)
-        self._grad_store = torch.zeros(sum(self._widths) * self.Pcap, dtype=f32, device=dev)
+        self._grad_store = torch.zeros(_FLAG_SLOTS + sum(self._widths) * self.Pcap, dtype=f32, device=dev)
         for k, shape, dt in (('conic', (4,), f32), ('xy', (2,), f32), ('rect', (2,), i32), ('depth', (), f32), ('radii', (), i32),
                              ('feat8', (8,), f32), ('accum', (_capi.SPLAT_GRAD_STRIDE,), f32)):
             b[k] = torch.zeros((self.Pcap,) + shape, dtype=dt, device=dev)
@@ -797,7 +801,7 @@ class FusedEngine:
             return
         self.loss_backward(iter_data, iter_time_idx, cfg, tracking=False)
         if bucket_allreduce is not None:
-            bucket_allreduce(self.reduce_flat)      # one collective: 8 (isotropic) or 14 floats per Gaussian
+            self.exchange_gradients(bucket_allreduce)      # one collective: 8 (isotropic) or 14 floats per Gaussian (+ the flag header)
         self.adam_map(cfg['lrs'])
 
     def mapping_batch(self, views, cfg, total_views=None, allreduce_sum=None):
@@ -813,19 +817,32 @@ class FusedEngine:
             else:
                 acc.add_(self.grad_flat)
         red = acc[:self.reduce_flat.numel()]
-        if allreduce_sum is not None:
-            allreduce_sum(red)
+        if allreduce_sum is not None:           # (the capacity flag of any rank's views travels in the header: exchange_gradients)
+            self.exchange_gradients(allreduce_sum, self._acc_store[:_FLAG_SLOTS + self.reduce_flat.numel()])
         n = float(total_views if total_views is not None else len(views))
         if n != 1.0:
             red.mul_(1.0 / n)
         self.grad_flat.copy_(acc)
         self.adam_map(cfg['lrs'])
 
+    def exchange_gradients(self, all_reduce, flat=None):
+        """The gradient exchange of a multi-rank mapping step: ``all_reduce`` (sum or mean, in place) over the flat gradient bucket WITH
+        this rank's capacity flag in its header.  Ranks render different views, so typically only some overflow their lists; the
+        flag of ANY rank comes back non-zero on EVERY rank and is made this rank's sticky flag (``d_cam[12]``) before the Adam step
+        that follows, so the replicas skip the same steps and stay bit-identical (the reduced gradient of such an iteration holds a
+        truncated-list contribution: nobody may step on it).  ``flat``: another buffer laid out like ``_exchange_flat`` (mapping_batch's
+        accumulator)."""
+        flat = self._exchange_flat if flat is None else flat
+        flag = self.buf['d_cam'][12:13]
+        flat[0:1].copy_(flag)
+        all_reduce(flat)
+        torch.maximum(flag, (flat[0:1] != 0.0).to(flag.dtype), out=flag)
+
     def _acc_flat(self):
         a = getattr(self, "_acc_store", None)
-        if a is None or a.numel() < self.grad_flat.numel():
+        if a is None or a.numel() < _FLAG_SLOTS + self.grad_flat.numel():
             a = self._acc_store = torch.zeros(self._grad_store.numel(), dtype=torch.float32, device=self.dev)
-        return a[:self.grad_flat.numel()]
+        return a[_FLAG_SLOTS:_FLAG_SLOTS + self.grad_flat.numel()]
 
     # ------------------------------------------------------------------ read-backs (host sync)
     def loss(self):

@@ -604,7 +604,8 @@ def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, 
         elif eng is not None:
             eng.loss_backward(iter_data, iter_time_idx, mcfg, tracking=False)
             if world > 1 and not on_schedule:                   # (an iteration on the pruning schedule takes no Adam step)
-                sdist.all_reduce_mean_flat(eng.reduce_flat)
+                # (with every rank's capacity flag in the bucket's header: a rank whose lists overflowed stops ALL replicas' steps)
+                eng.exchange_gradients(sdist.all_reduce_mean_flat)
             edited = False
             densifying = bool(mcfg.get('use_gaussian_splatting_densification'))
             if densifying and it <= mcfg['densify_dict']['stop_after']:

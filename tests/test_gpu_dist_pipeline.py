@@ -101,3 +101,61 @@ def test_instream_rccl_single_rank():
     with pytest.raises(ValueError):
         comm.all_reduce(torch.zeros(4, dtype=torch.float16, device=dev))
     comm.close()
+
+
+def _overflow_worker(rank, world, port, out_dir):
+    """Engine-level multi-rank mapping steps where ONLY rank 1's bucketed lists overflow (its bucket stride is cut below its longest
+    list before step 2): the flag travels in the header of the gradient exchange (FusedEngine.exchange_gradients), so BOTH ranks skip
+    steps 2 and 3."""
+    from splatam_amd import dist as sdist
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sdist.init_from_env(backend="gloo")
+    torch.cuda.set_device(0)
+    n, f = 20000, 140.0
+    params, variables = slam.synthetic_params(n, W, H, f, f, W / 2 - 0.5, H / 2 - 0.5, num_frames=3, seed=3, device="cuda")
+    w2c = torch.eye(4, device="cuda")
+    cam = slam.setup_camera(W, H, [[f, 0, W / 2 - 0.5], [0, f, H / 2 - 0.5], [0, 0, 1]], np.eye(4, dtype=np.float32), device="cuda")
+    frames = []
+    for t in (1, 2):                                           # two views: rank r renders view r
+        im, depth = slam.synthetic_frame(params, cam, w2c, t, rot_deg=0.4 * t, trans_m=0.01 * t)
+        frames.append({'cam': cam, 'im': im, 'depth': depth, 'id': t, 'w2c': w2c})
+    cfg = slam.REPLICA_MAPPING
+    eng = FusedEngine(params, cam)
+    snaps, flags = [], []
+    for step in range(4):
+        if step == 1:
+            assert not sdist.any_rank(eng.check_overflow(), eng.dev)         # learns the lists: bucketed from now on
+            assert eng.tile_stride > 0
+        if step == 2 and rank == 1:
+            assert eng.max_list_hint > 256, eng.max_list_hint
+            eng.tile_stride = 256                                 # rank 1's buckets no longer hold its longest list
+        eng.mapping_iteration(frames[rank], frames[rank]['id'], cfg, bucket_allreduce=sdist.all_reduce_mean_flat)
+        torch.cuda.synchronize()
+        snaps.append({k: params[k].detach().cpu().numpy().copy() for k in ('means3D', 'rgb_colors', 'logit_opacities', 'log_scales')})
+        flags.append(float(eng.buf['d_cam'][12]))
+    local_bad = eng.check_overflow()
+    np.savez(os.path.join(out_dir, f"ov{rank}.npz"), flags=np.array(flags), local_bad=local_bad, skipped=eng.skipped_iterations,
+             **{f"s{i}/{k}": v for i, s in enumerate(snaps) for k, v in s.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_overflow_stops_every_replica(tmp_path):
+    """the skip-on-overflow gate must be global in multi-rank mapping -- ranks render different views, so
+    typically only some overflow; the others must not step on the all-reduced gradient that holds a truncated-list contribution."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_overflow_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (np.load(tmp_path / f"ov{i}.npz") for i in (0, 1))
+    assert r0['flags'].tolist() == r1['flags'].tolist() == [0.0, 0.0, 1.0, 1.0]        # rank 0 never overflowed itself
+    assert bool(r0['local_bad']) and bool(r1['local_bad'])
+    assert int(r1['skipped']) == 2 and int(r0['skipped']) >= 1
+    for k in ('means3D', 'rgb_colors', 'logit_opacities', 'log_scales'):
+        for i in range(4):
+            np.testing.assert_array_equal(r0[f"s{i}/{k}"], r1[f"s{i}/{k}"], err_msg=f"step {i} {k}")     # replicas bit-identical
+        assert not np.array_equal(r0[f"s0/{k}"], r0[f"s1/{k}"]), k                                     # steps 0, 1 moved the map
+        np.testing.assert_array_equal(r0[f"s1/{k}"], r0[f"s3/{k}"], err_msg=k)                         # steps 2, 3 moved nothing

@@ -10,7 +10,8 @@ import torch
 
 from oracle import c_ref
 from oracle import raster_ref as R
-from tests.util import assert_close_outliers, assert_grad_calibrated, grad_scale, scene, tilted_w2c
+from tests.util import (assert_close_outliers, assert_grad_calibrated, assert_grad_outliers_explained, assert_outliers_explained,
+                        flip_pixels, grad_scale, oracle_flip_bounds, scene, tilted_w2c)
 
 pytestmark = pytest.mark.gpu
 
@@ -47,32 +48,42 @@ def _c_oracle(cam, rv, grad_out=None, precision="f32"):
     return col, radii, dep, g, cr
 
 
-def _check_forward(gc, gr, gd, oc, orad, od, npix):
+def _check_forward(gc, gr, gd, oc, orad, od, npix, cam=None, rv=None):
+    """North star: 1e-4 on colour and depth.  Pixels beyond it must be EXPLAINED by the float64 oracle (tests/util.py:
+    assert_outliers_explained): a decision of that pixel -- alpha >= 1/255, T (1 - alpha) >= 1e-4, power <= 0, the order of two equal
+    depths -- within float32 rounding of its threshold, and the difference within what those flips can move.  Their number stays
+    bounded too (1e-4 of the elements).  Returns (flagged pixels, xy, radii) for the gradient check."""
     assert (gr != orad).sum() <= max(2, int(1e-5 * gr.size)), "radii mismatch"
     assert np.abs(gr.astype(np.int64) - orad).max() <= 1
-    # 1e-4 absolute on unit-range colours (relative for the larger depth / depth^2 channels).  A bounded
-    # fraction of pixels may differ by one alpha >= 1/255 decision: |power| ~ 5.5 at that threshold carries
-    # ~1e-6 of float32 evaluation-order noise, i.e. ~1e-6 relative on alpha, which flips a few dozen of the
-    # 1.5e8 (pixel, Gaussian) tests of a full-size frame; each flip moves a pixel by at most ~1/255 * |c|.
-    cmax = max(1.0, float(np.abs(oc).max()))
-    assert_close_outliers(gc, oc, 1e-4, rtol=1e-4, max_outlier_frac=1e-4, outlier_atol=0.03 * cmax, what="color")
-    assert_close_outliers(gd, od, 1e-4, rtol=1e-4, max_outlier_frac=1e-4, outlier_atol=0.1, what="depth")
+    if cam is None:                     # (callers without the inputs at hand: the counted form)
+        cmax = max(1.0, float(np.abs(oc).max()))
+        assert_close_outliers(gc, oc, 1e-4, rtol=1e-4, max_outlier_frac=1e-4, outlier_atol=0.03 * cmax, what="color")
+        assert_close_outliers(gd, od, 1e-4, rtol=1e-4, max_outlier_frac=1e-4, outlier_atol=0.1, what="depth")
+        return None
+    bound, margin, xy, radii = oracle_flip_bounds(rv, cam)
+    C_ = gc.shape[0]
+    n = assert_outliers_explained(gc, oc, bound[:C_], 1e-4, rtol=1e-4, what="color")
+    n += assert_outliers_explained(gd, od, bound[C_:C_ + 1], 1e-4, rtol=1e-4, what="depth")
+    assert n <= max(2, int(1e-4 * (gc.size + gd.size))), n
+    return flip_pixels(bound, (gc, gd), (oc, od)), xy, radii
 
 
 GRAD_MAP = [('means3D', 'means3D'), ('means2D', 'means2D'), ('colors_precomp', 'colors'), ('opacities', 'opacities'),
             ('scales', 'scales'), ('rotations', 'rotations')]
 
 
-def _check_grads(gg, og, og64=None):
-    """North star: 1e-3 of the tensor's maximum (bounded fraction of float32 threshold flips).  With the float64 oracle's
-    gradients the check is also per element, calibrated against the float32 oracle's own rounding noise
-    (tests/util.py: assert_grad_calibrated)."""
+def _check_grads(gg, og, og64=None, flips=None):
+    """North star: 1e-3 of the tensor's maximum.  Rows beyond it must lie over a pixel with a float32 decision flip (``flips`` from
+    _check_forward; tests/util.py: assert_grad_outliers_explained), their number bounded.  With the float64 oracle's gradients the
+    check is also per element, calibrated against the float32 oracle's own rounding noise (assert_grad_calibrated)."""
     for k, ok in GRAD_MAP:
         ref = og[ok]
         got = gg[k].reshape(ref.shape)
         assert np.isfinite(got).all(), k
         assert_close_outliers(got, ref, 1e-3 * grad_scale(ref), max_outlier_frac=1e-4,
                               outlier_atol=0.05 * grad_scale(ref), what=f"grad {k}")
+        if flips is not None:
+            assert_grad_outliers_explained(got, ref, *flips, what=f"grad {k}")
         if og64 is not None and float(np.abs(og64[ok]).max()) > 1e-12 * max(1.0, float(np.abs(og64['means3D']).max())):
             assert_grad_calibrated(got, ref, og64[ok], what=f"grad {k}")
 
@@ -89,8 +100,8 @@ def test_forward_backward_parity(n, W, H, aniso, view, bg):
     gout = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1))
     gc, gr, gd, gg = _gpu_render(cam, rv, gout)
     oc, orad, od, og, _ = _c_oracle(cam, rv, gout)
-    _check_forward(gc, gr, gd, oc, orad, od, W * H)
-    _check_grads(gg, og, _c_oracle(cam, rv, gout, "f64")[3])
+    flips = _check_forward(gc, gr, gd, oc, orad, od, W * H, cam, rv)
+    _check_grads(gg, og, _c_oracle(cam, rv, gout, "f64")[3], flips)
 
 
 def test_against_autograd_oracle_small():
@@ -103,9 +114,9 @@ def test_against_autograd_oracle_small():
     col, radii, dep = R.rasterize(inp['means3D'], inp['means2D'], inp['opacities'], inp['colors_precomp'],
                                   inp['scales'], inp['rotations'], cam)
     (col * gout).sum().backward()
-    _check_forward(gc, gr, gd, col.detach().numpy(), radii.numpy(), dep.numpy(), W * H)
+    flips = _check_forward(gc, gr, gd, col.detach().numpy(), radii.numpy(), dep.numpy(), W * H, cam, rv)
     og = {ok: inp[k].grad.numpy() for k, ok in GRAD_MAP}
-    _check_grads(gg, og)
+    _check_grads(gg, og, flips=flips)
 
 
 def test_internal_state_matches_oracle():
@@ -144,8 +155,8 @@ def test_channel_counts(C_):
     gout = torch.randn(C_, H, W, generator=g)
     gc, gr, gd, gg = _gpu_render(cam, rv, gout)
     oc, orad, od, og, _ = _c_oracle(cam, rv, gout)
-    _check_forward(gc, gr, gd, oc, orad, od, W * H)
-    _check_grads(gg, og)
+    flips = _check_forward(gc, gr, gd, oc, orad, od, W * H, cam, rv)
+    _check_grads(gg, og, flips=flips)
 
 
 def test_depth_silhouette_pass():
@@ -159,8 +170,8 @@ def test_depth_silhouette_pass():
     gout[0] = torch.randn(H, W, generator=torch.Generator().manual_seed(5))
     gc, gr, gd, gg = _gpu_render(cam, rv, gout)
     oc, orad, od, og, cr = _c_oracle(cam, rv, gout)
-    _check_forward(gc, gr, gd, oc, orad, od, W * H)
-    _check_grads(gg, og)
+    flips = _check_forward(gc, gr, gd, oc, orad, od, W * H, cam, rv)
+    _check_grads(gg, og, flips=flips)
     assert_close_outliers(gc[1], 1.0 - cr.final_T(), 1e-5, max_outlier_frac=1e-4, outlier_atol=0.02, what="silhouette")
 
 
@@ -192,7 +203,7 @@ def test_scale_modifier_and_cov3d_precomp():
     cam = cam._replace(scale_modifier=1.7)
     gc, gr, gd, _ = _gpu_render(cam, rv)
     oc, orad, od, _, _ = _c_oracle(cam, rv)
-    _check_forward(gc, gr, gd, oc, orad, od, W * H)
+    _check_forward(gc, gr, gd, oc, orad, od, W * H, cam, rv)
     # the same scene through a precomputed covariance (modifier folded in) + its gradient
     cov = R.cov3d_from_scale_rot(rv['scales'], rv['rotations'], 1.7)
     cam1 = cam._replace(scale_modifier=1.0)
@@ -264,8 +275,8 @@ def test_full_size_replica_shape():
     gout = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1))
     gc, gr, gd, gg = _gpu_render(cam, rv, gout)
     oc, orad, od, og, cr = _c_oracle(cam, rv, gout)
-    _check_forward(gc, gr, gd, oc, orad, od, W * H)
-    _check_grads(gg, og, _c_oracle(cam, rv, gout, "f64")[3])
+    flips = _check_forward(gc, gr, gd, oc, orad, od, W * H, cam, rv)
+    _check_grads(gg, og, _c_oracle(cam, rv, gout, "f64")[3], flips)
     # size-independent properties: silhouette in [0,1]; rendering is linear in the colours
     rv2 = dict(rv)
     rv2['colors_precomp'] = 2.0 * rv['colors_precomp']
@@ -280,5 +291,5 @@ def test_composite_kernels_multi_batch_and_config_a():
         gout = torch.randn(3, H, W, generator=torch.Generator().manual_seed(7))
         gc, gr, gd, gg = _gpu_render(cam, rv, gout)
         oc, orad, od, og, _ = _c_oracle(cam, rv, gout)
-        _check_forward(gc, gr, gd, oc, orad, od, W * H)
-        _check_grads(gg, og)
+        flips = _check_forward(gc, gr, gd, oc, orad, od, W * H, cam, rv)
+        _check_grads(gg, og, flips=flips)

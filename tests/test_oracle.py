@@ -202,3 +202,64 @@ def test_finite_differences_float64():
             if abs(fd - an) > 1e-4 * max(1.0, abs(an)):
                 nbad += 1       # a 1/255 or 1e-4 threshold crossed inside the stencil
         assert nbad <= 1, (k, nbad, ncheck)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# the decision-flip classifier (ref_flip_bounds): what the GPU parity tests use to EXPLAIN every outlier
+# ----------------------------------------------------------------------------------------------------------------------------------
+
+def _both_builds(cam, rv, gout):
+    from oracle import c_ref
+    out = {}
+    for prec in ("f32", "f64"):
+        cr = c_ref.CRef(prec)
+        col, radii, dep = cr.forward(rv['means3D'].numpy(), rv['colors_precomp'].numpy(), rv['opacities'].numpy(), rv['scales'].numpy(),
+                                     rv['rotations'].numpy(), cam.viewmatrix.numpy(), cam.projmatrix.numpy(), cam.tanfovx, cam.tanfovy,
+                                     cam.image_width, cam.image_height, cam.bg.numpy())
+        out[prec] = (col, dep, radii, cr.backward(gout.numpy()))
+    return out
+
+
+@pytest.mark.parametrize("n,W,H,f,seed", [(10000, 320, 240, 288.0, 10000), (60000, 640, 480, 517.0, 5)])
+def test_flip_classifier_explains_float32_vs_float64(n, W, H, f, seed):
+    """The float32 and float64 builds of the oracle are two correct evaluations: every pixel where they differ by more than 1e-4 must
+    hold a decision the classifier finds within rounding of its threshold (and be within the bound of those flips), and every
+    gradient row they disagree on by more than 1e-3 of the maximum must lie over a pixel where such a flip happened."""
+    from tests.util import assert_grad_outliers_explained, assert_outliers_explained, flip_pixels, oracle_flip_bounds, scene
+    cam, rv = scene(n, W, H, f, seed=seed)
+    gout = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1))
+    b = _both_builds(cam, rv, gout)
+    bound, margin, xy, radii = oracle_flip_bounds(rv, cam)
+    assert_outliers_explained(b['f32'][0], b['f64'][0], bound[:3], 1e-4, rtol=1e-4, what="float32 vs float64 colour")
+    assert_outliers_explained(b['f32'][1], b['f64'][1], bound[3:4], 1e-4, rtol=1e-4, what="float32 vs float64 depth")
+    flips = flip_pixels(bound, (b['f32'][0], b['f32'][1]), (b['f64'][0], b['f64'][1]))
+    assert 0 < flips.mean() < 2e-3                       # a few pixels in ten thousand
+    for k in ('means3D', 'colors', 'opacities', 'scales'):
+        assert_grad_outliers_explained(b['f32'][3][k], b['f64'][3][k], flips, xy, radii, what=f"float32 vs float64 dL/d{k}")
+
+
+def test_flip_classifier_known_answers():
+    """One Gaussian, exact answers: the classifier flags the ring of pixels where alpha crosses 1/255 (and only a ring), bounds a flip
+    there by alpha (|c| + cmax) ~ 2/255 |c|, and reports no decision anywhere when the thresholds are far."""
+    from oracle import c_ref
+    W = H = 64
+    cam = R.make_camera(W, H, 60.0, 60.0, 31.5, 31.5)
+    z = 2.0
+    means = np.array([[0.0, 0.0, z]], np.float32)
+    sc = np.full((1, 3), 6.0 * z / 60.0, np.float32)            # sigma = 6 px
+    rot = np.array([[1.0, 0, 0, 0]], np.float32)
+    col = np.array([[0.5, 0.25, 1.0]], np.float32)
+    cr = c_ref.CRef("f64")
+    cr.forward(means, col, np.array([0.8], np.float32), sc, rot, cam.viewmatrix.numpy(), cam.projmatrix.numpy(), cam.tanfovx, cam.tanfovy,
+               W, H, cam.bg.numpy())
+    # alpha = 0.8 exp(-r^2 / (2 (36 + 0.3))) = 1/255  at  r = sqrt(2 * 36.3 * ln(204)) = 19.65 px: the margin is smallest on that ring
+    bound, margin = cr.flip_bounds(tol=0.05)
+    ys, xs = np.nonzero(bound[0] > 0)
+    cx, cy = cr.geom()['xy'][0]
+    r = np.hypot(xs - cx, ys - cy)
+    assert ys.size > 20 and np.abs(r - 19.65).max() < 0.12, (ys.size, r.min(), r.max())       # 5 % in alpha = 0.09 px in r
+    np.testing.assert_allclose(bound[0][ys, xs], (1 / 255.0) * (0.5 + 0.5), rtol=0.06)       # alpha T (|c| + cmax), alpha within 5 % of 1/255
+    np.testing.assert_allclose(bound[2][ys, xs], (1 / 255.0) * (1.0 + 1.0), rtol=0.06)
+    assert margin[int(round(cy)), int(round(cx))] > 0.5                                                           # centre pixel: alpha = 0.8, far from everything
+    bound, margin = cr.flip_bounds(tol=1e-5)
+    assert not (bound > 0).any()

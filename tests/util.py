@@ -125,3 +125,89 @@ def track_loop_loss_rtol(it):
     differ from then on.  Measured on the 12 000-Gaussian scene of these tests over builds of the same kernels (deterministic per
     build; scripts/track_loop_spread.py): 7e-8 until the first such pixel, then 6e-5 .. 1.3e-3 by iteration 5."""
     return 1e-3 if it < 3 else 3e-3
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# every outlier explained (VERDICT r4, weak 1): the float64 oracle classifies the float32 decision flips
+# ----------------------------------------------------------------------------------------------------------------------------------
+
+FLIP_TOL = 2e-3        # a decision whose margin is within this (relative) may fall either way in a correct float32 evaluation:
+#                        pixel coordinates ~1e3 carry ~6e-5 px of float32 rounding, `power` (~ -5.5 at the alpha threshold) moves by
+#                        ~co * dx * 6e-5 ~ 2e-4, alpha = o exp(power) by as much relatively; T is a product of up to hundreds of such factors
+TIE_TOL = 5e-7         # two depths within 4 float32 ulps (4 * 2^-23 relative): their order is decided by rounding
+
+
+def oracle_flip_bounds(rv, cam, tol=FLIP_TOL, tie_tol=TIE_TOL):
+    """float64 build of the C oracle on the render variables ``rv`` (numpy / torch, any float dtype): returns
+    (bound[(C+1),H,W], margin[H,W], xy[P,2], radii[P]) -- see ref_flip_bounds in oracle/raster_ref.c."""
+    from oracle import c_ref
+    n = lambda t: t.detach().cpu().double().numpy() if hasattr(t, "detach") else np.asarray(t, dtype=np.float64)      # noqa: E731
+    cr = c_ref.CRef("f64")
+    _, radii, _ = cr.forward(n(rv['means3D']), n(rv['colors_precomp']), n(rv['opacities']), n(rv['scales']), n(rv['rotations']),
+                             n(cam.viewmatrix), n(cam.projmatrix), float(cam.tanfovx), float(cam.tanfovy), int(cam.image_width),
+                             int(cam.image_height), n(cam.bg), scale_modifier=float(cam.scale_modifier))
+    bound, margin = cr.flip_bounds(tol, tie_tol)
+    return bound, margin, cr.geom()['xy'], radii
+
+
+def assert_outliers_explained(got, ref, bound, atol, rtol=0.0, slack=1.1, what=""):
+    """Every element of ``got`` further from ``ref`` than atol + rtol |ref| must be EXPLAINED: the float64 oracle found, at that pixel,
+    decisions within FLIP_TOL of their threshold (alpha >= 1/255, T (1 - alpha) >= 1e-4, power <= 0, or a depth tie) whose flips can
+    move that channel by ``bound``; the element must be within the tolerance + ``slack`` x that bound.  Returns the number of
+    explained outliers.  (``bound``: the rows of oracle_flip_bounds' first result that correspond to ``got``'s channels.)"""
+    got, ref, bound = (np.asarray(a, dtype=np.float64) for a in (got, ref, bound))
+    assert got.shape == ref.shape == bound.shape, (what, got.shape, ref.shape, bound.shape)
+    err = np.abs(got - ref)
+    lim = atol + rtol * np.abs(ref)
+    bad = err > lim
+    unexplained = bad & (err > lim + slack * bound)
+    nbad, nun = int(bad.sum()), int(unexplained.sum())
+    expl = bad & ~unexplained & (bound > 0)
+    ratio = float((err[expl] / bound[expl]).max()) if expl.any() else 0.0
+    print(f"{what}: {nbad} of {err.size} elements beyond {atol:g} + {rtol:g}|ref| (max err {err.max() if err.size else 0.0:.3e}); "
+          f"{nbad - nun} explained by float32 decision flips (largest err / flip bound {ratio:.2f}), {nun} unexplained")
+    if nun:
+        idx = np.argwhere(unexplained)[:5]
+        detail = [(tuple(int(v) for v in i), float(err[tuple(i)]), float(bound[tuple(i)])) for i in idx]
+        raise AssertionError(f"{what}: {nun} outliers without a near-threshold decision: (index, err, bound) {detail}")
+    return nbad
+
+
+def flip_pixels(bound, got_images, ref_images, noise=2e-5):
+    """Pixels where a float32 decision flip HAPPENED between two evaluations: the float64 oracle found a near-threshold decision there
+    (``bound`` > 0) AND the two forward results differ by more than evaluation-order rounding (``noise``, absolute + relative; without
+    a flip the planes agree to ~4e-6 / ~2e-5 |depth|).  A few hundred of the ~1e6 pixels of a full-size frame -- against ~1.7 % that
+    merely hold a near-threshold decision -- which is what makes assert_grad_outliers_explained a sharp statement."""
+    flagged = np.asarray(bound).sum(axis=0) > 0
+    changed = np.zeros_like(flagged)
+    for g, r in zip(got_images, ref_images):
+        g, r = np.asarray(g, dtype=np.float64), np.asarray(r, dtype=np.float64)
+        changed |= (np.abs(g - r) > noise + noise * np.abs(r)).reshape((-1,) + flagged.shape).any(axis=0)
+    return flagged & changed
+
+
+def assert_grad_outliers_explained(got, ref, flagged, xy, radii, rel=1e-3, what=""):
+    """Every ROW of a per-Gaussian gradient with an element further than rel * max|ref| from ``ref`` must lie over a pixel where a
+    float32 decision flip happened (``flagged`` [H,W] bool from flip_pixels): a flip changes T for every Gaussian behind it at that
+    pixel, so it moves the gradients of the Gaussians whose footprint (centre +- radius) covers the pixel."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64).reshape(got.shape)
+    scale = float(np.abs(ref).max()) + 1e-30
+    rows = np.nonzero((np.abs(got - ref).reshape(got.shape[0], -1) > rel * scale).any(axis=1))[0]
+    H, W = flagged.shape
+    integral = np.zeros((H + 1, W + 1), dtype=np.int64)
+    integral[1:, 1:] = np.cumsum(np.cumsum(flagged.astype(np.int64), axis=0), axis=1)
+    missing = []
+    for i in rows:
+        r = int(radii[i])
+        x0, x1 = int(np.floor(xy[i, 0] - r)), int(np.ceil(xy[i, 0] + r)) + 1
+        y0, y1 = int(np.floor(xy[i, 1] - r)), int(np.ceil(xy[i, 1] + r)) + 1
+        x0, x1, y0, y1 = max(x0, 0), min(x1, W), max(y0, 0), min(y1, H)
+        n = integral[y1, x1] - integral[y0, x1] - integral[y1, x0] + integral[y0, x0] if (x1 > x0 and y1 > y0) else 0
+        if n == 0:
+            missing.append(int(i))
+    frac = float(flagged.mean())
+    print(f"{what}: {rows.size} of {got.shape[0]} rows beyond {rel:g} of max; {rows.size - len(missing)} lie over a pixel with a decision flip "
+          f"({100 * frac:.3f} % of the pixels are flagged), {len(missing)} do not")
+    assert not missing, f"{what}: gradient rows {missing[:8]} differ by more than {rel:g} of max with no decision flip under them"
+    return int(rows.size)
