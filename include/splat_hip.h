@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define SPLAT_ABI_VERSION 8        /* 8: SplatIterWorkspace.d_cam is SPLAT_ITER_DCAM floats (loss terms, status snapshot, gated-iteration count),
+#define SPLAT_ABI_VERSION 9        /* 9: scratch layouts (splat_workspace_bytes, splat_state_layout / _bind, splat_iter_workspace_layout / _bind);
+                                      8: SplatIterWorkspace.d_cam is SPLAT_ITER_DCAM floats (loss terms, status snapshot, gated-iteration count),
                                       the Adam steps skip while the capacity flag is up (SplatAdamMap.gate), per-group bc2_sqrt;
                                       7: SplatState.long_items (work-item table of the multi-workgroup sort);
                                       6: SplatState.tile_row_begin / _end, SplatLossConfig.defer_finish, splat_iter_finish (tile-row-sharded tracking);
@@ -163,9 +164,8 @@ int splat_abi_version(void);
  * name: a binding that mirrors the structs by hand (ctypes, cgo, JNA) checks its layout against it at load time. */
 size_t splat_sizeof(const char *name);
 
-/* Bytes of scratch each SplatState array needs; lets a host binding size its
- * buffers the way the reference's resize-callback does. */
 size_t splat_num_tiles(int32_t width, int32_t height);
+
 
 /* K1 + tile scan.  Replaces the first half of `_C.rasterize_gaussians`
  * (preprocess, prefix sum).  Writes depth/xy/conic_opacity/rect/radii,
@@ -340,6 +340,48 @@ typedef struct SplatIterWorkspace {
     float *outlier_err;          /* [H*W] scratch: depth error per pixel */
     uint32_t *outlier_scratch;   /* splat_map_scratch_words(H*W) words: histograms of the radix selection of torch.median */
 } SplatIterWorkspace;
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Scratch layouts: what a binding needs to size and wire the caller-owned scratch WITHOUT reading the Python binding
+ * (`splat_workspace_bytes(P, W, H, R_cap)`).  The reference extension sizes its geomBuffer / binningBuffer /
+ * imgBuffer through a resize callback into torch byte tensors; here the library describes ONE slab: every array of a SplatState
+ * (+ SplatGrads.accum) or of a SplatIterWorkspace by field name, with its size, its offset in the slab (SPLAT_SLAB_ALIGN-aligned)
+ * and whether the caller must zero it once before the first call.  `splat_*_bind` writes the pointers into the struct.
+ * A caller may also allocate the arrays one by one from `bytes` and set the pointers itself (the Python binding of the fused
+ * iteration does: its per-Gaussian arrays grow with the map).
+ * ------------------------------------------------------------------------------------------------------------ */
+#define SPLAT_SLAB_ALIGN 256
+typedef struct SplatArrayInfo {
+    const char *name;            /* field name in SplatState / SplatGrads / SplatIterWorkspace ("st.keys" for the embedded state) */
+    size_t bytes;
+    size_t offset;               /* in the slab */
+    int32_t zero_init;           /* 1: zero it once before the first call (the kernels leave it zeroed afterwards) */
+} SplatArrayInfo;
+#define SPLAT_LAYOUT_SH 1        /* shs are used: SplatState.rgb / clamped */
+#define SPLAT_LAYOUT_LONG_LISTS 2 /* lists may exceed 4 096 entries: keys_alt, long_items (always needed while the lengths are unknown) */
+#define SPLAT_LAYOUT_BACKWARD 4  /* SplatGrads.accum */
+#define SPLAT_LAYOUT_SSIM 8      /* fused iteration: ssim_maps (mapping) */
+#define SPLAT_LAYOUT_OUTLIER 16  /* fused iteration: outlier_err / outlier_scratch (ignore_outlier_depth_loss) */
+#define SPLAT_LAYOUT_MAX_ARRAYS 48
+/* One rasterizer call (forward, + backward with SPLAT_LAYOUT_BACKWARD): arrays of SplatState for P Gaussians, a width x height
+ * image, `sub_bins` counters per tile (0 / 1 = one) and lists of `capacity` instances.  Writes up to `max_entries` entries to `out`
+ * (NULL: count only) and the slab size to *total_bytes; returns the number of arrays, or -SPLAT_E_INVALID. */
+int splat_state_layout(int32_t P, int32_t width, int32_t height, int32_t sub_bins, int64_t capacity, int32_t flags,
+                       SplatArrayInfo *out, int32_t max_entries, size_t *total_bytes);
+/* Points the fields of *st (and gr->accum when gr != NULL and the layout has it) into `slab` and sets st->capacity / st->sub_bins;
+ * fields the layout does not name are left as they are. */
+int splat_state_bind(SplatState *st, SplatGrads *gr, void *slab, const SplatArrayInfo *arrays, int32_t n, int32_t sub_bins,
+                     int64_t capacity);
+/* The slab size of splat_state_layout(P, width, height, 1, capacity, SPLAT_LAYOUT_LONG_LISTS | SPLAT_LAYOUT_BACKWARD): enough for
+ * any call without SHs whose lists hold at most `capacity` instances. */
+size_t splat_workspace_bytes(int32_t P, int32_t width, int32_t height, int64_t capacity);
+/* The fused iteration's SplatIterWorkspace (its embedded state as "st.<field>"): `group_stride` records per group bucket (0: no group
+ * binning).  Not in the layout: the gradient outputs d_* and max_2D_radius (the caller's own tensors). */
+int splat_iter_workspace_layout(int32_t P, int32_t width, int32_t height, int64_t capacity, int32_t group_stride, int32_t flags,
+                                SplatArrayInfo *out, int32_t max_entries, size_t *total_bytes);
+int splat_iter_workspace_bind(SplatIterWorkspace *ws, void *slab, const SplatArrayInfo *arrays, int32_t n, int64_t capacity,
+                              int32_t group_stride);
+size_t splat_iter_workspace_bytes(int32_t P, int32_t width, int32_t height, int64_t capacity, int32_t group_stride, int32_t flags);
 
 /* get_loss + loss.backward() of one iteration.  On return (stream order) ws->d_* hold the gradients and
  * ws->d_cam[7] the loss value.  The fused iteration renders on a ZERO background, as setup_camera builds it

@@ -134,14 +134,17 @@ class CRef:
                     conic_op=self._arr("ref_geom_conic_op", 4 * self.P, self.dt).reshape(-1, 4),
                     depth=self._arr("ref_geom_depth", self.P, self.dt))
 
-    def flip_bounds(self, tol=2e-3, tie_tol=1e-6):
-        """Per pixel and output channel (the C colour channels, then depth): how much ONE float32 decision flip can move the pixel --
+    def flip_bounds(self, tol=2e-3, tie_tol=1e-6, ulps=None):
+        """Per pixel and output channel (the C colour channels, then depth): how much float32 decision flips can move the pixel --
         summed over the decisions of the last forward that were within ``tol`` (relative) of their threshold, or depth ties within
-        ``tie_tol`` -- and the smallest margin of any decision of the pixel.  See ref_flip_bounds in raster_ref.c."""
+        ``tie_tol`` -- and the smallest margin of any decision of the pixel.  With ``ulps``: also the pixel's sensitivity to ``ulps``
+        float32 ulps of rounding in the projected centres (third result).  See ref_flip_bounds in raster_ref.c."""
         bound = np.zeros((self.C + 1, self.H, self.W), self.dt)
         margin = np.zeros((self.H, self.W), self.dt)
-        self.L.ref_flip_bounds(self.ctx, self._p(self.a['colors']), self.ct(tol), self.ct(tie_tol), self._p(bound), self._p(margin))
-        return bound, margin
+        noise = np.zeros((self.C + 1, self.H, self.W), self.dt) if ulps is not None else None
+        self.L.ref_flip_bounds(self.ctx, self._p(self.a['colors']), self.ct(tol), self.ct(tie_tol), self._p(bound), self._p(margin),
+                               self.ct(ulps or 0.0), self._p(noise))
+        return (bound, margin) if ulps is None else (bound, margin, noise)
 
     def backward(self, dL_dcolor):
         a = self.a

@@ -252,7 +252,7 @@ int ref_forward(ref_ctx *c, int P, int C, int W, int H,
  * with cmax the largest |colour| of the tile's list.  bound: [(C + 1), H, W] (channel C is the depth output); margin: [H, W], the
  * smallest relative margin of any decision of the pixel (reported, to show how close the flipped decisions were).  Meant for the
  * float64 build: margins measured there hold for every float32 evaluation. */
-void ref_flip_bounds(const ref_ctx *c, const real *colors, real tol, real tie_tol, real *bound, real *margin)
+void ref_flip_bounds(const ref_ctx *c, const real *colors, real tol, real tie_tol, real *bound, real *margin, real ulps, real *noise)
 {
     const int C = c->C, W = c->W, H = c->H, gx = c->gx, tiles = c->gx * c->gy;
     const size_t HW = (size_t)W * H;
@@ -311,6 +311,60 @@ void ref_flip_bounds(const ref_ctx *c, const real *colors, real tol, real tie_to
             size_t pix = (size_t)py * W + px;
             margin[pix] = mmin;
             for (int ch = 0; ch <= C; ch++) bound[(size_t)ch * HW + pix] = b[ch];
+            if (noise) {
+                /* Sensitivity to the float32 rounding of the projected CENTRES (no decision involved).  A centre at pixel coordinate
+                 * ~1e3 is known to `ulps` x 2^-23 x 1e3 ~ 1e-4 px in float32 (projection: a quotient and an affine map; the fused
+                 * path's in-kernel transform rounds differently from torch's); that moves power_k by |grad power| d ~ 1e-4 and alpha_k
+                 * by as much relatively, and the pixel by  |dC/dalpha_k| alpha_k dpower_k  with  dC/dalpha_k = T_k c_k - after_k / (1 -
+                 * alpha_k)  (what the backward pass calls dL/dalpha): weight moves between Gaussians of different colour / depth while
+                 * the silhouette hardly changes.  noise[ch] = the sum over the pixel's contributors: how far two CORRECT float32
+                 * evaluations may differ at this pixel without any decision flipping. */
+                real tot[MAXC + 1] = {0};
+                real T2 = 1.f;
+                int stop = e;
+                for (int k = s; k < e; k++) {               /* pass 1: the pixel's totals */
+                    int id = c->list[k];
+                    real dx = c->xy[2 * id] - (real)px, dy = c->xy[2 * id + 1] - (real)py;
+                    const real *co = c->conic_op + 4 * id;
+                    real power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > 0.f) continue;
+                    real alpha = R_MIN(0.99f, co[3] * R_EXP(power));
+                    if (alpha < 1.f / 255.f) continue;
+                    real test_T = T2 * (1.f - alpha);
+                    if (test_T < 0.0001f) { stop = k; break; }
+                    for (int ch = 0; ch < C; ch++) tot[ch] += colors[(size_t)id * C + ch] * alpha * T2;
+                    tot[C] += c->depth[id] * alpha * T2;
+                    T2 = test_T;
+                }
+                real pre[MAXC + 1] = {0}, nz[MAXC + 1] = {0};
+                T2 = 1.f;
+                const real eps = ulps * 1.1920929e-7f;
+                for (int k = s; k < stop; k++) {            /* pass 2: every contributor's share */
+                    int id = c->list[k];
+                    real dx = c->xy[2 * id] - (real)px, dy = c->xy[2 * id + 1] - (real)py;
+                    const real *co = c->conic_op + 4 * id;
+                    real power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > 0.f) continue;
+                    real a_raw = co[3] * R_EXP(power);
+                    real alpha = R_MIN(0.99f, a_raw);
+                    if (alpha < 1.f / 255.f) continue;
+                    real gxp = co[0] * dx + co[1] * dy, gyp = co[2] * dy + co[1] * dx;
+                    real ax = c->xy[2 * id], ay = c->xy[2 * id + 1];
+                    ax = ax < 0 ? -ax : ax; ay = ay < 0 ? -ay : ay;
+                    real dpow = (gxp < 0 ? -gxp : gxp) * eps * R_MAX(ax, 1.f) + (gyp < 0 ? -gyp : gyp) * eps * R_MAX(ay, 1.f);
+                    real dalpha = a_raw < 0.99f ? alpha * dpow : 0.f;
+                    for (int ch = 0; ch <= C; ch++) {
+                        real col = ch < C ? colors[(size_t)id * C + ch] : c->depth[id];
+                        real own = col * alpha * T2;
+                        real after = tot[ch] - pre[ch] - own;
+                        real dC = T2 * col - after / (1.f - alpha);
+                        nz[ch] += (dC < 0 ? -dC : dC) * dalpha;
+                        pre[ch] += own;
+                    }
+                    T2 *= (1.f - alpha);
+                }
+                for (int ch = 0; ch <= C; ch++) noise[(size_t)ch * HW + pix] = nz[ch];
+            }
         }
     }
     /* Per-GAUSSIAN decisions: the tile rectangle.  radius = ceil(3 sqrt(lambda)) and the rectangle's edges (int)((p -+ radius [+ 15]) /

@@ -18,7 +18,7 @@ SPLAT_MAX_CHANNELS = 8
 SPLAT_GRAD_STRIDE = 16
 SPLAT_COUNTER_STRIDE = 32
 SPLAT_GROUP_TILES = 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -111,8 +111,12 @@ class SplatPoseAdam(C.Structure):
                 ("step_size_rot", C.c_float), ("step_size_trans", C.c_float)]
 
 
+class SplatArrayInfo(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("bytes", C.c_size_t), ("offset", C.c_size_t), ("zero_init", C.c_int32)]
+
+
 MIRRORED_STRUCTS = (SplatCamera, SplatGaussians, SplatState, SplatGrads, SplatMap, SplatFrameData, SplatLossConfig, SplatIterWorkspace,
-                    SplatAdamMap, SplatMapStore, SplatAddArgs, SplatPruneArgs, SplatDensifyArgs, SplatPoseAdam)
+                    SplatAdamMap, SplatMapStore, SplatAddArgs, SplatPruneArgs, SplatDensifyArgs, SplatPoseAdam, SplatArrayInfo)
 
 
 SPLAT_ADD_VALID_DEPTH = 0
@@ -123,6 +127,9 @@ SPLAT_ITER_SUMS = 32
 SPLAT_ITER_SUM_COPIES = 64
 SPLAT_POSE_STATE = 24
 SPLAT_ITER_DCAM = 32
+SPLAT_SLAB_ALIGN = 256
+SPLAT_LAYOUT_SH, SPLAT_LAYOUT_LONG_LISTS, SPLAT_LAYOUT_BACKWARD, SPLAT_LAYOUT_SSIM, SPLAT_LAYOUT_OUTLIER = 1, 2, 4, 8, 16
+SPLAT_LAYOUT_MAX_ARRAYS = 48
 
 EXPORTS = (
     "splat_error_string", "splat_abi_version", "splat_sizeof", "splat_num_tiles",
@@ -132,6 +139,8 @@ EXPORTS = (
     "splat_iter_loss_backward", "splat_iter_adam_map", "splat_iter_adam_pose", "splat_iter_time_kernel",
     "splat_iter_tracking_step", "splat_iter_mapping_step", "splat_iter_finish", "splat_iter_fold_sums", "splat_iter_render", "splat_map_scratch_words", "splat_map_row_floats", "splat_map_add_new_gaussians", "splat_map_prune",
     "splat_iter_means2d_accumulate", "splat_map_densify_select", "splat_map_duplicate",
+    "splat_workspace_bytes", "splat_state_layout", "splat_state_bind", "splat_iter_workspace_layout", "splat_iter_workspace_bind",
+    "splat_iter_workspace_bytes",
 )
 
 _lib = None
@@ -210,6 +219,19 @@ def lib():
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [C.POINTER(SplatMapStore), C.POINTER(SplatDensifyArgs), _fp]
+    info = C.POINTER(SplatArrayInfo)
+    L.splat_workspace_bytes.restype = C.c_size_t
+    L.splat_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64]
+    L.splat_state_layout.restype = C.c_int
+    L.splat_state_layout.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, info, C.c_int32, C.POINTER(C.c_size_t)]
+    L.splat_state_bind.restype = C.c_int
+    L.splat_state_bind.argtypes = [st, gr, _fp, info, C.c_int32, C.c_int32, C.c_int64]
+    L.splat_iter_workspace_layout.restype = C.c_int
+    L.splat_iter_workspace_layout.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, info, C.c_int32, C.POINTER(C.c_size_t)]
+    L.splat_iter_workspace_bind.restype = C.c_int
+    L.splat_iter_workspace_bind.argtypes = [C.POINTER(SplatIterWorkspace), _fp, info, C.c_int32, C.c_int64, C.c_int32]
+    L.splat_iter_workspace_bytes.restype = C.c_size_t
+    L.splat_iter_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32]
     L.splat_debug_option.restype = C.c_int
     L.splat_debug_option.argtypes = [C.c_int, C.c_int]
     L.splat_debug_stamps.restype = C.c_int
@@ -227,6 +249,36 @@ def lib():
                                f"{C.sizeof(cls)} in the binding")
     _lib = L
     return L
+
+
+class Layout:
+    """A scratch layout as the library describes it (include/splat_hip.h, "Scratch layouts"): ``arrays`` (the C table, for
+    splat_*_bind), ``n``, ``total`` bytes of the slab, and by field name ``bytes`` / ``offset`` / ``zero_init``."""
+
+    def __init__(self, arrays, n, total):
+        self.arrays, self.n, self.total = arrays, n, total
+        self.names = [arrays[i].name.decode() for i in range(n)]
+        self.bytes = {self.names[i]: int(arrays[i].bytes) for i in range(n)}
+        self.offset = {self.names[i]: int(arrays[i].offset) for i in range(n)}
+        self.zero_init = {self.names[i]: bool(arrays[i].zero_init) for i in range(n)}
+
+
+def state_layout(P, width, height, sub_bins, capacity, flags):
+    arrays = (SplatArrayInfo * SPLAT_LAYOUT_MAX_ARRAYS)()
+    total = C.c_size_t(0)
+    n = lib().splat_state_layout(P, width, height, sub_bins, capacity, flags, arrays, SPLAT_LAYOUT_MAX_ARRAYS, C.byref(total))
+    if n < 0 or n > SPLAT_LAYOUT_MAX_ARRAYS:
+        raise RuntimeError(f"splat_state_layout({P}, {width}, {height}, {sub_bins}, {capacity}, {flags}) failed: {n}")
+    return Layout(arrays, n, int(total.value))
+
+
+def iter_workspace_layout(P, width, height, capacity, group_stride, flags):
+    arrays = (SplatArrayInfo * SPLAT_LAYOUT_MAX_ARRAYS)()
+    total = C.c_size_t(0)
+    n = lib().splat_iter_workspace_layout(P, width, height, capacity, group_stride, flags, arrays, SPLAT_LAYOUT_MAX_ARRAYS, C.byref(total))
+    if n < 0 or n > SPLAT_LAYOUT_MAX_ARRAYS:
+        raise RuntimeError(f"splat_iter_workspace_layout({P}, {width}, {height}, {capacity}, {group_stride}, {flags}) failed: {n}")
+    return Layout(arrays, n, int(total.value))
 
 
 def check(rc: int, what: str):

@@ -55,7 +55,7 @@ size_t splat_sizeof(const char *name) {
     SPLAT_SIZEOF_CASE(SplatCamera); SPLAT_SIZEOF_CASE(SplatGaussians); SPLAT_SIZEOF_CASE(SplatState); SPLAT_SIZEOF_CASE(SplatGrads);
     SPLAT_SIZEOF_CASE(SplatMap); SPLAT_SIZEOF_CASE(SplatFrameData); SPLAT_SIZEOF_CASE(SplatLossConfig); SPLAT_SIZEOF_CASE(SplatIterWorkspace);
     SPLAT_SIZEOF_CASE(SplatAdamMap); SPLAT_SIZEOF_CASE(SplatPoseAdam); SPLAT_SIZEOF_CASE(SplatMapStore); SPLAT_SIZEOF_CASE(SplatAddArgs);
-    SPLAT_SIZEOF_CASE(SplatPruneArgs); SPLAT_SIZEOF_CASE(SplatDensifyArgs);
+    SPLAT_SIZEOF_CASE(SplatPruneArgs); SPLAT_SIZEOF_CASE(SplatDensifyArgs); SPLAT_SIZEOF_CASE(SplatArrayInfo);
 #undef SPLAT_SIZEOF_CASE
     return 0;
 }
@@ -378,6 +378,156 @@ int splat_debug_stamps(void *buffer) {
 // test hook (tests/test_gpu_primitives.py): see launch_selftest in binning.hip
 int splat_selftest(int which, const void *in, void *out, int n, void *stream) {
     return check(launch_selftest(which, in, out, n, (hipStream_t)stream));
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// scratch layouts (include/splat_hip.h: "Scratch layouts")
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct LayoutWriter {
+    SplatArrayInfo *out;
+    int32_t max_entries, n = 0;
+    size_t offset = 0;
+    void add(const char *name, size_t bytes, int zero_init) {
+        offset = (offset + SPLAT_SLAB_ALIGN - 1) / SPLAT_SLAB_ALIGN * SPLAT_SLAB_ALIGN;
+        if (out && n < max_entries) out[n] = SplatArrayInfo{name, bytes, offset, zero_init};
+        ++n;
+        offset += bytes;
+    }
+};
+
+// the arrays of a SplatState; `prefix`: the names as fields of SplatState ("") or of SplatIterWorkspace ("st.").  `iter`: the fused
+// iteration's state (bucketed lists + group binning + launch order; its counters must start zeroed: no memset launches in the loop)
+void state_arrays(LayoutWriter &w, bool iter, int32_t P, int32_t width, int32_t height, int32_t sub_bins, int64_t capacity,
+                  int32_t group_stride, int32_t flags) {
+    const size_t T = splat_num_tiles(width, height), S = sub_bins > 1 ? (size_t)sub_bins : 1, n = (size_t)P, cap = (size_t)capacity;
+    const size_t G = (size_t)(((width + SPLAT_TILE - 1) / SPLAT_TILE + SPLAT_GROUP_TILES - 1) / SPLAT_GROUP_TILES) *
+                     (size_t)(((height + SPLAT_TILE - 1) / SPLAT_TILE + SPLAT_GROUP_TILES - 1) / SPLAT_GROUP_TILES);
+    const size_t HW = (size_t)width * (size_t)height;
+    const int z = iter ? 1 : 0;
+#define NAME(f) (iter ? "st." f : f)
+    w.add(NAME("depth"), 4 * n, 0);
+    w.add(NAME("xy"), 8 * n, 0);
+    w.add(NAME("conic_opacity"), 16 * n, 0);
+    w.add(NAME("rect"), 8 * n, 0);
+    w.add(NAME("radii"), 4 * n, z);
+    if (flags & SPLAT_LAYOUT_SH) {
+        w.add(NAME("rgb"), 12 * n, 0);
+        w.add(NAME("clamped"), 3 * n, 0);
+    }
+    w.add(NAME("tile_count"), 4 * T * S * SPLAT_COUNTER_STRIDE, z);
+    w.add(NAME("tile_base"), 4 * (T + 1), 0);
+    w.add(NAME("tile_cursor"), 4 * T * S * SPLAT_COUNTER_STRIDE, 0);
+    w.add(NAME("keys"), 8 * cap, 0);
+    w.add(NAME("point_list"), 4 * cap, 0);
+    if (flags & SPLAT_LAYOUT_LONG_LISTS) {
+        w.add(NAME("keys_alt"), 8 * cap, 0);
+        w.add(NAME("long_items"), 4 * (cap / 1024 + T + 1), 0);
+    }
+    w.add(NAME("long_base"), 4 * (T + 1), z);
+    if (iter) {
+        w.add("st.group_count", 4 * G * SPLAT_COUNTER_STRIDE, 1);
+        if (group_stride > 0) w.add("st.group_recs", 16 * G * (size_t)group_stride, 0);
+        w.add("st.tile_work", 4 * T, 1);
+        w.add("st.tile_order", 4 * 8 * ((T + 7) / 8), 0);        // the caller fills it with the natural order (0xFFFFFFFF = no tile)
+    }
+    w.add(NAME("final_T"), 4 * HW, 0);
+    w.add(NAME("n_contrib"), 4 * HW, 0);
+    w.add(NAME("status"), 4 * 4, z);
+#undef NAME
+}
+
+bool layout_args_ok(int32_t P, int32_t width, int32_t height, int64_t capacity) {
+    return P >= 0 && width > 0 && height > 0 && capacity >= 0 && width <= 65535 * SPLAT_TILE && height <= 65535 * SPLAT_TILE;
+}
+}  // namespace
+
+extern "C" {
+
+int splat_state_layout(int32_t P, int32_t width, int32_t height, int32_t sub_bins, int64_t capacity, int32_t flags,
+                       SplatArrayInfo *out, int32_t max_entries, size_t *total_bytes) {
+    if (!layout_args_ok(P, width, height, capacity) || sub_bins < 0 || (sub_bins & (sub_bins - 1)) != 0) return -SPLAT_E_INVALID;
+    LayoutWriter w{out, max_entries};
+    state_arrays(w, false, P, width, height, sub_bins, capacity, 0, flags);
+    if (flags & SPLAT_LAYOUT_BACKWARD) w.add("accum", 4 * (size_t)SPLAT_GRAD_STRIDE * (size_t)P, 0);
+    if (total_bytes) *total_bytes = (w.offset + SPLAT_SLAB_ALIGN - 1) / SPLAT_SLAB_ALIGN * SPLAT_SLAB_ALIGN;
+    return w.n;
+}
+
+size_t splat_workspace_bytes(int32_t P, int32_t width, int32_t height, int64_t capacity) {
+    size_t total = 0;
+    if (splat_state_layout(P, width, height, 1, capacity, SPLAT_LAYOUT_LONG_LISTS | SPLAT_LAYOUT_BACKWARD, nullptr, 0, &total) < 0) return 0;
+    return total;
+}
+
+int splat_state_bind(SplatState *st, SplatGrads *gr, void *slab, const SplatArrayInfo *arrays, int32_t n, int32_t sub_bins,
+                     int64_t capacity) {
+    if (!st || !slab || !arrays || n < 0 || ((uintptr_t)slab % SPLAT_SLAB_ALIGN) != 0) return SPLAT_E_INVALID;
+    char *base = static_cast<char *>(slab);
+    for (int32_t i = 0; i < n; ++i) {
+        const char *name = arrays[i].name;
+        void *p = base + arrays[i].offset;
+        if (!name) return SPLAT_E_INVALID;
+        if (strncmp(name, "st.", 3) == 0) name += 3;
+#define BIND(field, T) if (strcmp(name, #field) == 0) { st->field = static_cast<T>(p); continue; }
+        BIND(depth, float *) BIND(xy, float *) BIND(conic_opacity, float *) BIND(rect, uint32_t *) BIND(radii, int32_t *)
+        BIND(rgb, float *) BIND(clamped, uint8_t *) BIND(tile_count, uint32_t *) BIND(tile_base, uint32_t *) BIND(tile_cursor, uint32_t *)
+        BIND(keys, uint64_t *) BIND(point_list, uint32_t *) BIND(keys_alt, uint64_t *) BIND(long_base, uint32_t *) BIND(long_items, uint32_t *)
+        BIND(group_count, uint32_t *) BIND(group_recs, uint32_t *) BIND(tile_work, uint32_t *) BIND(tile_order, uint32_t *)
+        BIND(final_T, float *) BIND(n_contrib, int32_t *) BIND(status, int32_t *)
+#undef BIND
+        if (strcmp(name, "accum") == 0) { if (gr) gr->accum = static_cast<float *>(p); continue; }
+    }
+    st->capacity = capacity;
+    st->sub_bins = sub_bins;
+    return SPLAT_OK;
+}
+
+int splat_iter_workspace_layout(int32_t P, int32_t width, int32_t height, int64_t capacity, int32_t group_stride, int32_t flags,
+                                SplatArrayInfo *out, int32_t max_entries, size_t *total_bytes) {
+    if (!layout_args_ok(P, width, height, capacity) || group_stride < 0) return -SPLAT_E_INVALID;
+    LayoutWriter w{out, max_entries};
+    const size_t n = (size_t)P, HW = (size_t)width * (size_t)height;
+    state_arrays(w, true, P, width, height, 1, capacity, group_stride, flags | SPLAT_LAYOUT_LONG_LISTS);
+    w.add("feat8", 4 * 8 * n, 0);
+    w.add("out6", 4 * 6 * HW, 0);
+    w.add("dL_dout6", 4 * 6 * HW, 1);
+    w.add("accum", 4 * (size_t)SPLAT_GRAD_STRIDE * n, 1);
+    if (flags & SPLAT_LAYOUT_SSIM) w.add("ssim_maps", 4 * 9 * HW, 0);
+    w.add("sums", 8 * (size_t)SPLAT_ITER_SUM_COPIES * SPLAT_ITER_SUMS, 1);
+    w.add("d_cam", 4 * SPLAT_ITER_DCAM, 1);
+    if (flags & SPLAT_LAYOUT_OUTLIER) {
+        w.add("outlier_err", 4 * HW, 0);
+        w.add("outlier_scratch", 4 * splat_map_scratch_words((int64_t)HW), 1);
+    }
+    if (total_bytes) *total_bytes = (w.offset + SPLAT_SLAB_ALIGN - 1) / SPLAT_SLAB_ALIGN * SPLAT_SLAB_ALIGN;
+    return w.n;
+}
+
+size_t splat_iter_workspace_bytes(int32_t P, int32_t width, int32_t height, int64_t capacity, int32_t group_stride, int32_t flags) {
+    size_t total = 0;
+    if (splat_iter_workspace_layout(P, width, height, capacity, group_stride, flags, nullptr, 0, &total) < 0) return 0;
+    return total;
+}
+
+int splat_iter_workspace_bind(SplatIterWorkspace *ws, void *slab, const SplatArrayInfo *arrays, int32_t n, int64_t capacity,
+                              int32_t group_stride) {
+    if (!ws) return SPLAT_E_INVALID;
+    int rc = splat_state_bind(&ws->st, nullptr, slab, arrays, n, 1, capacity);
+    if (rc) return rc;
+    char *base = static_cast<char *>(slab);
+    for (int32_t i = 0; i < n; ++i) {
+        const char *name = arrays[i].name;
+        void *p = base + arrays[i].offset;
+#define BIND(field, T) if (strcmp(name, #field) == 0) { ws->field = static_cast<T>(p); continue; }
+        BIND(feat8, float *) BIND(out6, float *) BIND(dL_dout6, float *) BIND(accum, float *) BIND(ssim_maps, float *)
+        BIND(sums, double *) BIND(d_cam, float *) BIND(outlier_err, float *) BIND(outlier_scratch, uint32_t *)
+#undef BIND
+    }
+    ws->st.group_stride = ws->st.group_recs ? group_stride : 0;
+    return SPLAT_OK;
 }
 
 }  // extern "C"

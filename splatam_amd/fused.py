@@ -65,41 +65,23 @@ class FusedEngine:
         self.num_frames = params['cam_unnorm_rots'].shape[-1]
         H, W = int(cam.image_height), int(cam.image_width)
         self.H, self.W = H, W
-        T = ((W + 15) // 16) * ((H + 15) // 16)
+        T = int(self.L.splat_num_tiles(W, H))
         f32, i32 = torch.float32, torch.int32
-        CS = _capi.SPLAT_COUNTER_STRIDE
         self.capacity = int(capacity) if capacity else 4 * P + 65536
         z = dict(device=dev)
         b = self.buf = {}
-        b['conic'] = torch.empty(P_alloc, 4, dtype=f32, **z)
-        b['xy'] = torch.empty(P_alloc, 2, dtype=f32, **z)
-        b['rect'] = torch.empty(P_alloc, 2, dtype=i32, **z)
-        b['depth'] = torch.empty(P_alloc, dtype=f32, **z)
-        b['radii'] = torch.zeros(P_alloc, dtype=i32, **z)
-        b['tile_count'] = torch.zeros(T * CS, dtype=i32, **z)
-        b['tile_base'] = torch.empty(T + 1, dtype=i32, **z)
-        b['tile_cursor'] = torch.empty(T * CS, dtype=i32, **z)
-        b['long_base'] = torch.zeros(T + 1, dtype=i32, **z)
+        # every array of the iteration's workspace is sized by the LIBRARY (splat_iter_workspace_layout, include/splat_hip.h "Scratch
+        # layouts"); they are tensors of their own here because the per-Gaussian ones grow with the map (_grow_rows / rebind)
+        self._alloc_fixed(self._layout(P_alloc))
+        self._alloc_rows(self._layout(P_alloc))
         GT = _capi.SPLAT_GROUP_TILES
         self.num_groups = (((W + 15) // 16 + GT - 1) // GT) * (((H + 15) // 16 + GT - 1) // GT)
-        b['group_count'] = torch.zeros(self.num_groups * CS, dtype=i32, **z)
-        b['status'] = torch.zeros(4, dtype=i32, **z)
         # launch order of the composites' workgroups (SplatState.tile_work / tile_order): heaviest tiles of every XCD band first
         per = (T + 7) // 8
         nat = torch.arange(8 * per, dtype=torch.int64)
         b['tile_order'] = torch.where(nat < T, nat, torch.full_like(nat, 0xFFFFFFFF)).to(torch.uint32).view(i32).to(dev) \
             if hasattr(torch, "uint32") else None
-        b['tile_work'] = torch.zeros(T, dtype=i32, **z)
         self.tile_order_on = os.environ.get("SPLAT_TILE_ORDER", "1") != "0" and b['tile_order'] is not None
-        b['final_T'] = torch.empty(H, W, dtype=f32, **z)
-        b['n_contrib'] = torch.empty(H, W, dtype=i32, **z)
-        b['feat8'] = torch.empty(P_alloc, 8, dtype=f32, **z)
-        b['out6'] = torch.empty(6, H, W, dtype=f32, **z)
-        b['dL_dout6'] = torch.zeros(6, H, W, dtype=f32, **z)
-        b['accum'] = torch.zeros(P_alloc, _capi.SPLAT_GRAD_STRIDE, dtype=f32, **z)
-        b['ssim_maps'] = torch.empty(9, H, W, dtype=f32, **z)
-        b['sums'] = torch.zeros(_capi.SPLAT_ITER_SUM_COPIES * _capi.SPLAT_ITER_SUMS, dtype=torch.float64, **z)
-        b['d_cam'] = torch.zeros(_capi.SPLAT_ITER_DCAM, dtype=f32, **z)
         b['pose_state'] = torch.zeros(_capi.SPLAT_POSE_STATE, dtype=f32, **z)
         self.max_2D_radius = self.store['max_2D_radius'] if self.managed else track_max_radius
         b['counts'] = torch.zeros(8, dtype=i32, **z)
@@ -141,6 +123,37 @@ class FusedEngine:
         self._learnt_P = None           # rows of the map the list statistics were learnt on (rebind keeps them for a similar map)
 
     # ------------------------------------------------------------------ capacity-managed map
+    # workspace arrays by the library's field names: (key in self.buf, dtype, trailing shape); per-Gaussian ones grow with the map
+    _ROW_ARRAYS = (("st.conic_opacity", "conic", torch.float32, (4,)), ("st.xy", "xy", torch.float32, (2,)), ("st.rect", "rect", torch.int32, (2,)),
+                   ("st.depth", "depth", torch.float32, ()), ("st.radii", "radii", torch.int32, ()), ("feat8", "feat8", torch.float32, (8,)),
+                   ("accum", "accum", torch.float32, (_capi.SPLAT_GRAD_STRIDE,)))
+    _FIXED_ARRAYS = (("st.tile_count", "tile_count", torch.int32), ("st.tile_base", "tile_base", torch.int32),
+                     ("st.tile_cursor", "tile_cursor", torch.int32), ("st.long_base", "long_base", torch.int32),
+                     ("st.group_count", "group_count", torch.int32), ("st.status", "status", torch.int32),
+                     ("st.tile_work", "tile_work", torch.int32), ("st.final_T", "final_T", torch.float32),
+                     ("st.n_contrib", "n_contrib", torch.int32), ("out6", "out6", torch.float32), ("dL_dout6", "dL_dout6", torch.float32),
+                     ("ssim_maps", "ssim_maps", torch.float32), ("sums", "sums", torch.float64), ("d_cam", "d_cam", torch.float32))
+
+    def _layout(self, rows, capacity=0, group_stride=0, outlier=False):
+        flags = _capi.SPLAT_LAYOUT_SSIM | (_capi.SPLAT_LAYOUT_OUTLIER if outlier else 0)
+        return _capi.iter_workspace_layout(int(rows), self.W, self.H, int(capacity), int(group_stride), flags)
+
+    def _new(self, lay, name, dtype, tail=()):
+        n = lay.bytes[name] // torch.empty((), dtype=dtype).element_size()
+        t = (torch.zeros if lay.zero_init[name] else torch.empty)(n, dtype=dtype, device=self.dev)
+        return t.view((-1,) + tuple(tail)) if tail else t
+
+    def _alloc_fixed(self, lay):
+        for name, key, dtype in self._FIXED_ARRAYS:
+            self.buf[key] = self._new(lay, name, dtype)
+        H, W = self.H, self.W
+        for key, lead in (('final_T', ()), ('n_contrib', ()), ('out6', (6,)), ('dL_dout6', (6,)), ('ssim_maps', (9,))):
+            self.buf[key] = self.buf[key].view(lead + (H, W))
+
+    def _alloc_rows(self, lay):
+        for name, key, dtype, tail in self._ROW_ARRAYS:
+            self.buf[key] = self._new(lay, name, dtype, tail)
+
     def _adopt(self, params, variables):
         """Move the caller's Gaussian tensors into backing arrays of ``self.Pcap`` rows."""
         dev, P = self.dev, self.P
@@ -209,9 +222,7 @@ class FusedEngine:
             # by the per-Gaussian kernel before they are read
             cap = P + P // 8 + 1024
             f32, i32, b = torch.float32, torch.int32, self.buf
-            for k, shape, dt in (('conic', (4,), f32), ('xy', (2,), f32), ('rect', (2,), i32), ('depth', (), f32), ('radii', (), i32),
-                                 ('feat8', (8,), f32), ('accum', (_capi.SPLAT_GRAD_STRIDE,), f32)):
-                b[k] = torch.zeros((cap,) + shape, dtype=dt, device=dev)
+            self._alloc_rows(self._layout(cap))
             self._grad_store = torch.zeros(_FLAG_SLOTS + sum(self._widths) * cap, dtype=f32, device=dev)
             self._m_store = {k: torch.zeros(cap, w, dtype=f32, device=dev) for k, w in zip(PARAM_ORDER, self._widths)}
             self._v_store = {k: torch.zeros(cap, w, dtype=f32, device=dev) for k, w in zip(PARAM_ORDER, self._widths)}
@@ -244,9 +255,7 @@ class FusedEngine:
             self._m_store[k] = grown(self._m_store[k], self.Pcap)
             self._v_store[k] = grown(self._v_store[k], self.Pcap)
         self._grad_store = torch.zeros(_FLAG_SLOTS + sum(self._widths) * self.Pcap, dtype=f32, device=dev)
-        for k, shape, dt in (('conic', (4,), f32), ('xy', (2,), f32), ('rect', (2,), i32), ('depth', (), f32), ('radii', (), i32),
-                             ('feat8', (8,), f32), ('accum', (_capi.SPLAT_GRAD_STRIDE,), f32)):
-            b[k] = torch.zeros((self.Pcap,) + shape, dtype=dt, device=dev)
+        self._alloc_rows(self._layout(self.Pcap))
         b.pop('flags', None)
         b.pop('stage', None)
         b.pop('map_scratch', None)
@@ -529,11 +538,12 @@ class FusedEngine:
     # ------------------------------------------------------------------ plumbing
     def _alloc_lists(self, capacity):
         self.capacity = int(capacity)
-        self.buf['keys'] = torch.empty(self.capacity, dtype=torch.int64, device=self.dev)
-        self.buf['keys_alt'] = torch.empty(self.capacity, dtype=torch.int64, device=self.dev)     # merge passes of lists beyond LDS
-        self.buf['point_list'] = torch.empty(self.capacity, dtype=torch.int32, device=self.dev)
-        # work-item table of the multi-workgroup sort (SplatState.long_items): one word per 1024 keys of a long list
-        self.buf['long_items'] = torch.empty(self.capacity // 1024 + self.num_tiles + 1, dtype=torch.int32, device=self.dev)
+        lay = self._layout(0, capacity=self.capacity)
+        for name, key, dtype in (("st.keys", "keys", torch.int64), ("st.keys_alt", "keys_alt", torch.int64),        # keys_alt: merge passes of lists beyond LDS
+                                 ("st.point_list", "point_list", torch.int32),
+                                 # work-item table of the multi-workgroup sort (SplatState.long_items): one word per 1024 keys of a long list
+                                 ("st.long_items", "long_items", torch.int32)):
+            self.buf[key] = self._new(lay, name, dtype)
 
     def _make_cam(self, settings):
         bg = _cached_contiguous(settings.bg)
@@ -602,7 +612,8 @@ class FusedEngine:
             need = self.num_groups * gs * 4
             if need <= 1 << 30:                       # (int32 words; 4 GiB of records)
                 if b.get('group_recs') is None or b['group_recs'].numel() < need:
-                    b['group_recs'] = torch.empty(need, dtype=torch.int32, device=self.dev)
+                    b['group_recs'] = self._new(self._layout(0, group_stride=gs), "st.group_recs", torch.int32)
+                    assert b['group_recs'].numel() == need
                 st.group_recs, st.group_stride = b['group_recs'].data_ptr(), gs
         st.order_hint = int(self.creation_order)
         if self.tile_order_on:
@@ -666,9 +677,9 @@ class FusedEngine:
         self._stats_partial = tile_rows is not None
         self._lc_keep = lc
         if lc.ignore_outlier_depth_loss and 'outlier_err' not in self.buf:       # scratch of the median selection, on first use
-            self.buf['outlier_err'] = torch.empty(self.H * self.W, dtype=torch.float32, device=self.dev)
-            self.buf['outlier_scratch'] = torch.zeros(int(self.L.splat_map_scratch_words(self.H * self.W)), dtype=torch.int32,
-                                                      device=self.dev)
+            lay = self._layout(0, outlier=True)
+            self.buf['outlier_err'] = self._new(lay, "outlier_err", torch.float32)
+            self.buf['outlier_scratch'] = self._new(lay, "outlier_scratch", torch.int32)
         ws = self._workspace(map_grads, with_ssim=not tracking)
         m = self._map_struct()
         with torch.cuda.device(self.dev):

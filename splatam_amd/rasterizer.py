@@ -149,48 +149,33 @@ _longest_seen: dict = {}   # (device, P, H, W) -> longest per-tile list of the l
 
 
 def _alloc_state(pk: _Pack, dev, P: int, H: int, W: int, use_sh: bool):
-    """Per-call scratch (the reference's geomBuffer / imgBuffer): one int32 slab
-    for the per-Gaussian + per-tile words, torch's caching allocator makes this a
-    host-side pointer bump."""
-    T = ((W + 15) // 16) * ((H + 15) // 16)
+    """Per-call scratch (the reference's geomBuffer / imgBuffer): ONE slab laid out by the library (splat_state_layout /
+    splat_state_bind, include/splat_hip.h "Scratch layouts": sizes, offsets and alignment are the C side's, not this file's);
+    torch's caching allocator makes it a host-side pointer bump.  The lists (keys / point_list ...) follow in _alloc_lists once the
+    number of instances is known; radii / final_T / n_contrib are tensors of their own (an output; replaced when a second call
+    shares the first call's geometry)."""
     f32, i32 = torch.float32, torch.int32
-    CS = _capi.SPLAT_COUNTER_STRIDE
     # very long per-tile lists (clustered scenes): spread each tile's count / scatter atomics over several counters
     S = SUB_BINS_LONG if _longest_seen.get((dev.index, P, H, W), 0) > 2048 else 1
-    pk.st.sub_bins = S
-    geom = torch.empty(P * 9 + (2 * CS * S + 2) * T + 2 + 4 + 8, dtype=i32, device=dev)   # depth1 xy2 conic4 rect2 | tiles | long_base | status
-    o = 0
+    lay = _capi.state_layout(P, W, H, S, 0, _capi.SPLAT_LAYOUT_SH if use_sh else 0)
+    slab = torch.empty(lay.total, dtype=torch.uint8, device=dev)
+    _capi.check(_capi.lib().splat_state_bind(C.byref(pk.st), None, slab.data_ptr(), lay.arrays, lay.n, S, 0), "splat_state_bind")
 
-    def take(n, align=4):
-        nonlocal o
-        o = (o + align - 1) // align * align
-        v = geom[o:o + n]
-        o += n
-        return v
-    conic = take(4 * P)
-    xy = take(2 * P, 2)
-    rect = take(2 * P, 2)
-    depth = take(P, 1)
-    tile_count, tile_base, tile_cursor = take(T * CS * S, 1), take(T + 1, 1), take(T * CS * S, 1)
-    long_base = take(T + 1, 1)
-    status = take(4, 1)
+    def view(name, dtype):
+        o = lay.offset[name]
+        return slab[o:o + lay.bytes[name]].view(dtype)
+    status, tile_base = view("status", i32), view("tile_base", i32)
     radii = torch.empty(P, dtype=i32, device=dev)
     final_T = torch.empty(H, W, dtype=f32, device=dev)
     n_contrib = torch.empty(H, W, dtype=i32, device=dev)
     st = pk.st
-    st.depth, st.xy, st.conic_opacity, st.rect = depth.data_ptr(), xy.data_ptr(), conic.data_ptr(), rect.data_ptr()
-    st.radii = radii.data_ptr()
-    st.tile_count, st.tile_base, st.tile_cursor = tile_count.data_ptr(), tile_base.data_ptr(), tile_cursor.data_ptr()
-    st.status, st.long_base = status.data_ptr(), long_base.data_ptr()
-    st.final_T, st.n_contrib = final_T.data_ptr(), n_contrib.data_ptr()
-    rgb = clamped = None
-    if use_sh:
-        rgb = torch.empty(P, 3, dtype=f32, device=dev)
-        clamped = torch.empty(P, 3, dtype=torch.uint8, device=dev)
-        st.rgb, st.clamped = rgb.data_ptr(), clamped.data_ptr()
-    pk.tensors = dict(geom=geom, radii=radii, final_T=final_T, n_contrib=n_contrib, status=status,
+    st.radii, st.final_T, st.n_contrib = radii.data_ptr(), final_T.data_ptr(), n_contrib.data_ptr()
+    rgb = view("rgb", f32).view(P, 3) if use_sh else None
+    clamped = view("clamped", torch.uint8).view(P, 3) if use_sh else None
+    pk.tensors = dict(geom=slab, radii=radii, final_T=final_T, n_contrib=n_contrib, status=status,
                       tile_base=tile_base, rgb=rgb, clamped=clamped)
-    pk.num_tiles = T
+    pk.num_tiles = int(_capi.lib().splat_num_tiles(W, H))
+    pk.shape = (P, H, W, S)
     return radii, status
 
 
@@ -199,18 +184,22 @@ LONG_ITEM_TABLE = True   # SplatState.long_items (work-item table of those kerne
 
 
 def _alloc_lists(pk: _Pack, dev, capacity: int, longest=None):
-    """``longest``: the longest per-tile list if the host knows it (exact mode); None = unknown (lazy mode)."""
+    """``longest``: the longest per-tile list if the host knows it (exact mode); None = unknown (lazy mode).  Sizes from the library's
+    layout for this capacity (splat_state_layout)."""
     capacity = max(int(capacity), 1)
-    keys = torch.empty(capacity, dtype=torch.int64, device=dev)
-    plist = torch.empty(capacity, dtype=torch.int32, device=dev)
+    P, H, W, S = pk.shape
+    long_lists = longest is None or longest > LONG_LIST
+    lay = _capi.state_layout(P, W, H, S, capacity, _capi.SPLAT_LAYOUT_LONG_LISTS if long_lists else 0)
+    keys = torch.empty(lay.bytes["keys"] // 8, dtype=torch.int64, device=dev)
+    plist = torch.empty(lay.bytes["point_list"] // 4, dtype=torch.int32, device=dev)
     pk.st.keys, pk.st.point_list, pk.st.capacity = keys.data_ptr(), plist.data_ptr(), capacity
     pk.tensors.update(keys=keys, point_list=plist)
-    if longest is None or longest > LONG_LIST:
-        alt = torch.empty(capacity, dtype=torch.int64, device=dev)
+    if long_lists:
+        alt = torch.empty(lay.bytes["keys_alt"] // 8, dtype=torch.int64, device=dev)
         pk.st.keys_alt = alt.data_ptr()
         pk.tensors.update(keys_alt=alt)
         if LONG_ITEM_TABLE:
-            items = torch.empty(capacity // 1024 + pk.num_tiles + 1, dtype=torch.int32, device=dev)      # SplatState.long_items
+            items = torch.empty(lay.bytes["long_items"] // 4, dtype=torch.int32, device=dev)      # SplatState.long_items
             pk.st.long_items = items.data_ptr()
             pk.tensors.update(long_items=items)
 
@@ -315,7 +304,7 @@ def _shared_geometry(settings, means3D, colors, opac, scales, rots, cov3D, shs, 
     n_contrib = torch.empty(H, W, dtype=torch.int32, device=dev)
     pk.st.final_T, pk.st.n_contrib = final_T.data_ptr(), n_contrib.data_ptr()
     pk.tensors = dict(pk1.tensors, final_T=final_T, n_contrib=n_contrib)       # shares the first call's geometry + lists (ref-counted)
-    pk.num_tiles, pk.num_rendered = pk1.num_tiles, pk1.num_rendered
+    pk.num_tiles, pk.num_rendered, pk.shape = pk1.num_tiles, pk1.num_rendered, pk1.shape
     pk.shared_geometry = True
     geometry_cache_stats["shared"] += 1
     return pk
@@ -431,7 +420,8 @@ def rasterize_backward(pk: _Pack, grad_color, need_scale_rot: bool, need_cov3D: 
     f32 = torch.float32
     resolve_lazy(pk)
     grad_color = grad_color.contiguous()
-    accum = torch.empty(P, _capi.SPLAT_GRAD_STRIDE, dtype=f32, device=dev)
+    accum_bytes = _capi.state_layout(P, pk.shape[2], pk.shape[1], 1, 0, _capi.SPLAT_LAYOUT_BACKWARD).bytes["accum"]     # (the library's size)
+    accum = torch.empty(accum_bytes // 4, dtype=f32, device=dev)
     d_means3D = torch.empty(P, 3, dtype=f32, device=dev)
     d_means2D = torch.empty(P, 3, dtype=f32, device=dev)
     d_opac = torch.empty(P, 1, dtype=f32, device=dev)

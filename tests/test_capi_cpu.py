@@ -103,3 +103,55 @@ def test_product_does_not_import_the_oracle():
                     src = open(os.path.join(dirpath, f)).read()
                     assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                     assert "raster_ref" not in src, f
+
+
+def test_scratch_layouts_describe_the_structs():
+    """include/splat_hip.h "Scratch layouts": a binding sizes and wires the scratch without any Python arithmetic.  Every array a
+    SplatState / SplatIterWorkspace points at is named; offsets are SPLAT_SLAB_ALIGN-aligned, disjoint and inside the slab;
+    splat_workspace_bytes is the layout's total; bind() writes slab + offset into exactly those fields (no GPU needed: it only forms
+    pointers)."""
+    import ctypes as C
+    from splatam_amd import _capi
+    L = _capi.lib()
+    P, W, H, cap = 12345, 1200, 680, 700_000
+    T = L.splat_num_tiles(W, H)
+    lay = _capi.state_layout(P, W, H, 1, cap, _capi.SPLAT_LAYOUT_LONG_LISTS | _capi.SPLAT_LAYOUT_BACKWARD)
+    assert lay.total == L.splat_workspace_bytes(P, W, H, cap) and lay.total % _capi.SPLAT_SLAB_ALIGN == 0
+    want = {"depth": 4 * P, "xy": 8 * P, "conic_opacity": 16 * P, "rect": 8 * P, "radii": 4 * P, "tile_base": 4 * (T + 1),
+            "tile_count": 4 * T * _capi.SPLAT_COUNTER_STRIDE, "tile_cursor": 4 * T * _capi.SPLAT_COUNTER_STRIDE, "keys": 8 * cap,
+            "point_list": 4 * cap, "keys_alt": 8 * cap, "long_items": 4 * (cap // 1024 + T + 1), "long_base": 4 * (T + 1),
+            "final_T": 4 * W * H, "n_contrib": 4 * W * H, "status": 16, "accum": 4 * _capi.SPLAT_GRAD_STRIDE * P}
+    assert lay.bytes == want
+    spans = sorted((lay.offset[k], lay.offset[k] + lay.bytes[k]) for k in lay.names)
+    assert all(o % _capi.SPLAT_SLAB_ALIGN == 0 for o, _ in spans) and spans[-1][1] <= lay.total
+    assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))
+    assert "rgb" not in lay.bytes and "rgb" in _capi.state_layout(P, W, H, 1, cap, _capi.SPLAT_LAYOUT_SH).bytes
+    assert _capi.state_layout(P, W, H, 16, cap, 0).bytes["tile_count"] == 16 * want["tile_count"]
+    st, gr = _capi.SplatState(), _capi.SplatGrads()
+    base = 1 << 20                                               # any aligned address: bind only forms pointers
+    assert L.splat_state_bind(C.byref(st), C.byref(gr), base, lay.arrays, lay.n, 1, cap) == 0
+    for k in lay.names:
+        got = gr.accum if k == "accum" else getattr(st, k)
+        assert got == base + lay.offset[k], k
+    assert st.capacity == cap and st.sub_bins == 1 and st.group_recs is None
+    assert L.splat_state_bind(C.byref(st), None, base + 8, lay.arrays, lay.n, 1, cap) != 0       # a misaligned slab is refused
+    assert L.splat_state_layout(-1, W, H, 1, cap, 0, None, 0, None) < 0 and L.splat_state_layout(P, W, H, 3, cap, 0, None, 0, None) < 0
+    # the fused iteration's workspace
+    gs = 4 * 448
+    il = _capi.iter_workspace_layout(P, W, H, cap, gs, _capi.SPLAT_LAYOUT_SSIM | _capi.SPLAT_LAYOUT_OUTLIER)
+    assert il.total == L.splat_iter_workspace_bytes(P, W, H, cap, gs, _capi.SPLAT_LAYOUT_SSIM | _capi.SPLAT_LAYOUT_OUTLIER)
+    G = ((W + 15) // 16 + 1) // 2 * (((H + 15) // 16 + 1) // 2)
+    assert il.bytes["feat8"] == 32 * P and il.bytes["out6"] == il.bytes["dL_dout6"] == 24 * W * H and il.bytes["ssim_maps"] == 36 * W * H
+    assert il.bytes["sums"] == 8 * _capi.SPLAT_ITER_SUM_COPIES * _capi.SPLAT_ITER_SUMS and il.bytes["d_cam"] == 4 * _capi.SPLAT_ITER_DCAM
+    assert il.bytes["st.group_count"] == 4 * G * _capi.SPLAT_COUNTER_STRIDE and il.bytes["st.group_recs"] == 16 * G * gs
+    assert il.bytes["st.tile_order"] == 4 * 8 * ((T + 7) // 8) and il.bytes["outlier_scratch"] == 4 * L.splat_map_scratch_words(W * H)
+    zero = {k for k in il.names if il.zero_init[k]}
+    assert zero == {"st.radii", "st.tile_count", "st.long_base", "st.group_count", "st.tile_work", "st.status", "dL_dout6", "accum", "sums",
+                    "d_cam", "outlier_scratch"}
+    ws = _capi.SplatIterWorkspace()
+    assert L.splat_iter_workspace_bind(C.byref(ws), base, il.arrays, il.n, cap, gs) == 0
+    for k in il.names:
+        got = getattr(ws.st, k[3:]) if k.startswith("st.") else getattr(ws, k)
+        assert got == base + il.offset[k], k
+    assert ws.st.group_stride == gs and ws.st.capacity == cap and ws.d_means3D is None
+    assert "ssim_maps" not in _capi.iter_workspace_layout(P, W, H, cap, 0, 0).bytes

@@ -76,10 +76,10 @@ def _check_images(gc, gr, gd, oc, orad, od, cam, rv):
     (tests/util.py: assert_outliers_explained), their number bounded.  Returns (flagged pixels, xy, radii) for the gradient check."""
     assert (gr != orad).sum() <= max(2, int(1e-5 * gr.size)), "radii mismatch"
     assert np.abs(gr.astype(np.int64) - orad).max() <= 1
-    bound, margin, xy, radii = oracle_flip_bounds(rv, cam)
+    bound, margin, xy, radii, noise = oracle_flip_bounds(rv, cam)
     C_ = gc.shape[0]
-    n = assert_outliers_explained(gc, oc, bound[:C_], 1e-4, rtol=1e-4, what="color")
-    n += assert_outliers_explained(gd, od, bound[C_:C_ + 1], 1e-4, rtol=1e-4, what="depth")
+    n = assert_outliers_explained(gc, oc, bound[:C_], 1e-4, rtol=1e-4, noise=noise[:C_], what="color")
+    n += assert_outliers_explained(gd, od, bound[C_:C_ + 1], 1e-4, rtol=1e-4, noise=noise[C_:C_ + 1], what="depth")
     assert n <= max(2, int(1e-4 * (gc.size + gd.size))), n
     return flip_pixels(bound, (gc, gd), (oc, od)), xy, radii
 
@@ -275,10 +275,10 @@ def _fused_case(cfg_name, aniso, tracking, monkeypatch, seed=0, region=None):
     pc64, frame64 = _cpu_case(params, frame, cam_args, torch.float64)
     with torch.no_grad():
         tg64 = slam.transform_to_frame(pc64, 1, gaussians_grad=False, camera_grad=False)
-        b_im = oracle_flip_bounds(slam.transformed_params2rendervar(pc64, tg64), frame64['cam'])[0]
-        b_ds = oracle_flip_bounds(slam.transformed_params2depthplussilhouette(pc64, frame64['w2c'], tg64), frame64['cam'])[0]
-    nbad = assert_outliers_explained(got_im, renders[0].numpy(), b_im[:3], 1e-4, what=f"{what} im")
-    nbad += assert_outliers_explained(got_ds, renders[1].numpy(), b_ds[:3], 1e-4, rtol=1e-4, what=f"{what} depth/sil/depth^2")
+        b_im, _, _, _, n_im = oracle_flip_bounds(slam.transformed_params2rendervar(pc64, tg64), frame64['cam'])
+        b_ds, _, _, _, n_ds = oracle_flip_bounds(slam.transformed_params2depthplussilhouette(pc64, frame64['w2c'], tg64), frame64['cam'])
+    nbad = assert_outliers_explained(got_im, renders[0].numpy(), b_im[:3], 1e-4, noise=n_im[:3], what=f"{what} im")
+    nbad += assert_outliers_explained(got_ds, renders[1].numpy(), b_ds[:3], 1e-4, rtol=1e-4, noise=n_ds[:3], what=f"{what} depth/sil/depth^2")
     assert nbad <= nflip * (got_im.size + got_ds.size), nbad
     # one alpha >= 1/255 decision moves a pixel by <= ~1/255 |c|; anything larger must be a DEPTH TIE: two overlapping Gaussians
     # whose camera-space depths agree to float32 rounding are ordered by that rounding, and the in-kernel glue (FMA chain) rounds

@@ -60,10 +60,10 @@ def _check_forward(gc, gr, gd, oc, orad, od, npix, cam=None, rv=None):
         assert_close_outliers(gc, oc, 1e-4, rtol=1e-4, max_outlier_frac=1e-4, outlier_atol=0.03 * cmax, what="color")
         assert_close_outliers(gd, od, 1e-4, rtol=1e-4, max_outlier_frac=1e-4, outlier_atol=0.1, what="depth")
         return None
-    bound, margin, xy, radii = oracle_flip_bounds(rv, cam)
+    bound, margin, xy, radii, noise = oracle_flip_bounds(rv, cam)
     C_ = gc.shape[0]
-    n = assert_outliers_explained(gc, oc, bound[:C_], 1e-4, rtol=1e-4, what="color")
-    n += assert_outliers_explained(gd, od, bound[C_:C_ + 1], 1e-4, rtol=1e-4, what="depth")
+    n = assert_outliers_explained(gc, oc, bound[:C_], 1e-4, rtol=1e-4, noise=noise[:C_], what="color")
+    n += assert_outliers_explained(gd, od, bound[C_:C_ + 1], 1e-4, rtol=1e-4, noise=noise[C_:C_ + 1], what="depth")
     assert n <= max(2, int(1e-4 * (gc.size + gd.size))), n
     return flip_pixels(bound, (gc, gd), (oc, od)), xy, radii
 

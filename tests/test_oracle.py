@@ -229,9 +229,16 @@ def test_flip_classifier_explains_float32_vs_float64(n, W, H, f, seed):
     cam, rv = scene(n, W, H, f, seed=seed)
     gout = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1))
     b = _both_builds(cam, rv, gout)
-    bound, margin, xy, radii = oracle_flip_bounds(rv, cam)
-    assert_outliers_explained(b['f32'][0], b['f64'][0], bound[:3], 1e-4, rtol=1e-4, what="float32 vs float64 colour")
-    assert_outliers_explained(b['f32'][1], b['f64'][1], bound[3:4], 1e-4, rtol=1e-4, what="float32 vs float64 depth")
+    bound, margin, xy, radii, noise = oracle_flip_bounds(rv, cam)
+    assert_outliers_explained(b['f32'][0], b['f64'][0], bound[:3], 1e-4, rtol=1e-4, noise=noise[:3], what="float32 vs float64 colour")
+    assert_outliers_explained(b['f32'][1], b['f64'][1], bound[3:4], 1e-4, rtol=1e-4, noise=noise[3:4], what="float32 vs float64 depth")
+    # the rounding-sensitivity model against the two builds: away from decision flips the float32 build is within a few ulps' worth
+    quiet = bound[:3] == 0
+    ratio = np.abs(b['f32'][0] - b['f64'][0])[quiet] / np.maximum(noise[:3][quiet], 1e-12)
+    moved = np.abs(b['f32'][0] - b['f64'][0])[quiet] > 1e-5
+    print(f"float32 vs float64 colour, pixels without a near-threshold decision: |difference| / one-ulp sensitivity: median "
+          f"{np.median(ratio[moved]):.2f}, 99 % {np.quantile(ratio[moved], 0.99):.2f}, max {ratio[moved].max():.2f}")
+    assert np.quantile(ratio[moved], 0.99) < 3.0         # (the tail beyond: decisions just outside FLIP_TOL, all below the 1e-4 tolerance)
     flips = flip_pixels(bound, (b['f32'][0], b['f32'][1]), (b['f64'][0], b['f64'][1]))
     assert 0 < flips.mean() < 2e-3                       # a few pixels in ten thousand
     for k in ('means3D', 'colors', 'opacities', 'scales'):
