@@ -170,7 +170,10 @@ size_t splat_num_tiles(int32_t width, int32_t height);
 /* K1 + tile scan.  Replaces the first half of `_C.rasterize_gaussians`
  * (preprocess, prefix sum).  Writes depth/xy/conic_opacity/rect/radii,
  * tile_count/tile_base/tile_cursor and status[0..2].  The host may read
- * status[0] (num_rendered) to size keys/point_list, as the reference does. */
+ * status[0] (num_rendered) to size keys/point_list, as the reference does.
+ * The scan compares the count with st->capacity and publishes EMPTY ranges (status[1] set) when it is larger: a caller that
+ * allocates its lists AFTER this call sets st->capacity to an upper bound (e.g. INT64_MAX / 2) for this call and to the real
+ * capacity before splat_bin_forward (tests/capi_smoke.c, splatam_amd/rasterizer.py do). */
 int splat_preprocess_forward(const SplatCamera *cam, const SplatGaussians *g, SplatState *st, void *stream);
 
 /* Scatter (Gaussian, tile) instances into per-tile buckets and sort every

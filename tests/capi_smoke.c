@@ -123,6 +123,9 @@ int main(void) {
     memset(&st, 0, sizeof st);
     memset(&gr, 0, sizeof gr);
     SPLAT(splat_state_bind(&st, &gr, slab, arrays, n, 1, 0));
+    /* the lists do not exist yet: the tile scan of the first call publishes EMPTY lists when the count exceeds st.capacity, so a caller
+     * that sizes its lists from status[0] (as the reference does) declares the capacity unbounded for this call (include/splat_hip.h) */
+    st.capacity = INT64_MAX / 2;
     SPLAT(splat_preprocess_forward(&cam, &g, &st, stream));
     int32_t status[4];
     HIP(hipMemcpyAsync(status, st.status, sizeof status, hipMemcpyDeviceToHost, stream));
