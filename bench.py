@@ -282,18 +282,30 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
     k6 = pmc_kernel(pmc, "render_forward_kernel", "<6, 8, false, true, false>") or pmc_kernel(pmc, "render_forward_kernel", "<6, 8")
     dom = k7 if dominant == "render_backward" else k6
     rows = {}
-    trace = load_kernel_trace(workload)          # per-kernel average durations: the kernel TRACE of the bench command (not the counter passes)
+    trace = load_kernel_trace(workload)          # the committed kernel TRACE of the bench command: a cross-check of the live durations
+    live = live_kernel_times(eng, frames, dev)   # per-kernel average durations of THIS run
+    # counters may only describe the code they were taken on: the counter file and the trace must name the same git head (the profile
+    # script writes <tag>_meta.json beside a set); otherwise the traffic columns are withheld
+    trace_meta = load_profile_meta(trace[0]) if trace else None
+    pmc_head = pmc[1].get("git_head") if pmc else None
+    trace_head = trace_meta.get("git_head") if trace_meta else None
+    counters_ok = bool(pmc_head) and pmc_head == trace_head
+    counters_note = None if counters_ok else (f"counter file {pmc[0] if pmc else None} @ {pmc_head} and trace {trace[0] if trace else None} @ "
+                                              f"{trace_head} are not one profile set: traffic / valu columns withheld")
     # (the tracking iteration's composites are ONE kernel: the list is gathered once -- R x 52 --, the frame is read -- 16 B per pixel --, the
     #  planes stay in registers, six partial sums per Gaussian leave it)
     # (the SSIM kernels are templates since the column-first form: a counter file taken on the row-first kernels does not describe them)
     per_unit = {"render_track_fused_kernel": R * 52 + HW * 16 + N * 24, "fused_preprocess_kernel": N * (48 + 87), "ssim_forward_kernel<": HW * (2 * 12 + 36 + 16), "map_loss_backward_kernel<": HW * (36 + 24 + 16),
                 "fused_backward_kernel": N * (64 + 40 + 48), "adam_map_kernel": N * 12 * 4 * 6}
     for kname, abytes in per_unit.items():
-        d = pmc_kernel(pmc, kname) or {}
-        us = trace_avg_us(trace, kname)
+        d = (pmc_kernel(pmc, kname) or {}) if counters_ok else {}
+        us_live, us_trace = live_avg_us(live, kname), trace_avg_us(trace, kname)
+        us = us_live or us_trace
         kname = kname.rstrip("<")
         if us:
-            rows[kname] = {"avg_us": round(us, 1), "algorithmic_bytes": abytes, "GBps": round(abytes / us / 1e3, 1),
+            rows[kname] = {"avg_us": round(us, 1), "avg_us_source": "live" if us_live else "committed trace",
+                           "avg_us_committed_trace": None if us_trace is None else round(us_trace, 1),
+                           "algorithmic_bytes": abytes, "GBps": round(abytes / us / 1e3, 1),
                            "frac_of_hbm_peak": round(abytes / us / 1e3 / HBM_PEAK_GBS, 4), "traffic_bytes": d.get("traffic_bytes"),
                            "valu_cycles_frac": d.get("valu_cycles_frac")}
     r4 = lambda v: None if v is None else round(v, 4)          # noqa: E731
@@ -312,7 +324,9 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
              "valu_cycles_frac": dom.get("valu_cycles_frac") if dom else None,
              "valu_insts_per_launch": dom.get("SQ_INSTS_VALU") if dom else None,
              "pmc_source": (f"profiles/{pmc[0]} @ {pmc[1].get('git_head')}" if pmc else None),
-             "kernel_trace_source": (f"profiles/{trace[0]}" if trace else None),
+             "kernel_trace_source": (f"profiles/{trace[0]} @ {trace_head}" if trace else None),
+             "counters_withheld": counters_note,
+             "per_kernel_durations": "live (torch.profiler over this run's iterations)" if live else "committed trace (no tracer in this process)",
              "kernels": rows,
              "note": "K6 / K7 times are live HIP-event measurements of this run (30 launches in a row on the iteration's stream, learnt list "
                      "state, after a mapping iteration); counters (traffic = 2 x FETCH_SIZE + WRITE_SIZE) and the "
@@ -322,9 +336,58 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
                      "selects / DPP 4, exp / rcp ~20 in the visit's mix; round 2 priced every instruction at 4).  The composites are "
                      "bound by the vector pipe at ~21 % live lanes, not by HBM (DESIGN.md 5)"}
     return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-            "traffic": dom.get("traffic_bytes") if dom else None, "kernel": dominant + "_kernel<6,8> (fused iteration)",
+            "traffic": dom.get("traffic_bytes") if (dom and pmc_head) else None, "kernel": dominant + "_kernel<6,8> (fused iteration)",
             "kernel_ms": round(out[dominant], 4), "algorithmic_bytes": bytes_bwd if dominant == "render_backward" else bytes_fwd,
             "other": other}
+
+
+def live_kernel_times(eng, frames, dev, iters=20):
+    """Per-kernel average durations of the fused iteration measured IN THIS RUN: torch.profiler (kineto over the ROCm tracer) around
+    `iters` tracking and `iters` mapping iterations -- every kernel launched in the process is recorded, libsplat_hip.so's included.
+    Returns {kernel name: average us} or None when the tracer is not available (the committed trace is then the only source)."""
+    from splatam_amd import slam
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        eng.begin_tracking(1)
+        torch.cuda.synchronize(dev)
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(iters):
+                eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING)
+            for _ in range(iters):
+                eng.mapping_iteration(frames[2 % len(frames)], 2 % len(frames), slam.REPLICA_MAPPING)
+            torch.cuda.synchronize(dev)
+        acc = {}
+        for ev in prof.events():
+            dt = getattr(ev, "device_time", None) or getattr(ev, "cuda_time", 0.0)
+            if dt and "splat" in ev.name:
+                acc.setdefault(ev.name, []).append(float(dt))
+        return {k: sum(v) / len(v) for k, v in acc.items()} or None
+    except Exception as exc:            # noqa: BLE001 (a missing tracer must not cost the bench line)
+        print(f"live kernel timing unavailable: {exc!r}", file=sys.stderr)
+        return None
+
+
+def live_avg_us(live, needle):
+    if not live:
+        return None
+    for name, us in live.items():
+        if needle in name:
+            return us
+    return None
+
+
+def load_profile_meta(path_basename):
+    """profiles/<tag>_meta.json written by the profile script beside a set: {"git_head": ..., "files": [...]} -- the head a trace /
+    counter file was taken at (counter files also carry their own)."""
+    import glob
+    for meta in glob.glob(os.path.join(ROOT, "profiles", "*_meta.json")):
+        try:
+            d = json.load(open(meta))
+        except Exception:
+            continue
+        if path_basename in d.get("files", []):
+            return d
+    return None
 
 
 def load_pmc(workload):
@@ -492,7 +555,8 @@ def slam_loop_figure(name, dev, frames=13, engine="fused", runs=2):
         map_ms = sum(fr.get('mapping_iterations', 0.0) for fr in st['phase_ms'][1:])
         tcfg, mcfg = cfg['tracking'], cfg['mapping']
         run = {"frames_per_s": round(n_counted / max(sum(counted), 1e-9), 3),
-               "tracking_iters_per_s": round(1e3 * tcfg['num_iters'] * n_counted / max(track_ms, 1e-9), 1),
+               # (the iterations that RAN on the counted frames: the doubled budget and redone iterations included)
+               "tracking_iters_per_s": round(1e3 * sum(d['tracking_iters'] for d in st['decisions'][1:]) / max(track_ms, 1e-9), 1),
                "mapping_iters_per_s": round(1e3 * mcfg['num_iters'] * n_counted / max(map_ms, 1e-9), 1),     # the reference's timer: iterations only
                "ms_per_frame": round(1e3 * sum(counted) / n_counted, 2),
                "phase_ms_per_frame": {k: round(v / n_counted, 3) for k, v in sorted(phases.items())},
@@ -744,6 +808,13 @@ def main():
         track_rate = phase_rate(lambda: eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING, shard=(rank, world) if (world > 1 and SHARD_TRACKING) else None,
                                                                allreduce_sums=sdist.all_reduce_sum_flat), n_phase, dev)
         map_rate = phase_rate(lambda: eng.mapping_iteration(frames[2], 2, slam.REPLICA_MAPPING), n_phase, dev)
+
+        # the tracking iteration with EVERY gradient the reference's backward() forms (dL/d rgb, opacity, scale too: the reference steps
+        # them with learning rate 0, configs/replica/splatam.py:71-79): the headline's tracking iterations leave them out
+        def track_full():
+            eng.loss_backward(frames[1], eng.track_time_idx, slam.REPLICA_TRACKING, tracking=True, map_grads=True,
+                              pose_adam=eng._pose_adam_args(slam.REPLICA_TRACKING))
+        track_rate_full = phase_rate(track_full, n_phase, dev) if world == 1 else None
         # several ranks: the same tracking iteration replicated (every rank composites the whole frame, no exchange), and the mapping
         # iteration with its gradient exchange -- beside the sharded / local rates above, so that a reader of the N-GPU line sees what
         # each phase gains
@@ -843,6 +914,13 @@ def main():
             "tracking_replicated_iters_per_s": None if not (fused and world > 1) else round(track_rate_repl, 3),
             "mapping_with_exchange_iters_per_s": None if not (fused and world > 1) else round(map_rate_exch, 3),
             "tracking_iters_per_s": round(track_rate, 3), "mapping_iters_per_s": round(map_rate, 3),
+            # tracking with all of backward()'s gradients formed (see config.workload), and the 2:3 mix with it
+            "tracking_full_gradients_iters_per_s": (round(track_rate_full, 3) if fused and track_rate_full else None),
+            "mix_with_full_gradient_tracking_iters_per_s": (round(5.0 / (2.0 / track_rate_full + 3.0 / map_rate), 3) if fused and track_rate_full else None),
+            # what answers the north star's "scripts/splatam.py's loops run unmodified": the reference's statements on the drop-in package
+            # alone (no change at all), and the same statements after the ONE line `splatam_amd.plugin.install(module)`
+            "reference_loop_unmodified": {"dropin_package_only_iters_per_s": round(dropin_rate, 3),
+                                          "after_plugin_install_iters_per_s": round(plugin_rate, 3)},
             "plugin_iters_per_s": round(plugin_rate, 3), "plugin_tracking_iters_per_s": round(track_rate_p, 3),
             "plugin_mapping_iters_per_s": round(map_rate_p, 3),
             "dropin_iters_per_s": round(dropin_rate, 3), "dropin_tracking_iters_per_s": round(track_rate_d, 3),

@@ -1160,7 +1160,10 @@ __global__ __launch_bounds__(256, 5) void render_backward_kernel5_w5(SplatCamera
 // backward composite, profiles/r04_k7_account.md), the round trip of ten per-pixel planes (six rendered, four gradient; final_T and
 // n_contrib) and a launch; a tile with more batches re-stages all but its last one.  KEEP: the planes are written as well (what
 // FusedEngine.rendered() / the tests read); the tracking step of the product loop has no reader for them.
-template <bool KEEP>
+// DBG (measurement builds, splat_debug_option(4, bits); 0 in the product launches): 2 / 4 / 8 as in backward_core (stage only / no accumulator
+// atomics / phase 1 only), 16 = forward composite and loss only (the backward pass is not entered): the account of the kernel's memory
+// traffic in profiles/r05_track_fused_traffic.md is the differences of their FETCH_SIZE / WRITE_SIZE.
+template <bool KEEP, int DBG = 0>
 __global__ __launch_bounds__(256, 5) void render_track_fused_kernel(SplatCamera cam, const float *feat8, SplatState st, float *out6, float *accum,
                                                                     int T, int per_xcd, TrackLossEpilogue ep) {
     constexpr int C = 6, CS = 8, FP = forward_fp<C, CS, false>();
@@ -1247,7 +1250,12 @@ __global__ __launch_bounds__(256, 5) void render_track_fused_kernel(SplatCamera 
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) dpix[ch] = ch < 4 ? __shfl(g[ch < 4 ? ch : 0], src, 64) : 0.f;      // (outside the image g is zero)
     // ---- backward pass over the same lists, starting on the batch that is still staged
-    backward_core<C, CS, 0xFu, 0x8u, false, 0>(feat8, st, accum, B, PB, s_wmax, tile, tx, ty, tid, inside, Tfin, last, dpix, 0.f, staged);
+    if constexpr ((DBG & 16) != 0) {
+        // (measurement: forward + loss only; the per-pixel state is kept alive by a never-true store)
+        if (Tfin == 1.2345e-33f && last == 0xFFFFFFFFu) accum[0] = dpix[0] + dpix[3];
+        return;
+    }
+    backward_core<C, CS, 0xFu, 0x8u, false, (DBG & 14)>(feat8, st, accum, B, PB, s_wmax, tile, tx, ty, tid, inside, Tfin, last, dpix, 0.f, staged);
     // what the next launch's order is built from (SplatState.tile_work): the quadrants' deepest contributors, as the core left them
     if (st.tile_work && tid == 0) st.tile_work[tile] = s_wmax[0] + s_wmax[1] + s_wmax[2] + s_wmax[3];
 }
@@ -1391,6 +1399,16 @@ hipError_t launch_render_track_fused(const SplatCamera &cam, const float *feat8,
     const int T = launch_tiles(cam, st);
     if (T == 0) return hipSuccess;
     const int per = (T + 7) / 8;
+    if (!keep_planes && g_debug_k7_bits != 0) {           // measurement builds (see render_track_fused_kernel)
+        switch (g_debug_k7_bits) {
+            case 2: hipLaunchKernelGGL((render_track_fused_kernel<false, 2>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6, accum, T, per, ep); break;
+            case 4: hipLaunchKernelGGL((render_track_fused_kernel<false, 4>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6, accum, T, per, ep); break;
+            case 8: hipLaunchKernelGGL((render_track_fused_kernel<false, 8>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6, accum, T, per, ep); break;
+            case 16: hipLaunchKernelGGL((render_track_fused_kernel<false, 16>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6, accum, T, per, ep); break;
+            default: hipLaunchKernelGGL((render_track_fused_kernel<false>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6, accum, T, per, ep); break;
+        }
+        return hipGetLastError();
+    }
     if (keep_planes) hipLaunchKernelGGL((render_track_fused_kernel<true>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6, accum, T, per, ep);
     else hipLaunchKernelGGL((render_track_fused_kernel<false>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6, accum, T, per, ep);
     return hipGetLastError();

@@ -60,11 +60,13 @@ _ALL_KEYS = PARAM_ORDER + _POSE_KEYS
 
 class _Report:
     """One iteration's report (``d_cam``, SPLAT_ITER_DCAM floats) on the device, and its host copy once someone needed it."""
-    __slots__ = ("dev", "host", "args", "stepped", "digested")
+    __slots__ = ("dev", "host", "host_tensor", "args", "stepped", "digested", "optimizer")
 
     def __init__(self, dev):
         self.dev = dev              # device copy (the engine's own buffer is overwritten by the next iteration)
         self.host = None            # list of floats, after the first read
+        self.host_tensor = None     # the same 128 bytes as a CPU tensor (its int32 fields are read as int32: _report_values)
+        self.optimizer = None       # the mapping optimizer that stepped (or tried to) on this iteration
         self.args = None            # what get_loss was called with (a flagged tracking iteration is repeated from it)
         self.stepped = False        # optimizer.step() ran on this iteration
         self.digested = False
@@ -116,6 +118,16 @@ class _FusedLoss(torch.Tensor):
 
     def __ge__(self, o):
         return self._cmp(o, operator.ge, "__ge__")
+
+
+def _report_values(host):
+    """The report as Python numbers: float slots as floats, the int32 slots [16..21] (status words, flagged bit, skipped count) as
+    ints read THROUGH AN int32 VIEW -- their bit patterns are denormal as floats and would flush to zero under FTZ / DAZ
+    (torch.set_flush_denormal, a library built with -ffast-math) if they travelled as floats."""
+    vals = host.tolist()
+    ints = host.view(torch.int32)[16:22].tolist()
+    vals[16:22] = ints
+    return vals
 
 
 def _scalar(rep, slot):
@@ -182,7 +194,7 @@ class _Session:
                 ev.synchronize()
             self.pending.pop(0)
             if rep.host is None:
-                rep.host = host.tolist()
+                rep.host = _report_values(host)
             self.digest(eng, rep, host)
             self.pool.append((host, ev))
 
@@ -195,19 +207,39 @@ class _Session:
             return False
         rep.digested = True
         if host is None:
-            host = torch.tensor(rep.host, dtype=torch.float32)
+            host = rep.host_tensor
         if eng.digest_report(host):
             self.stats["skipped_iterations"] += eng.skipped_iterations
+            self.lost_steps(rep, eng.skipped_iterations)
             # reports already in flight were written under the same flag: they carry nothing new
             for _, r, _, _ in self.pending:
                 r.digested = True
             return True
         return False
 
+    def lost_steps(self, rep, skipped):
+        """A flagged MAPPING iteration (and every one until the host learnt of it) took no Adam step on the device, but the host-side
+        step counts of the optimizer advanced with every ``step()``: take them back, so that the bias corrections of the following
+        steps match the moments on the device.  The lost iterations are not repeated (the caller's loop has moved on: another
+        keyframe, another iteration index); they are counted in ``session_stats()['skipped_iterations']`` and warned about once."""
+        opt = rep.optimizer
+        if opt is None or rep.args is None or rep.args[-1] or skipped <= 0:
+            return                                              # (tracking: repeat_tracking re-runs the iteration instead)
+        for g in opt.param_groups:             # (the pose groups carry state only when bundle adjustment steps them)
+            st = opt.state.get(g['params'][0])
+            if st is not None and 'step' in st:
+                st['step'] = torch.clamp(st['step'] - float(skipped), min=0.0)
+        if not self.stats.get("warned_lost_steps"):
+            self.stats["warned_lost_steps"] = True
+            import warnings
+            warnings.warn(f"splatam_amd.plugin: {skipped} mapping iteration(s) ran on per-tile lists that did not fit and took no Adam "
+                          "step (the lists have been re-sized); see session_stats()['skipped_iterations']")
+
     def value_of(self, rep, slot):
         """The caller reads a value of an iteration's report: ONE device read fetches the whole report, flags included."""
         if rep.host is None:
-            rep.host = rep.dev.tolist()
+            rep.host_tensor = rep.dev.cpu()                     # ONE device read: the whole report, flags included
+            rep.host = _report_values(rep.host_tensor)
             eng = self.current[0] if self.current is not None and self.current[2] is rep else None
             if eng is not None and self.digest(eng, rep) and rep.args is not None and rep.args[-1]:
                 self.repeat_tracking(eng, rep)
@@ -230,13 +262,14 @@ class _Session:
                         if st is not None:
                             st['step'] -= 1
                     opt._step_gaussians(eng, bound, eps=1e-8, tracking=True)
-            fresh = eng.buf['d_cam'].tolist()
+            fresh_t = eng.buf['d_cam'].cpu()
+            fresh = _report_values(fresh_t)
             self.stats["repeats"] += 1
             if fresh[12] == 0.0:
                 rep.dev.copy_(eng.buf['d_cam'])
-                rep.host = fresh
+                rep.host, rep.host_tensor = fresh, fresh_t
                 return
-            eng.digest_report(torch.tensor(fresh, dtype=torch.float32))
+            eng.digest_report(fresh_t)
         raise RuntimeError("the instance lists overflowed three times in a row")
 
 
@@ -323,6 +356,7 @@ class FusedOptimizer(torch.optim.Adam):
             if self._steps_gaussians:
                 self._step_gaussians(eng, bound, eps=1e-8, tracking=True)       # torch.optim.Adam(param_groups): default eps
             return None
+        rep.optimizer = self
         self._step_gaussians(eng, bound, eps=1e-15, tracking=False)
         if self._steps_poses and rep.args is not None and rep.args[4]:
             self._step_poses_with_torch(rep)
@@ -357,17 +391,20 @@ class FusedOptimizer(torch.optim.Adam):
     def _step_poses_with_torch(self, rep):
         """Bundle adjustment (pose learning rates in the mapping optimizer, get_loss(do_ba=True)): the iteration's pose gradient -- one
         column of the two camera tensors -- through torch's own Adam step for those two parameters (every column moves with its
-        moments, as torch moves it).  A flagged iteration contributes a zero gradient."""
+        moments, as torch moves it).  A FLAGGED iteration takes no step at all -- poses, moments and step counts stay as they were
+        (decided on the device: the values after the step are kept only where the report's flag is down; no host read)."""
         by_name = {g['name']: g for g in self.param_groups}
         t = rep.args[2]
-        ok = (rep.dev[12] == 0).to(rep.dev.dtype)
-        pose = []
+        ok = rep.dev[12] == 0
+        pose, before = [], []
         for name, lo, hi in (('cam_unnorm_rots', 0, 4), ('cam_trans', 4, 7)):
             p = by_name[name]['params'][0]
             g = torch.zeros_like(p)
-            g[0, :, t] = rep.dev[lo:hi] * ok
+            g[0, :, t] = rep.dev[lo:hi]
             p.grad = g
             pose.append(p)
+            st = self.state.get(p, {})
+            before.append((p.detach().clone(), {k: v.clone() for k, v in st.items() if torch.is_tensor(v)}))
         saved = [(g, g['params']) for g in self.param_groups]
         try:
             for g in self.param_groups:             # torch steps the parameters that carry a .grad: only the two camera tensors here
@@ -377,8 +414,13 @@ class FusedOptimizer(torch.optim.Adam):
         finally:
             for g, params in saved:
                 g['params'] = params
-            for p in pose:
+            for p, (old, old_state) in zip(pose, before):
                 p.grad = None
+                p.data.copy_(torch.where(ok, p.data, old))
+                for k, v in self.state.get(p, {}).items():
+                    if torch.is_tensor(v) and v.device.type != "cpu":       # exp_avg, exp_avg_sq (torch keeps `step` on the host: lost_steps)
+                        prev = old_state.get(k)
+                        v.copy_(torch.where(ok, v, torch.zeros_like(v) if prev is None else prev))
 
 
 def initialize_optimizer(params, lrs_dict, tracking):

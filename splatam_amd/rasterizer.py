@@ -246,12 +246,14 @@ def clear_geometry_cache() -> None:
 
 
 def _cam_key(settings, view, proj):
+    bg = settings.bg
     return (int(settings.image_height), int(settings.image_width), float(settings.tanfovx), float(settings.tanfovy),
-            float(settings.scale_modifier), bool(settings.prefiltered), view.data_ptr(), view._version, proj.data_ptr(), proj._version)
+            float(settings.scale_modifier), bool(settings.prefiltered), view.data_ptr(), view._version, proj.data_ptr(), proj._version,
+            bg.data_ptr(), bg._version, _stream(view.device))        # (the stream: work queued on another stream is not ordered with the cached call)
 
 
 class _GeomEntry:
-    __slots__ = ("pk", "key", "tensors", "versions")
+    __slots__ = ("pk", "key", "tensors", "versions", "means_snapshot")
 
 
 def _remember_geometry(pk, settings, means3D_src, opac, scales, rots):
@@ -261,6 +263,9 @@ def _remember_geometry(pk, settings, means3D_src, opac, scales, rots):
     e.key = _cam_key(settings, view, proj)
     e.tensors = (means3D_src, opac, scales, rots, view, proj)      # alive: their storage cannot be handed to another tensor
     e.versions = (means3D_src._version, opac._version, scales._version, rots._version)
+    # a snapshot of the centres the cached geometry was projected from: version counters do not see raw-pointer writes (this library's own
+    # Adam / map-edit kernels, `.data` arithmetic), so the second call compares the VALUES on the device (3.6 MB at 300 k Gaussians)
+    e.means_snapshot = means3D_src.detach().contiguous().clone()
     _geom_last[means3D_src.device.index] = e
 
 
@@ -286,16 +291,21 @@ def _shared_geometry(settings, means3D, colors, opac, scales, rots, cov3D, shs, 
     if (o1._version, s1._version, r1._version) != tuple(e.versions[1:]):
         st["inputs_modified"] += 1
         return None                                                 # the first call's inputs were modified in place since
-    same_objects = o1.data_ptr() == opac.data_ptr() and s1.data_ptr() == scales.data_ptr() and r1.data_ptr() == rots.data_ptr()
-    if not same_objects:
-        flag = torch.empty(1, dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
-            _capi.check(_capi.lib().splat_same_geometry(P, o1.data_ptr(), opac.data_ptr(), s1.data_ptr(), scales.data_ptr(),
-                                                        r1.data_ptr(), rots.data_ptr(), flag.data_ptr(), _stream(dev)), "splat_same_geometry")
-        geometry_cache_stats["verified_on_device"] += 1
-        if flag.tolist()[0] != 0:                                   # (the host read an exact-mode forward makes anyway)
-            geometry_cache_stats["mismatch"] += 1
-            return None
+    # ALWAYS compared bit for bit on the device, centres included (identity of the tensors proves nothing about their contents: see
+    # _remember_geometry): two launches of the comparison kernel (the centres travel in its [P][3] slot), ONE host read of both flags
+    # -- the read an exact-mode forward makes anyway
+    flags = torch.empty(2, dtype=torch.int32, device=dev)
+    now = means3D_src.detach().contiguous()
+    L = _capi.lib()
+    with torch.cuda.device(dev):
+        _capi.check(L.splat_same_geometry(P, o1.data_ptr(), opac.data_ptr(), s1.data_ptr(), scales.data_ptr(),
+                                          r1.data_ptr(), rots.data_ptr(), flags.data_ptr(), _stream(dev)), "splat_same_geometry")
+        _capi.check(L.splat_same_geometry(P, opac.data_ptr(), opac.data_ptr(), e.means_snapshot.data_ptr(), now.data_ptr(),
+                                          rots.data_ptr(), rots.data_ptr(), flags.data_ptr() + 4, _stream(dev)), "splat_same_geometry")
+    geometry_cache_stats["verified_on_device"] += 1
+    if any(flags.tolist()):
+        geometry_cache_stats["mismatch"] += 1
+        return None
     pk1 = e.pk
     pk = _build_pack(settings, means3D, colors, opac, scales, rots, cov3D, shs)
     C.memmove(C.byref(pk.st), C.byref(pk1.st), C.sizeof(_capi.SplatState))
@@ -307,6 +317,9 @@ def _shared_geometry(settings, means3D, colors, opac, scales, rots, cov3D, shs, 
     pk.num_tiles, pk.num_rendered, pk.shape = pk1.num_tiles, pk1.num_rendered, pk1.shape
     pk.shared_geometry = True
     geometry_cache_stats["shared"] += 1
+    # one re-use per cached call (get_loss renders twice): the entry goes, so that the first call's geometry, keys and lists are freed
+    # with the two autograd graphs instead of living until the next render on this device
+    _geom_last.pop(dev.index, None)
     return pk
 
 
@@ -345,7 +358,7 @@ def _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotati
             with torch.cuda.device(dev):
                 _capi.check(L.splat_render_forward(C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), out_color.data_ptr(),
                                                    out_depth.data_ptr(), _stream(dev)), "splat_render_forward")
-            return out_color, pk.tensors['radii'], out_depth, pk
+            return out_color, pk.tensors['radii'].clone(), out_depth, pk       # (a tensor of its own: the two calls' results do not alias)
     pk = _build_pack(settings, means3D, colors, opacities, scales, rotations, cov3D, shs)
     radii, status = _alloc_state(pk, dev, P, H, W, use_sh)
     Cn = pk.g.channels

@@ -171,3 +171,36 @@ def test_geometry_cache_shares_only_what_is_proven_equal():
         assert rz.geometry_cache_stats["shared"] == n                # another view matrix tensor: full pass
     finally:
         rz.set_geometry_cache(True)
+
+
+def test_geometry_cache_sees_writes_that_bump_no_version_counter():
+    """`.data` arithmetic and raw-pointer kernels (this library's own Adam / map edits) change a tensor without moving its
+    version counter.  The cache compares VALUES on the device -- centres included, also when the second call passes the very same
+    tensors -- so such a write gives a full pass, not a stale projection; and the second call's radii are a tensor of their own."""
+    from diff_gaussian_rasterization import GaussianRasterizer as Renderer
+    from splatam_amd import rasterizer as rz
+    cam = _camera()
+    g = lambda k: torch.tensor(GOLD[f"call0/in/{k}"]).cuda()      # noqa: E731
+    base = {k: g(k) for k in ('means3D', 'colors_precomp', 'rotations', 'opacities', 'scales', 'means2D')}
+    rz.set_geometry_cache(True)
+    try:
+        def render():
+            n = rz.geometry_cache_stats["shared"]
+            out = Renderer(raster_settings=cam)(**base)
+            return out, rz.geometry_cache_stats["shared"] - n
+        (c0, r0, d0), s = render()
+        (c1, r1, d1), s = render()
+        assert s == 1 and torch.equal(c0, c1) and r0.data_ptr() != r1.data_ptr() and torch.equal(r0, r1)
+        for key, idx in (('means3D', (7, 0)), ('scales', (11, 1)), ('opacities', (13, 0))):
+            render()                                                    # (fills the cache)
+            v = base[key]._version
+            base[key].data[idx] += 0.05 if key != 'opacities' else -0.2
+            assert base[key]._version == v                               # the write is invisible to autograd's bookkeeping
+            (c2, _, _), s = render()
+            assert s == 0, key                                          # ... but not to the cache
+            rz.set_geometry_cache(False)
+            (c2_ref, _, _), _ = render()
+            rz.set_geometry_cache(True)
+            assert torch.equal(c2, c2_ref), key
+    finally:
+        rz.set_geometry_cache(True)
