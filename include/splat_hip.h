@@ -42,6 +42,8 @@ extern "C" {
 #define SPLAT_MAX_CHANNELS 8     /* colour channels per call: 3 for the reference API, up to 8 for fused passes */
 #define SPLAT_GRAD_STRIDE 16     /* floats per Gaussian in the backward accumulator (one 64-byte line) */
 #define SPLAT_GROUP_TILES 2      /* group binning: a group is 2 x 2 tiles (SplatState.group_count) */
+#define SPLAT_QUEUE_REGION_WORDS 256  /* SplatState.tile_queue: a region = 8 cursors, one 128-byte line each */
+#define SPLAT_QUEUE_WORDS (64 * SPLAT_QUEUE_REGION_WORDS)
 #define SPLAT_COUNTER_STRIDE 32  /* uint32 words between two tile counters: one 128-byte line per counter, so that
                                     the ~200 atomics a tile receives do not serialise with its neighbours' */
 
@@ -149,6 +151,16 @@ typedef struct SplatState {
      * schedule: any permutation of each band gives the same results. */
     uint32_t *tile_work;
     uint32_t *tile_order;
+    /* PERSISTENT composites (fused iteration; NULL: one workgroup per tile, started by the hardware dispatcher).  [SPLAT_QUEUE_WORDS]
+     * zero-initialised words, eight cursors per region (one per XCD band, one 128-byte line each: cursor b of region r is word
+     * r * SPLAT_QUEUE_REGION_WORDS + b * SPLAT_COUNTER_STRIDE).  With it a composite is launched as ONE workgroup per
+     * resident slot (CUs x workgroups per CU) that pops tiles until the queues are dry: first from the band of its own XCD (in
+     * tile_order, heaviest first: neighbouring tiles share an L2), then from the other bands.  3 225 tile workgroups of very different
+     * length left 22-32 % of the slot-time of a launch unused (profiles/r04_k7_account.md 2, r05_experiments.md); a resident workgroup
+     * takes its next tile the moment it is done, and the eight bands no longer end at eight different times.  Region 0: the forward
+     * composite, region 1: the backward / the fused tracking composite (the iteration's first kernel zeroes both); regions 2..: for
+     * callers that launch a composite repeatedly (splat_iter_time_kernel).  Only a schedule: results do not depend on it. */
+    uint32_t *tile_queue;
     /* per-pixel */
     float *final_T;              /* [H][W] */
     int32_t *n_contrib;          /* [H][W] 1-based list position of the last contributor */
@@ -551,7 +563,8 @@ int splat_map_prune(SplatMapStore *store, const SplatPruneArgs *args, void *stre
  * dL/dmeans2D (what variables['means2D'].grad holds in the reference: the r, g, b planes of the loss gradient only, not the
  * depth render's) is formed by one more backward composite over the three colour planes, and for every Gaussian seen by the
  * render (radius > 0):  means2D_gradient_accum += |dL/dmeans2D.xy|,  denom += 1.  means2D_grad ([P][2], may be NULL)
- * receives the gradient itself.  Leaves ws->accum zeroed. */
+ * receives the gradient itself; means2D_gradient_accum and denom may BOTH be NULL when only the gradient is wanted (a caller that
+ * keeps the reference's own accumulate_mean2d_gradient statement: splatam_amd.plugin).  Leaves ws->accum zeroed. */
 int splat_iter_means2d_accumulate(const SplatCamera *cam, const SplatMap *map, SplatIterWorkspace *ws,
                                   float *means2D_gradient_accum, float *denom, float *means2D_grad, void *stream);
 

@@ -46,7 +46,7 @@ class SplatState(C.Structure):
                 ("group_count", _fp), ("group_recs", _fp),
                 ("max_list_hint", C.c_int32), ("order_hint", C.c_int32), ("sub_bins", C.c_int32), ("tile_stride", C.c_int32),
                 ("group_stride", C.c_int32), ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),
-                ("tile_work", _fp), ("tile_order", _fp),
+                ("tile_work", _fp), ("tile_order", _fp), ("tile_queue", _fp),
                 ("final_T", _fp), ("n_contrib", _fp), ("status", _fp)]
 
 
@@ -128,6 +128,7 @@ SPLAT_ITER_SUM_COPIES = 64
 SPLAT_POSE_STATE = 24
 SPLAT_ITER_DCAM = 32
 SPLAT_SLAB_ALIGN = 256
+SPLAT_QUEUE_WORDS = 64 * 256
 SPLAT_LAYOUT_SH, SPLAT_LAYOUT_LONG_LISTS, SPLAT_LAYOUT_BACKWARD, SPLAT_LAYOUT_SSIM, SPLAT_LAYOUT_OUTLIER = 1, 2, 4, 8, 16
 SPLAT_LAYOUT_MAX_ARRAYS = 48
 

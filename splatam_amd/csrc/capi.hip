@@ -259,13 +259,26 @@ int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P,
     } else {
         st.group_stride = 0;
     }
+    // persistent composites (SplatState.tile_queue): every launch of the bracket pops from a queue region of its own (2..63), zeroed
+    // before the bracket; the iteration's own regions 0 and 1 are re-zeroed by its first kernel
+    int launches = 0;
+    auto next_region = [&]() {
+        if (!st.tile_queue) return;
+        if (launches > 0 && launches % 62 == 0) err = hipMemsetAsync(st.tile_queue, 0, sizeof(uint32_t) * SPLAT_QUEUE_WORDS, s);
+        g_debug_queue_region = 2 + launches % 62;
+        ++launches;
+    };
+    if (st.tile_queue) err = hipMemsetAsync(st.tile_queue, 0, sizeof(uint32_t) * SPLAT_QUEUE_WORDS, s);
     (void)hipEventRecord(e0, s);
     for (int i = 0; i < iters && err == hipSuccess; ++i) {
-        if (fn != 1 && fn != 4) err = launch_render_forward_feat8(*cam, ws->feat8, st, ws->out6, sort_form, s);
-        if ((fn == 1 || fn == 3) && err == hipSuccess)
+        if (fn != 1 && fn != 4) { next_region(); err = launch_render_forward_feat8(*cam, ws->feat8, st, ws->out6, sort_form, s); }
+        if ((fn == 1 || fn == 3) && err == hipSuccess) {
+            next_region();
             err = launch_render_backward_feat8(*cam, ws->feat8, st, ws->dL_dout6, ws->accum, P, false, true, s);
-        if (fn == 4) err = launch_render_backward_feat8(*cam, ws->feat8, st, ws->dL_dout6, ws->accum, P, false, false, s, false);     // tracking form
+        }
+        if (fn == 4) { next_region(); err = launch_render_backward_feat8(*cam, ws->feat8, st, ws->dL_dout6, ws->accum, P, false, false, s, false); }     // tracking form
     }
+    g_debug_queue_region = -1;
     (void)hipEventRecord(e1, s);
     // the timed backward launches accumulated into ws->accum: restore the workspace invariant (every iteration leaves the
     // accumulator zeroed; fused_backward_kernel relies on it) outside the timed bracket
@@ -339,7 +352,7 @@ int splat_map_prune(SplatMapStore *store, const SplatPruneArgs *a, void *stream)
 int splat_iter_means2d_accumulate(const SplatCamera *cam, const SplatMap *map, SplatIterWorkspace *ws, float *gaccum, float *denom,
                                   float *means2D_grad, void *stream) {
     if (!cam || !map || !ws || map->P < 0 || cam->image_width <= 0 || cam->image_height <= 0) return SPLAT_E_INVALID;
-    if (map->P > 0 && (!gaccum || !denom || !ws->accum || !ws->feat8 || !ws->dL_dout6 || !ws->st.radii || !ws->st.conic_opacity)) return SPLAT_E_INVALID;
+    if (map->P > 0 && ((!gaccum != !denom) || (!gaccum && !means2D_grad) || !ws->accum || !ws->feat8 || !ws->dL_dout6 || !ws->st.radii || !ws->st.conic_opacity)) return SPLAT_E_INVALID;
     if (!ws->st.point_list || !ws->st.final_T || !ws->st.n_contrib || !ws->st.tile_base) return SPLAT_E_INVALID;
     return check(launch_iter_means2d_accumulate(*cam, *map, *ws, gaccum, denom, means2D_grad, (hipStream_t)stream));
 }
@@ -432,6 +445,7 @@ void state_arrays(LayoutWriter &w, bool iter, int32_t P, int32_t width, int32_t 
         if (group_stride > 0) w.add("st.group_recs", 16 * G * (size_t)group_stride, 0);
         w.add("st.tile_work", 4 * T, 1);
         w.add("st.tile_order", 4 * 8 * ((T + 7) / 8), 0);        // the caller fills it with the natural order (0xFFFFFFFF = no tile)
+        w.add("st.tile_queue", 4 * SPLAT_QUEUE_WORDS, 1);
     }
     w.add(NAME("final_T"), 4 * HW, 0);
     w.add(NAME("n_contrib"), 4 * HW, 0);
@@ -475,7 +489,7 @@ int splat_state_bind(SplatState *st, SplatGrads *gr, void *slab, const SplatArra
         BIND(depth, float *) BIND(xy, float *) BIND(conic_opacity, float *) BIND(rect, uint32_t *) BIND(radii, int32_t *)
         BIND(rgb, float *) BIND(clamped, uint8_t *) BIND(tile_count, uint32_t *) BIND(tile_base, uint32_t *) BIND(tile_cursor, uint32_t *)
         BIND(keys, uint64_t *) BIND(point_list, uint32_t *) BIND(keys_alt, uint64_t *) BIND(long_base, uint32_t *) BIND(long_items, uint32_t *)
-        BIND(group_count, uint32_t *) BIND(group_recs, uint32_t *) BIND(tile_work, uint32_t *) BIND(tile_order, uint32_t *)
+        BIND(group_count, uint32_t *) BIND(group_recs, uint32_t *) BIND(tile_work, uint32_t *) BIND(tile_order, uint32_t *) BIND(tile_queue, uint32_t *)
         BIND(final_T, float *) BIND(n_contrib, int32_t *) BIND(status, int32_t *)
 #undef BIND
         if (strcmp(name, "accum") == 0) { if (gr) gr->accum = static_cast<float *>(p); continue; }

@@ -156,6 +156,12 @@ __global__ __launch_bounds__(BLOCK) void fused_preprocess_kernel(FusedArgs a) {
         // kernel that consumes the tile counters (fused_backward_kernel); [1] (overflow) stays sticky for the host
         a.ws.st.status[0] = 0; a.ws.st.status[2] = 0; a.ws.st.status[3] = 0;
     }
+    if (i == 0 && a.ws.st.tile_queue) {
+        // persistent composites (SplatState.tile_queue): the cursors of this iteration's forward (region 0) and backward / fused
+        // tracking (region 1) composite start at zero
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a.ws.st.tile_queue[(k >> 3) * SPLAT_QUEUE_REGION_WORDS + (k & 7) * SPLAT_COUNTER_STRIDE] = 0u;
+    }
     SplatState &st = a.ws.st;
     Projected o{};
     bool vis = false;
@@ -292,6 +298,7 @@ __global__ __launch_bounds__(kDenseBlock) void fused_preprocess_dense_kernel(Fus
     const int T = c.gx * c.gy;
     for (int t = tid; t < T; t += kDenseBlock) s_tile[t] = 0u;
     if (blockIdx.x == 0 && tid == 0) { a.ws.st.status[0] = 0; a.ws.st.status[2] = 0; a.ws.st.status[3] = 0; }     // (see fused_preprocess_kernel)
+    if (blockIdx.x == 0 && tid < 16 && a.ws.st.tile_queue) a.ws.st.tile_queue[(tid >> 3) * SPLAT_QUEUE_REGION_WORDS + (tid & 7) * SPLAT_COUNTER_STRIDE] = 0u;
     __syncthreads();
     const SplatState &st = a.ws.st;
     unsigned r0[kDensePerThread], r1[kDensePerThread], dbits[kDensePerThread];
@@ -1324,8 +1331,10 @@ __global__ __launch_bounds__(kBlock) void means2d_accumulate_kernel(SplatIterWor
         const float4 co = reinterpret_cast<const float4 *>(ws.st.conic_opacity)[i];
         gx = -(co.x * s0.x + co.y * s0.y) * 0.5f * (float)W;
         gy = -(co.z * s0.y + co.y * s0.x) * 0.5f * (float)H;
-        gaccum[i] += sqrtf(gx * gx + gy * gy);
-        denom[i] += 1.0f;
+        if (gaccum) {                       // (NULL: the caller only wants the gradient itself, splatam_amd.plugin)
+            gaccum[i] += sqrtf(gx * gx + gy * gy);
+            denom[i] += 1.0f;
+        }
     }
     if (out) { out[2 * (size_t)i] = gx; out[2 * (size_t)i + 1] = gy; }
 }

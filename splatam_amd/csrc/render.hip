@@ -337,6 +337,70 @@ __device__ __forceinline__ int block_tile(int per_xcd, int T, const uint32_t *or
     return pos < T ? pos : -1;
 }
 
+// The tiles of one workgroup of a composite launch.
+//   one-shot launch (queue == NULL; grid = 8 x per_xcd): the tile block_tile() names, once;
+//   PERSISTENT launch (SplatState.tile_queue; grid = 8 x resident slots per XCD): tiles popped from the eight band queues -- the band
+//   of this workgroup's XCD first (blockIdx & 7: the hardware deals workgroups to the XCDs round robin), in the band's order, then the
+//   other bands' leftovers -- until all are dry.  `region`: which eight cursors of the queue this launch uses (zero on entry).
+// next() is called by every thread of the workgroup (it contains barriers in the persistent form: the previous tile's LDS is free, the
+// popped index is shared through `s_pop`).
+// A kernel's argument block read AGAIN from the kernarg segment, through a pointer the optimiser cannot see through (an empty asm "changes"
+// it): the composites' arguments -- camera, state (some forty pointers), loss epilogue -- do not fit the scalar register file, and a
+// loop over tiles that keeps them alive from tile to tile spills them into vector registers and scratch (+21 % on the forward
+// composite, profiles/r05_experiments.md).  Re-read per tile (a few scalar loads, cached) they live exactly as long as in the one-tile
+// kernel.  The kernel must take its arguments as ONE struct (the kernarg segment then starts with exactly that struct).
+template <class A>
+__device__ __forceinline__ const A &reread_kernargs() {
+    const __attribute__((address_space(4))) char *p = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *reinterpret_cast<const A *>((const void *)p);      // (read in place: scalar loads from the constant segment, no copy)
+}
+
+#ifndef SPLAT_TILE_LOOP
+#define SPLAT_TILE_LOOP 0        // 1: persistent composites compiled in (make EXTRA=-DSPLAT_TILE_LOOP=1); measured and NOT adopted: profiles/r05_experiments.md 3
+#endif
+struct TileLoop {
+    int per_xcd, T, band_step, done;
+    const uint32_t *order;
+    uint32_t *cursor;
+    __device__ __forceinline__ TileLoop(const SplatState &st, int per_xcd_, int T_, int region)
+        : per_xcd(per_xcd_), T(T_), band_step(0), done(0), order(st.tile_row_end > st.tile_row_begin ? nullptr : st.tile_order),
+          cursor((SPLAT_TILE_LOOP && st.tile_queue) ? st.tile_queue + SPLAT_QUEUE_REGION_WORDS * region : nullptr) {}
+    __device__ __forceinline__ int next(int *s_pop) {
+        if (!SPLAT_TILE_LOOP || !cursor) {
+            if (done) return -1;
+            done = 1;
+            return block_tile(per_xcd, T, order);
+        }
+        for (;;) {
+            if (band_step >= 8) return -1;
+            const int band = ((int)blockIdx.x + band_step) & 7;
+            uint32_t *const c = cursor + band * SPLAT_COUNTER_STRIDE;     // one 128-byte line per cursor: read-modify-writes of ONE address
+            //                                                               are served one after the other (~12 ns each) -- eight cursors in
+            //                                                               one line made every pop wait for ~20 000 others
+            __syncthreads();                                    // every wave has left the previous tile (its LDS) and read the last pop
+            if (threadIdx.x == 0) {
+                // a dry band is recognised by a plain read (the cursor only grows: a stale value can only be too small): the
+                // workgroups that arrive when it is dry -- every one of them, eight times, at the end of the launch -- do not queue up
+                // behind each other's atomics
+                unsigned q = __atomic_load_n(c, __ATOMIC_RELAXED);
+                if (q < (unsigned)per_xcd) q = atomicAdd(c, 1u);
+                *s_pop = (int)min(q, (unsigned)per_xcd);
+            }
+            __syncthreads();
+            const int q = *s_pop;                               // (uniform)
+            if (q >= per_xcd) { ++band_step; continue; }        // this band is dry: the next one
+            const int pos = band * per_xcd + q;
+            if (order) {
+                const unsigned t = order[pos];
+                if (t < (unsigned)T) return (int)t;
+            } else if (pos < T) {
+                return pos;
+            }
+        }
+    }
+};
+
 // Per-lane predicates of the inner loops are kept as wave-uniform 64-bit masks in SGPRs (ballot in, inverse
 // ballot out): the kernels are instruction-issue bound, and masks in scalar registers cost one s_and / s_andn2
 // where a per-lane bool in divergent control flow costs the compiler a chain of exec-mask bookkeeping.
@@ -640,10 +704,17 @@ __device__ __forceinline__ int forward_tile(const float *colors, SplatState &st,
 #ifndef SPLAT_K6_WAVES
 #define SPLAT_K6_WAVES 6
 #endif
+struct FwdArgs {
+    SplatCamera cam;
+    const float *colors;
+    SplatState st;
+    float *out_color, *out_depth;
+    int T, per_xcd;
+    TrackLossEpilogue ep;
+    int region;
+};
 template <int C, int CS, bool WITH_DEPTH, bool SORT, bool TRACK = false>
-__global__ __launch_bounds__(256, (forward_compact6<C, CS, WITH_DEPTH>() ? SPLAT_K6_WAVES : 5)) void render_forward_kernel(SplatCamera cam, const float *colors, SplatState st,
-                                                             float *out_color, float *out_depth, int T, int per_xcd,
-                                                             TrackLossEpilogue ep = TrackLossEpilogue{}) {
+__global__ __launch_bounds__(256, (forward_compact6<C, CS, WITH_DEPTH>() ? SPLAT_K6_WAVES : 5)) void render_forward_kernel(FwdArgs args) {
     static_assert(!TRACK || (C == 6 && !WITH_DEPTH), "the tracking-loss epilogue reads the six fused channels");
     constexpr int FP = forward_fp<C, CS, WITH_DEPTH>();
     // ONE 4x4-PIXEL BLOCK PER 16-LANE ROW: row r of wave w composites block r of quadrant w (gather(): NL = 16) from the block's OWN
@@ -654,8 +725,16 @@ __global__ __launch_bounds__(256, (forward_compact6<C, CS, WITH_DEPTH>() ? SPLAT
     constexpr int NL = 16;
     __shared__ Batch<FP, NL> B;
     __shared__ __attribute__((aligned(16))) uint64_t s_keys[SORT ? kFusedSortMax + 2 : 2];
-    const int tile_local = block_tile(per_xcd, T, st.tile_row_end > st.tile_row_begin ? nullptr : st.tile_order);      // T: tiles of this launch (SplatState.tile_row_begin: a band of tile rows)
-    if (tile_local < 0) return;
+    __shared__ int s_pop;
+    TileLoop tiles(args.st, args.per_xcd, args.T, args.region);         // T: tiles of this launch (SplatState.tile_row_begin: a band of tile rows)
+    for (int tile_local = tiles.next(&s_pop); tile_local >= 0; tile_local = tiles.next(&s_pop)) {
+    const FwdArgs &a = SPLAT_TILE_LOOP ? reread_kernargs<FwdArgs>() : args;
+    const SplatCamera &cam = a.cam;
+    SplatState &st = const_cast<SplatState &>(a.st);            // (never written: forward_tile's signature is historical)
+    const float *const colors = a.colors;
+    float *const out_color = a.out_color, *const out_depth = a.out_depth;
+    const TrackLossEpilogue &ep = a.ep;
+    (void)out_depth; (void)ep;
     const int W = cam.image_width, H = cam.image_height;
     const int gx = (W + kTile - 1) / kTile;
     const int tile = tile_local + st.tile_row_begin * gx;
@@ -727,6 +806,7 @@ __global__ __launch_bounds__(256, (forward_compact6<C, CS, WITH_DEPTH>() ? SPLAT
             if (t != 0.0) atomicAdd(ep.sums + (size_t)(blockIdx.x % SPLAT_ITER_SUM_COPIES) * SPLAT_ITER_SUMS + tid, t);
         }
     }
+    }       // tiles of this workgroup
 }
 
 // ---------------------------------------------------------------------------
@@ -1089,9 +1169,19 @@ __device__ __forceinline__ void backward_core(const float *colors, const SplatSt
 // DBG (measurement builds of the SAME body, selected by splat_debug_option(4, bits); 0 in the product launches): 1 = every workgroup
 // leaves (start, end) wall-clock stamps in `stamps` [gridDim.x][2]; 2 = stage and commit the batches but visit nothing; 4 = everything
 // but the accumulator atomics; 8 = phase 1 only (the pairs are written, never read).  profiles/r04_k7_account.md is built from them.
+struct BwdArgs {
+    SplatCamera cam;
+    const float *colors;
+    SplatState st;
+    const float *dL_dcolor;
+    float *accum;
+    int T, per_xcd;
+    long long *stamps;
+    int region;
+};
 template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC, bool BG, int DBG = 0>
-__device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, const float *colors, const SplatState &st,
-                                                      const float *dL_dcolor, float *accum, int T, int per_xcd, long long *stamps = nullptr) {
+__device__ __forceinline__ void render_backward_body5(const BwdArgs &args) {
+    long long *const stamps = args.stamps;
     long long t_begin = 0;
     if constexpr ((DBG & 1) != 0) t_begin = (long long)wall_clock64();
     auto stamp = [&]() {
@@ -1104,8 +1194,14 @@ __device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, co
     __shared__ Batch<FP> B;
     __shared__ PairBuf PB;
     __shared__ unsigned s_wmax[4];
-    const int tile_local = block_tile(per_xcd, T, st.tile_row_end > st.tile_row_begin ? nullptr : st.tile_order);
-    if (tile_local < 0) { stamp(); return; }
+    __shared__ int s_pop;
+    TileLoop tiles(args.st, args.per_xcd, args.T, args.region);
+    for (int tile_local = tiles.next(&s_pop); tile_local >= 0; tile_local = tiles.next(&s_pop)) {
+    const BwdArgs &a = SPLAT_TILE_LOOP ? reread_kernargs<BwdArgs>() : args;
+    const SplatCamera &cam = a.cam;
+    const SplatState &st = a.st;
+    const float *const colors = a.colors, *const dL_dcolor = a.dL_dcolor;
+    float *const accum = a.accum;
     const int W = cam.image_width, H = cam.image_height;
     const int gx = (W + kTile - 1) / kTile;
     const int tile = tile_local + st.tile_row_begin * gx;
@@ -1129,22 +1225,24 @@ __device__ __forceinline__ void render_backward_body5(const SplatCamera &cam, co
         }
     }
     backward_core<C, CS, DMASK, SMASK, OPAC, DBG>(colors, st, accum, B, PB, s_wmax, tile, tx, ty, tid, inside, Tfin, last, dpix, R, -1);
+    }       // tiles of this workgroup
     stamp();
 }
 
 // Two launch shapes of the same body.  With at most two colour sums (the tracking form) the phase-2 gradient rows live in registers: the
 // kernel fits 96 VGPRs and 31 KB of LDS -> FIVE workgroups per CU (tracking +2.3 % at B); the mapping form (120 VGPRs, 35.7 KB) stays
 // at four with the compiler's own register budget (an explicit minimum of four waves made it 2 % slower).
+#ifndef SPLAT_K7_MIN_WAVES
+#define SPLAT_K7_MIN_WAVES (SPLAT_TILE_LOOP ? 4 : 1)       // the tile loop keeps a few more values alive: hold the mapping form at four workgroups per CU
+#endif
 template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC = true, bool BG = true>
-__global__ __launch_bounds__(256) void render_backward_kernel5(SplatCamera cam, const float *colors, SplatState st, const float *dL_dcolor,
-                                                               float *accum, int T, int per_xcd) {
-    render_backward_body5<C, CS, DMASK, SMASK, OPAC, BG>(cam, colors, st, dL_dcolor, accum, T, per_xcd);
+__global__ __launch_bounds__(256, (popcount_c(SMASK) <= 4 ? SPLAT_K7_MIN_WAVES : 1)) void render_backward_kernel5(BwdArgs args) {
+    render_backward_body5<C, CS, DMASK, SMASK, OPAC, BG>(args);
 }
 template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC = true, bool BG = true>
-__global__ __launch_bounds__(256, 5) void render_backward_kernel5_w5(SplatCamera cam, const float *colors, SplatState st,
-                                                                     const float *dL_dcolor, float *accum, int T, int per_xcd) {
+__global__ __launch_bounds__(256, 5) void render_backward_kernel5_w5(BwdArgs args) {
     static_assert(popcount_c(SMASK) <= 2, "the five-wave shape is for the forms whose gradient rows live in registers");
-    render_backward_body5<C, CS, DMASK, SMASK, OPAC, BG>(cam, colors, st, dL_dcolor, accum, T, per_xcd);
+    render_backward_body5<C, CS, DMASK, SMASK, OPAC, BG>(args);
 }
 
 // ---------------------------------------------------------------------------
@@ -1163,9 +1261,17 @@ __global__ __launch_bounds__(256, 5) void render_backward_kernel5_w5(SplatCamera
 // DBG (measurement builds, splat_debug_option(4, bits); 0 in the product launches): 2 / 4 / 8 as in backward_core (stage only / no accumulator
 // atomics / phase 1 only), 16 = forward composite and loss only (the backward pass is not entered): the account of the kernel's memory
 // traffic in profiles/r05_track_fused_traffic.md is the differences of their FETCH_SIZE / WRITE_SIZE.
+struct TrackFusedArgs {
+    SplatCamera cam;
+    const float *feat8;
+    SplatState st;
+    float *out6, *accum;
+    int T, per_xcd;
+    TrackLossEpilogue ep;
+    int region;
+};
 template <bool KEEP, int DBG = 0>
-__global__ __launch_bounds__(256, 5) void render_track_fused_kernel(SplatCamera cam, const float *feat8, SplatState st, float *out6, float *accum,
-                                                                    int T, int per_xcd, TrackLossEpilogue ep) {
+__global__ __launch_bounds__(256, 5) void render_track_fused_kernel(TrackFusedArgs args) {
     constexpr int C = 6, CS = 8, FP = forward_fp<C, CS, false>();
     using BatchT = Batch<FP, 16, true>;
     // LDS, 31.4 KB (five workgroups per CU): [records | quadrant masks + lists | counts] live through both passes; behind them ONE region
@@ -1180,8 +1286,16 @@ __global__ __launch_bounds__(256, 5) void render_track_fused_kernel(SplatCamera 
     BatchT &B = *reinterpret_cast<BatchT *>(s_raw);
     uint64_t *const s_keys = reinterpret_cast<uint64_t *>(s_raw + kKeysAt);
     PairBuf &PB = *reinterpret_cast<PairBuf *>(s_raw + (kHead + 15) / 16 * 16);
-    const int tile_local = block_tile(per_xcd, T, st.tile_row_end > st.tile_row_begin ? nullptr : st.tile_order);
-    if (tile_local < 0) return;
+    __shared__ int s_pop;
+    TileLoop tiles(args.st, args.per_xcd, args.T, args.region);
+    for (int tile_local = tiles.next(&s_pop); tile_local >= 0; tile_local = tiles.next(&s_pop)) {
+    const TrackFusedArgs &a = SPLAT_TILE_LOOP ? reread_kernargs<TrackFusedArgs>() : args;
+    const SplatCamera &cam = a.cam;
+    SplatState &st = const_cast<SplatState &>(a.st);
+    const float *const feat8 = a.feat8;
+    float *const out6 = a.out6, *const accum = a.accum;
+    const TrackLossEpilogue &ep = a.ep;
+    (void)out6;
     const int W = cam.image_width, H = cam.image_height;
     const int gx = (W + kTile - 1) / kTile;
     const int tile = tile_local + st.tile_row_begin * gx;
@@ -1253,24 +1367,40 @@ __global__ __launch_bounds__(256, 5) void render_track_fused_kernel(SplatCamera 
     if constexpr ((DBG & 16) != 0) {
         // (measurement: forward + loss only; the per-pixel state is kept alive by a never-true store)
         if (Tfin == 1.2345e-33f && last == 0xFFFFFFFFu) accum[0] = dpix[0] + dpix[3];
-        return;
+        continue;
     }
     backward_core<C, CS, 0xFu, 0x8u, false, (DBG & 14)>(feat8, st, accum, B, PB, s_wmax, tile, tx, ty, tid, inside, Tfin, last, dpix, 0.f, staged);
     // what the next launch's order is built from (SplatState.tile_work): the quadrants' deepest contributors, as the core left them
     if (st.tile_work && tid == 0) st.tile_work[tile] = s_wmax[0] + s_wmax[1] + s_wmax[2] + s_wmax[3];
+    }       // tiles of this workgroup
 }
 
 // measurement builds (splat_debug_option(4, bits)): the fused iteration's two forms only
 template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC, bool BG, int DBG>
-__global__ __launch_bounds__(256) void render_backward_kernel5_dbg(SplatCamera cam, const float *colors, SplatState st, const float *dL_dcolor,
-                                                                   float *accum, int T, int per_xcd, long long *stamps) {
-    render_backward_body5<C, CS, DMASK, SMASK, OPAC, BG, DBG>(cam, colors, st, dL_dcolor, accum, T, per_xcd, stamps);
+__global__ __launch_bounds__(256) void render_backward_kernel5_dbg(BwdArgs args) {
+    render_backward_body5<C, CS, DMASK, SMASK, OPAC, BG, DBG>(args);
 }
 template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC, bool BG, int DBG>
-__global__ __launch_bounds__(256, 5) void render_backward_kernel5_w5_dbg(SplatCamera cam, const float *colors, SplatState st,
-                                                                         const float *dL_dcolor, float *accum, int T, int per_xcd, long long *stamps) {
-    render_backward_body5<C, CS, DMASK, SMASK, OPAC, BG, DBG>(cam, colors, st, dL_dcolor, accum, T, per_xcd, stamps);
+__global__ __launch_bounds__(256, 5) void render_backward_kernel5_w5_dbg(BwdArgs args) {
+    render_backward_body5<C, CS, DMASK, SMASK, OPAC, BG, DBG>(args);
 }
+
+// The grid of a PERSISTENT composite launch (SplatState.tile_queue): 8 x min(tiles per band, 8 workgroups per CU x 32 CUs per XCD).
+// More workgroups than slots is harmless (the late ones find the queues dry); FEWER leaves slots empty for the whole launch -- the
+// occupancy query (hipOccupancyMaxActiveBlocksPerMultiprocessor) answered 2 per CU for kernels that run 4-6, so it is not asked.
+template <class K>
+static dim3 composite_grid(K, const SplatState &st, int per) {
+    int cus = 256, dev = 0;
+    static int cached_cus = 0;
+    if (cached_cus == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) cus = prop.multiProcessorCount;
+        cached_cus = cus;
+    }
+    return dim3(8u * (unsigned)((SPLAT_TILE_LOOP && st.tile_queue) ? min(per, 8 * (cached_cus / 8)) : per));
+}
+static SplatState one_shot(const SplatState &st) { SplatState c = st; c.tile_queue = nullptr; return c; }      // (measurement builds, helper passes)
+int g_debug_queue_region = -1;          // launches of the timing helper: the queue region of the next persistent launch (capi.hip)
 
 int g_debug_k7_bits = 0;                // splat_debug_option(4, bits)
 long long *g_debug_stamps = nullptr;    // splat_debug_stamps(buffer)
@@ -1281,8 +1411,9 @@ long long *g_debug_stamps = nullptr;    // splat_debug_stamps(buffer)
 template <int C, int CS, bool WITH_DEPTH, bool SORT = false>
 static void launch_fwd(const SplatCamera &cam, const float *colors, SplatState &st, float *oc, float *od, int T, hipStream_t s) {
     const int per = (T + 7) / 8;
-    hipLaunchKernelGGL((render_forward_kernel<C, CS, WITH_DEPTH, SORT, false>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, oc, od, T, per,
-                       TrackLossEpilogue{});
+    auto k = render_forward_kernel<C, CS, WITH_DEPTH, SORT, false>;
+    hipLaunchKernelGGL(k, composite_grid(k, st, per), dim3(256), 0, s,
+                       FwdArgs{cam, colors, st, oc, od, T, per, TrackLossEpilogue{}, g_debug_queue_region >= 0 ? g_debug_queue_region : 0});
 }
 template <int C, int CS, unsigned DMASK = (1u << C) - 1u, unsigned SMASK = (1u << C) - 1u, bool OPAC = true, bool BG = true>
 static void launch_bwd(const SplatCamera &cam, const float *colors, const SplatState &st, const float *dl, float *acc, int T,
@@ -1294,11 +1425,11 @@ static void launch_bwd(const SplatCamera &cam, const float *colors, const SplatS
             auto go = [&](auto D) {
                 constexpr int DBG = decltype(D)::value;
                 if constexpr (W5)
-                    hipLaunchKernelGGL((render_backward_kernel5_w5_dbg<C, CS, DMASK, SMASK, OPAC, BG, DBG>), dim3(8 * per), dim3(256), 0, s, cam, colors,
-                                       st, dl, acc, T, per, g_debug_stamps);
+                    hipLaunchKernelGGL((render_backward_kernel5_w5_dbg<C, CS, DMASK, SMASK, OPAC, BG, DBG>), dim3(8 * per), dim3(256), 0, s,
+                                       BwdArgs{cam, colors, one_shot(st), dl, acc, T, per, g_debug_stamps, 1});
                 else
-                    hipLaunchKernelGGL((render_backward_kernel5_dbg<C, CS, DMASK, SMASK, OPAC, BG, DBG>), dim3(8 * per), dim3(256), 0, s, cam, colors, st,
-                                       dl, acc, T, per, g_debug_stamps);
+                    hipLaunchKernelGGL((render_backward_kernel5_dbg<C, CS, DMASK, SMASK, OPAC, BG, DBG>), dim3(8 * per), dim3(256), 0, s,
+                                       BwdArgs{cam, colors, one_shot(st), dl, acc, T, per, g_debug_stamps, 1});
             };
             switch (g_debug_k7_bits) {
                 case 1: go(std::integral_constant<int, 1>{}); return;
@@ -1312,10 +1443,14 @@ static void launch_bwd(const SplatCamera &cam, const float *colors, const SplatS
             }
         }
     }
-    if constexpr (popcount_c(SMASK) <= 2)
-        hipLaunchKernelGGL((render_backward_kernel5_w5<C, CS, DMASK, SMASK, OPAC, BG>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
-    else
-        hipLaunchKernelGGL((render_backward_kernel5<C, CS, DMASK, SMASK, OPAC, BG>), dim3(8 * per), dim3(256), 0, s, cam, colors, st, dl, acc, T, per);
+    const int region = g_debug_queue_region >= 0 ? g_debug_queue_region : 1;
+    if constexpr (popcount_c(SMASK) <= 2) {
+        auto k = render_backward_kernel5_w5<C, CS, DMASK, SMASK, OPAC, BG>;
+        hipLaunchKernelGGL(k, composite_grid(k, st, per), dim3(256), 0, s, BwdArgs{cam, colors, st, dl, acc, T, per, nullptr, region});
+    } else {
+        auto k = render_backward_kernel5<C, CS, DMASK, SMASK, OPAC, BG>;
+        hipLaunchKernelGGL(k, composite_grid(k, st, per), dim3(256), 0, s, BwdArgs{cam, colors, st, dl, acc, T, per, nullptr, region});
+    }
 }
 
 static const float *colour_source(const SplatGaussians &g, const SplatState &st) {
@@ -1379,11 +1514,15 @@ hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat
     const int per = (T + 7) / 8;
     if (ep && ep_done) {
         if (sort_in_kernel)
-            hipLaunchKernelGGL((render_forward_kernel<6, 8, false, true, true>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6,
-                               (float *)nullptr, T, per, *ep);
+        {
+            auto k = render_forward_kernel<6, 8, false, true, true>;
+            hipLaunchKernelGGL(k, composite_grid(k, st, per), dim3(256), 0, s, FwdArgs{cam, feat8, st, out6, nullptr, T, per, *ep, 0});
+        }
         else
-            hipLaunchKernelGGL((render_forward_kernel<6, 8, false, false, true>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6,
-                               (float *)nullptr, T, per, *ep);
+        {
+            auto k = render_forward_kernel<6, 8, false, false, true>;
+            hipLaunchKernelGGL(k, composite_grid(k, st, per), dim3(256), 0, s, FwdArgs{cam, feat8, st, out6, nullptr, T, per, *ep, 0});
+        }
         *ep_done = true;
         return hipGetLastError();
     }
@@ -1401,16 +1540,21 @@ hipError_t launch_render_track_fused(const SplatCamera &cam, const float *feat8,
     const int per = (T + 7) / 8;
     if (!keep_planes && g_debug_k7_bits != 0) {           // measurement builds (see render_track_fused_kernel)
         switch (g_debug_k7_bits) {
-            case 2: hipLaunchKernelGGL((render_track_fused_kernel<false, 2>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6, accum, T, per, ep); break;
-            case 4: hipLaunchKernelGGL((render_track_fused_kernel<false, 4>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6, accum, T, per, ep); break;
-            case 8: hipLaunchKernelGGL((render_track_fused_kernel<false, 8>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6, accum, T, per, ep); break;
-            case 16: hipLaunchKernelGGL((render_track_fused_kernel<false, 16>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6, accum, T, per, ep); break;
-            default: hipLaunchKernelGGL((render_track_fused_kernel<false>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6, accum, T, per, ep); break;
+            case 2: hipLaunchKernelGGL((render_track_fused_kernel<false, 2>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, one_shot(st), out6, accum, T, per, ep, 1}); break;
+            case 4: hipLaunchKernelGGL((render_track_fused_kernel<false, 4>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, one_shot(st), out6, accum, T, per, ep, 1}); break;
+            case 8: hipLaunchKernelGGL((render_track_fused_kernel<false, 8>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, one_shot(st), out6, accum, T, per, ep, 1}); break;
+            case 16: hipLaunchKernelGGL((render_track_fused_kernel<false, 16>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, one_shot(st), out6, accum, T, per, ep, 1}); break;
+            default: hipLaunchKernelGGL((render_track_fused_kernel<false>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, one_shot(st), out6, accum, T, per, ep, 1}); break;
         }
         return hipGetLastError();
     }
-    if (keep_planes) hipLaunchKernelGGL((render_track_fused_kernel<true>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6, accum, T, per, ep);
-    else hipLaunchKernelGGL((render_track_fused_kernel<false>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, out6, accum, T, per, ep);
+    if (keep_planes) {
+        auto k = render_track_fused_kernel<true>;
+        hipLaunchKernelGGL(k, composite_grid(k, st, per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, st, out6, accum, T, per, ep, 1});
+    } else {
+        auto k = render_track_fused_kernel<false>;
+        hipLaunchKernelGGL(k, composite_grid(k, st, per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, st, out6, accum, T, per, ep, 1});
+    }
     return hipGetLastError();
 }
 
@@ -1438,7 +1582,7 @@ hipError_t launch_render_backward_rgb_only(const SplatCamera &cam, const float *
     const int T = launch_tiles(cam, st);
     if (T == 0 || P == 0) return hipSuccess;
     const int per = (T + 7) / 8;
-    hipLaunchKernelGGL((render_backward_kernel5_w5<6, 8, 0x7u, 0x0u, false, false>), dim3(8 * per), dim3(256), 0, s, cam, feat8, st, dL_dout6, accum, T, per);
+    hipLaunchKernelGGL((render_backward_kernel5_w5<6, 8, 0x7u, 0x0u, false, false>), dim3(8 * per), dim3(256), 0, s, BwdArgs{cam, feat8, one_shot(st), dL_dout6, accum, T, per, nullptr, 1});
     return hipGetLastError();
 }
 

@@ -81,6 +81,7 @@ size_t map_scratch_words(long long n);
 int map_row_floats(const SplatMapStore &st);
 extern int g_debug_skip_count;
 extern int g_debug_k7_bits;
+extern int g_debug_queue_region;       // >= 0: the queue region of the next persistent composite launch (splat_iter_time_kernel)
 extern long long *g_debug_stamps;
 hipError_t launch_selftest(int which, const void *in, void *out, int n, hipStream_t s);
 

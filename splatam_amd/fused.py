@@ -82,6 +82,9 @@ class FusedEngine:
         b['tile_order'] = torch.where(nat < T, nat, torch.full_like(nat, 0xFFFFFFFF)).to(torch.uint32).view(i32).to(dev) \
             if hasattr(torch, "uint32") else None
         self.tile_order_on = os.environ.get("SPLAT_TILE_ORDER", "1") != "0" and b['tile_order'] is not None
+        # persistent composites (SplatState.tile_queue): one workgroup per resident slot pops tiles from per-XCD queues instead of one
+        # hardware-dispatched workgroup per tile
+        self.persistent = os.environ.get("SPLAT_PERSISTENT", "0") != "0"        # (needs a library built with -DSPLAT_TILE_LOOP=1; not adopted: profiles/r05_experiments.md 3)
         b['pose_state'] = torch.zeros(_capi.SPLAT_POSE_STATE, dtype=f32, **z)
         self.max_2D_radius = self.store['max_2D_radius'] if self.managed else track_max_radius
         b['counts'] = torch.zeros(8, dtype=i32, **z)
@@ -130,7 +133,8 @@ class FusedEngine:
     _FIXED_ARRAYS = (("st.tile_count", "tile_count", torch.int32), ("st.tile_base", "tile_base", torch.int32),
                      ("st.tile_cursor", "tile_cursor", torch.int32), ("st.long_base", "long_base", torch.int32),
                      ("st.group_count", "group_count", torch.int32), ("st.status", "status", torch.int32),
-                     ("st.tile_work", "tile_work", torch.int32), ("st.final_T", "final_T", torch.float32),
+                     ("st.tile_work", "tile_work", torch.int32), ("st.tile_queue", "tile_queue", torch.int32),
+                     ("st.final_T", "final_T", torch.float32),
                      ("st.n_contrib", "n_contrib", torch.int32), ("out6", "out6", torch.float32), ("dL_dout6", "dL_dout6", torch.float32),
                      ("ssim_maps", "ssim_maps", torch.float32), ("sums", "sums", torch.float64), ("d_cam", "d_cam", torch.float32))
 
@@ -458,6 +462,21 @@ class FusedEngine:
                         "splat_iter_means2d_accumulate")
         return out
 
+    def means2d_gradient(self):
+        """The colour pass' screen-space gradient of the iteration whose ``loss_backward`` has just run (planes kept: every mapping
+        iteration, tracking with ``keep_planes``): [P, 2], the first two columns of the reference's ``variables['means2D'].grad``
+        (/root/reference/scripts/splatam.py:248-250).  One more backward composite over the three colour planes; nothing is
+        accumulated (the caller's own accumulate_mean2d_gradient statement does that)."""
+        out = torch.zeros(self.P, 2, dtype=torch.float32, device=self.dev)
+        if self.P == 0:
+            return out
+        ws = self._workspace(False, with_ssim=False)
+        m = self._map_struct()
+        with torch.cuda.device(self.dev):
+            _capi.check(self.L.splat_iter_means2d_accumulate(C.byref(self._cam), C.byref(m), C.byref(ws), None, None, out.data_ptr(),
+                                                             self._stream()), "splat_iter_means2d_accumulate")
+        return out
+
     def _densify_args(self, mode, thr, small, rows_with_grad, n=1, samples=None):
         b = self.buf
         if 'flags' not in b or b['flags'].numel() < self.Pcap:
@@ -618,6 +637,7 @@ class FusedEngine:
         st.order_hint = int(self.creation_order)
         if self.tile_order_on:
             st.tile_work, st.tile_order = b['tile_work'].data_ptr(), b['tile_order'].data_ptr()
+        st.tile_queue = b['tile_queue'].data_ptr() if self.persistent else None
         st.sub_bins = self.sub_bins if self.tile_stride == 0 else 1
         st.final_T, st.n_contrib, st.status = b['final_T'].data_ptr(), b['n_contrib'].data_ptr(), b['status'].data_ptr()
         ws.feat8, ws.out6, ws.dL_dout6, ws.accum = b['feat8'].data_ptr(), b['out6'].data_ptr(), b['dL_dout6'].data_ptr(), b['accum'].data_ptr()

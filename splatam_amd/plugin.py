@@ -41,8 +41,11 @@ Learning rates the shipped configurations leave at zero are honoured too: pose l
 adjustment, ``get_loss(..., do_ba=True)``: the pose gradient of the iteration's report goes through torch's own Adam on the two small
 camera tensors) and Gaussian learning rates in the tracking optimizer (rgb / opacity / scale gradients are then formed -- centres and
 rotations are detached while tracking, /root/reference/utils/slam_helpers.py:266-271 -- and stepped by the Adam kernel with the
-tracking optimizer's eps).  What the plug-in does NOT provide: ``variables['means2D'].grad`` (gradient-based densification:
-``use_gaussian_splatting_densification`` raises) and ``visualize_tracking_loss``.
+tracking optimizer's eps).  Gradient-based densification (``use_gaussian_splatting_densification``,
+/root/reference/scripts/splatam.py:863-866): ``variables['means2D']`` is an object whose ``.grad`` -- the colour pass' screen-space
+gradient the reference's ``accumulate_mean2d_gradient`` reads (/root/reference/utils/slam_external.py:100-104) -- is formed on first
+access by one extra RGB-only backward composite over the iteration's lists; configurations that never read it never pay for it.
+What the plug-in does NOT provide: ``visualize_tracking_loss``.
 """
 from __future__ import annotations
 
@@ -128,6 +131,33 @@ def _report_values(host):
     ints = host.view(torch.int32)[16:22].tolist()
     vals[16:22] = ints
     return vals
+
+
+class _Means2D:
+    """``variables['means2D']`` of a plug-in iteration: the reference keeps the (zero) render variable there to read its ``.grad``
+    after ``backward()`` (/root/reference/scripts/splatam.py:248-250, utils/slam_external.py:100-104).  Here ``.grad`` is the colour
+    pass' dL/dmeans2D [P, 3] (third column zero, as the rasterizer returns it), formed on first access from the iteration's
+    workspace -- valid until the next ``get_loss`` of the same engine."""
+
+    def __init__(self, eng, rep, tracking):
+        self._eng, self._rep, self._tracking, self._grad = eng, rep, tracking, None
+        self.shape = (eng.P, 3)
+
+    def retain_grad(self):
+        return None
+
+    @property
+    def grad(self):
+        if self._grad is None:
+            cur = _session.current
+            if cur is None or cur[2] is not self._rep:
+                raise RuntimeError("variables['means2D'].grad is formed from the iteration's workspace: read it before the next get_loss()")
+            if self._tracking:
+                raise RuntimeError("variables['means2D'].grad of a TRACKING iteration: the fused tracking composite keeps no planes "
+                                   "(the reference reads this gradient in mapping only: densify, scripts/splatam.py:863-866)")
+            g2 = self._eng.means2d_gradient()
+            self._grad = torch.cat((g2, torch.zeros(g2.shape[0], 1, device=g2.device)), dim=1)
+        return self._grad
 
 
 def _scalar(rep, slot):
@@ -309,6 +339,7 @@ def get_loss(params, curr_data, variables, iter_time_idx, loss_weights, use_sil_
         losses['depth'] = _scalar(rep, 14)
     if variables is not None:
         variables['seen'] = eng.seen
+        variables['means2D'] = _Means2D(eng, rep, tracking)
     return loss, variables, losses
 
 

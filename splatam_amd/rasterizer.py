@@ -253,7 +253,7 @@ def _cam_key(settings, view, proj):
 
 
 class _GeomEntry:
-    __slots__ = ("pk", "key", "tensors", "versions", "means_snapshot")
+    __slots__ = ("pk", "key", "tensors", "versions", "snapshot")
 
 
 def _remember_geometry(pk, settings, means3D_src, opac, scales, rots):
@@ -263,9 +263,10 @@ def _remember_geometry(pk, settings, means3D_src, opac, scales, rots):
     e.key = _cam_key(settings, view, proj)
     e.tensors = (means3D_src, opac, scales, rots, view, proj)      # alive: their storage cannot be handed to another tensor
     e.versions = (means3D_src._version, opac._version, scales._version, rots._version)
-    # a snapshot of the centres the cached geometry was projected from: version counters do not see raw-pointer writes (this library's own
-    # Adam / map-edit kernels, `.data` arithmetic), so the second call compares the VALUES on the device (3.6 MB at 300 k Gaussians)
-    e.means_snapshot = means3D_src.detach().contiguous().clone()
+    # SNAPSHOTS of what the cached geometry was projected from: version counters do not see raw-pointer writes (this library's own
+    # Adam / map-edit kernels, `.data` arithmetic), and the second call may pass the very same tensor objects, so it compares the VALUES
+    # on the device against these copies (44 bytes per Gaussian: 13 MB at 300 k)
+    e.snapshot = tuple(t.detach().contiguous().clone() for t in (means3D_src, opac, scales, rots))
     _geom_last[means3D_src.device.index] = e
 
 
@@ -298,10 +299,11 @@ def _shared_geometry(settings, means3D, colors, opac, scales, rots, cov3D, shs, 
     now = means3D_src.detach().contiguous()
     L = _capi.lib()
     with torch.cuda.device(dev):
-        _capi.check(L.splat_same_geometry(P, o1.data_ptr(), opac.data_ptr(), s1.data_ptr(), scales.data_ptr(),
-                                          r1.data_ptr(), rots.data_ptr(), flags.data_ptr(), _stream(dev)), "splat_same_geometry")
-        _capi.check(L.splat_same_geometry(P, opac.data_ptr(), opac.data_ptr(), e.means_snapshot.data_ptr(), now.data_ptr(),
-                                          rots.data_ptr(), rots.data_ptr(), flags.data_ptr() + 4, _stream(dev)), "splat_same_geometry")
+        m0, o0, s0, r0 = e.snapshot
+        _capi.check(L.splat_same_geometry(P, o0.data_ptr(), opac.data_ptr(), s0.data_ptr(), scales.data_ptr(),
+                                          r0.data_ptr(), rots.data_ptr(), flags.data_ptr(), _stream(dev)), "splat_same_geometry")
+        _capi.check(L.splat_same_geometry(P, o0.data_ptr(), o0.data_ptr(), m0.data_ptr(), now.data_ptr(),
+                                          r0.data_ptr(), r0.data_ptr(), flags.data_ptr() + 4, _stream(dev)), "splat_same_geometry")
     geometry_cache_stats["verified_on_device"] += 1
     if any(flags.tolist()):
         geometry_cache_stats["mismatch"] += 1

@@ -146,8 +146,9 @@ def test_scratch_layouts_describe_the_structs():
     assert il.bytes["st.group_count"] == 4 * G * _capi.SPLAT_COUNTER_STRIDE and il.bytes["st.group_recs"] == 16 * G * gs
     assert il.bytes["st.tile_order"] == 4 * 8 * ((T + 7) // 8) and il.bytes["outlier_scratch"] == 4 * L.splat_map_scratch_words(W * H)
     zero = {k for k in il.names if il.zero_init[k]}
-    assert zero == {"st.radii", "st.tile_count", "st.long_base", "st.group_count", "st.tile_work", "st.status", "dL_dout6", "accum", "sums",
-                    "d_cam", "outlier_scratch"}
+    assert zero == {"st.radii", "st.tile_count", "st.long_base", "st.group_count", "st.tile_work", "st.tile_queue", "st.status", "dL_dout6",
+                    "accum", "sums", "d_cam", "outlier_scratch"}
+    assert il.bytes["st.tile_queue"] == 4 * _capi.SPLAT_QUEUE_WORDS
     ws = _capi.SplatIterWorkspace()
     assert L.splat_iter_workspace_bind(C.byref(ws), base, il.arrays, il.n, cap, gs) == 0
     for k in il.names:

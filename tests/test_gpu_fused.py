@@ -439,7 +439,8 @@ def test_mapping_batch_equals_gradient_accumulation():
     other = {}
     e_b.loss_backward(*views[1], cfg, tracking=False)
     other['b'] = e_b.reduce_flat.clone()
-    e_a.mapping_batch([views[0], views[2]], cfg, total_views=3, allreduce_sum=lambda red: red.add_(other['b']))
+    # (the exchanged buffer = a 16-float header -- slot 0 carries the rank's capacity flag, FusedEngine.exchange_gradients -- + the gradients)
+    e_a.mapping_batch([views[0], views[2]], cfg, total_views=3, allreduce_sum=lambda red: red[red.numel() - other['b'].numel():].add_(other['b']))
     torch.cuda.synchronize()
     for k in ('means3D', 'rgb_colors', 'logit_opacities', 'log_scales'):
         ref = p_ref[k].detach()

@@ -306,3 +306,47 @@ def test_learning_rates_the_shipped_configs_leave_at_zero():
     assert torch.equal(mine['means3D'].detach(), before['means3D']) and torch.equal(ref['means3D'].detach(), before['means3D'])
     for k in ("cam_unnorm_rots", "cam_trans"):
         assert float((mine[k].detach() - ref[k].detach()).abs().max()) <= 0.02 * lrs[k], k
+
+
+def test_means2d_gradient_for_the_references_densification():
+    """use_gaussian_splatting_densification (/root/reference/scripts/splatam.py:863-866): the reference's own statement
+    `accumulate_mean2d_gradient(variables)` (/root/reference/utils/slam_external.py:100-104, mirrored in slam.accumulate_mean2d_gradient)
+    reads variables['means2D'].grad -- the COLOUR pass' screen-space gradient -- after backward().  Through the plug-in that gradient
+    is formed on first access (one RGB-only backward composite over the iteration's lists): equal to the drop-in path's autograd result,
+    and the statement accumulates the same statistic.  Tracking iterations keep no planes: reading it there raises."""
+    from splatam_amd import plugin, slam
+    params, _, frame, cam = _scene(8000, 208, 160, aniso=False, seed=11)
+    cfg = slam.REPLICA_MAPPING
+    ref = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    mine = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    args = (cfg['loss_weights'], cfg['use_sil_for_loss'], cfg['sil_thres'], cfg['use_l1'], cfg['ignore_outlier_depth_loss'])
+    ref_vars = _variables(ref)
+    loss, ref_vars, _ = slam.get_loss(ref, frame, ref_vars, 1, *args, mapping=True)
+    loss.backward()
+    want = ref_vars['means2D'].grad
+    slam.accumulate_mean2d_gradient(ref_vars)
+    with plugin.install(slam):
+        my_vars = _variables(mine)
+        loss, my_vars, _ = slam.get_loss(mine, frame, my_vars, 1, *args, mapping=True)
+        loss.backward()
+        got = my_vars['means2D'].grad
+        slam.accumulate_mean2d_gradient(my_vars)                    # the reference's statement, unchanged
+        scale = float(want[:, :2].abs().max())
+        err = float((got[:, :2] - want[:, :2]).abs().max())
+        print(f"means2D.grad: max |difference| {err:.3e} at scale {scale:.3e}")
+        assert got.shape == want.shape and err <= 1e-3 * scale and float(got[:, 2].abs().max()) == 0.0
+        assert torch.equal(my_vars['denom'], ref_vars['denom'])
+        acc_err = float((my_vars['means2D_gradient_accum'] - ref_vars['means2D_gradient_accum']).abs().max())
+        assert acc_err <= 1e-3 * float(ref_vars['means2D_gradient_accum'].max())
+        # the gradient belongs to the iteration: after the next get_loss the old object refuses
+        stale = my_vars['means2D']
+        stale._grad = None
+        loss, my_vars, _ = slam.get_loss(mine, frame, my_vars, 1, *args, mapping=True)
+        with pytest.raises(RuntimeError, match="before the next get_loss"):
+            stale.grad
+        tcfg = slam.REPLICA_TRACKING
+        slam.initialize_optimizer(mine, tcfg['lrs'], tracking=True)
+        loss, my_vars, _ = slam.get_loss(mine, frame, my_vars, 1, tcfg['loss_weights'], tcfg['use_sil_for_loss'], tcfg['sil_thres'],
+                                         tcfg['use_l1'], tcfg['ignore_outlier_depth_loss'], tracking=True)
+        with pytest.raises(RuntimeError, match="TRACKING"):
+            my_vars['means2D'].grad
