@@ -329,7 +329,9 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
              "per_kernel_durations": "live (torch.profiler over this run's iterations)" if live else "committed trace (no tracer in this process)",
              "kernels": rows,
              "note": "K6 / K7 times are live HIP-event measurements of this run (30 launches in a row on the iteration's stream, learnt list "
-                     "state, after a mapping iteration); counters (traffic = 2 x FETCH_SIZE + WRITE_SIZE) and the "
+                     "state, after a mapping iteration); counters (traffic = 2 x FETCH_SIZE + WRITE_SIZE as the microarchitecture guide prescribes: "
+                     "an UPPER bound here -- the factor 2 is for wide streaming reads, these kernels mostly gather 8-16 bytes; raw FETCH + WRITE "
+                     "and where they come from: profiles/r05_experiments.md 5) and the "
                      "per-kernel rows come from the committed rocprofv3 passes named in pmc_source.  valu_cycles_frac = vector-pipe cycles "
                      "of the kernel's instruction mix / (1024 SIMDs x kernel cycles) with the MEASURED issue costs of gfx950 "
                      "(profiles/r03_valu_issue_bench.txt, r03_visit_replay.txt: plain VALU 2 cycles per wave64 instruction, compares / "

@@ -217,7 +217,12 @@ typedef struct SplatGrads {
     float *dL_dmeans2D;          /* [P][3] NDC-space gradient of the projected centre, z = 0 */
     float *dL_dcolors;           /* [P][C] (NULL when shs are used) */
     float *dL_dopacities;        /* [P] */
-    float *dL_dscales;           /* [P][3] or NULL */
+    float *dL_dscales;           /* [P][3] or NULL.  Gradient w.r.t. the UNMODIFIED scales the caller passed: it carries the factor
+                                    cam->scale_modifier (Sigma = R diag((modifier s)^2) R^T).  DEVIATION from the CUDA original as recalled
+                                    (SURVEY.md Appendix A): its computeCov3D adjoint returns dL/d(modifier s) without that factor.  Equal at
+                                    modifier 1.0 -- every SplaTAM configuration, the viewers render without gradients --; a caller that
+                                    trains with another modifier and wants the original's numbers divides by it.  The oracle follows this
+                                    library (oracle/raster_ref.c), tests/test_gpu_configs.py covers modifier 1.6 */
     float *dL_drotations;        /* [P][4] or NULL */
     float *dL_dcov3D;            /* [P][6] or NULL */
     float *dL_dshs;              /* [P][M][3] or NULL */

@@ -10,7 +10,6 @@ here                                           reference
                                                best-candidate bookkeeping and the depth-loss retry, densification,
                                                keyframe selection, mapping with pruning, keyframe list)
 ``save_params`` / ``load_params``              utils/common_utils.py:25-52 (``params.npz``)
-``save_ply``                                   scripts/export_ply.py:20-42 (``splat.ply``; written without plyfile)
 ``SyntheticRGBDSequence``                      stands in for datasets/gradslam_datasets/* (no datasets offline)
 =============================================  =============================================
 
@@ -132,32 +131,6 @@ def load_params(path, device="cuda"):
     """Inverse of ``save_params`` the way the reference's checkpoint loader reads it (scripts/splatam.py:611-613)."""
     raw = dict(np.load(path, allow_pickle=True))
     return {k: torch.tensor(v).to(device).float().requires_grad_(True) for k, v in raw.items()}
-
-
-PLY_ATTRS = ('x', 'y', 'z', 'nx', 'ny', 'nz', 'f_dc_0', 'f_dc_1', 'f_dc_2', 'opacity', 'scale_0', 'scale_1', 'scale_2',
-             'rot_0', 'rot_1', 'rot_2', 'rot_3')
-_SH_C0 = 0.28209479177387814
-
-
-def save_ply(path, means, scales, rotations, rgbs, opacities, normals=None):
-    """The map as a 3D-Gaussian-Splatting ``splat.ply`` (binary little endian, one float32 vertex element with the 17
-    properties of ``PLY_ATTRS``): colours as the DC spherical-harmonic coefficient (rgb - 0.5) / C0, isotropic scales
-    repeated to three columns; opacities stay logits and scales logs, as the viewers expect."""
-    means = np.asarray(means, dtype=np.float32)
-    normals = np.zeros_like(means) if normals is None else np.asarray(normals, dtype=np.float32)
-    scales = np.asarray(scales, dtype=np.float32)
-    if scales.shape[1] == 1:
-        scales = np.tile(scales, (1, 3))
-    colors = (np.asarray(rgbs, dtype=np.float32) - 0.5) / _SH_C0
-    table = np.concatenate((means, normals, colors, np.asarray(opacities, dtype=np.float32).reshape(-1, 1), scales,
-                            np.asarray(rotations, dtype=np.float32)), axis=1).astype('<f4')
-    assert table.shape[1] == len(PLY_ATTRS)
-    header = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % table.shape[0]
-    header += "".join(f"property float {a}\n" for a in PLY_ATTRS) + "end_header\n"
-    with open(path, "wb") as f:
-        f.write(header.encode("ascii"))
-        f.write(np.ascontiguousarray(table).tobytes())
-    return path
 
 
 class SyntheticRGBDSequence:
