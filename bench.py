@@ -296,12 +296,16 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
     #  planes stay in registers, six partial sums per Gaussian leave it)
     # (the SSIM kernels are templates since the column-first form: a counter file taken on the row-first kernels does not describe them)
     per_unit = {"render_track_fused_kernel": R * 52 + HW * 16 + N * 24, "fused_preprocess_kernel": N * (48 + 87), "ssim_forward_kernel<": HW * (2 * 12 + 36 + 16), "map_loss_backward_kernel<": HW * (36 + 24 + 16),
-                "fused_backward_kernel": N * (64 + 40 + 48), "adam_map_kernel": N * 12 * 4 * 6}
+                # F6, mapping step: accumulator row 64 + geometry 40 + gradients out 48 + (Adam inside) parameters, two moments in and out 12 x 4 x 5;
+                # F6, tracking: accumulator row + geometry in, only the camera sums out
+                "fused_backward_kernel<true, true": N * (64 + 40 + 48 + 12 * 4 * 5), "fused_backward_kernel<false, false": N * (64 + 40),
+                "adam_map_kernel": N * 12 * 4 * 6}
     for kname, abytes in per_unit.items():
         d = (pmc_kernel(pmc, kname) or {}) if counters_ok else {}
         us_live, us_trace = live_avg_us(live, kname), trace_avg_us(trace, kname)
         us = us_live or us_trace
-        kname = kname.rstrip("<")
+        kname = {"fused_backward_kernel<true, true": "fused_backward_kernel (mapping, Adam inside)",
+                 "fused_backward_kernel<false, false": "fused_backward_kernel (tracking)"}.get(kname, kname.rstrip("<"))
         if us:
             rows[kname] = {"avg_us": round(us, 1), "avg_us_source": "live" if us_live else "committed trace",
                            "avg_us_committed_trace": None if us_trace is None else round(us_trace, 1),
