@@ -141,6 +141,14 @@ CASES = {
                     tracking=dict(num_iters=5, forward_prop=False, use_depth_loss_thres=True, depth_loss_thres=None),
                     mapping=dict(num_iters=6, pruning_dict=dict(start_after=1, remove_big_after=2, stop_after=4, prune_every=2,
                                                                 removal_opacity_threshold=0.515, final_removal_opacity_threshold=0.52)))),
+    # ground-truth poses instead of tracking (scripts/splatam.py:745-754: matrix_to_quaternion of the dataset's relative pose), no
+    # pruning, a keyframe on every frame, every keyframe in the window
+    "gtposes": dict(
+        scene=dict(n_gaussians=4000, W=80, H=64, f=70.0, frames=4, seed=11, step_m=0.02, step_deg=0.8),
+        config=dict(run_name="gtposes", map_every=1, keyframe_every=1, mapping_window_size=8, scene_radius_depth_ratio=3,
+                    data=dict(desired_image_height=64, desired_image_width=80, num_frames=-1),
+                    tracking=dict(num_iters=4, use_gt_poses=True),
+                    mapping=dict(num_iters=5, prune_gaussians=False))),
 }
 
 

@@ -167,6 +167,9 @@ def per_frame_decisions(events, selected, keyframe_time_indices, num_frames, pru
         elif k == LOSS and c:
             frames[t]['views'].append(a)
         elif k == ADD:
+            for f in frames[:t]:                               # (a recording without prune calls first learns the row count here)
+                if f['rows_end'] is None:
+                    f['rows_end'] = b
             frames[t]['rows_after_add'] = rows = c
         elif k == PRUNE:
             on_schedule = a <= prune_dict['stop_after'] and a >= prune_dict['start_after'] and a % prune_dict['prune_every'] == 0

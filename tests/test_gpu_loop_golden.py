@@ -76,7 +76,7 @@ def check_trajectory(case, params, what):
         assert d.max() < tol, (what, k, d.max())
 
 
-@pytest.mark.parametrize("case", ["base", "variant"])
+@pytest.mark.parametrize("case", ["base", "variant", "gtposes"])
 @pytest.mark.parametrize("engine", ["dropin", "plugin"])
 def test_statement_engines_make_the_reference_loops_calls(case, engine):
     cfg, rec, params, variables, stats = run_engine(case, engine)
@@ -96,7 +96,7 @@ def test_statement_engines_make_the_reference_loops_calls(case, engine):
         assert stats['plugin']['skipped_iterations'] == 0, stats['plugin']
 
 
-@pytest.mark.parametrize("case", ["base", "variant"])
+@pytest.mark.parametrize("case", ["base", "variant", "gtposes"])
 def test_fused_engine_takes_the_reference_loops_decisions(case):
     cfg, rec, params, variables, stats = run_engine(case, "fused")
     check_decisions(case, cfg, stats, f"{case}/fused")

@@ -14,7 +14,7 @@ import torch
 import loop_trace as LT
 
 GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loop_reference.npz"))
-CASES = ("base", "variant")
+CASES = ("base", "variant", "gtposes")
 
 
 def seed_everything(seed):
@@ -103,6 +103,8 @@ def test_decisions_view(run):
     assert want == got
     assert stats['decisions'] == want                     # ... and so does the table the loop itself keeps (every engine fills it)
     assert [f['rows_end'] for f in want] == stats['num_gaussians']
+    if case == "gtposes":
+        assert all(f['tracking_iters'] == 0 for f in want) and all(f['keyframe'] for f in want) and not any(f['prunes'] for f in want)
     if case == "variant":
         budgets = [f['tracking_iters'] for f in want]
         assert set(budgets[1:]) == {5, 10}, budgets               # the depth-loss retry doubled some frames' budget and not others'
