@@ -420,6 +420,10 @@ constexpr int kFusedSortMax = 1024;     // longest list the composite sorts itse
 //            local rank): C independent 8-step binary searches per key, interleaved.
 // ~250 instructions per wave at the ~220 entries of workload B (a full rank sort of the list: ~770; the bitonic network: ~36
 // barrier-separated stages), two barriers.
+#ifndef SPLAT_SORT_PAD
+#define SPLAT_SORT_PAD 0       // 1: one pad key per 32 keys of the scratch array S (A/B of VERDICT r4 item 7: measured, no gain -- r05_experiments.md 4)
+#endif
+__device__ __forceinline__ int sort_pad(int i) { return SPLAT_SORT_PAD ? i + (i >> 5) : i; }
 __device__ __forceinline__ void sort_keys_two_level(uint64_t *A, uint64_t *S, const int n, const int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const int C = n <= 512 ? 4 : 8;
@@ -452,8 +456,8 @@ __device__ __forceinline__ void sort_keys_two_level(uint64_t *A, uint64_t *S, co
             r0 -= (lane < len && extra < k0) ? 1u : 0u;
             r1 -= (lane + 64 < len && extra < k1) ? 1u : 0u;
         }
-        if (lane < len) S[start + r0] = k0;
-        if (lane + 64 < len) S[start + r1] = k1;
+        if (lane < len) S[sort_pad(start + (int)r0)] = k0;
+        if (lane + 64 < len) S[sort_pad(start + (int)r1)] = k1;
     }
     __syncthreads();
     // ---- level 2: a key's rank = its index in its own chunk + its insertion points in the OTHER chunks.  The probes of one
@@ -461,7 +465,7 @@ __device__ __forceinline__ void sort_keys_two_level(uint64_t *A, uint64_t *S, co
     //      other word of S, inside the LDS allocation, and is discarded by `probe <= len`); the step count follows the chunk size
     const int top = 1 << (31 - __builtin_clz((unsigned)cs));      // largest power of two <= cs (wave-uniform)
     for (int i = tid; i < n; i += 256) {
-        const uint64_t key = S[i];
+        const uint64_t key = S[sort_pad(i)];
         int oc = 0;
 #pragma unroll
         for (int c = 1; c < 8; ++c) oc += (i >= c * cs) ? 1 : 0;
@@ -482,7 +486,7 @@ __device__ __forceinline__ void sort_keys_two_level(uint64_t *A, uint64_t *S, co
 #pragma unroll
                 for (int d = 0; d < NC - 1; ++d) {
                     const unsigned probe = pos[d] + (unsigned)step;
-                    const uint64_t other = S[base[d] + (int)probe];
+                    const uint64_t other = S[sort_pad(base[d] + (int)probe)];
                     pos[d] = (((int)probe <= len[d]) & (other < key)) ? probe : pos[d];
                 }
             }
@@ -595,7 +599,7 @@ __device__ __forceinline__ int forward_tile(const float *colors, SplatState &st,
             for (int i = tid; i < n; i += 256) s_keys[i] = st.keys[lo + i];
         if (tid == 0 && (n & 1)) s_keys[n] = ~0ull;                  // pad to an even count (pair reads)
         __syncthreads();
-        static_assert(sizeof(B.rec) >= (kFusedSortMax + 256) * sizeof(uint64_t), "level-2 probes of the sort may read up to 255 words past the last chunk");
+        static_assert(sizeof(B.rec) >= (kFusedSortMax + 256 + (kFusedSortMax + 256) / 32 + 1) * sizeof(uint64_t), "level-2 probes of the sort may read up to 255 words past the last chunk");
         sort_keys_two_level(s_keys, reinterpret_cast<uint64_t *>(B.rec), n, tid);
         for (int i = tid; i < n; i += 256) st.point_list[lo + i] = (uint32_t)lk[i];
     }
