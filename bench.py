@@ -538,7 +538,8 @@ def slam_loop_figure(name, dev, frames=13, engine="fused", runs=2):
     densification), not the workload's fixed 300k.  `frames` frames, the FIRST EXCLUDED from every rate (it pays the allocations and has no
     tracking phase); run `runs` times in this process, every run reported; per-phase milliseconds per frame (means over the counted
     frames) from synchronised timers around the phases.  engine: "fused", or "plugin" (the reference-shaped loop -- add_new_gaussians /
-    prune_gaussians re-create every tensor -- with splatam_amd.plugin installed)."""
+    prune_gaussians re-create every tensor -- with splatam_amd.plugin installed), or "plugin_map_edits" (plugin.install(map_edits=True):
+    the two map edits are adapters as well and the engine owns the map)."""
     from splatam_amd import pipeline
     N, W, H, fx, fy, cx, cy = WORKLOADS[name]
     ds = pipeline.SyntheticRGBDSequence(N, W, H, fx, fy, cx, cy, num_frames=frames, seed=3, device=dev).preload()
@@ -941,6 +942,7 @@ def main():
         if world == 1 and fused and not args.no_slam_loop:
             result["slam_loop"] = slam_loop_figure(args.workload, dev, frames=args.slam_frames)
             result["slam_loop_plugin"] = slam_loop_figure(args.workload, dev, frames=args.slam_frames, engine="plugin")
+            result["slam_loop_plugin_map_edits"] = slam_loop_figure(args.workload, dev, frames=args.slam_frames, engine="plugin_map_edits", runs=1)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.workload, params_d, frames)
             pairs = result["cpu_baseline"].get("pairs_per_render")

@@ -274,7 +274,8 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
     reference-shaped PyTorch loop of splatam_amd.slam on the drop-in rasterizer), or "plugin": the SAME reference-shaped loop -- its
     ``add_new_gaussians`` / ``prune_gaussians`` / ``remove_points`` re-create every tensor, its statements are get_loss -> backward ->
     prune -> step -- with ``splatam_amd.plugin`` installed into the module that holds it, i.e. what
-    /root/reference/scripts/splatam.py:654-905 executes after ``plugin.install``.
+    /root/reference/scripts/splatam.py:654-905 executes after ``plugin.install``; "plugin_map_edits": the same with
+    ``plugin.install(map_edits=True)`` (the two map edits are adapters too: the engine owns the map and edits it in place).
 
     Per-tile list overflow (fused): a flagged iteration and every iteration after it take NO Adam step on the device
     (include/splat_hip.h, d_cam[12]); at the end of a phase ``check_overflow()`` says how many, the lists are re-sized and exactly
@@ -291,12 +292,13 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
         rank r renders the r-th, ONE gradient all-reduce (mean) follows, and every rank takes the identical Adam step;
       * after every edit of the map (densification, pruning) the row counts of the replicas are compared (all-reduce of min / max)."""
     from . import dist as sdist
-    if engine not in ("fused", "dropin", "plugin"):
+    if engine not in ("fused", "dropin", "plugin", "plugin_map_edits"):
         raise ValueError(engine)
     fused = engine == "fused"
+    plugged = engine in ("plugin", "plugin_map_edits")
     world, rank = sdist.world_size(), sdist.get_rank()
-    if engine == "plugin" and world > 1:
-        raise NotImplementedError("engine='plugin' runs the reference's single-process loop")
+    if plugged and world > 1:
+        raise NotImplementedError(f"engine='{engine}' runs the reference's single-process loop")
     num_frames = len(dataset) if num_frames is None else min(num_frames, len(dataset))
     tcfg, mcfg = config['tracking'], config['mapping']
     if mcfg.get('use_gaussian_splatting_densification') and not fused:
@@ -345,9 +347,9 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
                  num_gaussians=[], phase_ms=[], frame_s=[], decisions=[])
     phase = _PhaseTimer(dev)
     installed = None
-    if engine == "plugin":
+    if plugged:
         from . import plugin
-        installed = plugin.install(slam)
+        installed = plugin.install(slam, map_edits=engine == "plugin_map_edits")
     try:
         for time_idx in range(num_frames):
             t_frame = time.perf_counter()
@@ -367,7 +369,7 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
             with phase("tracking"):
                 t0 = time.perf_counter()
                 if time_idx > 0 and not tcfg['use_gt_poses']:
-                    if engine == "plugin":
+                    if plugged:
                         n_track, variables = _track_frame_statements(params, variables, curr_data, time_idx, tcfg)
                     else:
                         n_track = _track_frame(params, variables, curr_data, time_idx, tcfg, eng, stats)

@@ -178,9 +178,41 @@ class _Session:
         self.pending = []           # [(engine, report, pinned host tensor, event)] reports in flight to the host
         self.pool = []              # pinned buffers / events for re-use
         self.stats = {"iterations": 0, "rebuilds": 0, "engines_built": 0, "repeats": 0, "skipped_iterations": 0}
+        self.map_edits = False      # install(module, map_edits=True): the engine OWNS the map (capacity-managed, edited in place)
+        self.skip_gaussian_step = False     # map_edits: an edit re-created the parameters since backward(): the next step() leaves them alone
+        self.pending_map_reset = False      # map_edits: a mapping optimizer was created before the engine existed
 
     # ---------------------------------------------------------------- engines
+    def managed_engine(self, params, variables, cam):
+        """map_edits mode: ONE engine that owns the Gaussian tensors (FusedEngine(gaussian_capacity=...)): the caller's dict entries
+        are views of the first P rows of its backing arrays, re-pointed by the adapters of add_new_gaussians / prune_gaussians exactly
+        where the reference replaces them.  A tensor replaced behind the engine's back (an un-adapted edit) is an error, not a re-bind."""
+        hw = (int(cam.image_height), int(cam.image_width))
+        eng = self.engines.get(hw)
+        if eng is None:
+            if self.engines:
+                raise NotImplementedError("plugin.install(map_edits=True): one camera resolution per run (the engine owns the map)")
+            if variables is None:
+                raise RuntimeError("plugin.install(map_edits=True) needs the caller's `variables` dict (the per-Gaussian variables move with the rows)")
+            P = int(params['means3D'].shape[0])
+            cap = max(int(1.5 * P), int(2.5 * hw[0] * hw[1])) + 65536
+            eng = FusedEngine(params, cam, gaussian_capacity=cap, variables=variables)
+            self.engines[hw] = eng
+            self.stats["engines_built"] += 1
+            self.stats["rebuilds"] += 1
+            if self.pending_map_reset:
+                eng.reset_map_optimizer()
+                self.pending_map_reset = False
+        elif eng.params is not params or any(params[k].data_ptr() != eng.store[k].data_ptr() or params[k].shape[0] != eng.P for k in PARAM_ORDER):
+            raise RuntimeError("plugin.install(map_edits=True): the Gaussian tensors were replaced outside add_new_gaussians / prune_gaussians; "
+                               "the engine owns the map in this mode")
+        now = tuple(params[k] for k in _ALL_KEYS) + (variables.get('max_2D_radius') if variables is not None else None,)
+        self.bound[hw] = now
+        return eng, now
+
     def engine(self, params, variables, cam):
+        if self.map_edits:
+            return self.managed_engine(params, variables, cam)
         hw = (int(cam.image_height), int(cam.image_width))
         radius = variables.get('max_2D_radius') if variables is not None else None
         now = tuple(params[k] for k in _ALL_KEYS) + (radius,)
@@ -255,6 +287,9 @@ class _Session:
         opt = rep.optimizer
         if opt is None or rep.args is None or rep.args[-1] or skipped <= 0:
             return                                              # (tracking: repeat_tracking re-runs the iteration instead)
+        if self.map_edits:
+            for eng in self.engines.values():
+                eng.map_step = max(eng.map_step - int(skipped), 0)
         for g in opt.param_groups:             # (the pose groups carry state only when bundle adjustment steps them)
             st = opt.state.get(g['params'][0])
             if st is not None and 'step' in st:
@@ -364,6 +399,20 @@ class FusedOptimizer(torch.optim.Adam):
         if tracking:
             s.pending_tracking = True
             s.track_steps_gaussians = self._steps_gaussians
+        self._managed = bool(s.map_edits)
+        if self._managed:
+            # the engine owns parameters and moments: nothing is keyed by tensor here (the reference's own map edits, which slice
+            # optimizer.state, are replaced by the adapters below)
+            if tracking and self._steps_gaussians:
+                raise NotImplementedError("plugin.install(map_edits=True): Gaussian learning rates in the TRACKING optimizer are not supported")
+            if not tracking:
+                if s.engines:
+                    for eng in s.engines.values():
+                        eng.reset_map_optimizer()           # a new optimizer: fresh moments, step count 0 (:821)
+                else:
+                    s.pending_map_reset = True
+                s.skip_gaussian_step = False
+            return
         if self._steps_gaussians:
             # the state the reference's map edits expect to find and re-attach (exp_avg / exp_avg_sq per parameter)
             for g in self.param_groups:
@@ -388,6 +437,17 @@ class FusedOptimizer(torch.optim.Adam):
                 self._step_gaussians(eng, bound, eps=1e-8, tracking=True)       # torch.optim.Adam(param_groups): default eps
             return None
         rep.optimizer = self
+        if self._managed:
+            # an edit between backward() and step() re-created the parameters (remove_points does, whether or not a row goes):
+            # torch finds no .grad on them and leaves them alone -- so does this step
+            if s.skip_gaussian_step:
+                s.skip_gaussian_step = False
+            else:
+                eng.adam_map(self._lrs)
+            if self._steps_poses and rep.args is not None and rep.args[4]:
+                self._step_poses_with_torch(rep)
+            rep.stepped = True
+            return None
         self._step_gaussians(eng, bound, eps=1e-15, tracking=False)
         if self._steps_poses and rep.args is not None and rep.args[4]:
             self._step_poses_with_torch(rep)
@@ -458,6 +518,58 @@ def initialize_optimizer(params, lrs_dict, tracking):
     return FusedOptimizer(params, lrs_dict, tracking)
 
 
+def _refresh_bound(s, eng, params, variables):
+    hw = (eng.H, eng.W)
+    now = tuple(params[k] for k in _ALL_KEYS) + (variables.get('max_2D_radius') if variables is not None else None,)
+    s.bound[hw] = now
+    if s.current is not None and s.current[0] is eng:
+        s.current = (eng, now, s.current[2])
+
+
+def add_new_gaussians(params, variables, curr_data, sil_thres, time_idx, mean_sq_dist_method, gaussian_distribution):
+    """map_edits mode: /root/reference/scripts/splatam.py:378-420 as an in-place edit of the engine's map (render at the tracked pose,
+    non-presence masks with the exact median, one Gaussian per selected pixel appended in pixel order, variables reset as the reference
+    resets them); ``params`` / ``variables`` are the caller's dicts, their entries re-pointed at the grown arrays."""
+    s = _session
+    s.drain()
+    eng, _ = s.engine(params, variables, curr_data['cam'])
+    eng.add_new_gaussians(curr_data, sil_thres, time_idx, mean_sq_dist_method, gaussian_distribution)
+    eng.relearn_lists(curr_data, time_idx)              # the per-tile lists of the grown map (one probe render + one read)
+    _refresh_bound(s, eng, params, variables)
+    s.stats["rebuilds"] += 1
+    return params, variables
+
+
+def prune_gaussians(params, variables, optimizer, iter, prune_dict):
+    """map_edits mode: /root/reference/utils/slam_external.py:169-196 (+ remove_points :139-162) as an in-place stable compaction of the
+    engine's map, moments and per-Gaussian variables.  On the pruning schedule the reference re-creates every parameter whether or not
+    a row goes, so the ``optimizer.step()`` that follows moves none of them: remembered for that step."""
+    s = _session
+    on_schedule = iter <= prune_dict['stop_after'] and iter >= prune_dict['start_after'] and iter % prune_dict['prune_every'] == 0
+    resets = iter <= prune_dict['stop_after'] and iter > 0 and iter % prune_dict['reset_opacities_every'] == 0 and prune_dict['reset_opacities']
+    if not (on_schedule or resets):
+        return params, variables
+    if s.current is None:
+        raise RuntimeError("prune_gaussians() before any get_loss()")
+    eng, _, rep = s.current
+    if eng.params is not params:
+        raise RuntimeError("prune_gaussians(): not the params dict the engine owns")
+    s.drain()
+    removed = eng.prune_gaussians(iter, prune_dict, variables['scene_radius'])
+    if on_schedule:
+        s.skip_gaussian_step = True
+    if removed:
+        eng.relearn_lists(rep.args[1], rep.args[2])
+        s.stats["rebuilds"] += 1
+    _refresh_bound(s, eng, params, variables)
+    return params, variables
+
+
+def densify(params, variables, optimizer, iter, densify_dict):
+    raise NotImplementedError("plugin.install(map_edits=True) does not adapt densify(): run gradient-based densification with map_edits=False "
+                              "(variables['means2D'].grad is served) or on pipeline.rgbd_slam(engine='fused')")
+
+
 class _Installed:
     def __init__(self, module, saved):
         self.module, self.saved = module, saved
@@ -484,16 +596,32 @@ def _reset_session():
     s.engines.clear()
     s.bound.clear()
     s.current = None
+    s.map_edits = False
+    s.skip_gaussian_step = False
+    s.pending_map_reset = False
 
 
-def install(module):
+def install(module, map_edits=False):
     """Replace ``module.get_loss`` and ``module.initialize_optimizer`` (the reference's ``scripts/splatam.py`` module, or any module
-    shaped like it, e.g. ``splatam_amd.slam``) by the fused adapters.  Returns a handle with ``uninstall()`` (also a context manager)."""
-    saved = {k: getattr(module, k) for k in ("get_loss", "initialize_optimizer") if hasattr(module, k)}
-    if len(saved) != 2:
-        raise RuntimeError(f"{module!r} does not look like scripts/splatam.py: it has no get_loss / initialize_optimizer")
+    shaped like it, e.g. ``splatam_amd.slam``) by the fused adapters.  Returns a handle with ``uninstall()`` (also a context manager).
+
+    ``map_edits=True`` also replaces ``add_new_gaussians`` and ``prune_gaussians`` (and refuses ``densify``): the engine then OWNS the
+    map -- a capacity-managed struct of arrays edited in place on the device, the caller's dict entries re-pointed where the reference
+    replaces them -- instead of being re-bound to tensors that torch.cat / boolean indexing re-create three times per frame (at 816 k
+    Gaussians: add_new_gaussians 3-10 ms and pruning 3.3 ms per frame against 0.6 + 0.5 ms).  The loop statements stay the reference's."""
+    names = ("get_loss", "initialize_optimizer") + (("add_new_gaussians", "prune_gaussians") if map_edits else ())
+    saved = {k: getattr(module, k) for k in names if hasattr(module, k)}
+    if len(saved) != len(names):
+        raise RuntimeError(f"{module!r} does not look like scripts/splatam.py: it has no {' / '.join(n for n in names if n not in saved)}")
+    if map_edits and hasattr(module, "densify"):
+        saved["densify"] = module.densify
+        module.densify = densify
     module.get_loss = get_loss
     module.initialize_optimizer = initialize_optimizer
+    if map_edits:
+        module.add_new_gaussians = add_new_gaussians
+        module.prune_gaussians = prune_gaussians
     _reset_session()
+    _session.map_edits = bool(map_edits)
     _session.stats.update(iterations=0, rebuilds=0, engines_built=0, repeats=0, skipped_iterations=0)
     return _Installed(module, saved)

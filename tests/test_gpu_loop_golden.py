@@ -4,6 +4,8 @@ is tests/test_loop_golden.py).  Same frames, same configuration, same seeds thro
 
   * ``engine="dropin"``: the reference-shaped statements on the drop-in rasterizer,
   * ``engine="plugin"``: the same statements with ``splatam_amd.plugin`` installed (the fused iteration under them),
+  * ``engine="plugin_map_edits"``: ``plugin.install(map_edits=True)`` -- add_new_gaussians / prune_gaussians are adapters too (the engine
+    owns the map); the call sequence recorded is still the statements' own,
   * ``engine="fused"``: ``FusedEngine``'s own loop (map edits in place on the device).
 
 Drop-in and plug-in must make the reference loop's CALLS in its order with its arguments; all three must take its DECISIONS: the
@@ -77,7 +79,7 @@ def check_trajectory(case, params, what):
 
 
 @pytest.mark.parametrize("case", ["base", "variant", "gtposes"])
-@pytest.mark.parametrize("engine", ["dropin", "plugin"])
+@pytest.mark.parametrize("engine", ["dropin", "plugin", "plugin_map_edits"])
 def test_statement_engines_make_the_reference_loops_calls(case, engine):
     cfg, rec, params, variables, stats = run_engine(case, engine)
     events, values, selected = rec.arrays()
@@ -92,8 +94,10 @@ def test_statement_engines_make_the_reference_loops_calls(case, engine):
     print(f"{case}/{engine}: {int(is_loss.sum())} losses, relative difference to the reference loop: first {rel[0]:.1e}, median "
           f"{np.median(rel):.1e}, max {rel.max():.1e}")
     assert rel[0] < 1e-4 and np.median(rel) < 2e-3 and rel.max() < 3e-2
-    if engine == "plugin":
+    if engine.startswith("plugin"):
         assert stats['plugin']['skipped_iterations'] == 0, stats['plugin']
+    if engine == "plugin_map_edits":
+        assert stats['plugin']['engines_built'] == 1, stats['plugin']
 
 
 @pytest.mark.parametrize("case", ["base", "variant", "gtposes"])

@@ -68,6 +68,33 @@ def test_frame_loop_through_the_plugin_matches_the_fused_loop():
     assert st['skipped_iterations'] == 0 and st['repeats'] <= 1, st
 
 
+def test_frame_loop_through_the_plugin_with_map_edits_matches_the_fused_loop():
+    """engine="plugin_map_edits": the same statements after ``plugin.install(slam, map_edits=True)`` -- add_new_gaussians and
+    prune_gaussians are adapters as well, the engine owns a capacity-managed map and edits it in place, the caller's dict entries
+    are re-pointed where the reference replaces them.  Same keyframes, map sizes and trajectory as the fused loop; ONE engine, never
+    re-bound; the dict the statements hold stays consistent with the engine's rows."""
+    from splatam_amd import pipeline
+    ds, pf, vf, sf = _run("fused")
+    _, pp, vp, sp = _run("plugin_map_edits")
+    assert sf['keyframe_time_indices'] == sp['keyframe_time_indices'] == [0, 1, 3]
+    assert sp['tracking_iters'] == 4 * 12 and sp['mapping_iters'] == 5 * 24
+    for a, b in zip(sf['num_gaussians'], sp['num_gaussians']):
+        assert abs(a - b) <= max(3, int(2e-3 * b)), (sf['num_gaussians'], sp['num_gaussians'])
+    for t in range(len(ds)):
+        wf, wp, gt = pipeline._est_w2c(pf, t), pipeline._est_w2c(pp, t), ds.gt_w2c(t)
+        assert float((wf - wp).abs().max()) < 2e-3, (t, wf, wp)
+        assert float((wp[:3, 3] - gt[:3, 3]).norm()) < 0.02, (t, wp[:3, 3], gt[:3, 3])
+    st = sp['plugin']
+    assert st['iterations'] == 4 * 12 + 5 * 24 and st['engines_built'] == 1, st
+    assert st['skipped_iterations'] == 0 and st['repeats'] <= 1, st
+    P = pp['means3D'].shape[0]
+    assert all(pp[k].shape[0] == P for k in ('rgb_colors', 'unnorm_rotations', 'logit_opacities', 'log_scales'))
+    assert all(vp[k].shape[0] == P for k in ('max_2D_radius', 'means2D_gradient_accum', 'denom', 'timestep'))
+    assert vp['timestep'].max() == len(ds) - 1
+    n = min(vf['timestep'].shape[0], vp['timestep'].shape[0])
+    assert float((vf['timestep'][:n] != vp['timestep'][:n]).float().mean()) < 5e-3
+
+
 def test_params_survive_a_checkpoint_round_trip(tmp_path):
     from splatam_amd import pipeline
     _, params, _, _ = _run("fused", frames=2)

@@ -350,3 +350,104 @@ def test_means2d_gradient_for_the_references_densification():
                                          tcfg['use_l1'], tcfg['ignore_outlier_depth_loss'], tracking=True)
         with pytest.raises(RuntimeError, match="TRACKING"):
             my_vars['means2D'].grad
+
+
+def test_map_edits_mode_prunes_in_place_and_steps_like_torch():
+    """plugin.install(map_edits=True): prune_gaussians is an adapter too and the engine owns the map.  The same two iterations as above
+    in ONE session: iteration 0 prunes (no Adam step, as the reference's re-created parameters get none), iteration 1 steps the smaller
+    map -- rows after the prune bit-equal to the reference's remove_points, parameters and moments after the step element-wise against
+    torch.optim.Adam on the drop-in path; the caller's dicts are the same objects throughout, their entries views of the engine's rows."""
+    from splatam_amd import plugin, slam
+    params, _, frame, cam = _scene(8000, 208, 160, aniso=False, seed=7)
+    with torch.no_grad():
+        params['logit_opacities'][::5] = -6.0
+    cfg = slam.REPLICA_MAPPING
+    ref = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    mine = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    ref1, ref_vars, ref_opt = _mapping_loop(slam, {k: torch.nn.Parameter(v.detach().clone()) for k, v in ref.items()}, _variables(ref), frame, 1, cfg, 1,
+                                            _prune_dict())
+    before = {k: ref1[k].detach().clone() for k in ("means3D", "rgb_colors", "logit_opacities", "log_scales")}
+    ref2, ref_vars2, ref_opt2 = _mapping_loop(slam, ref, _variables(ref), frame, 1, cfg, 2, _prune_dict())
+    my_vars = _variables(mine)
+    with plugin.install(slam, map_edits=True):
+        assert slam.prune_gaussians is plugin.prune_gaussians and slam.add_new_gaussians is plugin.add_new_gaussians
+        out, out_vars, my_opt = _mapping_loop(slam, mine, my_vars, frame, 1, cfg, 1, _prune_dict())
+        assert out is mine and out_vars is my_vars
+        n = ref1['means3D'].shape[0]
+        assert n < 8000 and mine['means3D'].shape[0] == n and my_vars['timestep'].shape[0] == n
+        for k in before:
+            assert torch.equal(mine[k].detach(), before[k]), k
+        eng = next(iter(plugin._session.engines.values()))
+        assert eng.managed and eng.P == n and mine['means3D'].data_ptr() == eng.store['means3D'].data_ptr()
+        # iteration 1 (not on the pruning schedule): the first step of this optimizer
+        loss, my_vars, _ = slam.get_loss(mine, frame, my_vars, 1, cfg['loss_weights'], cfg['use_sil_for_loss'], cfg['sil_thres'], cfg['use_l1'],
+                                         cfg['ignore_outlier_depth_loss'], mapping=True)
+        loss.backward()
+        with torch.no_grad():
+            slam.prune_gaussians(mine, my_vars, my_opt, 1, _prune_dict())
+            my_opt.step()
+            my_opt.zero_grad(set_to_none=True)
+        stats = plugin.session_stats()
+        assert eng.map_step == 1
+        for k in ("means3D", "rgb_colors", "logit_opacities", "log_scales"):
+            _assert_adam_step_matches(k, mine[k].detach(), ref2[k].detach(), before[k], eng.exp_avg[k], ref_opt2.state[ref2[k]]['exp_avg'], cfg['lrs'][k])
+        assert torch.equal(my_vars['seen'], ref_vars2['seen'])
+        assert torch.equal(my_vars['max_2D_radius'], ref_vars2['max_2D_radius'])
+    assert stats["iterations"] == 2 and stats["engines_built"] == 1 and stats["skipped_iterations"] == 0, stats
+    assert slam.prune_gaussians is not plugin.prune_gaussians                     # uninstalled
+
+
+def test_map_edits_mode_adds_gaussians_in_place():
+    """add_new_gaussians through the adapter (the engine's in-place append) against the reference-shaped one on the drop-in path, from
+    the same map and frame: the same pixels selected (a count may differ by pixels whose silhouette sits on the threshold), the new
+    rows appended after the old ones with the frame's time index, the old rows untouched, the dicts re-pointed."""
+    from splatam_amd import plugin, slam
+    W, H = 208, 160
+    params, _, frame, cam = _scene(6000, W, H, aniso=False, seed=5)
+    frame['intrinsics'] = torch.tensor([[0.5 * W, 0, W / 2 - 0.5], [0, 0.5 * W, H / 2 - 0.5], [0, 0, 1]], device="cuda")
+    with torch.no_grad():
+        keep = params['means3D'][:, 0] < params['means3D'][:, 0].median()          # half of the scene is missing from the map
+    half = {k: (v.detach()[keep].clone() if v.shape[0] == keep.shape[0] and k not in ('cam_unnorm_rots', 'cam_trans') else v.detach().clone())
+            for k, v in params.items()}
+    ref = {k: torch.nn.Parameter(v.clone()) for k, v in half.items()}
+    mine = {k: torch.nn.Parameter(v.clone()) for k, v in half.items()}
+    ref_vars, my_vars = _variables(ref), _variables(mine)
+    n0 = ref['means3D'].shape[0]
+    ref, ref_vars = slam.add_new_gaussians(ref, ref_vars, frame, 0.5, 1, "projective", "isotropic")
+    with plugin.install(slam, map_edits=True):
+        out, out_vars = slam.add_new_gaussians(mine, my_vars, frame, 0.5, 1, "projective", "isotropic")
+        assert out is mine and out_vars is my_vars
+        n_ref, n = ref['means3D'].shape[0], mine['means3D'].shape[0]
+        assert n_ref > n0 + 1000 and abs(n - n_ref) <= max(3, int(2e-3 * n_ref)), (n0, n_ref, n)
+        for k in ("means3D", "rgb_colors", "unnorm_rotations", "logit_opacities", "log_scales"):
+            assert mine[k].shape[0] == n and torch.equal(mine[k].detach()[:n0], half[k]), k
+        assert my_vars['timestep'].shape[0] == n and bool((my_vars['timestep'][n0:] == 1).all()) and bool((my_vars['timestep'][:n0] == 0).all())
+        if n == n_ref:
+            assert float((mine['means3D'].detach() - ref['means3D'].detach()).abs().max()) < 1e-4
+            assert float((mine['log_scales'].detach() - ref['log_scales'].detach()).abs().max()) < 1e-4
+        # and the statements go on with the grown map: one mapping iteration steps it
+        cfg = slam.REPLICA_MAPPING
+        _mapping_loop(slam, mine, my_vars, frame, 1, cfg, 2, None)
+        stats = plugin.session_stats()
+    assert stats["engines_built"] == 1 and stats["skipped_iterations"] == 0, stats
+
+
+def test_map_edits_mode_refuses_what_it_does_not_own():
+    """plugin.install(map_edits=True): a Gaussian tensor replaced behind the engine's back is an error (not a silent re-bind), and
+    densify is refused by name."""
+    from splatam_amd import plugin, slam
+    params, _, frame, cam = _scene(3000, 160, 112, aniso=False, seed=3)
+    cfg = slam.REPLICA_MAPPING
+    mine = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    variables = _variables(mine)
+    args = (cfg['loss_weights'], cfg['use_sil_for_loss'], cfg['sil_thres'], cfg['use_l1'], cfg['ignore_outlier_depth_loss'])
+    with plugin.install(slam, map_edits=True):
+        opt = slam.initialize_optimizer(mine, cfg['lrs'], tracking=False)
+        loss, variables, _ = slam.get_loss(mine, frame, variables, 1, *args, mapping=True)
+        loss.backward()
+        opt.step()
+        with pytest.raises(NotImplementedError, match="densify"):
+            slam.densify(mine, variables, opt, 0, {})
+        mine['rgb_colors'] = torch.nn.Parameter(mine['rgb_colors'].detach().clone())
+        with pytest.raises(RuntimeError, match="replaced outside"):
+            slam.get_loss(mine, frame, variables, 1, *args, mapping=True)

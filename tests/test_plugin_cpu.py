@@ -113,7 +113,21 @@ for c in calls:
 assert seen == {"get_loss": 2, "initialize_optimizer": 2}, seen
 handle.uninstall()
 assert S.get_loss is ref_get_loss and S.initialize_optimizer is ref_init
-print("OK", seen)
+# map_edits=True: the two map edits (looked up the same way by the loop) and densify as well, every call site binds, all restored
+edits = ("add_new_gaussians", "prune_gaussians", "densify")
+ref_edits = {n: getattr(S, n) for n in edits}
+for name in edits:
+    assert name in S.rgbd_slam.__code__.co_names and name not in S.rgbd_slam.__code__.co_varnames, name
+handle = plugin.install(S, map_edits=True)
+assert all(getattr(S, n) is getattr(plugin, n) for n in edits) and S.get_loss is plugin.get_loss
+bound = {n: 0 for n in edits}
+for c in (n for n in ast.walk(tree) if isinstance(n, ast.Call) and isinstance(n.func, ast.Name) and n.func.id in edits):
+    inspect.signature(getattr(plugin, c.func.id)).bind(*[None] * len(c.args), **{k.arg: None for k in c.keywords})
+    bound[c.func.id] += 1
+assert bound == {"add_new_gaussians": 1, "prune_gaussians": 1, "densify": 1}, bound
+handle.uninstall()
+assert all(getattr(S, n) is ref_edits[n] for n in edits) and S.get_loss is ref_get_loss
+print("OK", seen, bound)
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
