@@ -90,3 +90,19 @@ for q in range(4):
             else:
                 occ |= int(m)
 print(f"trips after greedy in-order packing {trips} = {100 * trips / nv:.1f} % of the visits ({time.time() - t0:.1f} s)")
+# windowed block rows: the quadrant's visits are taken K at a time (K pair-buffer slots); within a window each 16-lane row walks ITS block's
+# entries, so a window costs max over the four blocks of its entries (trips), against K trips now
+for K in (8, 16, 32, 64):
+    tw = 0
+    for q in range(4):
+        col = blockmask[:, q]
+        for a, b in zip(starts, ends):
+            m = col[a:b]
+            m = m[m > 0]
+            if not len(m):
+                continue
+            pad = (-len(m)) % K
+            mm = np.concatenate([m, np.zeros(pad, np.uint8)]).reshape(-1, K)
+            per_block = np.stack([((mm >> bb) & 1).sum(1) for bb in range(4)], 1)
+            tw += int(per_block.max(1).sum())
+    print(f"windowed block rows, K = {K}: {tw} trips = {100 * tw / nv:.1f} % of the visits ({time.time() - t0:.1f} s)")

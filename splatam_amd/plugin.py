@@ -303,7 +303,16 @@ class _Session:
     def value_of(self, rep, slot):
         """The caller reads a value of an iteration's report: ONE device read fetches the whole report, flags included."""
         if rep.host is None:
-            rep.host_tensor = rep.dev.cpu()                     # ONE device read: the whole report, flags included
+            # ONE wait: the whole report, flags included.  Its asynchronous copy was queued right behind the iteration's kernels
+            # (post()): wait for THAT (the earliest moment the values exist on the host) instead of queueing a second, blocking copy
+            # behind whatever the caller has launched since (the pose's Adam step)
+            for _, r, host, ev in self.pending:
+                if r is rep:
+                    ev.synchronize()
+                    rep.host_tensor = host.clone()              # (the pinned buffer goes back to the pool when poll() reaches it)
+                    break
+            else:
+                rep.host_tensor = rep.dev.cpu()
             rep.host = _report_values(rep.host_tensor)
             eng = self.current[0] if self.current is not None and self.current[2] is rep else None
             if eng is not None and self.digest(eng, rep) and rep.args is not None and rep.args[-1]:
