@@ -46,6 +46,11 @@ tracking optimizer's eps).  Gradient-based densification (``use_gaussian_splatti
 gradient the reference's ``accumulate_mean2d_gradient`` reads (/root/reference/utils/slam_external.py:100-104) -- is formed on first
 access by one extra RGB-only backward composite over the iteration's lists; configurations that never read it never pay for it.
 What the plug-in does NOT provide: ``visualize_tracking_loss``.
+
+``install(module, map_edits=True)`` (opt-in) replaces ``add_new_gaussians`` and ``prune_gaussians`` too: ONE engine then owns a
+capacity-managed map for the run and edits it in place (``splat_map_add_new_gaussians`` / ``splat_map_prune``), the caller's dict
+entries are views of its rows, re-pointed where the reference replaces them, and the optimizer object carries no per-tensor state
+(see ``install``).  The loop statements are the reference's in both modes.
 """
 from __future__ import annotations
 
@@ -617,7 +622,8 @@ def install(module, map_edits=False):
     ``map_edits=True`` also replaces ``add_new_gaussians`` and ``prune_gaussians`` (and refuses ``densify``): the engine then OWNS the
     map -- a capacity-managed struct of arrays edited in place on the device, the caller's dict entries re-pointed where the reference
     replaces them -- instead of being re-bound to tensors that torch.cat / boolean indexing re-create three times per frame (at 816 k
-    Gaussians: add_new_gaussians 3-10 ms and pruning 3.3 ms per frame against 0.6 + 0.5 ms).  The loop statements stay the reference's."""
+    Gaussians: add_new_gaussians 3-10 ms and pruning 3.3 ms per frame against 0.6 + 0.5 ms).  The loop statements stay the reference's.
+    One camera resolution per run in this mode (separate tracking / densification resolutions raise)."""
     names = ("get_loss", "initialize_optimizer") + (("add_new_gaussians", "prune_gaussians") if map_edits else ())
     saved = {k: getattr(module, k) for k in names if hasattr(module, k)}
     if len(saved) != len(names):
