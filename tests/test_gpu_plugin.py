@@ -172,7 +172,8 @@ def test_losses_dict_is_the_references(tracking, use_l1):
         assert (loss < 1e20) is True and (loss > 1e20) is False and bool(loss < torch.tensor(1e20, device="cuda"))
 
 
-def test_a_flagged_iteration_moves_nothing_and_is_repeated_or_reported():
+@pytest.mark.parametrize("map_edits", [False, True])
+def test_a_flagged_iteration_moves_nothing_and_is_repeated_or_reported(map_edits):
     """Per-tile lists that do not fit raise a flag on the device; the Adam kernels skip while it is up.  Tracking: the caller's own
     `loss < current_min_loss` read fetches the flag and the iteration is repeated on re-sized lists (same values as an undisturbed run).
     Mapping: the iteration is skipped, the next ones run on re-sized lists, session_stats() reports it."""
@@ -181,9 +182,9 @@ def test_a_flagged_iteration_moves_nothing_and_is_repeated_or_reported():
     cfg = slam.REPLICA_TRACKING
     clean = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
     mine = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
-    with plugin.install(slam):
+    with plugin.install(slam, map_edits=map_edits):
         clean_losses = _tracking_loop(slam, clean, _variables(clean), frame, 1, cfg, 5)
-    with plugin.install(slam):
+    with plugin.install(slam, map_edits=map_edits):
         v = _variables(mine)
         _tracking_loop(slam, mine, v, frame, 1, cfg, 2)          # learns bucketed lists
         with torch.no_grad():
@@ -203,7 +204,7 @@ def test_a_flagged_iteration_moves_nothing_and_is_repeated_or_reported():
     # mapping: the flagged iteration takes no step
     mcfg = slam.REPLICA_MAPPING
     mp = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
-    with plugin.install(slam):
+    with plugin.install(slam, map_edits=map_edits):
         mv = _variables(mp)
         mp, mv, opt = _mapping_loop(slam, mp, mv, frame, 1, mcfg, 3, None)
         plugin._session.drain()
@@ -219,6 +220,8 @@ def test_a_flagged_iteration_moves_nothing_and_is_repeated_or_reported():
             assert torch.equal(mp[k].detach(), snap[k]), k          # nothing moved
         plugin._session.drain()
         assert plugin.session_stats()["skipped_iterations"] >= 1
+        if map_edits:
+            assert eng.map_step == 3                                # the flagged step's count was taken back
         assert eng.tile_stride != 64                                # lists re-sized
         loss, mv, _ = slam.get_loss(mp, frame, mv, 1, mcfg['loss_weights'], mcfg['use_sil_for_loss'], mcfg['sil_thres'], mcfg['use_l1'],
                                     mcfg['ignore_outlier_depth_loss'], mapping=True)
