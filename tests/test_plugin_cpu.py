@@ -132,3 +132,62 @@ print("OK", seen, bound)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_map_edits_prune_adapter_follows_the_references_schedule():
+    """plugin.prune_gaussians (map_edits mode) decides on the host WHEN the engine prunes / resets opacities and whether the
+    ``optimizer.step()`` that follows moves the Gaussians.  Against the reference-shaped prune_gaussians run on CPU tensors with a real
+    torch.optim.Adam: the engine is called exactly on the iterations where that function re-creates a parameter, and the step is
+    skipped exactly when it re-creates ALL of them (remove_points does, whether or not a row goes: torch then finds no .grad)."""
+    import torch
+    from splatam_amd import plugin, slam
+
+    class StubEngine:
+        H, W = 4, 4
+
+        def __init__(self, params):
+            self.params, self.calls = params, []
+
+        def prune_gaussians(self, it, pd, scene_radius):
+            self.calls.append(it)
+            return 0
+
+    class StubReport:
+        args = (None, {}, 0, {}, False, False)
+
+    schedules = [
+        dict(start_after=0, remove_big_after=0, stop_after=20, prune_every=20, removal_opacity_threshold=0.005,
+             final_removal_opacity_threshold=0.005, reset_opacities=False, reset_opacities_every=500),
+        dict(start_after=3, remove_big_after=5, stop_after=17, prune_every=4, removal_opacity_threshold=0.005,
+             final_removal_opacity_threshold=0.01, reset_opacities=True, reset_opacities_every=6),
+        dict(start_after=2, remove_big_after=0, stop_after=9, prune_every=3, removal_opacity_threshold=0.005,
+             final_removal_opacity_threshold=0.005, reset_opacities=True, reset_opacities_every=3),
+    ]
+    for pd in schedules:
+        n = 12
+        ref = {k: torch.nn.Parameter(torch.zeros(n, w)) for k, w in (('means3D', 3), ('rgb_colors', 3), ('unnorm_rotations', 4), ('logit_opacities', 1), ('log_scales', 1))}
+        ref['cam_unnorm_rots'] = torch.nn.Parameter(torch.zeros(1, 4, 2))
+        ref['cam_trans'] = torch.nn.Parameter(torch.zeros(1, 3, 2))
+        variables = {k: torch.zeros(n) for k in ('means2D_gradient_accum', 'denom', 'max_2D_radius', 'timestep')}
+        variables['scene_radius'] = torch.tensor(100.0)
+        opt = slam.initialize_optimizer(ref, slam.REPLICA_MAPPING['lrs'], tracking=False)
+        mine = {k: v.detach().clone() for k, v in ref.items()}
+        eng = StubEngine(mine)
+        s = plugin._session
+        saved = (s.current, s.map_edits, s.skip_gaussian_step, dict(s.bound))
+        try:
+            s.map_edits, s.current = True, (eng, (), StubReport())
+            for it in range(0, 25):
+                before = {k: ref[k] for k in ('means3D', 'logit_opacities')}
+                ref, variables = slam.prune_gaussians(ref, variables, opt, it, pd)
+                all_recreated = ref['means3D'] is not before['means3D']
+                any_recreated = all_recreated or ref['logit_opacities'] is not before['logit_opacities']
+                eng.calls.clear()
+                s.skip_gaussian_step = False
+                plugin.prune_gaussians(mine, dict(variables), None, it, pd)
+                assert bool(eng.calls) == any_recreated, (pd, it)
+                assert s.skip_gaussian_step == all_recreated, (pd, it)
+        finally:
+            s.current, s.map_edits, s.skip_gaussian_step = saved[:3]
+            s.bound.clear()
+            s.bound.update(saved[3])
