@@ -75,6 +75,60 @@ def test_rccl_two_ranks(tmp_path):
     _check_two_ranks(tmp_path, "nccl")
 
 
+def _rccl_ops_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    dev = torch.device("cuda", 0)
+    assert dist.get_backend() == "nccl"
+    # every (collective, reduction, dtype) the multi-rank paths issue through torch.distributed -- splatam_amd/dist.py, bench.py:
+    bucket = torch.arange(16 + 3_600_000, dtype=torch.float32, device=dev)     # the gradient bucket with its 16-float header: AVG
+    want = bucket.clone()
+    dist.all_reduce(bucket, op=dist.ReduceOp.AVG)
+    dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+    sums = torch.full((64 * 32,), 1.5, dtype=torch.float64, device=dev)         # tracking's partial sums (doubles): SUM
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    folded = sums[:32]                                                           # ... folded: 256 bytes, a view of the same buffer
+    dist.all_reduce(folded, op=dist.ReduceOp.SUM)
+    flag = torch.tensor([1], dtype=torch.int32, device=dev)                     # any_rank / all_agree: MAX / MIN of int32
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    rows = torch.tensor([816000, -816000], dtype=torch.int64, device=dev)       # assert_replicated_count / max_int: int64
+    dist.all_reduce(rows, op=dist.ReduceOp.MIN)
+    dist.all_reduce(rows, op=dist.ReduceOp.MAX)
+    t64 = torch.tensor([1.25, 2.5], dtype=torch.float64, device=dev)            # bench.py: elapsed times, MAX of doubles
+    dist.all_reduce(t64, op=dist.ReduceOp.MAX)
+    pose = torch.arange(7, dtype=torch.float32, device=dev)                     # broadcast_pose
+    dist.broadcast(pose, src=0)
+    box = [b"x" * 128]                                                          # the in-stream communicator's id
+    dist.broadcast_object_list(box, src=0)
+    dist.barrier()
+    torch.cuda.synchronize()
+    ok = (torch.equal(bucket, want) and float(sums.min()) == 1.5 and int(flag[0]) == 1 and rows.tolist() == [816000, -816000]
+          and t64.tolist() == [1.25, 2.5] and torch.equal(pose, torch.arange(7, dtype=torch.float32, device=dev)) and box[0] == b"x" * 128)
+    # ... and the library's own entry points on top of that group (what a multi-rank job calls them with)
+    from splatam_amd import dist as sdist
+    assert sdist.world_size() == 1 and sdist.get_rank() == 0
+    sdist.all_reduce_mean_flat(bucket)
+    sdist.all_reduce_sum_flat(sums)
+    assert sdist.any_rank(True, dev) and not sdist.any_rank(False, dev) and sdist.max_int(7, dev) == 7
+    sdist.assert_replicated_count(5, "test", dev)
+    np.savez(os.path.join(out_dir, "rccl_ops.npz"), ok=ok)
+    dist.destroy_process_group()
+
+
+def test_rccl_accepts_every_collective_the_multi_rank_paths_issue(tmp_path):
+    """No development box has two GPUs, so RCCL has never carried the multi-rank job.  What ONE GPU can settle: that this torch /
+    RCCL build accepts every collective, reduction and dtype the multi-rank paths issue (ReduceOp.AVG of floats, SUM of doubles, MIN /
+    MAX of int32 / int64, broadcast, object broadcast, barrier) on the "nccl" backend -- a one-rank group runs them through RCCL -- and
+    returns the buffers unchanged.  In a child process: the process group must not leak into the other tests."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rccl_ops_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    assert bool(np.load(tmp_path / "rccl_ops.npz")['ok'])
+
+
 def test_instream_rccl_single_rank():
     """splatam_amd.dist.InStreamRccl (ncclAllReduce on the caller's stream, own communicator): what one GPU can show -- the
     communicator initialises, the collective is ordered with the kernels queued before and after it on the SAME non-default stream
