@@ -147,8 +147,9 @@ typedef struct SplatState {
      * profiles/r04_k7_account.md): the forward composite leaves a work estimate per tile in tile_work ([T]: the sum over the
      * tile's four 8x8 quadrants of the deepest list entry any pixel blended -- what the backward composite will walk), eight extra
      * workgroups of the iteration's last kernel turn it into tile_order ([8 * ceil(T / 8)]: the tiles of every XCD band, heaviest first, 0xFFFFFFFF = no tile),
-     * and the NEXT iteration's composites start their workgroups in that order.  Only a
-     * schedule: any permutation of each band gives the same results. */
+     * and the NEXT iteration that is given this tile_order buffer starts its
+     * composites' workgroups in that order (a caller that alternates between views keeps one buffer per view: the estimate belongs
+     * to the view it was measured on -- splatam_amd/fused.py).  Only a schedule: any permutation of each band gives the same results. */
     uint32_t *tile_work;
     uint32_t *tile_order;
     /* PERSISTENT composites (fused iteration; NULL: one workgroup per tile, started by the hardware dispatcher).  [SPLAT_QUEUE_WORDS]

@@ -82,6 +82,11 @@ class FusedEngine:
         b['tile_order'] = torch.where(nat < T, nat, torch.full_like(nat, 0xFFFFFFFF)).to(torch.uint32).view(i32).to(dev) \
             if hasattr(torch, "uint32") else None
         self.tile_order_on = os.environ.get("SPLAT_TILE_ORDER", "1") != "0" and b['tile_order'] is not None
+        # ... one order PER VIEW (keyed by the frame's time index, the last 64 views): an iteration leaves the order for the NEXT visit
+        # of its view.  Mapping draws a random keyframe per iteration (/root/reference/scripts/splatam.py:831-845): the order the
+        # previous iteration left belongs to another view
+        self.order_per_view = os.environ.get("SPLAT_TILE_ORDER_PER_VIEW", "1") != "0"
+        self._natural_order, self._orders = b['tile_order'], {}
         # persistent composites (SplatState.tile_queue): one workgroup per resident slot pops tiles from per-XCD queues instead of one
         # hardware-dispatched workgroup per tile
         self.persistent = os.environ.get("SPLAT_PERSISTENT", "0") != "0"        # (needs a library built with -DSPLAT_TILE_LOOP=1; not adopted: profiles/r05_experiments.md 3)
@@ -305,6 +310,7 @@ class FusedEngine:
         fr.im, fr.depth, fr.w2c, fr.time_idx = None, None, w2c.data_ptr(), int(time_idx)
         self._frame_keep = (w2c,)
         self._tile_rows, self._stats_partial = None, False         # a whole-frame render: its list statistics are the frame's
+        self._select_order(int(time_idx))
         ws = self._workspace(False, with_ssim=False)
         ws.max_2D_radius = None
         m = self._map_struct()
@@ -654,6 +660,18 @@ class FusedEngine:
             ws.outlier_err, ws.outlier_scratch = b['outlier_err'].data_ptr(), b['outlier_scratch'].data_ptr()
         return ws
 
+    def _select_order(self, view):
+        """Point ``buf['tile_order']`` at the launch order view ``view`` left at its last visit (the natural order at its first)."""
+        if not (self.tile_order_on and self.order_per_view):
+            return
+        o = self._orders.pop(view, None)
+        if o is None:
+            if len(self._orders) >= 64:
+                self._orders.pop(next(iter(self._orders)))          # the view visited longest ago
+            o = self._natural_order.clone()
+        self._orders[view] = o                                      # (most recently visited last)
+        self.buf['tile_order'] = o
+
     def _stream(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
 
@@ -700,6 +718,7 @@ class FusedEngine:
             lay = self._layout(0, outlier=True)
             self.buf['outlier_err'] = self._new(lay, "outlier_err", torch.float32)
             self.buf['outlier_scratch'] = self._new(lay, "outlier_scratch", torch.int32)
+        self._select_order(int(time_idx))
         ws = self._workspace(map_grads, with_ssim=not tracking)
         m = self._map_struct()
         with torch.cuda.device(self.dev):

@@ -797,6 +797,49 @@ def test_tile_launch_order_changes_nothing_but_speed():
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, k
 
 
+def test_every_view_keeps_its_own_launch_order():
+    """Mapping draws another keyframe view every iteration: the order an iteration leaves is kept for the NEXT visit of ITS view (keyed
+    by the frame's time index; the last 64 views), not handed to whichever view comes next.  Each view's buffer is a permutation built
+    from that view's own work estimates; the planes do not depend on it."""
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    params, variables, frame, cam = _scene(30000, 424, 312, seed=78)
+    with torch.no_grad():                                           # a second view: the pose of time index 2 looks elsewhere
+        params['cam_unnorm_rots'][0, :, 2] = torch.tensor([0.99, -0.03, 0.05, 0.01], device="cuda")
+        params['cam_trans'][0, :, 2] = torch.tensor([-0.05, 0.04, 0.02], device="cuda")
+    cfg = slam.REPLICA_MAPPING
+    eng = FusedEngine({k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}, cam)
+    assert eng.order_per_view and eng.tile_order_on
+    natural = eng._natural_order.clone()
+    planes = {}
+    for it in range(6):
+        view = 1 + it % 2
+        eng.loss_backward(frame, view, cfg, tracking=False)
+        assert not eng.check_overflow()
+        assert eng.buf['tile_order'] is eng._orders[view]
+        planes[view] = eng.buf['out6'].clone()
+    torch.cuda.synchronize()
+    o1, o2 = eng._orders[1], eng._orders[2]
+    assert o1.data_ptr() != o2.data_ptr() and len(eng._orders) == 2
+    assert torch.equal(eng._natural_order, natural)                 # the natural order itself is never written
+    assert not torch.equal(o1, natural) and not torch.equal(o2, natural) and not torch.equal(o1, o2)
+    for o in (o1, o2):
+        assert torch.equal(torch.sort(o.view(torch.int32).long() & 0xFFFFFFFF).values, torch.sort(natural.long() & 0xFFFFFFFF).values)
+    single = FusedEngine({k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}, cam)
+    single.order_per_view = False
+    for it in range(6):
+        view = 1 + it % 2
+        single.loss_backward(frame, view, cfg, tracking=False)
+        assert not single.check_overflow()
+        if it >= 4:
+            assert torch.equal(single.buf['out6'], planes[view]), view
+    assert len(single._orders) == 0
+    # bounded: the 65th view evicts the one visited longest ago
+    for v in range(3, 3 + 64):
+        eng._select_order(v)
+    assert len(eng._orders) == 64 and 1 not in eng._orders and 2 not in eng._orders
+
+
 @pytest.mark.parametrize("n,W,H,label", [(20000, 328, 248, "one batch per tile"), (64000, 328, 248, "two to three batches per tile"),
                                          (4000, 200, 120, "sparse: empty tiles, pixels outside the image")])
 def test_tracking_composites_in_one_kernel_equal_the_two_kernels(n, W, H, label):
