@@ -293,13 +293,19 @@ class FusedEngine:
             sc = self.buf['map_scratch'] = torch.zeros(words, dtype=torch.int32, device=self.dev)
         return sc
 
-    def _set_rows(self, P):
+    def _set_rows(self, P, keep_lists_within=0.10):
         self.P = int(P)
         self._publish()
         self._layout_rows()
-        # the per-tile list statistics were learnt for the old map: back to exact lists until check_overflow() re-learns
-        self.tile_stride = 0
-        self.max_list_hint = 0
+        # the per-tile list statistics were learnt for another map: back to exact lists until check_overflow() / relearn_lists()
+        # re-learns them -- unless the number of rows moved by less than ``keep_lists_within`` of the rows they were learnt on (the frame
+        # loop's edits: +0.7 % per add_new_gaussians, a handful of rows per pruning): the buckets are 1.5x the longest list seen, the
+        # statistics are refreshed at the end of every phase, and a list that does outgrow its bucket raises the flag (the skipped
+        # iterations are run again), so stale statistics can cost time, never a wrong step
+        ref = self._learnt_P
+        if ref is None or self.tile_stride == 0 or abs(self.P - ref) > keep_lists_within * max(ref, 1):
+            self.tile_stride = 0
+            self.max_list_hint = 0
 
     def render(self, curr_data, time_idx):
         """Forward-only 6-channel render of the map from pose ``time_idx`` (no loss, no gradients): returns
@@ -319,9 +325,13 @@ class FusedEngine:
                         "splat_iter_render")
         return self.rendered()
 
+    def lists_known(self):
+        """The per-tile list statistics (bucket stride, longest list) are usable for the map as it is: an edit kept them (_set_rows)."""
+        return self.tile_stride > 0 and self.max_list_hint > 0
+
     def relearn_lists(self, curr_data, time_idx):
         """One probe render with exact lists + ``check_overflow()``: sizes the list capacity and the per-tile buckets
-        for the map as it is now (call after the map was edited; one D2H read)."""
+        for the map as it is now (call after an edit that did not keep them -- ``lists_known()``; one D2H read)."""
         self.tile_stride = 0
         self.max_list_hint = 0
         for _ in range(3):

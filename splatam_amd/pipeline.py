@@ -403,7 +403,7 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
                         selected.append(len(keyframe_list) - 1)
                     selected.append(-1)
                     decided['selected'] = [int(x) for x in selected[:-1 - (1 if len(keyframe_list) > 0 else 0)]]
-                if fused:
+                if fused and not eng.lists_known():
                     with phase("relearn_lists"):
                         eng.relearn_lists(curr_data, time_idx)
                 if dev.type == "cuda":
@@ -600,8 +600,9 @@ def _map_frame(params, variables, curr_data, time_idx, selected, keyframe_list, 
                 on_schedule = on_schedule or dens_sched                   # re-created parameters carry no gradient: no Adam step
             if edited:
                 sdist.assert_replicated_count(eng.P, f"map edit (frame {time_idx}, iteration {it})", dev)
-                with phase("relearn_lists"):
-                    eng.relearn_lists(curr_data, time_idx)
+                if not eng.lists_known():
+                    with phase("relearn_lists"):
+                        eng.relearn_lists(curr_data, time_idx)
             if not on_schedule:
                 eng.adam_map(mcfg['lrs'])
         else:

@@ -548,7 +548,8 @@ def add_new_gaussians(params, variables, curr_data, sil_thres, time_idx, mean_sq
     s.drain()
     eng, _ = s.engine(params, variables, curr_data['cam'])
     eng.add_new_gaussians(curr_data, sil_thres, time_idx, mean_sq_dist_method, gaussian_distribution)
-    eng.relearn_lists(curr_data, time_idx)              # the per-tile lists of the grown map (one probe render + one read)
+    if not eng.lists_known():
+        eng.relearn_lists(curr_data, time_idx)          # the per-tile lists of the grown map (one probe render + one read)
     _refresh_bound(s, eng, params, variables)
     s.stats["rebuilds"] += 1
     return params, variables
@@ -573,7 +574,8 @@ def prune_gaussians(params, variables, optimizer, iter, prune_dict):
     if on_schedule:
         s.skip_gaussian_step = True
     if removed:
-        eng.relearn_lists(rep.args[1], rep.args[2])
+        if not eng.lists_known():
+            eng.relearn_lists(rep.args[1], rep.args[2])
         s.stats["rebuilds"] += 1
     _refresh_bound(s, eng, params, variables)
     return params, variables
