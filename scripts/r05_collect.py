@@ -79,10 +79,10 @@ with open(os.path.join(P, "r05_workloads.md"), "w") as f:
             "`bench.py --workload <W>`: the 2:3 tracking:mapping mix (`value`), the phases alone (tracking: the headline form / with every "
             "gradient of the reference's backward formed), the two composites live (HIP events), the fraction of the 8 TB/s HBM peak the "
             "dominant kernel's algorithmic bytes reach, and the reference's own loop statements through the plug-in / on the drop-in package.\n\n"
-            "| workload | Gaussians | frame | mix it/s | tracking it/s (headline / full gradients) | mapping it/s | K6 / K7 us | roofline frac | plug-in it/s | drop-in it/s |\n"
+            "| workload | Gaussians | frame | mix it/s: the K timed steps (sustained) | tracking it/s (headline / full gradients) | mapping it/s | K6 / K7 us | roofline frac | plug-in it/s | drop-in it/s |\n"
             "|---|---|---|---|---|---|---|---|---|---|\n" + "\n".join(rows) + "\n")
     b = lines.get("B") or {}
-    for key in ("slam_loop", "slam_loop_plugin"):
+    for key in ("slam_loop", "slam_loop_plugin", "slam_loop_plugin_map_edits"):
         if key in b:
             f.write(f"\n`{key}` at B: {b[key]['frames_per_s']} frames/s (runs agree within {b[key]['runs_agree_within']}).\n")
 print("\n".join(rows))
