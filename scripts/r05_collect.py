@@ -70,7 +70,8 @@ for wl in ("A", "B", "B-loop", "D", "E", "E-clustered"):
     r = d.get("roofline") or {}
     o = r.get("other") or {}
     cfgd = d["config"]
-    rows.append(f"| {wl} | {cfgd['gaussians']:,} | {cfgd['width']}x{cfgd['height']} | {d['value']:.0f} | {d['tracking_iters_per_s']:.0f} / "
+    sus = (d.get("sustained") or {}).get("iters_per_s") or float("nan")
+    rows.append(f"| {wl} | {cfgd['gaussians']:,} | {cfgd['width']}x{cfgd['height']} | {d['value']:.0f} ({sus:.0f}) | {d['tracking_iters_per_s']:.0f} / "
                 f"{d.get('tracking_full_gradients_iters_per_s') or float('nan'):.0f} | {d['mapping_iters_per_s']:.0f} | "
                 f"{1e3 * (o.get('render_forward_ms') or float('nan')):.1f} / {1e3 * (o.get('render_backward_ms') or float('nan')):.1f} | "
                 f"{r.get('frac', float('nan')):.4f} | {d.get('plugin_iters_per_s', float('nan')):.0f} | {d.get('dropin_iters_per_s', float('nan')):.0f} |")
