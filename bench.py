@@ -628,6 +628,8 @@ def main():
     ap.add_argument("--sync-mode", default="exact", choices=["exact", "lazy"])
     ap.add_argument("--engine", default="fused", choices=["fused", "dropin"])
     ap.add_argument("--sustain-s", type=float, default=6.5, help="length of the sustained region in seconds")
+    ap.add_argument("--prewarm-s", type=float, default=0.15,
+                    help="run the step schedule for this long BEFORE the W warm-up steps so that the GPU's clocks have ramped (0: off)")
     ap.add_argument("--instream-rccl", action="store_true",
                     help="N > 1 over RCCL: issue the per-iteration all-reduces on the iteration's own stream (splatam_amd.dist.InStreamRccl)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -705,6 +707,37 @@ def main():
                 run_steps_views(eng, frames, rank, world, n)
             else:
                 run_steps_fused(eng, frames, rank, world, n, start)
+        # clock pre-warm, before the W warm-up steps: an MI355X that has idled for >= 20 ms (scene set-up, the host-side legs above) runs
+        # its first ~25 ms of work 10-15 % slower than steady state (power management ramps the clocks: scripts/r05_timed_region.py,
+        # profiles/r05_experiments.md 10) -- with the driver's K = 20 the whole timed region (5 ms) sat inside that ramp.  The same step
+        # schedule runs here in blocks of 50 until >= --prewarm-s seconds have passed (decided jointly by the ranks), the map, the
+        # poses and the Adam state going back to the seeded values after every block; the W warm-up steps and the K timed steps then
+        # follow without an idle gap, on the seeded scene, exactly as before.  Reported as "prewarm" in the JSON line
+        prewarm = {"seconds": 0.0, "steps": 0}
+        if args.prewarm_s > 0:
+            seeded = {k: v.detach().clone() for k, v in eparams.items()}
+            barrier()
+            tp = time.perf_counter()
+            while True:
+                steps(50, prewarm["steps"])
+                prewarm["steps"] += 50
+                if prewarm["steps"] == 50 and eng.check_overflow():
+                    raise SystemExit("instance lists overflowed during the clock pre-warm")
+                with torch.no_grad():
+                    for k, v in eparams.items():
+                        v.copy_(seeded[k])
+                eng.reset_map_optimizer()
+                eng.begin_tracking(1)
+                barrier()
+                el = torch.tensor([time.perf_counter() - tp], device=dev, dtype=torch.float64)
+                if world > 1:
+                    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+                prewarm["seconds"] = round(float(el[0]), 3)
+                if prewarm["seconds"] >= args.prewarm_s or prewarm["steps"] >= 5000:
+                    break
+            if eng.check_overflow():
+                raise SystemExit("instance lists overflowed during the clock pre-warm")
+            del seeded
         # warm-up: the list statistics are learnt from its first steps (check_overflow: bucketed lists, group records, no long-list
         # sort launch), the last ones already run the learnt configuration -- whose buffers are allocated there, not in the timed region
         w0 = max(args.warmup - 3, 0)
@@ -911,6 +944,9 @@ def main():
                                              "ranks, one all-reduce of the partial sums per iteration, counted once" if (world > 1 and SHARD_TRACKING) else
                                             ("1 process/GPU; mapping: one view per rank per step, one gradient all-reduce (mean); tracking: replicas, counted once"
                                              if world > 1 else "1 process/GPU")))},
+            # untimed work in front of the W warm-up steps (fused engine): the same schedule, state restored, so that the K timed steps do not
+            # run inside the clock ramp of a GPU that idled through the set-up
+            "prewarm": (prewarm if fused else None),
             "sustained": ({"steps": n_sus, "seconds": round(sustained_s, 3), "iters_per_s": round(units(n_sus) / sustained_s, 3)} if sustained_ok
                           else {"steps": n_sus, "invalid": "a per-tile list outgrew its bucket during the sustained region"}),
             "collectives": ("in-stream RCCL (splatam_amd.dist.InStreamRccl)" if sdist._instream is not None else
