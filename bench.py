@@ -24,6 +24,9 @@ Three ways through the same iteration (same loss, same gradients, same Adam upda
 Beside them: ``slam_loop`` / ``slam_loop_plugin`` (the whole frame loop, 13 frames, two runs, per-phase milliseconds), ``roofline`` (the
 dominant kernel live + counters of the committed profile set), ``cpu_baseline`` (the C oracle + PyTorch-CPU glue on the host cores).
 ``python bench.py --gpus N`` started without a launcher starts its own N ranks (torch.distributed.run, 127.0.0.1).
+Timing: W untimed warm-up steps, then EXACTLY K steps between barrier + torch.cuda.synchronize() on both sides, maximum over the ranks.  In
+front of the W warm-up steps the same schedule runs for >= --prewarm-s seconds (state restored afterwards; ``prewarm`` in the JSON line): an
+MI355X that idled through the set-up runs its first ~25 ms of work 10-15 % slow, and K = 20 steps are 5 ms (profiles/r05_experiments.md 10).
 
 Prints ONE JSON line on rank 0.
 """
@@ -247,6 +250,14 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
         eng.loss_backward(frames[1], 1, slam.REPLICA_TRACKING, tracking=True)
         torch.cuda.synchronize(dev)
         eng.check_overflow()
+    # steady clocks first: the kernels below are timed over a few milliseconds each, and a GPU that idled through the scene set-up runs its
+    # first ~25 ms of work 10-15 % slow (profiles/r05_experiments.md 10): >= 0.1 s of mapping iterations (gradients formed, no Adam step:
+    # the map does not move)
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.1:
+        for _ in range(25):
+            eng.loss_backward(frames[2 % len(frames)], 2 % len(frames), slam.REPLICA_MAPPING, tracking=False)
+        torch.cuda.synchronize(dev)
     # the state the mapping loop runs in: learnt lists, the gradient planes of a mapping iteration
     eng.loss_backward(frames[2 % len(frames)], 2 % len(frames), slam.REPLICA_MAPPING, tracking=False)
     torch.cuda.synchronize(dev)
