@@ -636,7 +636,8 @@ def main():
                     help="C = BASELINE config 3: workload B's map, mapping-only, a fixed batch of 8 keyframe views per step "
                          "split over the ranks (strong scaling)")
     ap.add_argument("--views", type=int, default=8)
-    ap.add_argument("--sync-mode", default="exact", choices=["exact", "lazy"])
+    ap.add_argument("--sync-mode", default="auto", choices=["auto", "exact", "lazy"],
+                    help="capacity policy of the drop-in rasterizer (splatam_amd/rasterizer.py): auto = exact on a scene's first call, then no host read")
     ap.add_argument("--engine", default="fused", choices=["fused", "dropin"])
     ap.add_argument("--sustain-s", type=float, default=6.5, help="length of the sustained region in seconds")
     ap.add_argument("--prewarm-s", type=float, default=0.15,

@@ -30,7 +30,11 @@
 extern "C" {
 #endif
 
-#define SPLAT_ABI_VERSION 9        /* 9: scratch layouts (splat_workspace_bytes, splat_state_layout / _bind, splat_iter_workspace_layout / _bind);
+#define SPLAT_ABI_VERSION 10       /* 10: group binning behind the reference API (SplatState.group_* in splat_preprocess_forward / splat_render_forward,
+                                      SPLAT_LAYOUT_GROUPS), SplatCamera.bg == NULL = black, SplatGrads.flags (SPLAT_GRADS_UPSTREAM_SCALE), SplatState.status_host,
+                                      SplatState.tile_order entries hold tile + 1 (a zeroed buffer is the natural order) and are laid out on request (SPLAT_LAYOUT_TILE_ORDER),
+                                      SplatState.tile_queue (persistent composites: measured, not adopted, removed) is gone;
+                                      9: scratch layouts (splat_workspace_bytes, splat_state_layout / _bind, splat_iter_workspace_layout / _bind);
                                       8: SplatIterWorkspace.d_cam is SPLAT_ITER_DCAM floats (loss terms, status snapshot, gated-iteration count),
                                       the Adam steps skip while the capacity flag is up (SplatAdamMap.gate), per-group bc2_sqrt;
                                       7: SplatState.long_items (work-item table of the multi-workgroup sort);
@@ -42,8 +46,6 @@ extern "C" {
 #define SPLAT_MAX_CHANNELS 8     /* colour channels per call: 3 for the reference API, up to 8 for fused passes */
 #define SPLAT_GRAD_STRIDE 16     /* floats per Gaussian in the backward accumulator (one 64-byte line) */
 #define SPLAT_GROUP_TILES 2      /* group binning: a group is 2 x 2 tiles (SplatState.group_count) */
-#define SPLAT_QUEUE_REGION_WORDS 256  /* SplatState.tile_queue: a region = 8 cursors, one 128-byte line each */
-#define SPLAT_QUEUE_WORDS (64 * SPLAT_QUEUE_REGION_WORDS)
 #define SPLAT_COUNTER_STRIDE 32  /* uint32 words between two tile counters: one 128-byte line per counter, so that
                                     the ~200 atomics a tile receives do not serialise with its neighbours' */
 
@@ -61,7 +63,8 @@ typedef struct SplatCamera {
     int32_t image_width;
     float tanfovx;
     float tanfovy;
-    const float *bg;             /* [channels] */
+    const float *bg;             /* [channels], or NULL = black (every SplaTAM camera: /root/reference/utils/recon_helpers.py:17); with NULL
+                                    the backward composite drops the background term of dL/dalpha at compile time */
     float scale_modifier;
     const float *viewmatrix;     /* [16] */
     const float *projmatrix;     /* [16] */
@@ -146,22 +149,14 @@ typedef struct SplatState {
      * 3 225 tile workgroups of very different length on 1 024 resident slots leaves a long tail (time-weighted occupancy 67-76 %,
      * profiles/r04_k7_account.md): the forward composite leaves a work estimate per tile in tile_work ([T]: the sum over the
      * tile's four 8x8 quadrants of the deepest list entry any pixel blended -- what the backward composite will walk), eight extra
-     * workgroups of the iteration's last kernel turn it into tile_order ([8 * ceil(T / 8)]: the tiles of every XCD band, heaviest first, 0xFFFFFFFF = no tile),
+     * workgroups of the iteration's last kernel turn it into tile_order ([8 * ceil(T / 8)]: the tiles of every XCD band, heaviest first; an
+     * entry holds tile + 1, 0 = not written yet: the natural tile of the slot -- a ZERO-INITIALISED buffer is the natural order --,
+     * 0xFFFFFFFF = no tile),
      * and the NEXT iteration that is given this tile_order buffer starts its
      * composites' workgroups in that order (a caller that alternates between views keeps one buffer per view: the estimate belongs
      * to the view it was measured on -- splatam_amd/fused.py).  Only a schedule: any permutation of each band gives the same results. */
     uint32_t *tile_work;
     uint32_t *tile_order;
-    /* PERSISTENT composites (fused iteration; NULL: one workgroup per tile, started by the hardware dispatcher).  [SPLAT_QUEUE_WORDS]
-     * zero-initialised words, eight cursors per region (one per XCD band, one 128-byte line each: cursor b of region r is word
-     * r * SPLAT_QUEUE_REGION_WORDS + b * SPLAT_COUNTER_STRIDE).  With it a composite is launched as ONE workgroup per
-     * resident slot (CUs x workgroups per CU) that pops tiles until the queues are dry: first from the band of its own XCD (in
-     * tile_order, heaviest first: neighbouring tiles share an L2), then from the other bands.  3 225 tile workgroups of very different
-     * length left 22-32 % of the slot-time of a launch unused (profiles/r04_k7_account.md 2, r05_experiments.md); a resident workgroup
-     * takes its next tile the moment it is done, and the eight bands no longer end at eight different times.  Region 0: the forward
-     * composite, region 1: the backward / the fused tracking composite (the iteration's first kernel zeroes both); regions 2..: for
-     * callers that launch a composite repeatedly (splat_iter_time_kernel).  Only a schedule: results do not depend on it. */
-    uint32_t *tile_queue;
     /* per-pixel */
     float *final_T;              /* [H][W] */
     int32_t *n_contrib;          /* [H][W] 1-based list position of the last contributor */
@@ -169,6 +164,10 @@ typedef struct SplatState {
      *               [2] longest tile list  [3] a list longer than the wave-sort limit met a stale max_list_hint
      *               that had skipped the long-list sort kernel (the lists are then NOT sorted: re-run) */
     int32_t *status;             /* [4] */
+    /* optional (NULL: none): ONE int32 in pinned HOST memory that the group-binning kernels set to 1 whenever they raise status[1] or
+     * status[3] -- a caller that never waits for the device between the forward and the backward pass reads it (after an event that
+     * follows the forward composite) without queueing a copy.  The caller zeroes it before the call. */
+    int32_t *status_host;
 } SplatState;
 
 const char *splat_error_string(int code);
@@ -179,6 +178,19 @@ size_t splat_sizeof(const char *name);
 
 size_t splat_num_tiles(int32_t width, int32_t height);
 
+
+/* GROUP BINNING behind the reference API (ABI 10) -- the front end of the fused iteration for callers of splat_forward / splat_backward
+ * who know that the scene's per-tile lists are short (an earlier call on the same scene left its longest list in status[2]):
+ *   st->tile_stride  = S > 0      bucket of tile t in point_list = [t * S, t * S + count); S <= 1024 entries is all the composite sorts
+ *   st->max_list_hint = L with L + L / 4 <= 1024   (the longest list the caller expects)
+ *   st->group_count / group_recs / group_stride (>= 4 * S can never overflow first), st->capacity >= S * tiles; st->keys may be NULL
+ * splat_preprocess_forward then zeroes group_count and status, and files ONE 16-byte record per (Gaussian, touched group of 2 x 2 tiles);
+ * splat_bin_forward is a no-op; splat_render_forward (3 colour channels) filters, sorts and publishes every tile's list itself
+ * (point_list, tile_count) and composites; splat_backward walks the published lists.  Two launches forward instead of six, and NOTHING
+ * the host has to read before the composite may be launched (the exact path reads status[0] to size keys / point_list, as the CUDA
+ * original reads num_rendered).  A list longer than S or 1024 entries, or a group bucket that overflowed, raises status[1] / status[3]:
+ * the images and gradients of that call are then built from TRUNCATED lists (memory-safe, wrong) and the caller must repeat the call
+ * on exact lists (tile_stride = 0).  status[0] and status[2] are not maintained in this mode. */
 
 /* K1 + tile scan.  Replaces the first half of `_C.rasterize_gaussians`
  * (preprocess, prefix sum).  Writes depth/xy/conic_opacity/rect/radii,
@@ -227,7 +239,14 @@ typedef struct SplatGrads {
     float *dL_drotations;        /* [P][4] or NULL */
     float *dL_dcov3D;            /* [P][6] or NULL */
     float *dL_dshs;              /* [P][M][3] or NULL */
+    int32_t flags;               /* SPLAT_GRADS_* */
 } SplatGrads;
+#define SPLAT_GRADS_POISON_IF_FLAGGED 2 /* group binning behind the reference API: splat_preprocess_backward writes NaN into EVERY gradient output when
+                                        the forward pass of this state raised status[1] or status[3] (its lists were truncated).  For a caller that
+                                        launches the backward pass without having looked at the flags: gradients formed on truncated lists never
+                                        reach an optimizer as plausible numbers */
+#define SPLAT_GRADS_UPSTREAM_SCALE 1 /* dL_dscales WITHOUT the factor cam->scale_modifier: the numbers the CUDA original returns (its computeCov3D
+                                        adjoint forms dL/d(modifier * s) and hands it out as dL/ds; see dL_dscales above).  Identical at modifier 1.0 */
 
 /* Per-pixel back-to-front replay; accumulates per-Gaussian partial sums into gr->accum. */
 int splat_render_backward(const SplatCamera *cam, const SplatGaussians *g, const SplatState *st,
@@ -383,6 +402,12 @@ typedef struct SplatArrayInfo {
 #define SPLAT_LAYOUT_BACKWARD 4  /* SplatGrads.accum */
 #define SPLAT_LAYOUT_SSIM 8      /* fused iteration: ssim_maps (mapping) */
 #define SPLAT_LAYOUT_OUTLIER 16  /* fused iteration: outlier_err / outlier_scratch (ignore_outlier_depth_loss) */
+#define SPLAT_LAYOUT_GROUPS 32   /* splat_state_layout: group binning behind the reference API -- group_count (right in front of status: the library
+                                    zeroes both with one memset), group_recs for `group_stride` = 4 * tile_stride records per group, where
+                                    tile_stride = capacity / tiles; no key buckets */
+#define SPLAT_LAYOUT_TILE_ORDER 64 /* splat_iter_workspace_layout / _bind: st.tile_work, st.tile_order (launch order of the composites; the
+                                    library's first iteration on a workspace treats an order buffer it has not written yet as the natural
+                                    order -- see SplatState.tile_order) */
 #define SPLAT_LAYOUT_MAX_ARRAYS 48
 /* One rasterizer call (forward, + backward with SPLAT_LAYOUT_BACKWARD): arrays of SplatState for P Gaussians, a width x height
  * image, `sub_bins` counters per tile (0 / 1 = one) and lists of `capacity` instances.  Writes up to `max_entries` entries to `out`

@@ -50,6 +50,8 @@ def lib(precision: str = "f32"):
         L.ref_forward.restype = C.c_int
         L.ref_flip_bounds.restype = None
         L.ref_backward.restype = C.c_int
+        L.ref_set_upstream_scale.restype = None
+        L.ref_set_upstream_scale.argtypes = [C.c_void_p, C.c_int]
         _libs[precision] = L
     return _libs[precision]
 
@@ -145,6 +147,10 @@ class CRef:
         self.L.ref_flip_bounds(self.ctx, self._p(self.a['colors']), self.ct(tol), self.ct(tie_tol), self._p(bound), self._p(margin),
                                self.ct(ulps or 0.0), self._p(noise))
         return (bound, margin) if ulps is None else (bound, margin, noise)
+
+    def set_upstream_scale(self, on: bool):
+        """dscales without the scale_modifier factor: the numbers the CUDA original returns (ref_set_upstream_scale)."""
+        self.L.ref_set_upstream_scale(self.ctx, int(bool(on)))
 
     def backward(self, dL_dcolor):
         a = self.a

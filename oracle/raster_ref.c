@@ -58,6 +58,7 @@ typedef struct {
     /* binning */
     int64_t R;
     int64_t pairs;              /* live (pixel, Gaussian) pairs composited by the last forward */
+    int upstream_scale;         /* ref_set_upstream_scale: dscales without the scale_modifier factor (the CUDA original's numbers) */
     int *range;                 /* [tiles+1] */
     int *list;                  /* [R] Gaussian ids, per tile sorted by (depth bits, id) */
     /* per-pixel */
@@ -74,6 +75,11 @@ static void ctx_release(ref_ctx *c) {
     memset(c, 0, sizeof(*c));
 }
 void ref_destroy(ref_ctx *c) { if (c) { ctx_release(c); free(c); } }
+/* The CUDA original's computeCov3D adjoint returns dL/d(mod * s) as dL/dscale ([UPSTREAM-RECALLED] dL_dscale->x = dot(Rt[0],
+ * dL_dMt[0]) with M = S R built from s = mod * scale): without the factor `mod` of the chain rule.  on != 0: ref_backward hands out
+ * those numbers (the twin of SplatGrads.flags SPLAT_GRADS_UPSTREAM_SCALE, include/splat_hip.h); 0 (default): the true gradient w.r.t.
+ * the scales the caller passed.  Equal at mod = 1 (every SplaTAM configuration). */
+void ref_set_upstream_scale(ref_ctx *c, int on) { if (c) c->upstream_scale = on; }
 int64_t ref_num_rendered(const ref_ctx *c) { return c->R; }
 int64_t ref_num_pairs(const ref_ctx *c) { return c->pairs; }
 const int *ref_ranges(const ref_ctx *c) { return c->range; }
@@ -569,7 +575,7 @@ int ref_backward(const ref_ctx *c, const real *bg, const real *means3D, const re
                 dM[r][k] = 2.f * v;
             }
             for (int k = 0; k < 3; k++) {
-                dscales[3 * i + k] = mod * (dM[0][k] * R[0][k] + dM[1][k] * R[1][k] + dM[2][k] * R[2][k]);
+                dscales[3 * i + k] = (c->upstream_scale ? (real)1 : mod) * (dM[0][k] * R[0][k] + dM[1][k] * R[1][k] + dM[2][k] * R[2][k]);
                 for (int r = 0; r < 3; r++) A[r][k] = dM[r][k] * sv[k];
             }
             real r_ = q[0], x = q[1], y = q[2], z = q[3];

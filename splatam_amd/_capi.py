@@ -18,7 +18,7 @@ SPLAT_MAX_CHANNELS = 8
 SPLAT_GRAD_STRIDE = 16
 SPLAT_COUNTER_STRIDE = 32
 SPLAT_GROUP_TILES = 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -46,14 +46,14 @@ class SplatState(C.Structure):
                 ("group_count", _fp), ("group_recs", _fp),
                 ("max_list_hint", C.c_int32), ("order_hint", C.c_int32), ("sub_bins", C.c_int32), ("tile_stride", C.c_int32),
                 ("group_stride", C.c_int32), ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),
-                ("tile_work", _fp), ("tile_order", _fp), ("tile_queue", _fp),
-                ("final_T", _fp), ("n_contrib", _fp), ("status", _fp)]
+                ("tile_work", _fp), ("tile_order", _fp),
+                ("final_T", _fp), ("n_contrib", _fp), ("status", _fp), ("status_host", _fp)]
 
 
 class SplatGrads(C.Structure):
     _fields_ = [("dL_dcolor", _fp), ("accum", _fp), ("dL_dmeans3D", _fp), ("dL_dmeans2D", _fp),
                 ("dL_dcolors", _fp), ("dL_dopacities", _fp), ("dL_dscales", _fp), ("dL_drotations", _fp),
-                ("dL_dcov3D", _fp), ("dL_dshs", _fp)]
+                ("dL_dcov3D", _fp), ("dL_dshs", _fp), ("flags", C.c_int32)]
 
 
 class SplatMap(C.Structure):
@@ -128,8 +128,9 @@ SPLAT_ITER_SUM_COPIES = 64
 SPLAT_POSE_STATE = 24
 SPLAT_ITER_DCAM = 32
 SPLAT_SLAB_ALIGN = 256
-SPLAT_QUEUE_WORDS = 64 * 256
 SPLAT_LAYOUT_SH, SPLAT_LAYOUT_LONG_LISTS, SPLAT_LAYOUT_BACKWARD, SPLAT_LAYOUT_SSIM, SPLAT_LAYOUT_OUTLIER = 1, 2, 4, 8, 16
+SPLAT_LAYOUT_GROUPS, SPLAT_LAYOUT_TILE_ORDER = 32, 64
+SPLAT_GRADS_UPSTREAM_SCALE, SPLAT_GRADS_POISON_IF_FLAGGED = 1, 2
 SPLAT_LAYOUT_MAX_ARRAYS = 48
 
 EXPORTS = (
@@ -264,7 +265,21 @@ class Layout:
         self.zero_init = {self.names[i]: bool(arrays[i].zero_init) for i in range(n)}
 
 
+_state_layouts: dict = {}
+
+
 def state_layout(P, width, height, sub_bins, capacity, flags):
+    """(memoised: the drop-in path asks twice per rasterizer call, and a layout is a pure function of its arguments)"""
+    key = (P, width, height, sub_bins, capacity, flags)
+    hit = _state_layouts.get(key)
+    if hit is None:
+        if len(_state_layouts) > 256:
+            _state_layouts.clear()
+        hit = _state_layouts[key] = _state_layout(*key)
+    return hit
+
+
+def _state_layout(P, width, height, sub_bins, capacity, flags):
     arrays = (SplatArrayInfo * SPLAT_LAYOUT_MAX_ARRAYS)()
     total = C.c_size_t(0)
     n = lib().splat_state_layout(P, width, height, sub_bins, capacity, flags, arrays, SPLAT_LAYOUT_MAX_ARRAYS, C.byref(total))

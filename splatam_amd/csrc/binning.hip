@@ -376,6 +376,8 @@ __global__ __launch_bounds__(kBlock) void long_publish_kernel(SplatState st, int
 hipError_t launch_bin_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s, bool sort, bool counted_per_workgroup) {
     const int gx = (cam.image_width + kTile - 1) / kTile;
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
+    // group binning behind the reference API (launch_preprocess_forward filed the records): the forward composite builds the lists
+    if (group_binning(st, cam.image_width, cam.image_height)) return hipSuccess;
     // bucketed lists were filled by the per-Gaussian kernel: only the per-tile sort remains
     if (g.P > 0 && st.tile_stride == 0) {
         if (counted_per_workgroup && dense_exact_lists(st, g.P, T))

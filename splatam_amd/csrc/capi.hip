@@ -13,7 +13,7 @@ bool valid_inputs(const SplatCamera *cam, const SplatGaussians *g) {
     if (g->P < 0 || cam->image_width <= 0 || cam->image_height <= 0) return false;
     if (cam->image_width > 65535 * SPLAT_TILE || cam->image_height > 65535 * SPLAT_TILE) return false;
     if (g->channels < 1 || g->channels > SPLAT_MAX_CHANNELS) return false;
-    if (!cam->viewmatrix || !cam->projmatrix || !cam->bg) return false;
+    if (!cam->viewmatrix || !cam->projmatrix) return false;         // (bg == NULL: black)
     if (g->P > 0) {
         if (!g->means3D || !g->opacities) return false;
         if ((g->colors_precomp == nullptr) == (g->shs == nullptr)) return false;
@@ -30,7 +30,10 @@ bool valid_state(const SplatGaussians *g, const SplatState *st, bool need_lists)
     if (!st || !st->tile_count || !st->tile_base || !st->tile_cursor || !st->status) return false;
     if (g->P > 0 && (!st->depth || !st->xy || !st->conic_opacity || !st->rect || !st->radii)) return false;
     if (g->shs && g->P > 0 && (!st->rgb || !st->clamped)) return false;
-    if (need_lists && (st->capacity < 0 || (st->capacity > 0 && (!st->keys || !st->point_list)))) return false;
+    // (group binning: the composite builds the lists from the group records -- no key buckets)
+    const bool groups = st->group_stride > 0 && st->group_count && st->group_recs && st->tile_stride > 0;
+    if (need_lists && (st->capacity < 0 || (st->capacity > 0 && ((!st->keys && !groups) || !st->point_list)))) return false;
+    if (st->tile_stride < 0 || st->group_stride < 0) return false;
     return true;
 }
 }  // namespace
@@ -259,26 +262,12 @@ int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P,
     } else {
         st.group_stride = 0;
     }
-    // persistent composites (SplatState.tile_queue): every launch of the bracket pops from a queue region of its own (2..63), zeroed
-    // before the bracket; the iteration's own regions 0 and 1 are re-zeroed by its first kernel
-    int launches = 0;
-    auto next_region = [&]() {
-        if (!st.tile_queue) return;
-        if (launches > 0 && launches % 62 == 0) err = hipMemsetAsync(st.tile_queue, 0, sizeof(uint32_t) * SPLAT_QUEUE_WORDS, s);
-        g_debug_queue_region = 2 + launches % 62;
-        ++launches;
-    };
-    if (st.tile_queue) err = hipMemsetAsync(st.tile_queue, 0, sizeof(uint32_t) * SPLAT_QUEUE_WORDS, s);
     (void)hipEventRecord(e0, s);
     for (int i = 0; i < iters && err == hipSuccess; ++i) {
-        if (fn != 1 && fn != 4) { next_region(); err = launch_render_forward_feat8(*cam, ws->feat8, st, ws->out6, sort_form, s); }
-        if ((fn == 1 || fn == 3) && err == hipSuccess) {
-            next_region();
-            err = launch_render_backward_feat8(*cam, ws->feat8, st, ws->dL_dout6, ws->accum, P, false, true, s);
-        }
-        if (fn == 4) { next_region(); err = launch_render_backward_feat8(*cam, ws->feat8, st, ws->dL_dout6, ws->accum, P, false, false, s, false); }     // tracking form
+        if (fn != 1 && fn != 4) err = launch_render_forward_feat8(*cam, ws->feat8, st, ws->out6, sort_form, s);
+        if ((fn == 1 || fn == 3) && err == hipSuccess) err = launch_render_backward_feat8(*cam, ws->feat8, st, ws->dL_dout6, ws->accum, P, false, true, s);
+        if (fn == 4) err = launch_render_backward_feat8(*cam, ws->feat8, st, ws->dL_dout6, ws->accum, P, false, false, s, false);     // tracking form
     }
-    g_debug_queue_region = -1;
     (void)hipEventRecord(e1, s);
     // the timed backward launches accumulated into ws->accum: restore the workspace invariant (every iteration leaves the
     // accumulator zeroed; fused_backward_kernel relies on it) outside the timed bracket
@@ -433,7 +422,7 @@ void state_arrays(LayoutWriter &w, bool iter, int32_t P, int32_t width, int32_t 
     w.add(NAME("tile_count"), 4 * T * S * SPLAT_COUNTER_STRIDE, z);
     w.add(NAME("tile_base"), 4 * (T + 1), 0);
     w.add(NAME("tile_cursor"), 4 * T * S * SPLAT_COUNTER_STRIDE, 0);
-    w.add(NAME("keys"), 8 * cap, 0);
+    if (iter || !(flags & SPLAT_LAYOUT_GROUPS)) w.add(NAME("keys"), 8 * cap, 0);
     w.add(NAME("point_list"), 4 * cap, 0);
     if (flags & SPLAT_LAYOUT_LONG_LISTS) {
         w.add(NAME("keys_alt"), 8 * cap, 0);
@@ -443,12 +432,19 @@ void state_arrays(LayoutWriter &w, bool iter, int32_t P, int32_t width, int32_t 
     if (iter) {
         w.add("st.group_count", 4 * G * SPLAT_COUNTER_STRIDE, 1);
         if (group_stride > 0) w.add("st.group_recs", 16 * G * (size_t)group_stride, 0);
-        w.add("st.tile_work", 4 * T, 1);
-        w.add("st.tile_order", 4 * 8 * ((T + 7) / 8), 0);        // the caller fills it with the natural order (0xFFFFFFFF = no tile)
-        w.add("st.tile_queue", 4 * SPLAT_QUEUE_WORDS, 1);
+        if (flags & SPLAT_LAYOUT_TILE_ORDER) {
+            w.add("st.tile_work", 4 * T, 1);
+            w.add("st.tile_order", 4 * 8 * ((T + 7) / 8), 1);        // (zero = the natural order: SplatState.tile_order)
+        }
     }
     w.add(NAME("final_T"), 4 * HW, 0);
     w.add(NAME("n_contrib"), 4 * HW, 0);
+    if (!iter && (flags & SPLAT_LAYOUT_GROUPS)) {
+        // group binning behind the reference API: the counters sit right in front of the status words (the library zeroes both with
+        // one memset per call: launch_preprocess_forward)
+        if (group_stride > 0) w.add("group_recs", 16 * G * (size_t)group_stride, 0);
+        w.add("group_count", 4 * G * SPLAT_COUNTER_STRIDE, 0);
+    }
     w.add(NAME("status"), 4 * 4, z);
 #undef NAME
 }
@@ -464,7 +460,10 @@ int splat_state_layout(int32_t P, int32_t width, int32_t height, int32_t sub_bin
                        SplatArrayInfo *out, int32_t max_entries, size_t *total_bytes) {
     if (!layout_args_ok(P, width, height, capacity) || sub_bins < 0 || (sub_bins & (sub_bins - 1)) != 0) return -SPLAT_E_INVALID;
     LayoutWriter w{out, max_entries};
-    state_arrays(w, false, P, width, height, sub_bins, capacity, 0, flags);
+    const size_t tiles = splat_num_tiles(width, height);
+    const int64_t tile_stride = tiles ? capacity / (int64_t)tiles : 0;
+    if ((flags & SPLAT_LAYOUT_GROUPS) && (tile_stride < 1 || tile_stride > (1 << 20) || sub_bins > 1)) return -SPLAT_E_INVALID;
+    state_arrays(w, false, P, width, height, sub_bins, capacity, (flags & SPLAT_LAYOUT_GROUPS) ? (int32_t)(SPLAT_GROUP_TILES * SPLAT_GROUP_TILES * tile_stride) : 0, flags);
     if (flags & SPLAT_LAYOUT_BACKWARD) w.add("accum", 4 * (size_t)SPLAT_GRAD_STRIDE * (size_t)P, 0);
     if (total_bytes) *total_bytes = (w.offset + SPLAT_SLAB_ALIGN - 1) / SPLAT_SLAB_ALIGN * SPLAT_SLAB_ALIGN;
     return w.n;
@@ -489,7 +488,7 @@ int splat_state_bind(SplatState *st, SplatGrads *gr, void *slab, const SplatArra
         BIND(depth, float *) BIND(xy, float *) BIND(conic_opacity, float *) BIND(rect, uint32_t *) BIND(radii, int32_t *)
         BIND(rgb, float *) BIND(clamped, uint8_t *) BIND(tile_count, uint32_t *) BIND(tile_base, uint32_t *) BIND(tile_cursor, uint32_t *)
         BIND(keys, uint64_t *) BIND(point_list, uint32_t *) BIND(keys_alt, uint64_t *) BIND(long_base, uint32_t *) BIND(long_items, uint32_t *)
-        BIND(group_count, uint32_t *) BIND(group_recs, uint32_t *) BIND(tile_work, uint32_t *) BIND(tile_order, uint32_t *) BIND(tile_queue, uint32_t *)
+        BIND(group_count, uint32_t *) BIND(group_recs, uint32_t *) BIND(tile_work, uint32_t *) BIND(tile_order, uint32_t *)
         BIND(final_T, float *) BIND(n_contrib, int32_t *) BIND(status, int32_t *)
 #undef BIND
         if (strcmp(name, "accum") == 0) { if (gr) gr->accum = static_cast<float *>(p); continue; }

@@ -73,16 +73,7 @@ __device__ __forceinline__ void load_gaussian(const SplatMap &m, int i, float *p
 constexpr int kAggSlots = 128;
 constexpr int kAggPerLane = 8;
 
-// MODE 2, group binning (SplatState.group_count): the 512 Gaussians of a workgroup count their records per GROUP of 2 x 2 tiles in
-// an LDS histogram (one counter per group of the frame: dynamic LDS, 4 bytes x groups), the workgroup takes ONE returning global
-// atomic per non-empty group, and a record's slot is the group's base + its LDS rank: ~1.0 global atomics per Gaussian in ANY
-// row order (1.56 records per Gaussian over 836 groups at workload B) instead of 2.36, far fewer for a map in creation order.
-// Measured at B (iterations/s, tracking / mapping): per-tile buckets 3 700 / 2 945; groups with 256-Gaussian workgroups 3 900 / 3 025,
-// 512: 4 120 / 3 165, 1 024: 3 990 / 3 090 (fewer atomics, but one workgroup per CU leaves its phases unoverlapped).
-constexpr int kGroupBlock = 512;
-constexpr int kGroupPerLane = 4;            // groups a lane files through the histogram; a Gaussian's further groups take own atomics
-constexpr int kGT = SPLAT_GROUP_TILES;
-static_assert(kGT == 2, "the group index is tile >> 1");
+// MODE 2, group binning (SplatState.group_count): splat_device.h, file_group_records
 
 // One Gaussian of F1: pose transform, activations, projection; writes its geometry, feature record and (mapping) seen radius.
 // Returns its visibility; `o` holds the tile rectangle (clipped to the launch's band of tile rows) and the depth.
@@ -147,20 +138,11 @@ __global__ __launch_bounds__(BLOCK) void fused_preprocess_kernel(FusedArgs a) {
     }
     const int ggx = (((a.cam.image_width + kTile - 1) / kTile) + kGT - 1) / kGT;
     const int num_groups = ggx * ((((a.cam.image_height + kTile - 1) / kTile) + kGT - 1) / kGT);
-    if constexpr (GROUP) {
-        for (int g = threadIdx.x; g < num_groups; g += BLOCK) s_grp[g] = 0u;
-        __syncthreads();
-    }
+    if constexpr (GROUP) group_hist_reset<BLOCK>(s_grp, num_groups);
     if (i == 0 && a.ws.st.tile_stride > 0) {
         // bucketed lists have no scan kernel: the per-iteration status words are reset here and re-accumulated by the
         // kernel that consumes the tile counters (fused_backward_kernel); [1] (overflow) stays sticky for the host
         a.ws.st.status[0] = 0; a.ws.st.status[2] = 0; a.ws.st.status[3] = 0;
-    }
-    if (i == 0 && a.ws.st.tile_queue) {
-        // persistent composites (SplatState.tile_queue): the cursors of this iteration's forward (region 0) and backward / fused
-        // tracking (region 1) composite start at zero
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a.ws.st.tile_queue[(k >> 3) * SPLAT_QUEUE_REGION_WORDS + (k & 7) * SPLAT_COUNTER_STRIDE] = 0u;
     }
     SplatState &st = a.ws.st;
     Projected o{};
@@ -176,44 +158,7 @@ __global__ __launch_bounds__(BLOCK) void fused_preprocess_kernel(FusedArgs a) {
         return;                                              // (uniform over the launch)
     }
     if constexpr (GROUP) {
-        const unsigned gstride = (unsigned)st.group_stride;
-        const int gx0 = o.x0 >> 1, gy0 = o.y0 >> 1;
-        const bool filed = vis && o.y1 > o.y0;
-        const int gw = filed ? ((o.x1 - 1) >> 1) - gx0 + 1 : 0, ng = filed ? gw * (((o.y1 - 1) >> 1) - gy0 + 1) : 0;
-        unsigned rank[kGroupPerLane];
-        const int nh = min(ng, kGroupPerLane);
-#pragma unroll
-        for (int t = 0; t < kGroupPerLane; ++t)
-            if (t < nh) {
-                const int yy = t / gw, xx = t - yy * gw;
-                rank[t] = atomicAdd(&s_grp[(gy0 + yy) * ggx + gx0 + xx], 1u);
-            }
-        __syncthreads();
-        // (one returning atomic per non-empty group; two in flight per lane -- with a zero added where one of a lane's two groups is
-        //  empty -- was measured: 27.4 -> 34.1 us, the kernel is bound by the NUMBER of L2 atomics, not by their latency)
-        for (int g = threadIdx.x; g < num_groups; g += BLOCK) {
-            const unsigned cnt = s_grp[g];
-            if (cnt) s_grp[g] = atomicAdd(&st.group_count[(size_t)g * SPLAT_COUNTER_STRIDE], cnt);
-        }
-        __syncthreads();
-        const uint4 rec = make_uint4((unsigned)i, __float_as_uint(o.depth), (unsigned)o.x0 | ((unsigned)o.y0 << 16), (unsigned)o.x1 | ((unsigned)o.y1 << 16));
-        uint4 *recs = reinterpret_cast<uint4 *>(st.group_recs);
-        bool spilled = false;
-        for (int t = 0; t < ng; ++t) {
-            const int yy = t / gw, xx = t - yy * gw;
-            const unsigned g = (unsigned)((gy0 + yy) * ggx + gx0 + xx);
-            unsigned slot;
-            if (t < kGroupPerLane) {
-                // (compile-time indices only: a dynamically indexed rank[] would live in scratch memory)
-                const unsigned r = t == 0 ? rank[0] : (t == 1 ? rank[1] : (t == 2 ? rank[2] : rank[3]));
-                slot = s_grp[g] + r;
-            } else {
-                slot = atomicAdd(&st.group_count[(size_t)g * SPLAT_COUNTER_STRIDE], 1u);
-            }
-            if (slot < gstride) recs[(size_t)g * gstride + slot] = rec;
-            else spilled = true;
-        }
-        if (spilled) st.status[1] = 1;
+        file_group_records<BLOCK>(st, s_grp, i, vis && o.y1 > o.y0, o.x0, o.y0, o.x1, o.y1, o.depth, ggx, num_groups);
         return;
     }
     // bucketed path: the returning atomic IS the slot
@@ -298,7 +243,6 @@ __global__ __launch_bounds__(kDenseBlock) void fused_preprocess_dense_kernel(Fus
     const int T = c.gx * c.gy;
     for (int t = tid; t < T; t += kDenseBlock) s_tile[t] = 0u;
     if (blockIdx.x == 0 && tid == 0) { a.ws.st.status[0] = 0; a.ws.st.status[2] = 0; a.ws.st.status[3] = 0; }     // (see fused_preprocess_kernel)
-    if (blockIdx.x == 0 && tid < 16 && a.ws.st.tile_queue) a.ws.st.tile_queue[(tid >> 3) * SPLAT_QUEUE_REGION_WORDS + (tid & 7) * SPLAT_COUNTER_STRIDE] = 0u;
     __syncthreads();
     const SplatState &st = a.ws.st;
     unsigned r0[kDensePerThread], r1[kDensePerThread], dbits[kDensePerThread];
@@ -1142,19 +1086,8 @@ __global__ void adam_pose_kernel(SplatMap map, int time_idx, const float *d_cam,
 hipError_t launch_depth_error_median(const float *out6, const float *depth, float *err, uint32_t *scratch, int HW, int32_t *counts,
                                      hipStream_t s);
 
-// lists known (host hint, possibly stale: then flagged) to be short are sorted by the composite kernel itself
-static bool lists_sorted_by_composite(const SplatState &st) { return st.max_list_hint > 0 && st.max_list_hint + st.max_list_hint / 4 <= 1024; }
-
-static int num_tile_groups(const SplatCamera &cam) {
-    const int gx = (cam.image_width + kTile - 1) / kTile, gy = (cam.image_height + kTile - 1) / kTile;
-    return ((gx + kGT - 1) / kGT) * ((gy + kGT - 1) / kGT);
-}
-
-// group binning (SplatState.group_count) needs bucketed lists that the composite sorts itself, and one LDS counter per group
-static bool group_binning(const SplatState &st, const SplatCamera &cam) {
-    return st.group_stride > 0 && st.group_count && st.group_recs && st.tile_stride > 0 && lists_sorted_by_composite(st) &&
-           num_tile_groups(cam) <= 8192;
-}
+static int num_tile_groups(const SplatCamera &cam) { return tile_groups(cam.image_width, cam.image_height); }
+static bool group_binning(const SplatState &st, const SplatCamera &cam) { return group_binning(st, cam.image_width, cam.image_height); }
 
 // workgroups of the iteration's last kernel: the one that closes the iteration + one per XCD band when the composites' launch order is kept
 // (whole frames only: a band of tile rows is composited in the natural order)

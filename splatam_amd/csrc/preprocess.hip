@@ -62,6 +62,25 @@ __global__ __launch_bounds__(kBlock) void preprocess_forward_kernel(SplatCamera 
     }
 }
 
+// K1 with GROUP BINNING (SplatState.group_count / group_recs / group_stride, bucketed lists the forward composite sorts itself: the
+// front end of the fused iteration, splat_device.h file_group_records): one 16-byte record per touched group of 2 x 2 tiles instead of a
+// count per tile now and a scatter later -- no tile scan, no scatter pass, no sort launch (K2-K4), and nothing the host must read
+// before it may launch the composite.  The caller knows (from an earlier call on this scene: SplatState.max_list_hint) that the lists
+// are short; a list that has outgrown the hint is flagged (status[1] / status[3]) by the composite and the call must be repeated on
+// exact lists.
+__global__ __launch_bounds__(kGroupBlock) void preprocess_forward_group_kernel(SplatCamera cam, SplatGaussians g, SplatState st) {
+    extern __shared__ unsigned s_grp[];
+    const int i = blockIdx.x * kGroupBlock + threadIdx.x;
+    const int ggx = tile_groups_x(cam.image_width), num_groups = tile_groups(cam.image_width, cam.image_height);
+    group_hist_reset<kGroupBlock>(s_grp, num_groups);
+    CamConst c;
+    load_cam(c, cam);
+    Projected o{};
+    bool vis = false;
+    if (i < g.P) vis = preprocess_forward_one(cam, c, g, st, i, o);
+    file_group_records<kGroupBlock>(st, s_grp, i, vis && o.y1 > o.y0 && o.x1 > o.x0, o.x0, o.y0, o.x1, o.y1, o.depth, ggx, num_groups);
+}
+
 // K1 for exact lists known to be very long (dense_exact_lists, splat_device.h): the workgroup's instances are counted per tile in LDS and
 // added to the tiles' counters (sub-bin: the workgroup's) with one atomic per non-empty tile -- 5 M clustered Gaussians on ~400 tiles took
 // 497 us of same-address atomics with one per instance.
@@ -230,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(SplatCamera
             const float s[3] = {g.scales[3 * i], g.scales[3 * i + 1], g.scales[3 * i + 2]};
             const float q[4] = {g.rotations[4 * i], g.rotations[4 * i + 1], g.rotations[4 * i + 2], g.rotations[4 * i + 3]};
             float ds[3], dq[4];
-            cov3d_backward(s, c.scale_modifier, q, dS6, ds, dq);
+            cov3d_backward(s, c.scale_modifier, q, dS6, ds, dq, (gr.flags & SPLAT_GRADS_UPSTREAM_SCALE) != 0);
             for (int k = 0; k < 3; ++k) gr.dL_dscales[3 * i + k] = ds[k];
             for (int k = 0; k < 4; ++k) gr.dL_drotations[4 * i + k] = dq[k];
         }
@@ -269,13 +288,26 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(SplatCamera
             for (int k = 0; k < g.sh_coeffs * 3; ++k) dsh[k] = 0.f;
         }
     }
+    if ((gr.flags & SPLAT_GRADS_POISON_IF_FLAGGED) && st.tile_stride > 0 && (st.status[1] | st.status[3]) != 0) {
+        // the forward pass ran on truncated lists and nobody has looked (SplatGrads.flags): nothing plausible leaves this call
+        const float nan = __int_as_float(0x7fc00000);
+        for (int k = 0; k < 3; ++k) dmean[k] = nan;
+        for (int k = 0; k < 6; ++k) dS6[k] = nan;
+        g_ndc[0] = g_ndc[1] = nan;
+        for (int k = 0; k < SPLAT_GRAD_STRIDE; ++k) acc[k] = nan;
+        if (gr.dL_dscales) {
+            for (int k = 0; k < 3; ++k) gr.dL_dscales[3 * i + k] = nan;
+            for (int k = 0; k < 4; ++k) gr.dL_drotations[4 * i + k] = nan;
+        }
+    }
     for (int k = 0; k < 3; ++k) gr.dL_dmeans3D[3 * i + k] = dmean[k];
     gr.dL_dmeans2D[3 * i] = g_ndc[0];
     gr.dL_dmeans2D[3 * i + 1] = g_ndc[1];
     gr.dL_dmeans2D[3 * i + 2] = 0.f;
-    gr.dL_dopacities[i] = vis ? acc[5] : 0.f;
+    const bool poisoned = acc[5] != acc[5] && g_ndc[0] != g_ndc[0];     // (see above: a poisoned row is NaN whether or not the Gaussian was seen)
+    gr.dL_dopacities[i] = (vis || poisoned) ? acc[5] : 0.f;
     if (gr.dL_dcolors)
-        for (int ch = 0; ch < C; ++ch) gr.dL_dcolors[(size_t)i * C + ch] = vis ? acc[6 + ch] : 0.f;
+        for (int ch = 0; ch < C; ++ch) gr.dL_dcolors[(size_t)i * C + ch] = (vis || poisoned) ? acc[6 + ch] : 0.f;
     if (gr.dL_dcov3D)
         for (int k = 0; k < 6; ++k) gr.dL_dcov3D[6 * i + k] = dS6[k];
 }
@@ -303,6 +335,24 @@ hipError_t launch_tile_scan(SplatState &st, int T, hipStream_t s) {
 
 hipError_t launch_preprocess_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st, hipStream_t s) {
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
+    if (group_binning(st, cam.image_width, cam.image_height)) {
+        // group counters and status words start at zero: ONE memset when the caller laid the state out with splat_state_layout
+        // (SPLAT_LAYOUT_GROUPS puts the status words right behind the counters), two otherwise
+        const size_t cbytes = sizeof(uint32_t) * (size_t)tile_groups(cam.image_width, cam.image_height) * SPLAT_COUNTER_STRIDE;
+        const char *c0 = reinterpret_cast<const char *>(st.group_count), *s0 = reinterpret_cast<const char *>(st.status);
+        hipError_t e;
+        if (s0 >= c0 + cbytes && s0 <= c0 + cbytes + SPLAT_SLAB_ALIGN) {
+            e = hipMemsetAsync(st.group_count, 0, (size_t)(s0 - c0) + 4 * sizeof(int32_t), s);
+        } else {
+            e = hipMemsetAsync(st.group_count, 0, cbytes, s);
+            if (e == hipSuccess) e = hipMemsetAsync(st.status, 0, 4 * sizeof(int32_t), s);
+        }
+        if (e != hipSuccess) return e;
+        if (g.P > 0)
+            hipLaunchKernelGGL(preprocess_forward_group_kernel, dim3((g.P + kGroupBlock - 1) / kGroupBlock), dim3(kGroupBlock),
+                               sizeof(unsigned) * (size_t)tile_groups(cam.image_width, cam.image_height), s, cam, g, st);
+        return hipGetLastError();
+    }
     hipError_t e = launch_tile_count_reset(st, T, s);
     if (e != hipSuccess) return e;
     if (g.P > 0) {

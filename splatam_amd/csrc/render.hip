@@ -325,81 +325,24 @@ __device__ __forceinline__ unsigned long long mask_word(const Batch<FP, NL, BOTH
 }
 
 // blockIdx -> tile: XCD x (blocks with b % 8 == x) owns tiles [x*per, (x+1)*per)
-// `order` (SplatState.tile_order): the band's tiles in the order they should START (heaviest first), or NULL for the natural order
+// `order` (SplatState.tile_order): the band's tiles in the order they should START (heaviest first), or NULL for the natural order.
+// An entry holds tile + 1; 0 = "not written yet: the natural tile of this slot" (a zero-initialised buffer IS the natural order),
+// 0xFFFFFFFF = no tile
 __device__ __forceinline__ int block_tile(int per_xcd, int T, const uint32_t *order = nullptr) {
     const int b = blockIdx.x, slot = b >> 3;
     const int pos = (b & 7) * per_xcd + slot;
     if (slot >= per_xcd) return -1;
     if (order) {
         const unsigned t = order[pos];
-        return t < (unsigned)T ? (int)t : -1;
+        if (t != 0u) return t - 1u < (unsigned)T ? (int)(t - 1u) : -1;
     }
     return pos < T ? pos : -1;
 }
+// the launch order applies to whole frames (a band of tile rows is composited in the natural order)
+__device__ __forceinline__ const uint32_t *launch_order(const SplatState &st) { return st.tile_row_end > st.tile_row_begin ? nullptr : st.tile_order; }
 
-// The tiles of one workgroup of a composite launch.
-//   one-shot launch (queue == NULL; grid = 8 x per_xcd): the tile block_tile() names, once;
-//   PERSISTENT launch (SplatState.tile_queue; grid = 8 x resident slots per XCD): tiles popped from the eight band queues -- the band
-//   of this workgroup's XCD first (blockIdx & 7: the hardware deals workgroups to the XCDs round robin), in the band's order, then the
-//   other bands' leftovers -- until all are dry.  `region`: which eight cursors of the queue this launch uses (zero on entry).
-// next() is called by every thread of the workgroup (it contains barriers in the persistent form: the previous tile's LDS is free, the
-// popped index is shared through `s_pop`).
-// A kernel's argument block read AGAIN from the kernarg segment, through a pointer the optimiser cannot see through (an empty asm "changes"
-// it): the composites' arguments -- camera, state (some forty pointers), loss epilogue -- do not fit the scalar register file, and a
-// loop over tiles that keeps them alive from tile to tile spills them into vector registers and scratch (+21 % on the forward
-// composite, profiles/r05_experiments.md).  Re-read per tile (a few scalar loads, cached) they live exactly as long as in the one-tile
-// kernel.  The kernel must take its arguments as ONE struct (the kernarg segment then starts with exactly that struct).
-template <class A>
-__device__ __forceinline__ const A &reread_kernargs() {
-    const __attribute__((address_space(4))) char *p = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
-    return *reinterpret_cast<const A *>((const void *)p);      // (read in place: scalar loads from the constant segment, no copy)
-}
-
-#ifndef SPLAT_TILE_LOOP
-#define SPLAT_TILE_LOOP 0        // 1: persistent composites compiled in (make EXTRA=-DSPLAT_TILE_LOOP=1); measured and NOT adopted: profiles/r05_experiments.md 3
-#endif
-struct TileLoop {
-    int per_xcd, T, band_step, done;
-    const uint32_t *order;
-    uint32_t *cursor;
-    __device__ __forceinline__ TileLoop(const SplatState &st, int per_xcd_, int T_, int region)
-        : per_xcd(per_xcd_), T(T_), band_step(0), done(0), order(st.tile_row_end > st.tile_row_begin ? nullptr : st.tile_order),
-          cursor((SPLAT_TILE_LOOP && st.tile_queue) ? st.tile_queue + SPLAT_QUEUE_REGION_WORDS * region : nullptr) {}
-    __device__ __forceinline__ int next(int *s_pop) {
-        if (!SPLAT_TILE_LOOP || !cursor) {
-            if (done) return -1;
-            done = 1;
-            return block_tile(per_xcd, T, order);
-        }
-        for (;;) {
-            if (band_step >= 8) return -1;
-            const int band = ((int)blockIdx.x + band_step) & 7;
-            uint32_t *const c = cursor + band * SPLAT_COUNTER_STRIDE;     // one 128-byte line per cursor: read-modify-writes of ONE address
-            //                                                               are served one after the other (~12 ns each) -- eight cursors in
-            //                                                               one line made every pop wait for ~20 000 others
-            __syncthreads();                                    // every wave has left the previous tile (its LDS) and read the last pop
-            if (threadIdx.x == 0) {
-                // a dry band is recognised by a plain read (the cursor only grows: a stale value can only be too small): the
-                // workgroups that arrive when it is dry -- every one of them, eight times, at the end of the launch -- do not queue up
-                // behind each other's atomics
-                unsigned q = __atomic_load_n(c, __ATOMIC_RELAXED);
-                if (q < (unsigned)per_xcd) q = atomicAdd(c, 1u);
-                *s_pop = (int)min(q, (unsigned)per_xcd);
-            }
-            __syncthreads();
-            const int q = *s_pop;                               // (uniform)
-            if (q >= per_xcd) { ++band_step; continue; }        // this band is dry: the next one
-            const int pos = band * per_xcd + q;
-            if (order) {
-                const unsigned t = order[pos];
-                if (t < (unsigned)T) return (int)t;
-            } else if (pos < T) {
-                return pos;
-            }
-        }
-    }
-};
+// background colour of channel ch; SplatCamera.bg == NULL: black
+__device__ __forceinline__ float bg_of(const SplatCamera &cam, int ch) { return cam.bg ? cam.bg[ch] : 0.f; }
 
 // Per-lane predicates of the inner loops are kept as wave-uniform 64-bit masks in SGPRs (ballot in, inverse
 // ballot out): the kernels are instruction-issue bound, and masks in scalar registers cost one s_and / s_andn2
@@ -584,13 +527,13 @@ __device__ __forceinline__ int forward_tile(const float *colors, SplatState &st,
             if (tid == 0) {
                 // (a count that is flagged below is published CLAMPED: the backward composite must not walk past the published ids)
                 st.tile_count[(size_t)tile * SPLAT_COUNTER_STRIDE] = (unsigned)min(n, min(st.tile_stride, kFusedSortMax));
-                if (n > st.tile_stride) st.status[1] = 1;         // the published list would not fit its bucket
+                if (n > st.tile_stride) raise_status(st, 1);      // the published list would not fit its bucket
             }
             n = min(n, st.tile_stride);
         }
         if (n > kFusedSortMax) {        // the host's list-length hint was stale: flag it (the host repeats the iteration)
             if (tid == 0) {
-                st.status[3] = 1;
+                raise_status(st, 3);
                 if (st.tile_stride > 0) st.tile_count[(size_t)tile * SPLAT_COUNTER_STRIDE] = (unsigned)kFusedSortMax;    // (see above)
             }
             n = kFusedSortMax;
@@ -715,7 +658,6 @@ struct FwdArgs {
     float *out_color, *out_depth;
     int T, per_xcd;
     TrackLossEpilogue ep;
-    int region;
 };
 template <int C, int CS, bool WITH_DEPTH, bool SORT, bool TRACK = false>
 __global__ __launch_bounds__(256, (forward_compact6<C, CS, WITH_DEPTH>() ? SPLAT_K6_WAVES : 5)) void render_forward_kernel(FwdArgs args) {
@@ -729,10 +671,9 @@ __global__ __launch_bounds__(256, (forward_compact6<C, CS, WITH_DEPTH>() ? SPLAT
     constexpr int NL = 16;
     __shared__ Batch<FP, NL> B;
     __shared__ __attribute__((aligned(16))) uint64_t s_keys[SORT ? kFusedSortMax + 2 : 2];
-    __shared__ int s_pop;
-    TileLoop tiles(args.st, args.per_xcd, args.T, args.region);         // T: tiles of this launch (SplatState.tile_row_begin: a band of tile rows)
-    for (int tile_local = tiles.next(&s_pop); tile_local >= 0; tile_local = tiles.next(&s_pop)) {
-    const FwdArgs &a = SPLAT_TILE_LOOP ? reread_kernargs<FwdArgs>() : args;
+    const int tile_local = block_tile(args.per_xcd, args.T, launch_order(args.st));     // T: tiles of this launch (SplatState.tile_row_begin: a band of tile rows)
+    if (tile_local < 0) return;
+    const FwdArgs &a = args;
     const SplatCamera &cam = a.cam;
     SplatState &st = const_cast<SplatState &>(a.st);            // (never written: forward_tile's signature is historical)
     const float *const colors = a.colors;
@@ -772,7 +713,7 @@ __global__ __launch_bounds__(256, (forward_compact6<C, CS, WITH_DEPTH>() ? SPLAT
         float o[C];
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) {
-            o[ch] = Cc[ch] + Tr * cam.bg[ch];
+            o[ch] = Cc[ch] + Tr * bg_of(cam, ch);
             out_color[ch * HW + pix] = o[ch];
         }
         if constexpr (WITH_DEPTH) out_depth[pix] = D;
@@ -810,7 +751,6 @@ __global__ __launch_bounds__(256, (forward_compact6<C, CS, WITH_DEPTH>() ? SPLAT
             if (t != 0.0) atomicAdd(ep.sums + (size_t)(blockIdx.x % SPLAT_ITER_SUM_COPIES) * SPLAT_ITER_SUMS + tid, t);
         }
     }
-    }       // tiles of this workgroup
 }
 
 // ---------------------------------------------------------------------------
@@ -1181,7 +1121,6 @@ struct BwdArgs {
     float *accum;
     int T, per_xcd;
     long long *stamps;
-    int region;
 };
 template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC, bool BG, int DBG = 0>
 __device__ __forceinline__ void render_backward_body5(const BwdArgs &args) {
@@ -1198,10 +1137,9 @@ __device__ __forceinline__ void render_backward_body5(const BwdArgs &args) {
     __shared__ Batch<FP> B;
     __shared__ PairBuf PB;
     __shared__ unsigned s_wmax[4];
-    __shared__ int s_pop;
-    TileLoop tiles(args.st, args.per_xcd, args.T, args.region);
-    for (int tile_local = tiles.next(&s_pop); tile_local >= 0; tile_local = tiles.next(&s_pop)) {
-    const BwdArgs &a = SPLAT_TILE_LOOP ? reread_kernargs<BwdArgs>() : args;
+    const int tile_local = block_tile(args.per_xcd, args.T, launch_order(args.st));
+    if (tile_local < 0) { stamp(); return; }
+    const BwdArgs &a = args;
     const SplatCamera &cam = a.cam;
     const SplatState &st = a.st;
     const float *const colors = a.colors, *const dL_dcolor = a.dL_dcolor;
@@ -1225,11 +1163,10 @@ __device__ __forceinline__ void render_backward_body5(const BwdArgs &args) {
         dpix[ch] = 0.f;
         if ((DMASK >> ch) & 1u) {
             dpix[ch] = inside ? dL_dcolor[ch * HW + pix] : 0.f;
-            if constexpr (BG) R += Tfin * cam.bg[ch] * dpix[ch];      // the background term of dL/dalpha: -T_final bg.dL/dC / (1 - alpha)
+            if constexpr (BG) R += Tfin * bg_of(cam, ch) * dpix[ch];      // the background term of dL/dalpha: -T_final bg.dL/dC / (1 - alpha)
         }
     }
     backward_core<C, CS, DMASK, SMASK, OPAC, DBG>(colors, st, accum, B, PB, s_wmax, tile, tx, ty, tid, inside, Tfin, last, dpix, R, -1);
-    }       // tiles of this workgroup
     stamp();
 }
 
@@ -1237,7 +1174,7 @@ __device__ __forceinline__ void render_backward_body5(const BwdArgs &args) {
 // kernel fits 96 VGPRs and 31 KB of LDS -> FIVE workgroups per CU (tracking +2.3 % at B); the mapping form (120 VGPRs, 35.7 KB) stays
 // at four with the compiler's own register budget (an explicit minimum of four waves made it 2 % slower).
 #ifndef SPLAT_K7_MIN_WAVES
-#define SPLAT_K7_MIN_WAVES (SPLAT_TILE_LOOP ? 4 : 1)       // the tile loop keeps a few more values alive: hold the mapping form at four workgroups per CU
+#define SPLAT_K7_MIN_WAVES 1
 #endif
 template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC = true, bool BG = true>
 __global__ __launch_bounds__(256, (popcount_c(SMASK) <= 4 ? SPLAT_K7_MIN_WAVES : 1)) void render_backward_kernel5(BwdArgs args) {
@@ -1272,7 +1209,6 @@ struct TrackFusedArgs {
     float *out6, *accum;
     int T, per_xcd;
     TrackLossEpilogue ep;
-    int region;
 };
 template <bool KEEP, int DBG = 0>
 __global__ __launch_bounds__(256, 5) void render_track_fused_kernel(TrackFusedArgs args) {
@@ -1290,10 +1226,9 @@ __global__ __launch_bounds__(256, 5) void render_track_fused_kernel(TrackFusedAr
     BatchT &B = *reinterpret_cast<BatchT *>(s_raw);
     uint64_t *const s_keys = reinterpret_cast<uint64_t *>(s_raw + kKeysAt);
     PairBuf &PB = *reinterpret_cast<PairBuf *>(s_raw + (kHead + 15) / 16 * 16);
-    __shared__ int s_pop;
-    TileLoop tiles(args.st, args.per_xcd, args.T, args.region);
-    for (int tile_local = tiles.next(&s_pop); tile_local >= 0; tile_local = tiles.next(&s_pop)) {
-    const TrackFusedArgs &a = SPLAT_TILE_LOOP ? reread_kernargs<TrackFusedArgs>() : args;
+    const int tile_local = block_tile(args.per_xcd, args.T, launch_order(args.st));
+    if (tile_local < 0) return;
+    const TrackFusedArgs &a = args;
     const SplatCamera &cam = a.cam;
     SplatState &st = const_cast<SplatState &>(a.st);
     const float *const feat8 = a.feat8;
@@ -1324,7 +1259,7 @@ __global__ __launch_bounds__(256, 5) void render_track_fused_kernel(TrackFusedAr
         const float im3[3] = {ep.im[pix], ep.im[HW + pix], ep.im[2 * HW + pix]};
         float o[C];
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) o[ch] = Cc[ch] + Tr * cam.bg[ch];
+        for (int ch = 0; ch < C; ++ch) o[ch] = Cc[ch] + Tr * bg_of(cam, ch);
         const float unc = o[5] - o[3] * o[3];
         bool m = gt > 0.f && !(o[3] != o[3]) && !(unc != unc);
         if (ep.use_sil_for_loss) m = m && (o[4] > ep.sil_thres);
@@ -1371,12 +1306,11 @@ __global__ __launch_bounds__(256, 5) void render_track_fused_kernel(TrackFusedAr
     if constexpr ((DBG & 16) != 0) {
         // (measurement: forward + loss only; the per-pixel state is kept alive by a never-true store)
         if (Tfin == 1.2345e-33f && last == 0xFFFFFFFFu) accum[0] = dpix[0] + dpix[3];
-        continue;
+        return;
     }
     backward_core<C, CS, 0xFu, 0x8u, false, (DBG & 14)>(feat8, st, accum, B, PB, s_wmax, tile, tx, ty, tid, inside, Tfin, last, dpix, 0.f, staged);
     // what the next launch's order is built from (SplatState.tile_work): the quadrants' deepest contributors, as the core left them
     if (st.tile_work && tid == 0) st.tile_work[tile] = s_wmax[0] + s_wmax[1] + s_wmax[2] + s_wmax[3];
-    }       // tiles of this workgroup
 }
 
 // measurement builds (splat_debug_option(4, bits)): the fused iteration's two forms only
@@ -1389,23 +1323,6 @@ __global__ __launch_bounds__(256, 5) void render_backward_kernel5_w5_dbg(BwdArgs
     render_backward_body5<C, CS, DMASK, SMASK, OPAC, BG, DBG>(args);
 }
 
-// The grid of a PERSISTENT composite launch (SplatState.tile_queue): 8 x min(tiles per band, 8 workgroups per CU x 32 CUs per XCD).
-// More workgroups than slots is harmless (the late ones find the queues dry); FEWER leaves slots empty for the whole launch -- the
-// occupancy query (hipOccupancyMaxActiveBlocksPerMultiprocessor) answered 2 per CU for kernels that run 4-6, so it is not asked.
-template <class K>
-static dim3 composite_grid(K, const SplatState &st, int per) {
-    int cus = 256, dev = 0;
-    static int cached_cus = 0;
-    if (cached_cus == 0) {
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) cus = prop.multiProcessorCount;
-        cached_cus = cus;
-    }
-    return dim3(8u * (unsigned)((SPLAT_TILE_LOOP && st.tile_queue) ? min(per, 8 * (cached_cus / 8)) : per));
-}
-static SplatState one_shot(const SplatState &st) { SplatState c = st; c.tile_queue = nullptr; return c; }      // (measurement builds, helper passes)
-int g_debug_queue_region = -1;          // launches of the timing helper: the queue region of the next persistent launch (capi.hip)
-
 int g_debug_k7_bits = 0;                // splat_debug_option(4, bits)
 long long *g_debug_stamps = nullptr;    // splat_debug_stamps(buffer)
 
@@ -1416,8 +1333,8 @@ template <int C, int CS, bool WITH_DEPTH, bool SORT = false>
 static void launch_fwd(const SplatCamera &cam, const float *colors, SplatState &st, float *oc, float *od, int T, hipStream_t s) {
     const int per = (T + 7) / 8;
     auto k = render_forward_kernel<C, CS, WITH_DEPTH, SORT, false>;
-    hipLaunchKernelGGL(k, composite_grid(k, st, per), dim3(256), 0, s,
-                       FwdArgs{cam, colors, st, oc, od, T, per, TrackLossEpilogue{}, g_debug_queue_region >= 0 ? g_debug_queue_region : 0});
+    hipLaunchKernelGGL(k, dim3(8 * per), dim3(256), 0, s,
+                       FwdArgs{cam, colors, st, oc, od, T, per, TrackLossEpilogue{}});
 }
 template <int C, int CS, unsigned DMASK = (1u << C) - 1u, unsigned SMASK = (1u << C) - 1u, bool OPAC = true, bool BG = true>
 static void launch_bwd(const SplatCamera &cam, const float *colors, const SplatState &st, const float *dl, float *acc, int T,
@@ -1430,10 +1347,10 @@ static void launch_bwd(const SplatCamera &cam, const float *colors, const SplatS
                 constexpr int DBG = decltype(D)::value;
                 if constexpr (W5)
                     hipLaunchKernelGGL((render_backward_kernel5_w5_dbg<C, CS, DMASK, SMASK, OPAC, BG, DBG>), dim3(8 * per), dim3(256), 0, s,
-                                       BwdArgs{cam, colors, one_shot(st), dl, acc, T, per, g_debug_stamps, 1});
+                                       BwdArgs{cam, colors, st, dl, acc, T, per, g_debug_stamps});
                 else
                     hipLaunchKernelGGL((render_backward_kernel5_dbg<C, CS, DMASK, SMASK, OPAC, BG, DBG>), dim3(8 * per), dim3(256), 0, s,
-                                       BwdArgs{cam, colors, one_shot(st), dl, acc, T, per, g_debug_stamps, 1});
+                                       BwdArgs{cam, colors, st, dl, acc, T, per, g_debug_stamps});
             };
             switch (g_debug_k7_bits) {
                 case 1: go(std::integral_constant<int, 1>{}); return;
@@ -1447,13 +1364,12 @@ static void launch_bwd(const SplatCamera &cam, const float *colors, const SplatS
             }
         }
     }
-    const int region = g_debug_queue_region >= 0 ? g_debug_queue_region : 1;
     if constexpr (popcount_c(SMASK) <= 2) {
         auto k = render_backward_kernel5_w5<C, CS, DMASK, SMASK, OPAC, BG>;
-        hipLaunchKernelGGL(k, composite_grid(k, st, per), dim3(256), 0, s, BwdArgs{cam, colors, st, dl, acc, T, per, nullptr, region});
+        hipLaunchKernelGGL(k, dim3(8 * per), dim3(256), 0, s, BwdArgs{cam, colors, st, dl, acc, T, per, nullptr});
     } else {
         auto k = render_backward_kernel5<C, CS, DMASK, SMASK, OPAC, BG>;
-        hipLaunchKernelGGL(k, composite_grid(k, st, per), dim3(256), 0, s, BwdArgs{cam, colors, st, dl, acc, T, per, nullptr, region});
+        hipLaunchKernelGGL(k, dim3(8 * per), dim3(256), 0, s, BwdArgs{cam, colors, st, dl, acc, T, per, nullptr});
     }
 }
 
@@ -1466,6 +1382,13 @@ hipError_t launch_render_forward(const SplatCamera &cam, const SplatGaussians &g
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
     const float *col = colour_source(g, st);
     if (T == 0) return hipSuccess;
+    if (group_binning(st, cam.image_width, cam.image_height)) {
+        // the front end of the fused iteration behind the reference API (splat_preprocess_forward filed one record per touched group
+        // of 2 x 2 tiles): the composite filters, sorts and publishes its tile's list itself -- no scan, scatter or sort launch
+        if (g.channels != 3) return hipErrorInvalidValue;
+        launch_fwd<3, 3, true, true>(cam, col, st, out_color, out_depth, T, s);
+        return hipGetLastError();
+    }
     switch (g.channels) {
         case 1: launch_fwd<1, 1, true>(cam, col, st, out_color, out_depth, T, s); break;
         case 2: launch_fwd<2, 2, true>(cam, col, st, out_color, out_depth, T, s); break;
@@ -1487,6 +1410,10 @@ hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &
     hipError_t e = hipMemsetAsync(gr.accum, 0, sizeof(float) * SPLAT_GRAD_STRIDE * (size_t)g.P, s);
     if (e != hipSuccess) return e;
     if (T == 0 || g.P == 0) return hipSuccess;
+    if (!cam.bg && g.channels == 3) {           // black background (SplatCamera.bg == NULL): the background term of dL/dalpha falls away at compile time
+        launch_bwd<3, 3, 7u, 7u, true, false>(cam, col, st, gr.dL_dcolor, gr.accum, T, s);
+        return hipGetLastError();
+    }
     switch (g.channels) {
         case 1: launch_bwd<1, 1>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
         case 2: launch_bwd<2, 2>(cam, col, st, gr.dL_dcolor, gr.accum, T, s); break;
@@ -1520,12 +1447,12 @@ hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat
         if (sort_in_kernel)
         {
             auto k = render_forward_kernel<6, 8, false, true, true>;
-            hipLaunchKernelGGL(k, composite_grid(k, st, per), dim3(256), 0, s, FwdArgs{cam, feat8, st, out6, nullptr, T, per, *ep, 0});
+            hipLaunchKernelGGL(k, dim3(8 * per), dim3(256), 0, s, FwdArgs{cam, feat8, st, out6, nullptr, T, per, *ep});
         }
         else
         {
             auto k = render_forward_kernel<6, 8, false, false, true>;
-            hipLaunchKernelGGL(k, composite_grid(k, st, per), dim3(256), 0, s, FwdArgs{cam, feat8, st, out6, nullptr, T, per, *ep, 0});
+            hipLaunchKernelGGL(k, dim3(8 * per), dim3(256), 0, s, FwdArgs{cam, feat8, st, out6, nullptr, T, per, *ep});
         }
         *ep_done = true;
         return hipGetLastError();
@@ -1544,20 +1471,20 @@ hipError_t launch_render_track_fused(const SplatCamera &cam, const float *feat8,
     const int per = (T + 7) / 8;
     if (!keep_planes && g_debug_k7_bits != 0) {           // measurement builds (see render_track_fused_kernel)
         switch (g_debug_k7_bits) {
-            case 2: hipLaunchKernelGGL((render_track_fused_kernel<false, 2>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, one_shot(st), out6, accum, T, per, ep, 1}); break;
-            case 4: hipLaunchKernelGGL((render_track_fused_kernel<false, 4>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, one_shot(st), out6, accum, T, per, ep, 1}); break;
-            case 8: hipLaunchKernelGGL((render_track_fused_kernel<false, 8>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, one_shot(st), out6, accum, T, per, ep, 1}); break;
-            case 16: hipLaunchKernelGGL((render_track_fused_kernel<false, 16>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, one_shot(st), out6, accum, T, per, ep, 1}); break;
-            default: hipLaunchKernelGGL((render_track_fused_kernel<false>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, one_shot(st), out6, accum, T, per, ep, 1}); break;
+            case 2: hipLaunchKernelGGL((render_track_fused_kernel<false, 2>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, st, out6, accum, T, per, ep}); break;
+            case 4: hipLaunchKernelGGL((render_track_fused_kernel<false, 4>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, st, out6, accum, T, per, ep}); break;
+            case 8: hipLaunchKernelGGL((render_track_fused_kernel<false, 8>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, st, out6, accum, T, per, ep}); break;
+            case 16: hipLaunchKernelGGL((render_track_fused_kernel<false, 16>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, st, out6, accum, T, per, ep}); break;
+            default: hipLaunchKernelGGL((render_track_fused_kernel<false>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, st, out6, accum, T, per, ep}); break;
         }
         return hipGetLastError();
     }
     if (keep_planes) {
         auto k = render_track_fused_kernel<true>;
-        hipLaunchKernelGGL(k, composite_grid(k, st, per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, st, out6, accum, T, per, ep, 1});
+        hipLaunchKernelGGL(k, dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, st, out6, accum, T, per, ep});
     } else {
         auto k = render_track_fused_kernel<false>;
-        hipLaunchKernelGGL(k, composite_grid(k, st, per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, st, out6, accum, T, per, ep, 1});
+        hipLaunchKernelGGL(k, dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, st, out6, accum, T, per, ep});
     }
     return hipGetLastError();
 }
@@ -1586,7 +1513,7 @@ hipError_t launch_render_backward_rgb_only(const SplatCamera &cam, const float *
     const int T = launch_tiles(cam, st);
     if (T == 0 || P == 0) return hipSuccess;
     const int per = (T + 7) / 8;
-    hipLaunchKernelGGL((render_backward_kernel5_w5<6, 8, 0x7u, 0x0u, false, false>), dim3(8 * per), dim3(256), 0, s, BwdArgs{cam, feat8, one_shot(st), dL_dout6, accum, T, per, nullptr, 1});
+    hipLaunchKernelGGL((render_backward_kernel5_w5<6, 8, 0x7u, 0x0u, false, false>), dim3(8 * per), dim3(256), 0, s, BwdArgs{cam, feat8, st, dL_dout6, accum, T, per, nullptr});
     return hipGetLastError();
 }
 

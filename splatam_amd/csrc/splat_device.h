@@ -31,6 +31,14 @@ constexpr int kDenseThreads = 1024, kDenseGaussians = 4096, kDenseMaxTilesLds = 
 inline bool dense_exact_lists(const SplatState &st, int P, int T) {
     return st.tile_stride == 0 && st.sub_bins > 1 && P >= 8 * kDenseGaussians && T <= kDenseMaxTilesLds;
 }
+// lists known (host hint, possibly stale: then flagged) to be short are sorted by the composite kernel itself
+inline bool lists_sorted_by_composite(const SplatState &st) { return st.max_list_hint > 0 && st.max_list_hint + st.max_list_hint / 4 <= 1024; }
+// group binning (SplatState.group_count) needs bucketed lists that the composite sorts itself, and one LDS counter per group
+inline bool group_binning(const SplatState &st, int W, int H) {
+    const int gx = (W + SPLAT_TILE - 1) / SPLAT_TILE, gy = (H + SPLAT_TILE - 1) / SPLAT_TILE;
+    const int groups = ((gx + SPLAT_GROUP_TILES - 1) / SPLAT_GROUP_TILES) * ((gy + SPLAT_GROUP_TILES - 1) / SPLAT_GROUP_TILES);
+    return st.group_stride > 0 && st.group_count && st.group_recs && st.tile_stride > 0 && lists_sorted_by_composite(st) && groups <= 8192;
+}
 hipError_t launch_render_forward(const SplatCamera &cam, const SplatGaussians &g, SplatState &st,
                                  float *out_color, float *out_depth, hipStream_t s);
 hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &g, const SplatState &st,
@@ -81,7 +89,6 @@ size_t map_scratch_words(long long n);
 int map_row_floats(const SplatMapStore &st);
 extern int g_debug_skip_count;
 extern int g_debug_k7_bits;
-extern int g_debug_queue_region;       // >= 0: the queue region of the next persistent composite launch (splat_iter_time_kernel)
 extern long long *g_debug_stamps;
 hipError_t launch_selftest(int which, const void *in, void *out, int n, hipStream_t s);
 
@@ -94,6 +101,12 @@ __device__ __forceinline__ void load_cam(CamConst &c, const SplatCamera &cam) {
 }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// status word k (1: a bucket overflowed, 3: a list beyond the composite's sort) is raised, and with it the caller's pinned host word
+__device__ __forceinline__ void raise_status(const SplatState &st, int k) {
+    st.status[k] = 1;
+    if (st.status_host) *st.status_host = 1;
+}
 
 // counter of (tile, sub-bin of Gaussian i): SplatState.sub_bins counters per tile, one 128-byte line each
 __device__ __forceinline__ size_t sub_counter(const SplatState &st, int tile, int i) {
@@ -536,6 +549,74 @@ __device__ __forceinline__ uint64_t *radix_sort_lds_private(uint64_t *buf_a, uin
     return dst;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// GROUP BINNING (SplatState.group_count / group_recs; the per-Gaussian kernels of both paths: fused.hip F1, preprocess.hip K1): the
+// kGroupBlock Gaussians of a workgroup count their records per GROUP of 2 x 2 tiles in an LDS histogram (one counter per group of the
+// frame: dynamic LDS, 4 bytes x groups), the workgroup takes ONE returning global atomic per non-empty group, and a record's slot is the
+// group's base + its LDS rank: ~1.0 global atomics per Gaussian in ANY row order (1.56 records per Gaussian over 836 groups at workload B)
+// instead of 2.36 per-tile ones, far fewer for a map in creation order.
+// Measured at B (iterations/s, tracking / mapping): per-tile buckets 3 700 / 2 945; groups with 256-Gaussian workgroups 3 900 / 3 025,
+// 512: 4 120 / 3 165, 1 024: 3 990 / 3 090 (fewer atomics, but one workgroup per CU leaves its phases unoverlapped).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kGroupBlock = 512;
+constexpr int kGroupPerLane = 4;            // groups a lane files through the histogram; a Gaussian's further groups take own atomics
+constexpr int kGT = SPLAT_GROUP_TILES;
+static_assert(kGT == 2, "the group index is tile >> 1");
+
+__host__ __device__ inline int tile_groups_x(int W) { return (((W + SPLAT_TILE - 1) / SPLAT_TILE) + kGT - 1) / kGT; }
+__host__ __device__ inline int tile_groups(int W, int H) { return tile_groups_x(W) * ((((H + SPLAT_TILE - 1) / SPLAT_TILE) + kGT - 1) / kGT); }
+
+// step 0 (every thread of the workgroup, BEFORE the projection work, which hides the barrier): the histogram starts at zero
+template <int BLOCK>
+__device__ __forceinline__ void group_hist_reset(unsigned *s_grp, int num_groups) {
+    for (int g = (int)threadIdx.x; g < num_groups; g += BLOCK) s_grp[g] = 0u;
+    __syncthreads();
+}
+
+// step 1 (every thread of the workgroup): one 16-byte record (Gaussian id, depth bits, tile rectangle) per touched group of Gaussian i,
+// whose tile rectangle is [x0, x1) x [y0, y1) (`filed`: it has one).  A record that finds its group's bucket full raises status[1].
+template <int BLOCK>
+__device__ __forceinline__ void file_group_records(const SplatState &st, unsigned *s_grp, int i, bool filed, int x0, int y0, int x1, int y1, float depth,
+                                                   int ggx, int num_groups) {
+    const unsigned gstride = (unsigned)st.group_stride;
+    const int gx0 = x0 >> 1, gy0 = y0 >> 1;
+    const int gw = filed ? ((x1 - 1) >> 1) - gx0 + 1 : 0, ng = filed ? gw * (((y1 - 1) >> 1) - gy0 + 1) : 0;
+    unsigned rank[kGroupPerLane];
+    const int nh = min(ng, kGroupPerLane);
+#pragma unroll
+    for (int t = 0; t < kGroupPerLane; ++t)
+        if (t < nh) {
+            const int yy = t / gw, xx = t - yy * gw;
+            rank[t] = atomicAdd(&s_grp[(gy0 + yy) * ggx + gx0 + xx], 1u);
+        }
+    __syncthreads();
+    // (one returning atomic per non-empty group; two in flight per lane -- with a zero added where one of a lane's two groups is
+    //  empty -- was measured: 27.4 -> 34.1 us, the kernel is bound by the NUMBER of L2 atomics, not by their latency)
+    for (int g = (int)threadIdx.x; g < num_groups; g += BLOCK) {
+        const unsigned cnt = s_grp[g];
+        if (cnt) s_grp[g] = atomicAdd(&st.group_count[(size_t)g * SPLAT_COUNTER_STRIDE], cnt);
+    }
+    __syncthreads();
+    const uint4 rec = make_uint4((unsigned)i, __float_as_uint(depth), (unsigned)x0 | ((unsigned)y0 << 16), (unsigned)x1 | ((unsigned)y1 << 16));
+    uint4 *recs = reinterpret_cast<uint4 *>(st.group_recs);
+    bool spilled = false;
+    for (int t = 0; t < ng; ++t) {
+        const int yy = t / gw, xx = t - yy * gw;
+        const unsigned g = (unsigned)((gy0 + yy) * ggx + gx0 + xx);
+        unsigned slot;
+        if (t < kGroupPerLane) {
+            // (compile-time indices only: a dynamically indexed rank[] would live in scratch memory)
+            const unsigned r = t == 0 ? rank[0] : (t == 1 ? rank[1] : (t == 2 ? rank[2] : rank[3]));
+            slot = s_grp[g] + r;
+        } else {
+            slot = atomicAdd(&st.group_count[(size_t)g * SPLAT_COUNTER_STRIDE], 1u);
+        }
+        if (slot < gstride) recs[(size_t)g * gstride + slot] = rec;
+        else spilled = true;
+    }
+    if (spilled) raise_status(st, 1);
+}
+
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     for (int m = 32; m >= 1; m >>= 1) {
         const unsigned o = (unsigned)__shfl_xor((int)v, m, 64);
@@ -580,7 +661,7 @@ __device__ __forceinline__ void tile_order_band(const uint32_t *work, uint32_t *
     __syncthreads();
     for (int t = t0 + tid; t < t1; t += 256) {
         const unsigned pos = atomicAdd(&s_off[255 - (int)((float)work[t] * scale)], 1u);
-        order[t0 + pos] = (uint32_t)t;
+        order[t0 + pos] = (uint32_t)t + 1u;              // (tile + 1: zero means "not written yet", block_tile)
     }
     for (int t = max(t1, t0) + tid; t < t0 + per_xcd; t += 256) order[t] = 0xFFFFFFFFu;       // (the last band may be short)
 }

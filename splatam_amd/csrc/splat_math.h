@@ -222,9 +222,11 @@ SPLAT_HD void project_gaussian_backward(const CamConst &c, const float *p, const
     }
 }
 
-// Adjoint of cov3d_from_scale_rot.
+// Adjoint of cov3d_from_scale_rot.  dscale is the gradient w.r.t. the scales the caller passed (it carries the factor `mod`);
+// upstream_scale: WITHOUT that factor -- what the CUDA original hands out (its computeCov3D adjoint forms dL/d(mod * s) =
+// dot(R^T[k], dL/dM^T[k]) and returns it as dL/dscale: SURVEY.md Appendix A, SplatGrads.flags SPLAT_GRADS_UPSTREAM_SCALE)
 SPLAT_HD void cov3d_backward(const float *s, float mod, const float *q, const float *dS6,
-                             float *dscale, float *dq) {
+                             float *dscale, float *dq, bool upstream_scale = false) {
     float R[9];
     quat_to_rot(q, R);
     const float sv[3] = {mod * s[0], mod * s[1], mod * s[2]};
@@ -235,7 +237,7 @@ SPLAT_HD void cov3d_backward(const float *s, float mod, const float *q, const fl
         float col[3];
         for (int r = 0; r < 3; ++r)   // dL/dM[:,k] = 2 G R[:,k] s_k
             col[r] = 2.f * sv[k] * (G[3 * r] * R[k] + G[3 * r + 1] * R[3 + k] + G[3 * r + 2] * R[6 + k]);
-        dscale[k] = mod * (col[0] * R[k] + col[1] * R[3 + k] + col[2] * R[6 + k]);
+        dscale[k] = (upstream_scale ? 1.0f : mod) * (col[0] * R[k] + col[1] * R[3 + k] + col[2] * R[6 + k]);
         for (int r = 0; r < 3; ++r) A[3 * r + k] = col[r] * sv[k];
     }
     const float r_ = q[0], x = q[1], y = q[2], z = q[3];

@@ -76,20 +76,14 @@ class FusedEngine:
         self._alloc_rows(self._layout(P_alloc))
         GT = _capi.SPLAT_GROUP_TILES
         self.num_groups = (((W + 15) // 16 + GT - 1) // GT) * (((H + 15) // 16 + GT - 1) // GT)
-        # launch order of the composites' workgroups (SplatState.tile_work / tile_order): heaviest tiles of every XCD band first
-        per = (T + 7) // 8
-        nat = torch.arange(8 * per, dtype=torch.int64)
-        b['tile_order'] = torch.where(nat < T, nat, torch.full_like(nat, 0xFFFFFFFF)).to(torch.uint32).view(i32).to(dev) \
-            if hasattr(torch, "uint32") else None
-        self.tile_order_on = os.environ.get("SPLAT_TILE_ORDER", "1") != "0" and b['tile_order'] is not None
+        # launch order of the composites' workgroups (SplatState.tile_work / tile_order): heaviest tiles of every XCD band first.  An entry
+        # holds tile + 1; the zero-initialised buffer of the library's layout IS the natural order
+        self.tile_order_on = os.environ.get("SPLAT_TILE_ORDER", "1") != "0"
         # ... one order PER VIEW (keyed by the frame's time index, the last 64 views): an iteration leaves the order for the NEXT visit
         # of its view.  Mapping draws a random keyframe per iteration (/root/reference/scripts/splatam.py:831-845): the order the
         # previous iteration left belongs to another view
         self.order_per_view = os.environ.get("SPLAT_TILE_ORDER_PER_VIEW", "1") != "0"
-        self._natural_order, self._orders = b['tile_order'], {}
-        # persistent composites (SplatState.tile_queue): one workgroup per resident slot pops tiles from per-XCD queues instead of one
-        # hardware-dispatched workgroup per tile
-        self.persistent = os.environ.get("SPLAT_PERSISTENT", "0") != "0"        # (needs a library built with -DSPLAT_TILE_LOOP=1; not adopted: profiles/r05_experiments.md 3)
+        self._natural_order, self._orders = torch.zeros_like(b['tile_order']), {}
         b['pose_state'] = torch.zeros(_capi.SPLAT_POSE_STATE, dtype=f32, **z)
         self.max_2D_radius = self.store['max_2D_radius'] if self.managed else track_max_radius
         b['counts'] = torch.zeros(8, dtype=i32, **z)
@@ -138,13 +132,13 @@ class FusedEngine:
     _FIXED_ARRAYS = (("st.tile_count", "tile_count", torch.int32), ("st.tile_base", "tile_base", torch.int32),
                      ("st.tile_cursor", "tile_cursor", torch.int32), ("st.long_base", "long_base", torch.int32),
                      ("st.group_count", "group_count", torch.int32), ("st.status", "status", torch.int32),
-                     ("st.tile_work", "tile_work", torch.int32), ("st.tile_queue", "tile_queue", torch.int32),
+                     ("st.tile_work", "tile_work", torch.int32), ("st.tile_order", "tile_order", torch.int32),
                      ("st.final_T", "final_T", torch.float32),
                      ("st.n_contrib", "n_contrib", torch.int32), ("out6", "out6", torch.float32), ("dL_dout6", "dL_dout6", torch.float32),
                      ("ssim_maps", "ssim_maps", torch.float32), ("sums", "sums", torch.float64), ("d_cam", "d_cam", torch.float32))
 
     def _layout(self, rows, capacity=0, group_stride=0, outlier=False):
-        flags = _capi.SPLAT_LAYOUT_SSIM | (_capi.SPLAT_LAYOUT_OUTLIER if outlier else 0)
+        flags = _capi.SPLAT_LAYOUT_SSIM | _capi.SPLAT_LAYOUT_TILE_ORDER | (_capi.SPLAT_LAYOUT_OUTLIER if outlier else 0)
         return _capi.iter_workspace_layout(int(rows), self.W, self.H, int(capacity), int(group_stride), flags)
 
     def _new(self, lay, name, dtype, tail=()):
@@ -653,7 +647,6 @@ class FusedEngine:
         st.order_hint = int(self.creation_order)
         if self.tile_order_on:
             st.tile_work, st.tile_order = b['tile_work'].data_ptr(), b['tile_order'].data_ptr()
-        st.tile_queue = b['tile_queue'].data_ptr() if self.persistent else None
         st.sub_bins = self.sub_bins if self.tile_stride == 0 else 1
         st.final_T, st.n_contrib, st.status = b['final_T'].data_ptr(), b['n_contrib'].data_ptr(), b['status'].data_ptr()
         ws.feat8, ws.out6, ws.dL_dout6, ws.accum = b['feat8'].data_ptr(), b['out6'].data_ptr(), b['dL_dout6'].data_ptr(), b['accum'].data_ptr()

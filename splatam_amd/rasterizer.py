@@ -50,20 +50,102 @@ class GaussianRasterizationSettings(NamedTuple):
 #   "lazy" : no host sync.  Lists are sized from the high-water mark of earlier
 #            calls (x1.5); status words are checked when they are next needed
 #            and an overflow re-runs the binning with a larger capacity.
+#   "auto" (default): the FIRST call on a scene (device, Gaussian count, image size, field of view) runs the exact path and
+#            learns the scene's longest per-tile list; while that list is short (x1.6 <= 1 024 entries: every SplaTAM configuration)
+#            the following calls run the front end of the fused iteration -- group binning in the per-Gaussian kernel, the lists
+#            sorted inside the forward composite (include/splat_hip.h "GROUP BINNING behind the reference API"): two launches
+#            instead of six and NO host synchronisation.  The device raises a flag in pinned host memory when a list has outgrown
+#            its bucket after all; the flag is looked at when the backward pass starts (or at once for a render that will have no
+#            backward pass): the pass is then repeated on exact lists, the scene goes back to the exact path and a warning is
+#            issued (the image of THAT one forward call had been composited from truncated lists).  Every 64th call of a scene is
+#            an exact one and refreshes the statistics.  Scenes with long lists stay on the exact path.
 # ---------------------------------------------------------------------------
-_SYNC_MODE = "exact"
+_SYNC_MODE = "auto"
 _capacity_hint: dict = {}
+
+FAST_STRIDE = 1024          # bucket of a tile's published list: all the forward composite sorts itself
+FAST_MARGIN = 1.6           # fast path while longest list x margin <= FAST_STRIDE
+FAST_REFRESH = 64           # every n-th call of a scene runs the exact path and refreshes its statistics
+_scene_stats: dict = {}     # scene key -> {'longest': longest per-tile list of the last exact call, 'since_exact': calls since}
+fast_path_stats = {"fast": 0, "exact": 0, "flagged": 0}
 
 
 def set_sync_mode(mode: str) -> None:
     global _SYNC_MODE
-    if mode not in ("exact", "lazy"):
+    if mode not in ("exact", "lazy", "auto"):
         raise ValueError(mode)
     _SYNC_MODE = mode
 
 
 def get_sync_mode() -> str:
     return _SYNC_MODE
+
+
+_UPSTREAM_SCALE_GRADIENT = False
+
+
+def set_upstream_scale_gradient(on: bool) -> None:
+    """``scales.grad`` as the CUDA original returns it: WITHOUT the factor ``raster_settings.scale_modifier`` (its computeCov3D adjoint
+    hands out dL/d(modifier * s) as dL/ds; include/splat_hip.h: SPLAT_GRADS_UPSTREAM_SCALE).  Off (default): the gradient w.r.t. the
+    scales the caller passed.  Identical at scale_modifier = 1, i.e. for every call SplaTAM makes."""
+    global _UPSTREAM_SCALE_GRADIENT
+    _UPSTREAM_SCALE_GRADIENT = bool(on)
+
+
+def reset_scene_stats() -> None:
+    """Forgets what the "auto" mode has learnt about the scenes it has rendered (the next call of every scene is an exact one)."""
+    _scene_stats.clear()
+
+
+class _FlagRing:
+    """Pinned host words the device raises when a fast-path call met a list beyond its bucket (SplatState.status_host): one word per
+    call in flight, re-used round robin -- a word is handed out again only after the call that held it has finished."""
+    SLOTS = 1024
+
+    def __init__(self):
+        self.words = torch.zeros(self.SLOTS, dtype=torch.int32).pin_memory()
+        self.host = self.words.numpy()          # (the same memory: element access without a tensor operation)
+        self.base = self.words.data_ptr()
+        self.events = [None] * self.SLOTS
+        self.next = 0
+
+    def take(self, dev):
+        i = self.next
+        self.next = (i + 1) % self.SLOTS
+        ev = self.events[i]
+        if ev is not None:
+            ev.synchronize()            # (the call that used this word 1 024 calls ago)
+        else:
+            ev = self.events[i] = torch.cuda.Event()
+        self.host[i] = 0
+        return i, self.base + 4 * i, ev
+
+
+_flag_ring = None
+
+
+def _ring() -> _FlagRing:
+    global _flag_ring
+    if _flag_ring is None:
+        _flag_ring = _FlagRing()
+    return _flag_ring
+
+
+_zero_bg: dict = {}
+
+
+def _bg_is_zero(bg: torch.Tensor) -> bool:
+    """Is the background black (every SplaTAM camera: /root/reference/utils/recon_helpers.py:17)?  Read from the device ONCE per
+    tensor and version; the library then drops the background term of the backward composite at compile time (SplatCamera.bg NULL)."""
+    key = (bg.data_ptr(), bg._version, bg.numel())
+    hit = _zero_bg.get(key)
+    if hit is not None and hit[0] is bg:
+        return hit[1]
+    z = not bool(bg.detach().ne(0).any().item())
+    if len(_zero_bg) > 64:
+        _zero_bg.clear()
+    _zero_bg[key] = (bg, z)
+    return z
 
 
 _contig_cache: dict = {}
@@ -105,15 +187,22 @@ class _Pack:
 
     def __init__(self):
         self.keep = []
-        self.cam = _capi.SplatCamera()
+        self.cam = None                 # (the shared struct of the settings tuple: _camera_struct)
         self.g = _capi.SplatGaussians()
         self.st = _capi.SplatState()
 
 
-def _build_pack(settings, means3D, colors, opacities, scales, rotations, cov3D, shs) -> _Pack:
-    dev = means3D.device
-    pk = _Pack()
-    P = means3D.shape[0]
+_cam_structs: dict = {}
+
+
+def _camera_struct(settings, dev):
+    """The SplatCamera of a settings tuple and the tensors that keep its pointers alive.  The callers pass ONE settings object thousands
+    of times (curr_data['cam'], /root/reference/scripts/splatam.py:249,253): the struct is built once per object and re-used while the
+    tuple's tensors are at the version it was built from."""
+    hit = _cam_structs.get(id(settings))
+    if hit is not None and hit[0] is settings and hit[3] == (settings.bg._version, settings.viewmatrix._version, settings.projmatrix._version,
+                                                             settings.campos._version) and hit[4] == dev:
+        return hit[1], hit[2]
     bg = _cached_contiguous(settings.bg)
     view = _cached_contiguous(settings.viewmatrix)
     proj = _cached_contiguous(settings.projmatrix)
@@ -121,18 +210,31 @@ def _build_pack(settings, means3D, colors, opacities, scales, rotations, cov3D, 
     for name, t in (("bg", bg), ("viewmatrix", view), ("projmatrix", proj), ("campos", campos)):
         if not t.is_cuda or t.device != dev:
             raise RuntimeError(f"raster_settings.{name} must be on {dev} (got {t.device})")
+    cam = _capi.SplatCamera()
+    cam.image_height, cam.image_width = int(settings.image_height), int(settings.image_width)
+    cam.tanfovx, cam.tanfovy = float(settings.tanfovx), float(settings.tanfovy)
+    cam.bg, cam.scale_modifier = (None if _bg_is_zero(bg) else bg.data_ptr()), float(settings.scale_modifier)
+    cam.viewmatrix, cam.projmatrix = view.data_ptr(), proj.data_ptr()
+    cam.sh_degree, cam.campos, cam.prefiltered = int(settings.sh_degree), campos.data_ptr(), int(bool(settings.prefiltered))
+    keep = (bg, view, proj, campos)
+    if len(_cam_structs) > 64:
+        _cam_structs.clear()
+    _cam_structs[id(settings)] = (settings, cam, keep, (settings.bg._version, settings.viewmatrix._version, settings.projmatrix._version,
+                                                        settings.campos._version), dev)
+    return cam, keep
+
+
+def _build_pack(settings, means3D, colors, opacities, scales, rotations, cov3D, shs) -> _Pack:
+    dev = means3D.device
+    pk = _Pack()
+    P = means3D.shape[0]
+    pk.cam, (bg, view, proj, campos) = _camera_struct(settings, dev)
     use_sh = shs.numel() > 0
     channels = 3 if use_sh else colors.shape[1]
     if not (1 <= channels <= _capi.SPLAT_MAX_CHANNELS):
         raise RuntimeError(f"colors_precomp must have 1..{_capi.SPLAT_MAX_CHANNELS} channels, got {channels}")
     if bg.numel() < channels:
         raise RuntimeError(f"raster_settings.bg has {bg.numel()} entries for {channels} channels")
-    cam = pk.cam
-    cam.image_height, cam.image_width = int(settings.image_height), int(settings.image_width)
-    cam.tanfovx, cam.tanfovy = float(settings.tanfovx), float(settings.tanfovy)
-    cam.bg, cam.scale_modifier = bg.data_ptr(), float(settings.scale_modifier)
-    cam.viewmatrix, cam.projmatrix = view.data_ptr(), proj.data_ptr()
-    cam.sh_degree, cam.campos, cam.prefiltered = int(settings.sh_degree), campos.data_ptr(), int(bool(settings.prefiltered))
     g = pk.g
     g.P, g.channels = P, channels
     g.means3D, g.opacities = _ptr(means3D), _ptr(opacities)
@@ -140,7 +242,7 @@ def _build_pack(settings, means3D, colors, opacities, scales, rotations, cov3D, 
     g.scales, g.rotations, g.cov3D_precomp = _ptr(scales), _ptr(rotations), _ptr(cov3D)
     g.shs = _ptr(shs) if use_sh else None
     g.sh_coeffs = shs.shape[1] if use_sh else 0
-    pk.keep += [bg, view, proj, campos, means3D, colors, opacities, scales, rotations, cov3D, shs]
+    pk.keep += [bg, view, proj, campos, means3D, colors, opacities, scales, rotations, cov3D, shs]      # (rasterize_backward reads [4:11])
     return pk
 
 
@@ -204,8 +306,51 @@ def _alloc_lists(pk: _Pack, dev, capacity: int, longest=None):
             pk.tensors.update(long_items=items)
 
 
+def _alloc_state_fast(pk: _Pack, dev, P: int, H: int, W: int, longest: int):
+    """Scratch of a fast-path call ("auto" sync mode): group binning + published lists, ONE slab laid out by the library
+    (splat_state_layout with SPLAT_LAYOUT_GROUPS: no key buckets, no sort scratch; the group counters sit in front of the status words
+    so that the library zeroes both with one memset)."""
+    i32 = torch.int32
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    cap = T * FAST_STRIDE
+    lay = _capi.state_layout(P, W, H, 1, cap, _capi.SPLAT_LAYOUT_GROUPS)
+    slab = torch.empty(lay.total, dtype=torch.uint8, device=dev)
+    _capi.check(_capi.lib().splat_state_bind(C.byref(pk.st), None, slab.data_ptr(), lay.arrays, lay.n, 1, cap), "splat_state_bind")
+    # (final_T / n_contrib stay where the library's layout put them, inside the slab; radii is an OUTPUT of the call and a tensor of its own,
+    #  so that a caller who keeps it does not keep the slab)
+    radii = torch.empty(P, dtype=i32, device=dev)
+    st = pk.st
+    st.radii = radii.data_ptr()
+    st.tile_stride = FAST_STRIDE
+    st.group_stride = _capi.SPLAT_GROUP_TILES ** 2 * FAST_STRIDE
+    st.max_list_hint = max(1, min(int(longest * FAST_MARGIN), FAST_STRIDE * 4 // 5))
+    pk.tensors = dict(geom=slab, radii=radii)
+    pk.num_tiles = T
+    pk.shape = (P, H, W, 1)
+    return radii, None
+
+
 def _stream(dev) -> int:
-    return torch.cuda.current_stream(dev).cuda_stream
+    # (the raw handle of torch's current stream; torch.cuda.current_stream(dev).cuda_stream builds a Stream object on the way: 13 us)
+    return torch._C._cuda_getCurrentRawStream(dev.index)
+
+
+class _on_device:
+    """``with torch.cuda.device(dev)`` only when ``dev`` is not the current device already (the guard costs ~6 us per use, twice per
+    rasterizer call; the callers render on the current device)."""
+    __slots__ = ("guard",)
+
+    def __init__(self, dev):
+        self.guard = None if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.guard is not None:
+            self.guard.__enter__()
+
+    def __exit__(self, *exc):
+        if self.guard is not None:
+            return self.guard.__exit__(*exc)
+        return False
 
 
 class LazyOverflow(RuntimeError):
@@ -335,6 +480,12 @@ def rasterize_forward(settings, means3D, colors, opacities, scales, rotations, c
     for _ in range(4):
         out = _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotations, cov3D, shs,
                                       means3D if means3D_src is None else means3D_src)
+        if not will_backward and getattr(out[3], "fast", None) is not None:
+            # a fast-path render nobody will differentiate: its flag is resolved here (the wait the exact path makes anyway), and a
+            # flagged render is repeated on exact lists -- what is returned was never composited from truncated lists
+            if fast_call_flagged(out[3]):
+                continue                # (the scene's statistics are gone: the next pass is an exact one)
+            return out
         if will_backward or getattr(out[3], "pending_status", None) is None:
             return out
         try:
@@ -345,12 +496,95 @@ def rasterize_forward(settings, means3D, colors, opacities, scales, rotations, c
     raise RuntimeError("lazy sync mode: the instance lists could not be sized")
 
 
-def _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotations, cov3D, shs, means3D_src):
+def _scene_key(dev, P, settings):
+    return (dev.index, P, int(settings.image_height), int(settings.image_width), float(settings.tanfovx), float(settings.tanfovy))
+
+
+def _fast_eligible(key, channels, use_sh) -> bool:
+    if _SYNC_MODE != "auto" or use_sh or channels != 3 or key[1] == 0:
+        return False
+    stt = _scene_stats.get(key)
+    return stt is not None and 0 < stt['longest'] * FAST_MARGIN <= FAST_STRIDE and stt['since_exact'] < FAST_REFRESH
+
+
+def _rasterize_forward_fast(settings, means3D, colors, opacities, scales, rotations, cov3D, shs, key):
+    """The front end of the fused iteration behind the reference API: K1 with group binning, the forward composite that sorts its
+    own lists.  Nothing is read back; the device raises pk.flag_word (pinned host memory) if a list did not fit after all."""
+    L = _capi.lib()
+    dev = means3D.device
+    H, W = int(settings.image_height), int(settings.image_width)
+    P = means3D.shape[0]
+    pk = _build_pack(settings, means3D, colors, opacities, scales, rotations, cov3D, shs)
+    radii, _ = _alloc_state_fast(pk, dev, P, H, W, _scene_stats[key]['longest'])
+    out_color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+    out_depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+    ring = _ring()
+    idx, word, ev = ring.take(dev)
+    pk.st.status_host = word
+    stream = _stream(dev)
+    with _on_device(dev):
+        # (splat_forward = preprocess + bin (a no-op with group binning) + render: one crossing of the ABI)
+        _capi.check(L.splat_forward(C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), out_color.data_ptr(), out_depth.data_ptr(), stream), "splat_forward")
+        ev.record()
+    pk.fast = (idx, ev, key)
+    pk.settings = settings
+    pk.num_rendered = None
+    _scene_stats[key]['since_exact'] += 1
+    fast_path_stats["fast"] += 1
+    return out_color, radii, out_depth, pk
+
+
+_unchecked: list = []        # fast-path calls whose backward pass was launched before their flag could be read (oldest first)
+
+
+def _poll_unchecked(wait: bool = False) -> None:
+    """Reads the flags of the fast-path calls that were never waited for, as far as their forward passes have finished (all of them
+    with ``wait``).  A flagged one had its gradients poisoned with NaN on the device: that is reported here, loudly."""
+    while _unchecked:
+        idx, ev, key = _unchecked[0]
+        if not ev.query():
+            if not wait:
+                return
+            ev.synchronize()
+        _unchecked.pop(0)
+        if int(_ring().host[idx]) != 0:
+            fast_path_stats["flagged"] += 1
+            _scene_stats.pop(key, None)
+            raise RuntimeError("splatam_amd rasterizer (sync mode 'auto'): a per-tile Gaussian list outgrew the bucket learnt for its scene in an "
+                               "EARLIER call whose backward pass had been issued before its forward pass finished; that call's image was composited "
+                               "from truncated lists and its gradients were set to NaN on the device.  The scene is back on the exact path; "
+                               "repeat the iteration (set_sync_mode('exact') rules this out)")
+
+
+def check_pending() -> None:
+    """Waits for every fast-path call whose flag has not been read yet and raises if one of them was flagged (see _poll_unchecked)."""
+    _poll_unchecked(wait=True)
+
+
+def fast_call_flagged(pk) -> bool:
+    """Did the device flag this fast-path call (a list beyond its bucket)?  Waits for the call's forward composite if it is still
+    running (in a training loop the loss sits between the forward and the backward pass: it has long finished)."""
+    idx, ev, key = pk.fast
+    if not ev.query():
+        ev.synchronize()
+    flagged = int(_ring().host[idx]) != 0
+    if flagged:
+        fast_path_stats["flagged"] += 1
+        _scene_stats.pop(key, None)         # the scene goes back to the exact path (and learns its lists again)
+    return flagged
+
+
+def _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotations, cov3D, shs, means3D_src, force_exact=False):
     L = _capi.lib()
     dev = means3D.device
     H, W = int(settings.image_height), int(settings.image_width)
     P = means3D.shape[0]
     use_sh = shs.numel() > 0
+    scene = _scene_key(dev, P, settings)
+    if _unchecked:
+        _poll_unchecked()
+    if not force_exact and _fast_eligible(scene, 3 if use_sh else colors.shape[1], use_sh) and cov3D.numel() == 0:
+        return _rasterize_forward_fast(settings, means3D, colors, opacities, scales, rotations, cov3D, shs, scene)
     cacheable = _GEOM_CACHE and _SYNC_MODE == "exact" and not use_sh and cov3D.numel() == 0 and scales.numel() > 0 and rotations.numel() > 0
     if cacheable:
         pk = _shared_geometry(settings, means3D, colors, opacities, scales, rotations, cov3D, shs, means3D_src)
@@ -379,7 +613,9 @@ def _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotati
             stat = status.tolist()
             num_rendered = int(stat[0])
             _longest_seen[hint_key] = int(stat[2])
-            if _SYNC_MODE == "exact":
+            _scene_stats[scene] = {'longest': int(stat[2]), 'since_exact': 0}
+            fast_path_stats["exact"] += 1
+            if _SYNC_MODE != "lazy":
                 _alloc_lists(pk, dev, num_rendered, longest=int(stat[2]))
                 pk.st.max_list_hint = int(stat[2])        # lets the library skip the long-list sort kernel
             else:                                         # lazy, first call for this shape: learn the size
@@ -398,6 +634,7 @@ def _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotati
             pk.hint_key = hint_key
     if cacheable:
         _remember_geometry(pk, settings, means3D_src, opacities, scales, rotations)
+    pk.settings = settings
     return out_color, radii, out_depth, pk
 
 
@@ -434,23 +671,48 @@ def rasterize_backward(pk: _Pack, grad_color, need_scale_rot: bool, need_cov3D: 
     dev = grad_color.device
     f32 = torch.float32
     resolve_lazy(pk)
+    poison = False
+    if getattr(pk, "fast", None) is not None and not pk.fast[1].query():
+        # the forward composite is still running (a backward pass issued right behind its forward pass; in a training loop the loss sits
+        # between them): nobody waits.  The backward pass is launched as it is and told to POISON its gradients with NaN should the
+        # forward pass turn out to have been flagged; the flag is read when a later call finds the event complete (_poll_unchecked)
+        poison = True
+        _unchecked.append(pk.fast)
+    elif getattr(pk, "fast", None) is not None and fast_call_flagged(pk):
+        # the forward pass ran on truncated lists: the gradients are formed on exact ones (the same inputs, kept alive by the pack)
+        import warnings
+        warnings.warn("splatam_amd rasterizer (sync mode 'auto'): a per-tile Gaussian list outgrew the bucket learnt for this scene; the "
+                      "backward pass was repeated on exact lists and the scene returns to the exact path, but the image of this ONE "
+                      "forward call had been composited from truncated lists (set_sync_mode('exact') rules that out)", RuntimeWarning)
+        means3D, colors, opac, scales, rots, cov3D, shs = pk.keep[4:11]
+        _, _, _, pk = _rasterize_forward_once(pk.settings, means3D, colors, opac, scales, rots, cov3D, shs, means3D, force_exact=True)
     grad_color = grad_color.contiguous()
     accum_bytes = _capi.state_layout(P, pk.shape[2], pk.shape[1], 1, 0, _capi.SPLAT_LAYOUT_BACKWARD).bytes["accum"]     # (the library's size)
-    accum = torch.empty(accum_bytes // 4, dtype=f32, device=dev)
-    d_means3D = torch.empty(P, 3, dtype=f32, device=dev)
-    d_means2D = torch.empty(P, 3, dtype=f32, device=dev)
-    d_opac = torch.empty(P, 1, dtype=f32, device=dev)
-    d_colors = None if use_sh else torch.empty(P, Cn, dtype=f32, device=dev)
-    d_scales = torch.empty(P, 3, dtype=f32, device=dev) if need_scale_rot else None
-    d_rots = torch.empty(P, 4, dtype=f32, device=dev) if need_scale_rot else None
-    d_cov = torch.empty(P, 6, dtype=f32, device=dev) if need_cov3D else None
-    d_sh = torch.empty(sh_shape, dtype=f32, device=dev) if use_sh else None
+    # the accumulator and every gradient in ONE allocation, cut into views by one split (eight allocator calls were ~30 us of host time
+    # per backward pass; rows of 4-float multiples first, so that every piece is 16-byte aligned)
+    sh_n = 1
+    for d in sh_shape:
+        sh_n *= int(d)
+    sizes = [accum_bytes // 4, 4 * P if need_scale_rot else 0, 3 * P, 3 * P, P, 0 if use_sh else Cn * P, 3 * P if need_scale_rot else 0,
+             6 * P if need_cov3D else 0, sh_n if use_sh else 0]
+    sizes = [(n + 3) // 4 * 4 for n in sizes]
+    parts = torch.empty(sum(sizes), dtype=f32, device=dev).split_with_sizes(sizes)
+    accum = parts[0]
+    d_rots = parts[1][:4 * P].view(P, 4) if need_scale_rot else None
+    d_means3D = parts[2][:3 * P].view(P, 3)
+    d_means2D = parts[3][:3 * P].view(P, 3)
+    d_opac = parts[4][:P].view(P, 1)
+    d_colors = None if use_sh else parts[5][:Cn * P].view(P, Cn)
+    d_scales = parts[6][:3 * P].view(P, 3) if need_scale_rot else None
+    d_cov = parts[7][:6 * P].view(P, 6) if need_cov3D else None
+    d_sh = parts[8][:sh_n].view(sh_shape) if use_sh else None
     gr = _capi.SplatGrads()
     gr.dL_dcolor, gr.accum = grad_color.data_ptr(), _ptr(accum)
     gr.dL_dmeans3D, gr.dL_dmeans2D = _ptr(d_means3D), _ptr(d_means2D)
     gr.dL_dcolors, gr.dL_dopacities = _ptr(d_colors), _ptr(d_opac)
     gr.dL_dscales, gr.dL_drotations, gr.dL_dcov3D, gr.dL_dshs = _ptr(d_scales), _ptr(d_rots), _ptr(d_cov), _ptr(d_sh)
-    with torch.cuda.device(dev):
+    gr.flags = (_capi.SPLAT_GRADS_UPSTREAM_SCALE if _UPSTREAM_SCALE_GRADIENT else 0) | (_capi.SPLAT_GRADS_POISON_IF_FLAGGED if poison else 0)
+    with _on_device(dev):
         _capi.check(L.splat_backward(C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), C.byref(gr), _stream(dev)), "splat_backward")
     return d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rots, d_cov
 
@@ -484,6 +746,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         color, radii, depth, pk = rasterize_forward(raster_settings, means3D, colors, opac, scales_c, rots_c, cov_c, sh,
                                                     will_backward=bool(grad_enabled) and any(ctx.needs_input_grad), means3D_src=means3D_src)
         ctx.pack = pk
+        ctx.set_materialize_grads(False)        # (radii and depth carry no gradient: no zero tensors are built for them per backward)
         ctx.use_sh = sh.numel() > 0
         ctx.sh_shape = tuple(sh.shape)
         ctx.use_cov = cov_c.numel() > 0
@@ -503,15 +766,51 @@ class _RasterizeGaussians(torch.autograd.Function):
         return (d_means3D, d_means2D, d_sh, d_colors, d_opac.reshape(ctx.opac_shape), d_scales, d_rots, d_cov, None, None)
 
 
+_apply_c = super(torch.autograd.Function, _RasterizeGaussians).apply
+_empties: dict = {}
+
+
+def _empty_on(dev):
+    e = _empties.get(dev)
+    if e is None:
+        e = _empties[dev] = torch.empty(0, dtype=torch.float32, device=dev)
+    return e
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, torch.is_grad_enabled())
+    # (the C-level apply: torch.autograd.Function.apply first walks its arguments for functorch wrappers, ~8 us per call; no transform
+    #  of that kind can differentiate through a ctypes call anyway)
+    if torch._C._are_functorch_transforms_active():
+        return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                         cov3Ds_precomp, raster_settings, torch.is_grad_enabled())
+    return _apply_c(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                    torch.is_grad_enabled())
 
 
 class GaussianRasterizer(nn.Module):
+    """``GaussianRasterizer(raster_settings=cam)(**rendervar)`` -- the callers build a FRESH module for every render
+    (/root/reference/scripts/splatam.py:249,253,384), so construction and call are kept cheap: the ``nn.Module`` bookkeeping (a dozen
+    ordered dicts, ~13 us) is only built when something asks for it (hooks, ``parameters()``, ``repr`` ...), and a module without it is
+    called straight through to ``forward``."""
+
     def __init__(self, raster_settings):
-        super().__init__()
-        self.raster_settings = raster_settings
+        object.__setattr__(self, "raster_settings", raster_settings)
+
+    def _materialise(self):
+        settings = self.__dict__["raster_settings"]
+        nn.Module.__init__(self)
+        object.__setattr__(self, "raster_settings", settings)
+
+    def __getattr__(self, name):
+        if "_parameters" not in self.__dict__:          # nn.Module state asked for the first time
+            self._materialise()
+            return getattr(self, name)
+        return super().__getattr__(name)
+
+    def __call__(self, *args, **kwargs):
+        if "_parameters" not in self.__dict__:          # no hooks can be registered on a module without its state
+            return self.forward(*args, **kwargs)
+        return super().__call__(*args, **kwargs)
 
     def markVisible(self, positions):
         """Boolean mask of the Gaussians in front of the near plane (view-space z > 0.2)."""
@@ -533,7 +832,7 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
-        empty = torch.empty(0, dtype=torch.float32, device=means3D.device)
+        empty = _empty_on(means3D.device)
         shs = empty if shs is None else shs
         colors_precomp = empty if colors_precomp is None else colors_precomp
         scales = empty if scales is None else scales

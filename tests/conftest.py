@@ -24,3 +24,18 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _fresh_rasterizer_policy(request):
+    """GPU tests start from the rasterizer's default capacity policy ("auto") with nothing learnt about any scene: what one test's
+    scene taught the drop-in path (longest list per image size) must not steer the next test's first render."""
+    if "gpu" not in request.keywords:
+        yield
+        return
+    from splatam_amd import rasterizer as rz
+    rz.set_sync_mode("auto")
+    rz.reset_scene_stats()
+    yield
+    rz.set_sync_mode("auto")
+    rz.reset_scene_stats()

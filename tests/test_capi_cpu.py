@@ -138,17 +138,25 @@ def test_scratch_layouts_describe_the_structs():
     assert L.splat_state_layout(-1, W, H, 1, cap, 0, None, 0, None) < 0 and L.splat_state_layout(P, W, H, 3, cap, 0, None, 0, None) < 0
     # the fused iteration's workspace
     gs = 4 * 448
-    il = _capi.iter_workspace_layout(P, W, H, cap, gs, _capi.SPLAT_LAYOUT_SSIM | _capi.SPLAT_LAYOUT_OUTLIER)
-    assert il.total == L.splat_iter_workspace_bytes(P, W, H, cap, gs, _capi.SPLAT_LAYOUT_SSIM | _capi.SPLAT_LAYOUT_OUTLIER)
+    fl = _capi.SPLAT_LAYOUT_SSIM | _capi.SPLAT_LAYOUT_OUTLIER | _capi.SPLAT_LAYOUT_TILE_ORDER
+    il = _capi.iter_workspace_layout(P, W, H, cap, gs, fl)
+    assert il.total == L.splat_iter_workspace_bytes(P, W, H, cap, gs, fl)
     G = ((W + 15) // 16 + 1) // 2 * (((H + 15) // 16 + 1) // 2)
     assert il.bytes["feat8"] == 32 * P and il.bytes["out6"] == il.bytes["dL_dout6"] == 24 * W * H and il.bytes["ssim_maps"] == 36 * W * H
     assert il.bytes["sums"] == 8 * _capi.SPLAT_ITER_SUM_COPIES * _capi.SPLAT_ITER_SUMS and il.bytes["d_cam"] == 4 * _capi.SPLAT_ITER_DCAM
     assert il.bytes["st.group_count"] == 4 * G * _capi.SPLAT_COUNTER_STRIDE and il.bytes["st.group_recs"] == 16 * G * gs
     assert il.bytes["st.tile_order"] == 4 * 8 * ((T + 7) // 8) and il.bytes["outlier_scratch"] == 4 * L.splat_map_scratch_words(W * H)
     zero = {k for k in il.names if il.zero_init[k]}
-    assert zero == {"st.radii", "st.tile_count", "st.long_base", "st.group_count", "st.tile_work", "st.tile_queue", "st.status", "dL_dout6",
+    # (the launch order is zero-initialised: a zeroed buffer IS the natural order -- a binding that merely zeroes what the layout marks
+    #  can run the iteration)
+    assert zero == {"st.radii", "st.tile_count", "st.long_base", "st.group_count", "st.tile_work", "st.tile_order", "st.status", "dL_dout6",
                     "accum", "sums", "d_cam", "outlier_scratch"}
-    assert il.bytes["st.tile_queue"] == 4 * _capi.SPLAT_QUEUE_WORDS
+    # ... and it is only laid out (and bound) on request
+    plain = _capi.iter_workspace_layout(P, W, H, cap, gs, _capi.SPLAT_LAYOUT_SSIM)
+    assert "st.tile_order" not in plain.bytes and "st.tile_work" not in plain.bytes
+    ws0 = _capi.SplatIterWorkspace()
+    assert L.splat_iter_workspace_bind(C.byref(ws0), base, plain.arrays, plain.n, cap, gs) == 0
+    assert ws0.st.tile_order is None and ws0.st.tile_work is None
     ws = _capi.SplatIterWorkspace()
     assert L.splat_iter_workspace_bind(C.byref(ws), base, il.arrays, il.n, cap, gs) == 0
     for k in il.names:

@@ -28,14 +28,19 @@ def _camera():
                   sh_degree=0, campos=t("campos"), prefiltered=False)
 
 
-@pytest.fixture(params=["geometry cache on", "geometry cache off"])
+@pytest.fixture(params=["geometry cache on", "geometry cache off", "auto policy: fast path"])
 def geometry_cache(request):
+    """The reference's capacity policy ("exact": one host read per forward, as the CUDA original) with the geometry shared between the
+    two renders or not; and the default policy's steady state (no host read, every render its own two launches)."""
     from splatam_amd import rasterizer as rz
     on = request.param.endswith("on")
+    auto = request.param.startswith("auto")
+    rz.set_sync_mode("auto" if auto else "exact")
     rz.set_geometry_cache(on)
     before = dict(rz.geometry_cache_stats)
     yield on, before
     rz.set_geometry_cache(True)
+    rz.set_sync_mode("auto")
 
 
 @pytest.mark.parametrize("mode", ["tracking", "mapping"])
@@ -65,6 +70,10 @@ def test_reference_call_sequence_replayed_on_hip(mode, geometry_cache):
             if k == 'means3D':
                 shared[k] = kw[k]
         calls.append(kw)
+    if rz.get_sync_mode() == "auto":
+        with torch.no_grad():           # the scene's first call (exact lists; learns the longest list): the replay below is its steady state
+            Renderer(raster_settings=cam)(**calls[0])
+        fast_before = rz.fast_path_stats["fast"]
     # forward: two fresh modules, keyword arguments, 3-tuples (the second forward precedes the first backward)
     outs = []
     for kw in calls:
@@ -75,6 +84,8 @@ def test_reference_call_sequence_replayed_on_hip(mode, geometry_cache):
     # rotations are distinct tensors, as in the caller) -- or, with the cache off, ran the whole pass
     on, before = geometry_cache
     assert rz.geometry_cache_stats["shared"] - before["shared"] == (1 if on else 0), (rz.geometry_cache_stats, before)
+    if rz.get_sync_mode() == "auto":
+        assert rz.fast_path_stats["fast"] == fast_before + 2, rz.fast_path_stats
     for ci, (color, radii, depth) in enumerate(outs):
         assert radii.dtype == torch.int32 and tuple(depth.shape) == (1,) + tuple(color.shape[1:])
         assert (radii.cpu().numpy() != GOLD[f"call{ci}/out/radii"]).sum() <= 1
@@ -132,6 +143,7 @@ def test_geometry_cache_shares_only_what_is_proven_equal():
     cam = _camera()
     g = lambda k: torch.tensor(GOLD[f"call0/in/{k}"]).cuda()      # noqa: E731
     base = {k: g(k) for k in ('means3D', 'colors_precomp', 'rotations', 'opacities', 'scales', 'means2D')}
+    rz.set_sync_mode("exact")           # (the cache belongs to the reference's capacity policy: the one host read proves the equality)
     rz.set_geometry_cache(True)
     try:
         def render(**over):
@@ -182,6 +194,7 @@ def test_geometry_cache_sees_writes_that_bump_no_version_counter():
     cam = _camera()
     g = lambda k: torch.tensor(GOLD[f"call0/in/{k}"]).cuda()      # noqa: E731
     base = {k: g(k) for k in ('means3D', 'colors_precomp', 'rotations', 'opacities', 'scales', 'means2D')}
+    rz.set_sync_mode("exact")           # (the cache belongs to the reference's capacity policy: the one host read proves the equality)
     rz.set_geometry_cache(True)
     try:
         def render():

@@ -54,10 +54,22 @@ GRAD_MAP = [('means3D', 'means3D'), ('means2D', 'means2D'), ('colors_precomp', '
             ('scales', 'scales'), ('rotations', 'rotations')]
 
 
-def _dropin(cam, rv, gout):
+def _dropin(cam, rv, gout, path="second"):
+    """The call under test is the scene's SECOND one: the first (exact lists, learns the scene's longest list) is what every loop pays
+    once; "fast" asserts that the second then ran on group binning + the sorting composite (the "auto" policy's steady state)."""
     from diff_gaussian_rasterization import GaussianRasterizer as Renderer
+    from splatam_amd import rasterizer as rz
     inp = {k: rv[k].detach().cuda().requires_grad_(True) for k in KEYS}
-    color, radii, depth = Renderer(raster_settings=_cuda_settings(cam))(**inp)
+    cs = _cuda_settings(cam)
+    if path in ("fast", "second"):
+        with torch.no_grad():
+            Renderer(raster_settings=cs)(**inp)
+    before = dict(rz.fast_path_stats)
+    color, radii, depth = Renderer(raster_settings=cs)(**inp)
+    took = "fast" if rz.fast_path_stats["fast"] == before["fast"] + 1 else "exact"
+    print(f"[dropin] {path}: took the {took} path, scene statistics {list(rz._scene_stats.values())}")
+    if path != "second":                # ("second": whatever the policy decides for this scene's second call -- long lists stay exact)
+        assert took == path, (path, before, rz.fast_path_stats)
     (color * gout.cuda()).sum().backward()
     torch.cuda.synchronize()
     return color.detach().cpu().numpy(), radii.cpu().numpy(), depth.detach().cpu().numpy(), {k: inp[k].grad.cpu().numpy() for k in KEYS}
@@ -94,12 +106,14 @@ def _check_dropin_grads(gg, og32, og64, what, aniso, flips=None):
         assert_grad_calibrated(gg[k].reshape(og32[ok].shape), og32[ok], og64[ok], what=f"{what} grad {k}")
 
 
-@pytest.mark.parametrize("cfg,aniso", [('D', False), ('D', True), ('B', True), ('E', False), ('E', True)])
-def test_dropin_full_size(cfg, aniso):
-    """Drop-in forward + backward vs the C oracle at the BASELINE configurations round 1 left uncovered."""
+@pytest.mark.parametrize("cfg,aniso,path", [('D', False, "fast"), ('D', True, "second"), ('B', True, "second"), ('E', False, "fast"), ('E', True, "second"),
+                                            ('D', False, "exact"), ('B', True, "exact")])
+def test_dropin_full_size(cfg, aniso, path):
+    """Drop-in forward + backward vs the C oracle at the BASELINE configurations round 1 left uncovered, on both paths of the default
+    capacity policy (_dropin)."""
     cam, rv = _scene(cfg, seed=7, aniso=aniso)
     gout = torch.randn(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(1))
-    gc, gr, gd, gg = _dropin(cam, rv, gout)
+    gc, gr, gd, gg = _dropin(cam, rv, gout, path)
     oc, orad, od, og, _ = _oracle(cam, rv, gout)
     flips = _check_images(gc, gr, gd, oc, orad, od, cam, rv)
     og64 = _oracle(cam, rv, gout, "f64")[3]

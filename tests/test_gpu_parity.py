@@ -24,11 +24,20 @@ def _to_cuda_settings(cam):
                   prefiltered=cam.prefiltered)
 
 
-def _gpu_render(cam, rv, grad_out=None, keys=('means3D', 'means2D', 'opacities', 'colors_precomp', 'scales', 'rotations')):
+def _gpu_render(cam, rv, grad_out=None, keys=('means3D', 'means2D', 'opacities', 'colors_precomp', 'scales', 'rotations'), path=None):
+    """path: None = whatever the default policy does on a scene's first call (the exact path); "exact" / "fast": the call under test
+    must take that path of the "auto" policy -- "fast" is preceded by the scene's first (exact, list-learning) call, as in a loop."""
     from diff_gaussian_rasterization import GaussianRasterizer as Renderer
+    from splatam_amd import rasterizer as rz
     cs = _to_cuda_settings(cam)
     inp = {k: rv[k].detach().cuda().requires_grad_(grad_out is not None) for k in keys}
+    if path == "fast":
+        with torch.no_grad():
+            Renderer(raster_settings=cs)(**inp)
+    before = dict(rz.fast_path_stats)
     color, radii, depth = Renderer(raster_settings=cs)(**inp)
+    if path is not None:
+        assert rz.fast_path_stats[path] == before[path] + 1, (path, before, rz.fast_path_stats)
     grads = None
     if grad_out is not None:
         (color * grad_out.cuda()).sum().backward()
@@ -95,10 +104,18 @@ def _check_grads(gg, og, og64=None, flips=None):
     (50, 64, 48, False, False, (0.1, 0.2, 0.3)),           # sparse: most tiles empty
     (20000, 96, 64, False, False, (0, 0, 0)),              # dense: > 1000 Gaussians per tile, early termination
 ])
-def test_forward_backward_parity(n, W, H, aniso, view, bg):
+@pytest.mark.parametrize("path", ["exact", "fast"])
+def test_forward_backward_parity(n, W, H, aniso, view, bg, path):
+    """Both paths of the default capacity policy: a scene's first call (exact lists: scan, scatter, per-tile sort) and its later ones
+    (group binning, lists sorted inside the forward composite, nothing read back) -- the dense scene's lists are beyond what the
+    composite sorts, so it must stay on the exact path."""
     cam, rv = scene(n, W, H, 0.9 * W, seed=n, anisotropic=aniso, w2c=tilted_w2c() if view else None, bg=bg)
     gout = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1))
-    gc, gr, gd, gg = _gpu_render(cam, rv, gout)
+    if path == "fast" and n == 20000:
+        path = "exact"
+        with torch.no_grad():           # (the scene's first call; the call under test is its second)
+            _gpu_render(cam, rv)
+    gc, gr, gd, gg = _gpu_render(cam, rv, gout, path=path)
     oc, orad, od, og, _ = _c_oracle(cam, rv, gout)
     flips = _check_forward(gc, gr, gd, oc, orad, od, W * H, cam, rv)
     _check_grads(gg, og, _c_oracle(cam, rv, gout, "f64")[3], flips)
