@@ -476,13 +476,59 @@ def render_mpix(params, frames, shape, dev, reps=10):
     return W * H * rate / 1e6, 1e3 / rate
 
 
+REFERENCE_DIR = os.environ.get("SPLAT_REFERENCE_DIR", "/root/reference")
+
+
+def cpu_baseline_reference(name, params, frames, budget_s=25.0, max_iters=5):
+    """The cpu_baseline leg through the REFERENCE's own modules (utils/slam_helpers.py, utils/slam_external.py, get_loss /
+    initialize_optimizer of scripts/splatam.py) around the C oracle: scripts/cpu_baseline_reference.py in a process of its own (its
+    device shim patches torch), on the scene written to a temporary .npz.  None where the reference is not present (the GPU box)."""
+    import subprocess
+    import tempfile
+    from splatam_amd import slam
+    if not os.path.isdir(os.path.join(REFERENCE_DIR, "utils")):
+        return None
+    f = frames[1]
+    cam = f['cam']
+    cfg = slam.REPLICA_TRACKING
+    blob = {f"param/{k}": v.detach().cpu().numpy() for k, v in params.items()}
+    blob.update({f"lr/{k}": np.float64(v) for k, v in cfg['lrs'].items()})
+    blob.update(H=cam.image_height, W=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=cam.bg.cpu().numpy(),
+                viewmatrix=cam.viewmatrix.cpu().numpy(), projmatrix=cam.projmatrix.cpu().numpy(), campos=cam.campos.cpu().numpy(),
+                im=f['im'].cpu().numpy(), depth=f['depth'].cpu().numpy(), time_idx=1, w_im=cfg['loss_weights']['im'],
+                w_depth=cfg['loss_weights']['depth'], use_sil_for_loss=cfg['use_sil_for_loss'], sil_thres=cfg['sil_thres'],
+                use_l1=cfg['use_l1'], ignore_outlier_depth_loss=cfg['ignore_outlier_depth_loss'])
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "scene.npz")
+        np.savez(path, **blob)
+        script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "cpu_baseline_reference.py")
+        env = dict(os.environ, OMP_NUM_THREADS=str(os.cpu_count() or 1))
+        res = subprocess.run([sys.executable, script, path, str(budget_s), str(max_iters)], capture_output=True, text=True, env=env,
+                             timeout=20 * budget_s + 600)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    if res.returncode != 0 or not lines:
+        sys.stderr.write("cpu_baseline through the reference failed; falling back to the mirror\n" + res.stderr[-2000:] + "\n")
+        return None
+    d = json.loads(lines[-1])
+    if "error" in d:
+        return None
+    return {"value": d["value"], "unit": "iters/s", "cores": os.cpu_count(), "kind": "reference glue + oracle",
+            "sample": f"{d['iterations']} tracking iterations (2 fwd + 2 bwd rasterizations + host glue + Adam) of workload {name} at full size; the "
+                      f"REFERENCE's own utils/slam_helpers.py, utils/slam_external.py, get_loss and initialize_optimizer (scripts/splatam.py) imported "
+                      f"from {d['reference']} with its .cuda() calls redirected to the CPU, around the C oracle (OpenMP, {os.cpu_count()} threads; "
+                      f"torch {d['threads']} threads); median {d['median_s']:.3f} s/iter",
+            "first_loss": d["first_loss"]}
+
+
 def cpu_baseline(name, params, frames, budget_s=25.0):
     """The reference's CPU plumbing (same host-side code on CPU tensors) around the
     C oracle rasterizer (oracle/raster_ref.c, 'port'), one tracking iteration of the
-    same workload, timed on this box's host cores."""
+    same workload, timed on this box's host cores.  Where the reference itself is present (this container, not the GPU box) its own
+    modules are timed instead (cpu_baseline_reference: kind "reference glue + oracle"); the mirror's figure rides along."""
     from oracle import c_ref
     from splatam_amd import slam
     import numpy as np
+    via_ref = cpu_baseline_reference(name, params, frames, budget_s)
 
     class _CpuRaster(torch.autograd.Function):
         @staticmethod
@@ -537,9 +583,72 @@ def cpu_baseline(name, params, frames, budget_s=25.0):
     finally:
         slam.Renderer = saved
     med = float(np.median(times))
-    return {"value": round(1.0 / med, 4), "unit": "iters/s", "cores": os.cpu_count(), "kind": "port", "pairs_per_render": _CpuRaster.last.num_pairs(),
+    port = {"value": round(1.0 / med, 4), "unit": "iters/s", "cores": os.cpu_count(), "kind": "port", "pairs_per_render": _CpuRaster.last.num_pairs(),
             "sample": f"{len(times)} tracking iterations (2 fwd + 2 bwd rasterizations + host glue + Adam) of workload {name} "
-                      f"at full size; C oracle (OpenMP, {os.cpu_count()} threads) + PyTorch-CPU glue; median {med:.3f} s/iter"}
+                      f"at full size; C oracle (OpenMP, {os.cpu_count()} threads) + PyTorch-CPU glue (the mirror splatam_amd/slam.py: the "
+                      f"reference is not on this box); median {med:.3f} s/iter"}
+    if via_ref is None:
+        return port
+    via_ref["pairs_per_render"] = port["pairs_per_render"]
+    via_ref["mirror_glue_iters_per_s"] = port["value"]      # (the same iteration on the repository's mirror of the glue, for comparison)
+    return via_ref
+
+
+def b_loop_headline(dev, steps=40):
+    """The SECOND headline: the same figures at the map SplaTAM really builds at B's frame size -- workload B-loop,
+    ~816 k Gaussians in creation order (one per valid first-frame pixel, initialize_first_timestep) -- from this run: the 2:3 mix of
+    tracking and mapping iterations of the fused engine, and the backward composite's launch time and roofline fraction there."""
+    import ctypes as C
+    from splatam_amd import _capi, slam
+    from splatam_amd.fused import FusedEngine
+    params, variables, frames, shape = build_scene("B-loop", dev, 2)
+    N, W, H = shape
+    eng = FusedEngine({k: v.detach().clone() for k, v in params.items()}, frames[1]['cam'], track_max_radius=variables['max_2D_radius'])
+    eng.begin_tracking(1)
+    for _ in range(3):
+        eng.loss_backward(frames[1], 1, slam.REPLICA_TRACKING, tracking=True)
+        torch.cuda.synchronize(dev)
+        eng.check_overflow()
+    snap = {k: v.detach().clone() for k, v in eng.params.items()}
+
+    def restore():
+        with torch.no_grad():
+            for k, v in eng.params.items():
+                v.copy_(snap[k])
+        eng.reset_map_optimizer()
+        eng.begin_tracking(1)
+    for _ in range(20):
+        eng.mapping_iteration(frames[2], 2, slam.REPLICA_MAPPING)
+    map_rate = phase_rate(lambda: eng.mapping_iteration(frames[2], 2, slam.REPLICA_MAPPING), steps, dev)
+    restore()
+    for _ in range(10):
+        eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING)
+    track_rate = phase_rate(lambda: eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING), steps, dev)
+    restore()
+    eng.loss_backward(frames[2], 2, slam.REPLICA_MAPPING, tracking=False)
+    torch.cuda.synchronize(dev)
+    R = int(eng.buf['status'][0])
+    ws = eng._workspace(False, False)
+    L = _capi.lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    t = {}
+    for fn in (2, 3):
+        ms = C.c_float(0)
+        rc = 0
+        for iters in (5, 30):
+            rc = L.splat_iter_time_kernel(fn, iters, C.byref(eng._cam), N, C.byref(ws), stream, C.byref(ms))
+        t[fn] = ms.value if rc == 0 else None
+    ok = not eng.check_overflow(grow=False)
+    k6 = t[2]
+    k7 = (t[3] - t[2]) if (t[2] and t[3]) else None
+    bytes_bwd = R * 52 + W * H * 32 + N * 48
+    out = {"workload": f"B-loop: {N} Gaussians in creation order, {W}x{H} (the map the frame loop builds at B's frame size)",
+           "iters_per_s": round(5.0 / (2.0 / track_rate + 3.0 / map_rate), 3), "tracking_iters_per_s": round(track_rate, 3),
+           "mapping_iters_per_s": round(map_rate, 3), "render_forward_ms": None if k6 is None else round(k6, 4),
+           "render_backward_ms": None if k7 is None else round(k7, 4), "num_rendered": R, "algorithmic_bytes": bytes_bwd,
+           "roofline_frac": None if not k7 else round(bytes_bwd / (k7 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "valid": ok}
+    del eng
+    return out
 
 
 def slam_loop_figure(name, dev, frames=13, engine="fused", runs=2):
@@ -646,6 +755,7 @@ def main():
                     help="N > 1 over RCCL: issue the per-iteration all-reduces on the iteration's own stream (splatam_amd.dist.InStreamRccl)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-b-loop", action="store_true", help="skip the second headline (the same figures at workload B-loop, the frame loop's map size)")
     ap.add_argument("--no-slam-loop", action="store_true", help="skip the end-to-end frame-loop figures (slam_loop, slam_loop_plugin)")
     ap.add_argument("--slam-frames", type=int, default=13, help="frames of the frame-loop figures (the first is not counted)")
     ap.add_argument("--launch-check", action="store_true", help="only exercise the N-rank launch (no GPU needed)")
@@ -987,6 +1097,9 @@ def main():
         }
         if roof is not None:
             result["roofline"] = roof
+        if world == 1 and fused and args.workload == "B" and not mode_c and not args.no_b_loop:
+            # the second headline, in the same JSON line: the representative map size (2.5x lower than B's 300 k: say so where B is quoted)
+            result["b_loop"] = b_loop_headline(dev)
         if world == 1 and fused and not args.no_slam_loop:
             result["slam_loop"] = slam_loop_figure(args.workload, dev, frames=args.slam_frames)
             result["slam_loop_plugin"] = slam_loop_figure(args.workload, dev, frames=args.slam_frames, engine="plugin")

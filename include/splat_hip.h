@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define SPLAT_ABI_VERSION 10       /* 10: group binning behind the reference API (SplatState.group_* in splat_preprocess_forward / splat_render_forward,
-                                      SPLAT_LAYOUT_GROUPS), SplatCamera.bg == NULL = black, SplatGrads.flags (SPLAT_GRADS_UPSTREAM_SCALE), SplatState.status_host,
+                                      SPLAT_LAYOUT_GROUPS), SplatState.tile_recs (staged records handed from the forward to the backward composite), SplatCamera.bg == NULL = black, SplatGrads.flags (SPLAT_GRADS_UPSTREAM_SCALE), SplatState.status_host,
                                       SplatState.tile_order entries hold tile + 1 (a zeroed buffer is the natural order) and are laid out on request (SPLAT_LAYOUT_TILE_ORDER),
                                       SplatState.tile_queue (persistent composites: measured, not adopted, removed) is gone;
                                       9: scratch layouts (splat_workspace_bytes, splat_state_layout / _bind, splat_iter_workspace_layout / _bind);
@@ -109,6 +109,12 @@ typedef struct SplatState {
     uint64_t *keys;              /* [capacity] (float bits of depth << 32) | Gaussian id, bucketed by tile */
     uint32_t *point_list;        /* [capacity] Gaussian ids, each tile's slice sorted by key */
     int64_t capacity;
+    /* optional (NULL: none): [capacity][12] floats, the STAGED RECORD of every list entry as the forward composite held it -- conic
+     * (pre-scaled) + opacity, colours, centre, id, quadrant mask: 48 bytes, at the entry's position in point_list.  The forward
+     * composite writes it (calls with up to three colour channels + depth, and the fused iteration's six), the backward composite
+     * then re-stages a tile's list with one coalesced read per entry instead of gathering conic / centre / colours through the
+     * id and repeating the culling tests.  Valid only for the backward pass that follows THAT forward pass on this state */
+    float *tile_recs;
     /* scratch of the multi-workgroup sort of per-tile lists longer than 4096 entries (NULL: such a list is sorted in place
      * by one workgroup -- correct, but O(n log^2 n) barrier stages) */
     uint64_t *keys_alt;          /* [capacity] ping-pong partner of `keys` for the merge passes */
@@ -168,6 +174,10 @@ typedef struct SplatState {
      * status[3] -- a caller that never waits for the device between the forward and the backward pass reads it (after an event that
      * follows the forward composite) without queueing a copy.  The caller zeroes it before the call. */
     int32_t *status_host;
+    /* optional (NULL: none; group binning behind the reference API only): the backward accumulator [P][SPLAT_GRAD_STRIDE] that the backward
+     * pass of THIS forward pass will use -- splat_preprocess_forward zeroes row i beside Gaussian i's geometry (stores the kernel has
+     * room for), and splat_backward with SPLAT_GRADS_ACCUM_ZEROED then skips its 64-byte-per-Gaussian memset launch */
+    float *accum_to_zero;
 } SplatState;
 
 const char *splat_error_string(int code);
@@ -245,6 +255,7 @@ typedef struct SplatGrads {
                                         the forward pass of this state raised status[1] or status[3] (its lists were truncated).  For a caller that
                                         launches the backward pass without having looked at the flags: gradients formed on truncated lists never
                                         reach an optimizer as plausible numbers */
+#define SPLAT_GRADS_ACCUM_ZEROED 4 /* gr->accum is zero already (SplatState.accum_to_zero of the forward pass): splat_render_backward does not clear it */
 #define SPLAT_GRADS_UPSTREAM_SCALE 1 /* dL_dscales WITHOUT the factor cam->scale_modifier: the numbers the CUDA original returns (its computeCov3D
                                         adjoint forms dL/d(modifier * s) and hands it out as dL/ds; see dL_dscales above).  Identical at modifier 1.0 */
 
@@ -405,6 +416,7 @@ typedef struct SplatArrayInfo {
 #define SPLAT_LAYOUT_GROUPS 32   /* splat_state_layout: group binning behind the reference API -- group_count (right in front of status: the library
                                     zeroes both with one memset), group_recs for `group_stride` = 4 * tile_stride records per group, where
                                     tile_stride = capacity / tiles; no key buckets */
+#define SPLAT_LAYOUT_RECS 128     /* tile_recs: 48 bytes x capacity (a forward pass that a backward pass will follow) */
 #define SPLAT_LAYOUT_TILE_ORDER 64 /* splat_iter_workspace_layout / _bind: st.tile_work, st.tile_order (launch order of the composites; the
                                     library's first iteration on a workspace treats an order buffer it has not written yet as the natural
                                     order -- see SplatState.tile_order) */

@@ -42,12 +42,12 @@ class SplatState(C.Structure):
     _fields_ = [("depth", _fp), ("xy", _fp), ("conic_opacity", _fp), ("rect", _fp), ("radii", _fp),
                 ("rgb", _fp), ("clamped", _fp),
                 ("tile_count", _fp), ("tile_base", _fp), ("tile_cursor", _fp),
-                ("keys", _fp), ("point_list", _fp), ("capacity", C.c_int64), ("keys_alt", _fp), ("long_base", _fp), ("long_items", _fp),
+                ("keys", _fp), ("point_list", _fp), ("capacity", C.c_int64), ("tile_recs", _fp), ("keys_alt", _fp), ("long_base", _fp), ("long_items", _fp),
                 ("group_count", _fp), ("group_recs", _fp),
                 ("max_list_hint", C.c_int32), ("order_hint", C.c_int32), ("sub_bins", C.c_int32), ("tile_stride", C.c_int32),
                 ("group_stride", C.c_int32), ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),
                 ("tile_work", _fp), ("tile_order", _fp),
-                ("final_T", _fp), ("n_contrib", _fp), ("status", _fp), ("status_host", _fp)]
+                ("final_T", _fp), ("n_contrib", _fp), ("status", _fp), ("status_host", _fp), ("accum_to_zero", _fp)]
 
 
 class SplatGrads(C.Structure):
@@ -129,8 +129,8 @@ SPLAT_POSE_STATE = 24
 SPLAT_ITER_DCAM = 32
 SPLAT_SLAB_ALIGN = 256
 SPLAT_LAYOUT_SH, SPLAT_LAYOUT_LONG_LISTS, SPLAT_LAYOUT_BACKWARD, SPLAT_LAYOUT_SSIM, SPLAT_LAYOUT_OUTLIER = 1, 2, 4, 8, 16
-SPLAT_LAYOUT_GROUPS, SPLAT_LAYOUT_TILE_ORDER = 32, 64
-SPLAT_GRADS_UPSTREAM_SCALE, SPLAT_GRADS_POISON_IF_FLAGGED = 1, 2
+SPLAT_LAYOUT_GROUPS, SPLAT_LAYOUT_TILE_ORDER, SPLAT_LAYOUT_RECS = 32, 64, 128
+SPLAT_GRADS_UPSTREAM_SCALE, SPLAT_GRADS_POISON_IF_FLAGGED, SPLAT_GRADS_ACCUM_ZEROED = 1, 2, 4
 SPLAT_LAYOUT_MAX_ARRAYS = 48
 
 EXPORTS = (

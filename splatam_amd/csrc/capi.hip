@@ -246,6 +246,10 @@ int splat_iter_time_kernel(int fn, int iters, const SplatCamera *cam, int32_t P,
     // bucketed lists: the iteration's last kernel consumed and reset the tile counters and left the counts in the cursor words
     SplatState st = ws->st;
     if (st.tile_stride > 0) st.tile_count = st.tile_cursor;
+    // the backward composite ALONE (fn 1, 4): the records in tile_recs belong to whatever forward composite ran last on this state
+    // (the one-kernel tracking form writes none for a list's last batch): it gathers.  fn 3 alternates with the forward composite,
+    // which writes them: the product's pair
+    if (fn == 1 || fn == 4) st.tile_recs = nullptr;
     // fn 2: the forward composite in the form the iteration launches when the lists are short -- it filters its group's records (or
     // reads its bucket), sorts and publishes the tile's list itself.  The iteration's last kernel left the groups' record counts in
     // word 1 of their counter lines and the tiles' counts in the cursor words; the re-published lists and counts are the same values
@@ -424,6 +428,7 @@ void state_arrays(LayoutWriter &w, bool iter, int32_t P, int32_t width, int32_t 
     w.add(NAME("tile_cursor"), 4 * T * S * SPLAT_COUNTER_STRIDE, 0);
     if (iter || !(flags & SPLAT_LAYOUT_GROUPS)) w.add(NAME("keys"), 8 * cap, 0);
     w.add(NAME("point_list"), 4 * cap, 0);
+    if (flags & SPLAT_LAYOUT_RECS) w.add(NAME("tile_recs"), 48 * cap, 0);
     if (flags & SPLAT_LAYOUT_LONG_LISTS) {
         w.add(NAME("keys_alt"), 8 * cap, 0);
         w.add(NAME("long_items"), 4 * (cap / 1024 + T + 1), 0);
@@ -487,7 +492,7 @@ int splat_state_bind(SplatState *st, SplatGrads *gr, void *slab, const SplatArra
 #define BIND(field, T) if (strcmp(name, #field) == 0) { st->field = static_cast<T>(p); continue; }
         BIND(depth, float *) BIND(xy, float *) BIND(conic_opacity, float *) BIND(rect, uint32_t *) BIND(radii, int32_t *)
         BIND(rgb, float *) BIND(clamped, uint8_t *) BIND(tile_count, uint32_t *) BIND(tile_base, uint32_t *) BIND(tile_cursor, uint32_t *)
-        BIND(keys, uint64_t *) BIND(point_list, uint32_t *) BIND(keys_alt, uint64_t *) BIND(long_base, uint32_t *) BIND(long_items, uint32_t *)
+        BIND(keys, uint64_t *) BIND(point_list, uint32_t *) BIND(tile_recs, float *) BIND(keys_alt, uint64_t *) BIND(long_base, uint32_t *) BIND(long_items, uint32_t *)
         BIND(group_count, uint32_t *) BIND(group_recs, uint32_t *) BIND(tile_work, uint32_t *) BIND(tile_order, uint32_t *)
         BIND(final_T, float *) BIND(n_contrib, int32_t *) BIND(status, int32_t *)
 #undef BIND

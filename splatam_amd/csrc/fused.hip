@@ -1280,6 +1280,7 @@ hipError_t launch_iter_means2d_accumulate(const SplatCamera &cam, const SplatMap
     // bucketed lists: the iteration's last kernel folded and reset the tile counters, and left the counts in the cursor words
     SplatState st = ws.st;
     if (st.tile_stride > 0) st.tile_count = st.tile_cursor;
+    st.tile_recs = nullptr;         // (whichever composite ran last on this state may not have left every batch's records: gather)
     hipError_t e = launch_render_backward_rgb_only(cam, ws.feat8, st, ws.dL_dout6, ws.accum, P, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(means2d_accumulate_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, ws, P, cam.image_width, cam.image_height, gaccum,

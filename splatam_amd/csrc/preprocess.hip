@@ -77,7 +77,14 @@ __global__ __launch_bounds__(kGroupBlock) void preprocess_forward_group_kernel(S
     load_cam(c, cam);
     Projected o{};
     bool vis = false;
-    if (i < g.P) vis = preprocess_forward_one(cam, c, g, st, i, o);
+    if (i < g.P) {
+        vis = preprocess_forward_one(cam, c, g, st, i, o);
+        if (st.accum_to_zero) {         // the accumulator row the backward pass of this call will add into (SplatState.accum_to_zero)
+            float4 *a4 = reinterpret_cast<float4 *>(st.accum_to_zero + (size_t)i * SPLAT_GRAD_STRIDE);
+#pragma unroll
+            for (int k = 0; k < SPLAT_GRAD_STRIDE / 4; ++k) a4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     file_group_records<kGroupBlock>(st, s_grp, i, vis && o.y1 > o.y0 && o.x1 > o.x0, o.x0, o.y0, o.x1, o.y1, o.depth, ggx, num_groups);
 }
 

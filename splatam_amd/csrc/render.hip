@@ -457,7 +457,10 @@ constexpr int forward_fp() { return forward_compact6<C, CS, WITH_DEPTH>() ? 4 : 
 // The forward composite of ONE tile up to its per-pixel results (the kernels below add their epilogues): builds / reads the tile's list,
 // stages it batch by batch into B and composites front to back.  Returns the index of the LAST batch it staged (the one B still holds;
 // -1: empty list).  Lane l of wave w = pixel (l & 3, (l >> 2) & 3) of block (l >> 4) of quadrant w (one 4x4 block per 16-lane row).
-template <int C, int CS, bool WITH_DEPTH, bool SORT, class BatchT>
+// WRITE_RECS: SplatState.tile_recs (when the caller gave one) receives the staged record of every list entry, for a SEPARATE backward
+// composite (the fused forward + backward composite keeps gathering what it re-stages: measured -1 % with records at B-loop,
+// profiles/r06_experiments.md 2)
+template <int C, int CS, bool WITH_DEPTH, bool SORT, bool WRITE_RECS = true, class BatchT>
 __device__ __forceinline__ int forward_tile(const float *colors, SplatState &st, BatchT &B, uint64_t *s_keys, const int tile, const int tx, const int ty,
                                             const int gx, const int tid, const float fpx, const float fpy, const bool inside, float &Tr, float &D,
                                             float (&Cc)[C], unsigned &last) {
@@ -558,6 +561,23 @@ __device__ __forceinline__ int forward_tile(const float *colors, SplatState &st,
             __syncthreads();                        // every wave has finished reading the previous batch; this batch's list counts are in
             commit(B, pre, tid, wdone ? 1u : 0u, bi & 1);
             staged = bi;
+            if constexpr (FP == 4 && WRITE_RECS) {
+                // the staged record goes to memory as well (SplatState.tile_recs): the backward composite re-stages the list from ONE
+                // coalesced 48-byte read per entry instead of the id -> conic / centre / colour gathers and the culling tests.  The
+                // spare word carries the quadrant mask (a quadrant is visited when one of its four blocks is)
+                if (st.tile_recs) {
+                    const int e = bi * kBatchEntries + tid;
+                    if (tid < kBatchEntries && e < n) {
+                        unsigned qm = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) qm |= ((pre.mask >> (4 * q)) & 0xFu) ? (1u << q) : 0u;
+                        float4 *dst = reinterpret_cast<float4 *>(st.tile_recs) + (size_t)(lo + (unsigned)e) * 3;
+                        dst[0] = pre.ga;
+                        dst[1] = make_float4(pre.feat[0], pre.feat[1], pre.feat[2], pre.feat[3]);
+                        dst[2] = make_float4(pre.mu.x, pre.mu.y, __uint_as_float(pre.id), __uint_as_float(qm));
+                    }
+                }
+            }
             __syncthreads();
             // every wave was finished when this batch was committed: the rest of the list cannot contribute
             const unsigned alldone = B.flag[0] & B.flag[1] & B.flag[2] & B.flag[3];
@@ -994,9 +1014,37 @@ __device__ __forceinline__ void backward_core(const float *colors, const SplatSt
     int nslot = 0;                                              // wave-uniform
     Staged<FP> pre;
     const bool handed_over = staged == nb - 1;                  // (uniform) the first batch of this pass is the one already in B
+    // one list entry as the backward pass stages it: the record the forward composite left in SplatState.tile_recs (one coalesced
+    // 48-byte read: parameters, colours, centre, id, quadrant mask), or gathered and culled again from the per-Gaussian arrays
+    const float4 *const recs = FP == 4 ? reinterpret_cast<const float4 *>(st.tile_recs) : nullptr;
+    auto stage = [&](unsigned e, bool valid) {
+        if (recs) {
+            pre.ga = make_float4(0.f, 0.f, 0.f, 0.f);
+            pre.mu = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int f = 0; f < FP; ++f) pre.feat[f] = 0.f;
+            pre.mask = 0;
+            pre.id = 0;
+            pre.aux = 0.f;
+            if (valid) {
+                const float4 *r = recs + (size_t)(lo + e) * 3;
+                const float4 a = r[0], f = r[1], m = r[2];
+                pre.ga = a;
+                pre.feat[0] = f.x;
+                if constexpr (FP > 1) pre.feat[1] = f.y;
+                if constexpr (FP > 2) pre.feat[2] = f.z;
+                if constexpr (FP > 3) pre.feat[3] = f.w;
+                pre.mu = make_float2(m.x, m.y);
+                pre.id = __float_as_uint(m.z);
+                pre.mask = __float_as_uint(m.w) & 15u;
+            }
+        } else {
+            gather<CL, CS, false, FP>(pre, st, colors, lo + e, valid, tile_x0, tile_y0);
+        }
+    };
     if (!handed_over) {
         const unsigned e = (unsigned)((nb - 1) * kBatchEntries + tid);
-        gather<CL, CS, false, FP>(pre, st, colors, lo + e, tid < kBatchEntries && e < tmax, tile_x0, tile_y0);
+        stage(e, tid < kBatchEntries && e < tmax);
     }
     for (int bi = nb - 1; bi >= 0; --bi) {
         if (!(handed_over && bi == nb - 1)) {
@@ -1005,7 +1053,7 @@ __device__ __forceinline__ void backward_core(const float *colors, const SplatSt
             __syncthreads();
         }
         const bool more = bi > 0;
-        if (more) gather<CL, CS, false, FP>(pre, st, colors, lo + (unsigned)((bi - 1) * kBatchEntries + tid), tid < kBatchEntries, tile_x0, tile_y0);
+        if (more) stage((unsigned)((bi - 1) * kBatchEntries + tid), tid < kBatchEntries);
         const int base = bi * kBatchEntries;
         const int lim = (int)wmax - base;                      // entries [0, lim) of this batch can matter to this wave
         const int last_rec = ((int)last - base - 1) * (int)(R4 * sizeof(float4));      // this pixel blended the batch's records at byte offsets [0, last_rec]
@@ -1249,7 +1297,7 @@ __global__ __launch_bounds__(256, 5) void render_track_fused_kernel(TrackFusedAr
     unsigned flast = 0;
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) Cc[ch] = 0.f;
-    const int staged = forward_tile<C, CS, false, true>(feat8, st, B, s_keys, tile, tx, ty, gx, tid, (float)fx_, (float)fy_, finside, Tr, D, Cc, flast);
+    const int staged = forward_tile<C, CS, false, true, false>(feat8, st, B, s_keys, tile, tx, ty, gx, tid, (float)fx_, (float)fy_, finside, Tr, D, Cc, flast);
     (void)D;
     // ---- the loss of this pixel and its gradient planes, in registers (the arithmetic of render_forward_kernel's TRACK epilogue)
     float acc_depth = 0.f, acc_im = 0.f, g[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1407,8 +1455,10 @@ hipError_t launch_render_backward(const SplatCamera &cam, const SplatGaussians &
                                   hipStream_t s) {
     const int T = (int)splat_num_tiles(cam.image_width, cam.image_height);
     const float *col = colour_source(g, st);
-    hipError_t e = hipMemsetAsync(gr.accum, 0, sizeof(float) * SPLAT_GRAD_STRIDE * (size_t)g.P, s);
-    if (e != hipSuccess) return e;
+    if (!(gr.flags & SPLAT_GRADS_ACCUM_ZEROED)) {
+        hipError_t e = hipMemsetAsync(gr.accum, 0, sizeof(float) * SPLAT_GRAD_STRIDE * (size_t)g.P, s);
+        if (e != hipSuccess) return e;
+    }
     if (T == 0 || g.P == 0) return hipSuccess;
     if (!cam.bg && g.channels == 3) {           // black background (SplatCamera.bg == NULL): the background term of dL/dalpha falls away at compile time
         launch_bwd<3, 3, 7u, 7u, true, false>(cam, col, st, gr.dL_dcolor, gr.accum, T, s);
@@ -1464,11 +1514,13 @@ hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat
 
 // The tracking iteration's composites as ONE launch (render_track_fused_kernel): lists short enough for the composite's own sort, a
 // pixel-local loss (no outlier rejection).  keep_planes: also write out6 / final_T / n_contrib / dL_dout6.
-hipError_t launch_render_track_fused(const SplatCamera &cam, const float *feat8, SplatState &st, float *out6, float *accum,
+hipError_t launch_render_track_fused(const SplatCamera &cam, const float *feat8, SplatState &st_in, float *out6, float *accum,
                                      const TrackLossEpilogue &ep, bool keep_planes, hipStream_t s) {
-    const int T = launch_tiles(cam, st);
+    const int T = launch_tiles(cam, st_in);
     if (T == 0) return hipSuccess;
     const int per = (T + 7) / 8;
+    SplatState st = st_in;
+    st.tile_recs = nullptr;                               // (forward_tile<.., WRITE_RECS = false>: the backward pass gathers what it re-stages)
     if (!keep_planes && g_debug_k7_bits != 0) {           // measurement builds (see render_track_fused_kernel)
         switch (g_debug_k7_bits) {
             case 2: hipLaunchKernelGGL((render_track_fused_kernel<false, 2>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, st, out6, accum, T, per, ep}); break;

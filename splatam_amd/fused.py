@@ -115,6 +115,7 @@ class FusedEngine:
         # rows in creation (pixel-scan) order: true for a map this engine grew itself (add_valid_depth_points / add_new_gaussians
         # append per pixel in scan order); callers that hand over such a map may set it.  Only a speed hint (SplatState.order_hint)
         self.creation_order = bool(self.managed and P == 0)
+        self.use_recs = {"0": 0, "1": 1}.get(os.environ.get("SPLAT_TILE_RECS", "auto"), 2)      # SplatState.tile_recs: 0 never, 1 always, 2 by list length
         self._alloc_lists(self.capacity)
         self._cam = self._make_cam(cam)
         self._cam_ok = {}
@@ -138,7 +139,7 @@ class FusedEngine:
                      ("ssim_maps", "ssim_maps", torch.float32), ("sums", "sums", torch.float64), ("d_cam", "d_cam", torch.float32))
 
     def _layout(self, rows, capacity=0, group_stride=0, outlier=False):
-        flags = _capi.SPLAT_LAYOUT_SSIM | _capi.SPLAT_LAYOUT_TILE_ORDER | (_capi.SPLAT_LAYOUT_OUTLIER if outlier else 0)
+        flags = _capi.SPLAT_LAYOUT_SSIM | _capi.SPLAT_LAYOUT_TILE_ORDER | _capi.SPLAT_LAYOUT_RECS | (_capi.SPLAT_LAYOUT_OUTLIER if outlier else 0)
         return _capi.iter_workspace_layout(int(rows), self.W, self.H, int(capacity), int(group_stride), flags)
 
     def _new(self, lay, name, dtype, tail=()):
@@ -573,6 +574,12 @@ class FusedEngine:
                                  # work-item table of the multi-workgroup sort (SplatState.long_items): one word per 1024 keys of a long list
                                  ("st.long_items", "long_items", torch.int32)):
             self.buf[key] = self._new(lay, name, dtype)
+        # the staged record of every list entry, handed from the forward to the backward composite (SplatState.tile_recs: 48 bytes per
+        # slot; left out beyond 16 GB -- the clustered stress scenes' hundreds of millions of slots -- where the backward composite
+        # gathers as before)
+        self.buf['tile_recs'] = None
+        if self.use_recs and lay.bytes["st.tile_recs"] <= 16 << 30:
+            self.buf['tile_recs'] = self._new(lay, "st.tile_recs", torch.float32)
 
     def _make_cam(self, settings):
         bg = _cached_contiguous(settings.bg)
@@ -631,6 +638,11 @@ class FusedEngine:
         st.tile_count, st.tile_base, st.tile_cursor = b['tile_count'].data_ptr(), b['tile_base'].data_ptr(), b['tile_cursor'].data_ptr()
         st.keys, st.point_list, st.capacity = b['keys'].data_ptr(), b['point_list'].data_ptr(), self.capacity
         st.keys_alt, st.long_base = b['keys_alt'].data_ptr(), b['long_base'].data_ptr()
+        # staged records handed from the forward to the backward composite: pays where a tile's list is several batches long (every batch
+        # but the last is re-staged: B-loop, mapping +1.4 %) and costs where it is one (B: the forward composite's 34 MB of extra stores,
+        # mapping -1.4 %): profiles/r06_experiments.md 2.  SPLAT_TILE_RECS=1 / 0 forces it on / off
+        recs_on = self.use_recs == 1 or (self.use_recs == 2 and self.max_list_hint > 255)
+        st.tile_recs = b['tile_recs'].data_ptr() if (recs_on and b.get('tile_recs') is not None) else None
         st.long_items = b['long_items'].data_ptr()
         st.max_list_hint = self.max_list_hint
         st.tile_stride = self.tile_stride

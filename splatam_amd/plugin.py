@@ -275,9 +275,23 @@ class _Session:
         rep.digested = True
         if host is None:
             host = rep.host_tensor
+        # a flagged report: the iterations of this engine that were launched behind it (their reports are still in flight) were gated on
+        # the device too -- every one of them raised the skipped count d_cam[21], and the host-side step counts advanced with every
+        # step().  The NEWEST of those reports carries the total: wait for it BEFORE the flag is cleared (digest_report queues the
+        # clear behind them), so that all of them are taken back, not just the first
+        flagged = float(host[12]) != 0.0 or any(int(v) != 0 for v in host.view(torch.int32)[[17, 19]].tolist())
+        skipped_in_flight = 0
+        if flagged:
+            for e2, r2, h2, ev2 in reversed(self.pending):
+                if e2 is eng and r2 is not rep:
+                    ev2.synchronize()
+                    skipped_in_flight = int(h2.view(torch.int32)[21])
+                    break
         if eng.digest_report(host):
-            self.stats["skipped_iterations"] += eng.skipped_iterations
-            self.lost_steps(rep, eng.skipped_iterations)
+            skipped = max(eng.skipped_iterations, skipped_in_flight)
+            eng.skipped_iterations = skipped
+            self.stats["skipped_iterations"] += skipped
+            self.lost_steps(rep, skipped)
             # reports already in flight were written under the same flag: they carry nothing new
             for _, r, _, _ in self.pending:
                 r.digested = True

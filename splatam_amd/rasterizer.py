@@ -285,7 +285,18 @@ LONG_LIST = 4096        # per-tile lists beyond this are sorted by the multi-wor
 LONG_ITEM_TABLE = True   # SplatState.long_items (work-item table of those kernels); False: they binary-search long_base (tests)
 
 
-def _alloc_lists(pk: _Pack, dev, capacity: int, longest=None):
+# the forward composite leaves its staged records for the backward one (SplatState.tile_recs): pays where a tile's list is several
+# 255-entry batches long, costs where it is one (profiles/r06_experiments.md 2).  None: by the scene's longest list; True / False: forced
+USE_TILE_RECS = None
+
+
+def _want_recs(will_backward: bool, longest) -> bool:
+    if not will_backward or USE_TILE_RECS is False:
+        return False
+    return bool(USE_TILE_RECS) or (longest is not None and longest > 255)
+
+
+def _alloc_lists(pk: _Pack, dev, capacity: int, longest=None, recs=False):
     """``longest``: the longest per-tile list if the host knows it (exact mode); None = unknown (lazy mode).  Sizes from the library's
     layout for this capacity (splat_state_layout)."""
     capacity = max(int(capacity), 1)
@@ -296,6 +307,10 @@ def _alloc_lists(pk: _Pack, dev, capacity: int, longest=None):
     plist = torch.empty(lay.bytes["point_list"] // 4, dtype=torch.int32, device=dev)
     pk.st.keys, pk.st.point_list, pk.st.capacity = keys.data_ptr(), plist.data_ptr(), capacity
     pk.tensors.update(keys=keys, point_list=plist)
+    if recs and pk.g.channels <= 3:
+        tr = torch.empty(12 * capacity, dtype=torch.float32, device=dev)
+        pk.st.tile_recs = tr.data_ptr()
+        pk.tensors.update(tile_recs=tr)
     if long_lists:
         alt = torch.empty(lay.bytes["keys_alt"] // 8, dtype=torch.int64, device=dev)
         pk.st.keys_alt = alt.data_ptr()
@@ -306,16 +321,22 @@ def _alloc_lists(pk: _Pack, dev, capacity: int, longest=None):
             pk.tensors.update(long_items=items)
 
 
-def _alloc_state_fast(pk: _Pack, dev, P: int, H: int, W: int, longest: int):
+def _alloc_state_fast(pk: _Pack, dev, P: int, H: int, W: int, longest: int, recs: bool = True, backward: bool = True):
     """Scratch of a fast-path call ("auto" sync mode): group binning + published lists, ONE slab laid out by the library
     (splat_state_layout with SPLAT_LAYOUT_GROUPS: no key buckets, no sort scratch; the group counters sit in front of the status words
     so that the library zeroes both with one memset)."""
     i32 = torch.int32
     T = ((W + 15) // 16) * ((H + 15) // 16)
     cap = T * FAST_STRIDE
-    lay = _capi.state_layout(P, W, H, 1, cap, _capi.SPLAT_LAYOUT_GROUPS)
+    lay = _capi.state_layout(P, W, H, 1, cap, _capi.SPLAT_LAYOUT_GROUPS | (_capi.SPLAT_LAYOUT_RECS if recs else 0) |
+                             (_capi.SPLAT_LAYOUT_BACKWARD if backward else 0))
     slab = torch.empty(lay.total, dtype=torch.uint8, device=dev)
-    _capi.check(_capi.lib().splat_state_bind(C.byref(pk.st), None, slab.data_ptr(), lay.arrays, lay.n, 1, cap), "splat_state_bind")
+    base = slab.data_ptr()
+    _capi.check(_capi.lib().splat_state_bind(C.byref(pk.st), None, base, lay.arrays, lay.n, 1, cap), "splat_state_bind")
+    if backward:
+        # the backward pass' accumulator lives in the slab and is zeroed by the per-Gaussian kernel of THIS forward pass
+        # (SplatState.accum_to_zero): no memset launch per backward pass
+        pk.accum_ptr = pk.st.accum_to_zero = base + lay.offset["accum"]
     # (final_T / n_contrib stay where the library's layout put them, inside the slab; radii is an OUTPUT of the call and a tensor of its own,
     #  so that a caller who keeps it does not keep the slab)
     radii = torch.empty(P, dtype=i32, device=dev)
@@ -479,7 +500,7 @@ def rasterize_forward(settings, means3D, colors, opacities, scales, rotations, c
     the exact mode does) and the render is repeated with the raised capacity."""
     for _ in range(4):
         out = _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotations, cov3D, shs,
-                                      means3D if means3D_src is None else means3D_src)
+                                      means3D if means3D_src is None else means3D_src, will_backward=will_backward)
         if not will_backward and getattr(out[3], "fast", None) is not None:
             # a fast-path render nobody will differentiate: its flag is resolved here (the wait the exact path makes anyway), and a
             # flagged render is repeated on exact lists -- what is returned was never composited from truncated lists
@@ -507,7 +528,7 @@ def _fast_eligible(key, channels, use_sh) -> bool:
     return stt is not None and 0 < stt['longest'] * FAST_MARGIN <= FAST_STRIDE and stt['since_exact'] < FAST_REFRESH
 
 
-def _rasterize_forward_fast(settings, means3D, colors, opacities, scales, rotations, cov3D, shs, key):
+def _rasterize_forward_fast(settings, means3D, colors, opacities, scales, rotations, cov3D, shs, key, will_backward=True):
     """The front end of the fused iteration behind the reference API: K1 with group binning, the forward composite that sorts its
     own lists.  Nothing is read back; the device raises pk.flag_word (pinned host memory) if a list did not fit after all."""
     L = _capi.lib()
@@ -515,7 +536,8 @@ def _rasterize_forward_fast(settings, means3D, colors, opacities, scales, rotati
     H, W = int(settings.image_height), int(settings.image_width)
     P = means3D.shape[0]
     pk = _build_pack(settings, means3D, colors, opacities, scales, rotations, cov3D, shs)
-    radii, _ = _alloc_state_fast(pk, dev, P, H, W, _scene_stats[key]['longest'])
+    radii, _ = _alloc_state_fast(pk, dev, P, H, W, _scene_stats[key]['longest'], recs=_want_recs(will_backward, _scene_stats[key]['longest']),
+                                 backward=will_backward)
     out_color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
     out_depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
     ring = _ring()
@@ -574,7 +596,8 @@ def fast_call_flagged(pk) -> bool:
     return flagged
 
 
-def _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotations, cov3D, shs, means3D_src, force_exact=False):
+def _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotations, cov3D, shs, means3D_src, force_exact=False,
+                            will_backward=True):
     L = _capi.lib()
     dev = means3D.device
     H, W = int(settings.image_height), int(settings.image_width)
@@ -584,11 +607,17 @@ def _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotati
     if _unchecked:
         _poll_unchecked()
     if not force_exact and _fast_eligible(scene, 3 if use_sh else colors.shape[1], use_sh) and cov3D.numel() == 0:
-        return _rasterize_forward_fast(settings, means3D, colors, opacities, scales, rotations, cov3D, shs, scene)
+        return _rasterize_forward_fast(settings, means3D, colors, opacities, scales, rotations, cov3D, shs, scene, will_backward)
     cacheable = _GEOM_CACHE and _SYNC_MODE == "exact" and not use_sh and cov3D.numel() == 0 and scales.numel() > 0 and rotations.numel() > 0
     if cacheable:
         pk = _shared_geometry(settings, means3D, colors, opacities, scales, rotations, cov3D, shs, means3D_src)
         if pk is not None:                  # K6 alone, on the cached call's geometry and sorted lists
+            # (the staged records hold THIS call's colours: a buffer of its own, or none -- never the cached call's)
+            pk.st.tile_recs = None
+            if _want_recs(will_backward, _longest_seen.get((dev.index, P, H, W))) and pk.g.channels <= 3 and pk.st.capacity > 0:
+                tr = torch.empty(12 * int(pk.st.capacity), dtype=torch.float32, device=dev)
+                pk.st.tile_recs = tr.data_ptr()
+                pk.tensors = dict(pk.tensors, tile_recs=tr)
             out_color = torch.empty(pk.g.channels, H, W, dtype=torch.float32, device=dev)
             out_depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
@@ -616,14 +645,14 @@ def _rasterize_forward_once(settings, means3D, colors, opacities, scales, rotati
             _scene_stats[scene] = {'longest': int(stat[2]), 'since_exact': 0}
             fast_path_stats["exact"] += 1
             if _SYNC_MODE != "lazy":
-                _alloc_lists(pk, dev, num_rendered, longest=int(stat[2]))
+                _alloc_lists(pk, dev, num_rendered, longest=int(stat[2]), recs=_want_recs(will_backward, int(stat[2])))
                 pk.st.max_list_hint = int(stat[2])        # lets the library skip the long-list sort kernel
             else:                                         # lazy, first call for this shape: learn the size
                 _capacity_hint[hint_key] = int(num_rendered * 1.5) + 1024
-                _alloc_lists(pk, dev, _capacity_hint[hint_key])
+                _alloc_lists(pk, dev, _capacity_hint[hint_key], recs=_want_recs(will_backward, int(stat[2])))
             pk.num_rendered = num_rendered
         else:
-            _alloc_lists(pk, dev, cap)
+            _alloc_lists(pk, dev, cap, recs=_want_recs(will_backward, _longest_seen.get(hint_key)))
             _capi.check(L.splat_preprocess_forward(C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), stream), "splat_preprocess_forward")
             pk.num_rendered = None
         _capi.check(L.splat_bin_forward(C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), stream), "splat_bin_forward")
@@ -693,25 +722,29 @@ def rasterize_backward(pk: _Pack, grad_color, need_scale_rot: bool, need_cov3D: 
     sh_n = 1
     for d in sh_shape:
         sh_n *= int(d)
-    sizes = [accum_bytes // 4, 4 * P if need_scale_rot else 0, 3 * P, 3 * P, P, 0 if use_sh else Cn * P, 3 * P if need_scale_rot else 0,
+    # (the accumulator first: its rows are read as float4; then the quaternion rows; the rest needs no alignment)
+    accum_ptr = getattr(pk, "accum_ptr", None)          # (a fast-path forward pass left a zeroed accumulator in its slab)
+    if accum_ptr is not None:
+        pk.accum_ptr = None                             # (one backward pass per zeroing)
+    sizes = [0 if accum_ptr is not None else accum_bytes // 4, 4 * P if need_scale_rot else 0, 3 * P, 3 * P, P, 0 if use_sh else Cn * P, 3 * P if need_scale_rot else 0,
              6 * P if need_cov3D else 0, sh_n if use_sh else 0]
-    sizes = [(n + 3) // 4 * 4 for n in sizes]
     parts = torch.empty(sum(sizes), dtype=f32, device=dev).split_with_sizes(sizes)
     accum = parts[0]
-    d_rots = parts[1][:4 * P].view(P, 4) if need_scale_rot else None
-    d_means3D = parts[2][:3 * P].view(P, 3)
-    d_means2D = parts[3][:3 * P].view(P, 3)
-    d_opac = parts[4][:P].view(P, 1)
-    d_colors = None if use_sh else parts[5][:Cn * P].view(P, Cn)
-    d_scales = parts[6][:3 * P].view(P, 3) if need_scale_rot else None
-    d_cov = parts[7][:6 * P].view(P, 6) if need_cov3D else None
-    d_sh = parts[8][:sh_n].view(sh_shape) if use_sh else None
+    d_rots = parts[1].view(P, 4) if need_scale_rot else None
+    d_means3D = parts[2].view(P, 3)
+    d_means2D = parts[3].view(P, 3)
+    d_opac = parts[4].view(P, 1)
+    d_colors = None if use_sh else parts[5].view(P, Cn)
+    d_scales = parts[6].view(P, 3) if need_scale_rot else None
+    d_cov = parts[7].view(P, 6) if need_cov3D else None
+    d_sh = parts[8].view(sh_shape) if use_sh else None
     gr = _capi.SplatGrads()
-    gr.dL_dcolor, gr.accum = grad_color.data_ptr(), _ptr(accum)
+    gr.dL_dcolor, gr.accum = grad_color.data_ptr(), (accum_ptr if accum_ptr is not None else _ptr(accum))
     gr.dL_dmeans3D, gr.dL_dmeans2D = _ptr(d_means3D), _ptr(d_means2D)
     gr.dL_dcolors, gr.dL_dopacities = _ptr(d_colors), _ptr(d_opac)
     gr.dL_dscales, gr.dL_drotations, gr.dL_dcov3D, gr.dL_dshs = _ptr(d_scales), _ptr(d_rots), _ptr(d_cov), _ptr(d_sh)
-    gr.flags = (_capi.SPLAT_GRADS_UPSTREAM_SCALE if _UPSTREAM_SCALE_GRADIENT else 0) | (_capi.SPLAT_GRADS_POISON_IF_FLAGGED if poison else 0)
+    gr.flags = ((_capi.SPLAT_GRADS_UPSTREAM_SCALE if _UPSTREAM_SCALE_GRADIENT else 0) | (_capi.SPLAT_GRADS_POISON_IF_FLAGGED if poison else 0) |
+                (_capi.SPLAT_GRADS_ACCUM_ZEROED if accum_ptr is not None else 0))
     with _on_device(dev):
         _capi.check(L.splat_backward(C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), C.byref(gr), _stream(dev)), "splat_backward")
     return d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rots, d_cov

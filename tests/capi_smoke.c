@@ -3,7 +3,8 @@
  * What a maintainer of the reference would write to call this library from C / cgo / JNI: size the scratch with
  * splat_state_layout, hipMalloc ONE slab, splat_state_bind, then splat_preprocess_forward -> (read status[0]) -> splat_bin_forward ->
  * splat_render_forward -> splat_backward on 1 000 Gaussians, and compare every output with the CPU oracle through ITS C entry
- * points (oracle/raster_ref.c; test infrastructure: the checker, linked here only because this is a test).
+ * points (oracle/raster_ref.c; test infrastructure: the checker, linked here only because this is a test).  Part 2: the same call with
+ * group binning (no host read between the calls); part 3: the fused iteration through splat_iter_workspace_layout / _bind.
  *
  * Built by tests/test_gpu_capi_c.py (gcc, no hipcc needed):
  *   gcc -std=c99 -O1 -D__HIP_PLATFORM_AMD__ -I include -I /opt/rocm/include tests/capi_smoke.c \
@@ -177,6 +178,116 @@ int main(void) {
     fail += compare("dL/dopacities", h_dop, o_dop, P, 0.f, 1e-3f, 2);
     fail += compare("dL/dscales", h_dsc, o_dsc, P * 3, 0.f, 1e-3f, 2);
     fail += compare("dL/drotations", h_drot, o_drot, P * 4, 0.f, 1e-3f, 2);
+    /* ---- part 2: the same call with GROUP BINNING (include/splat_hip.h, ABI 10): the lists of this scene are known to be short
+     *      (status[2] of the call above), so K1 files group records, the forward composite sorts its own lists and nothing has to be read
+     *      between the calls; staged records handed to the backward composite (SPLAT_LAYOUT_RECS); the overflow flag in a host word ---- */
+    {
+        const int32_t longest = status[2];
+        const int64_t tiles = (int64_t)splat_num_tiles(W, H), stride = 1024, cap2 = tiles * stride;
+        SplatArrayInfo a2[SPLAT_LAYOUT_MAX_ARRAYS];
+        size_t total2 = 0;
+        int n2 = splat_state_layout(P, W, H, 1, cap2, SPLAT_LAYOUT_GROUPS | SPLAT_LAYOUT_BACKWARD | SPLAT_LAYOUT_RECS, a2, SPLAT_LAYOUT_MAX_ARRAYS, &total2);
+        if (n2 <= 0 || n2 > SPLAT_LAYOUT_MAX_ARRAYS) return 1;
+        void *slab2 = NULL;
+        HIP(hipMalloc(&slab2, total2));
+        SplatState s2;
+        SplatGrads g2 = gr;                     /* the same gradient outputs, a scratch of its own */
+        memset(&s2, 0, sizeof s2);
+        SPLAT(splat_state_bind(&s2, &g2, slab2, a2, n2, 1, cap2));
+        if (!s2.group_count || !s2.group_recs || !s2.tile_recs || s2.keys) { fprintf(stderr, "GROUPS layout: unexpected arrays\n"); return 1; }
+        s2.tile_stride = (int32_t)stride;
+        s2.group_stride = (int32_t)(SPLAT_GROUP_TILES * SPLAT_GROUP_TILES * stride);
+        s2.max_list_hint = longest + longest / 2 + 1;
+        int32_t *flag_host = NULL;
+        HIP(hipHostMalloc((void **)&flag_host, sizeof(int32_t), hipHostMallocDefault));
+        *flag_host = 0;
+        s2.status_host = flag_host;
+        HIP(hipMemsetAsync(d_color, 0, sizeof o_color, stream));
+        SPLAT(splat_forward(&cam, &g, &s2, d_color, d_depth, stream));     /* two launches, no host read */
+        SPLAT(splat_backward(&cam, &g, &s2, &g2, stream));
+        HIP(hipStreamSynchronize(stream));
+        if (*flag_host != 0) { fprintf(stderr, "group binning: a list outgrew its bucket (flag %d)\n", *flag_host); return 5; }
+        HIP(hipMemcpy(h_color, d_color, sizeof h_color, hipMemcpyDeviceToHost)); HIP(hipMemcpy(h_depth, d_depth, sizeof h_depth, hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(h_dm3, g2.dL_dmeans3D, sizeof h_dm3, hipMemcpyDeviceToHost)); HIP(hipMemcpy(h_dsc, g2.dL_dscales, sizeof h_dsc, hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(h_dcol, g2.dL_dcolors, sizeof h_dcol, hipMemcpyDeviceToHost));
+        printf("capi_smoke (group binning, longest list %d, slab %zu bytes):\n", longest, total2);
+        fail += compare("color", h_color, o_color, (size_t)C * H * W, 1e-4f, 0.f, 2);
+        fail += compare("depth", h_depth, o_depth, (size_t)H * W, 1e-4f, 1e-4f, 2);
+        fail += compare("dL/dmeans3D", h_dm3, o_dm3, P * 3, 0.f, 1e-3f, 2);
+        fail += compare("dL/dcolors", h_dcol, o_dcol, P * C, 0.f, 1e-3f, 2);
+        fail += compare("dL/dscales", h_dsc, o_dsc, P * 3, 0.f, 1e-3f, 2);
+    }
+
+    /* ---- part 3: the FUSED iteration through splat_iter_workspace_layout / _bind: ONE slab, zeroed as a binding would zero
+     *      it (a superset of what the layout marks zero_init -- the launch order among it: a zeroed tile_order IS the natural order), a
+     *      render, one mapping iteration (which writes the launch order), the render again: bit-identical, and equal to the oracle ---- */
+    {
+        static float logit[P], logsc[P * 3], camq[4] = {1.f, 0.f, 0.f, 0.f}, camt[3] = {0.f, 0.f, 0.f}, w2c[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        static float zeros6[6];
+        for (int i = 0; i < P; i++) {
+            logit[i] = logf(opac[i] / (1.f - opac[i]));
+            for (int k = 0; k < 3; k++) logsc[3 * i + k] = logf(scales[3 * i + k]);
+        }
+        SplatCamera cam0 = cam;
+        cam0.bg = (const float *)to_device(zeros6, sizeof zeros6);          /* the fused iteration renders on black */
+        SplatMap map;
+        memset(&map, 0, sizeof map);
+        map.P = P; map.isotropic = 0; map.num_frames = 1;
+        map.means3D = (float *)to_device(means, sizeof means); map.rgb_colors = (float *)to_device(colors, sizeof colors);
+        map.unnorm_rotations = (float *)to_device(rot, sizeof rot); map.logit_opacities = (float *)to_device(logit, sizeof logit);
+        map.log_scales = (float *)to_device(logsc, sizeof logsc);
+        map.cam_unnorm_rots = (float *)to_device(camq, sizeof camq); map.cam_trans = (float *)to_device(camt, sizeof camt);
+        const int64_t cap3 = 4 * P + 65536;
+        const int fl = SPLAT_LAYOUT_SSIM | SPLAT_LAYOUT_TILE_ORDER;
+        SplatArrayInfo a3[SPLAT_LAYOUT_MAX_ARRAYS];
+        size_t total3 = 0;
+        int n3 = splat_iter_workspace_layout(P, W, H, cap3, 0, fl, a3, SPLAT_LAYOUT_MAX_ARRAYS, &total3);
+        if (n3 <= 0 || n3 > SPLAT_LAYOUT_MAX_ARRAYS || total3 != splat_iter_workspace_bytes(P, W, H, cap3, 0, fl)) return 1;
+        void *slab3 = NULL;
+        HIP(hipMalloc(&slab3, total3));
+        HIP(hipMemset(slab3, 0, total3));
+        SplatIterWorkspace ws;
+        memset(&ws, 0, sizeof ws);
+        SPLAT(splat_iter_workspace_bind(&ws, slab3, a3, n3, cap3, 0));
+        if (!ws.st.tile_order || !ws.st.tile_work || !ws.out6 || !ws.ssim_maps) { fprintf(stderr, "iteration layout: missing arrays\n"); return 1; }
+        SplatFrameData frame;
+        memset(&frame, 0, sizeof frame);
+        frame.w2c = (const float *)to_device(w2c, sizeof w2c);
+        frame.time_idx = 0;
+        SPLAT(splat_iter_render(&cam0, &map, &frame, &ws, stream));
+        static float r_a[6 * H * W], r_b[6 * H * W], o_black[C * H * W], o_bdepth[H * W];
+        static int o_bradii[P];
+        HIP(hipStreamSynchronize(stream));
+        HIP(hipMemcpy(r_a, ws.out6, sizeof r_a, hipMemcpyDeviceToHost));
+        /* a frame to fit: the render itself, brightened (a non-zero loss with a gradient) */
+        static float im[3 * H * W], dep[H * W];
+        for (int i = 0; i < 3 * H * W; i++) im[i] = 0.9f * r_a[i] + 0.05f;
+        for (int i = 0; i < H * W; i++) dep[i] = r_a[3 * H * W + i] * 1.02f;
+        frame.im = (const float *)to_device(im, sizeof im);
+        frame.depth = (const float *)to_device(dep, sizeof dep);
+        SplatLossConfig cfg;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.gaussians_grad = 1; cfg.use_l1 = 1; cfg.sil_thres = 0.5f; cfg.w_im = 0.5f; cfg.w_depth = 1.0f;
+        HIP(hipMalloc((void **)&ws.d_means3D, sizeof o_dm3));
+        SPLAT(splat_iter_loss_backward(&cam0, &map, &frame, &cfg, &ws, stream));      /* its last kernel writes the launch order (tile + 1) */
+        SPLAT(splat_iter_render(&cam0, &map, &frame, &ws, stream));                   /* ... which this render's composite follows */
+        float d_cam[SPLAT_ITER_DCAM];
+        HIP(hipStreamSynchronize(stream));
+        HIP(hipMemcpy(r_b, ws.out6, sizeof r_b, hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(d_cam, ws.d_cam, sizeof d_cam, hipMemcpyDeviceToHost));
+        static uint32_t order[8 * ((W / 16 + 1) * (H / 16 + 1) / 8 + 1)];
+        const size_t order_words = 8 * ((splat_num_tiles(W, H) + 7) / 8);
+        HIP(hipMemcpy(order, ws.st.tile_order, sizeof(uint32_t) * order_words, hipMemcpyDeviceToHost));
+        size_t written = 0;
+        for (size_t i = 0; i < order_words; i++) written += order[i] != 0;
+        int same = memcmp(r_a, r_b, sizeof r_a) == 0;
+        if (ref_forward(ref, P, C, W, H, zeros6, means, colors, opac, scales, 1.f, rot, NULL, view, proj, tanx, tany, o_black, o_bdepth, o_bradii)) return 4;
+        printf("capi_smoke (fused iteration through the layout, slab %zu bytes): loss %.6f, flag %.0f, %zu of %zu order words written, renders %s\n",
+               total3, d_cam[7], d_cam[12], written, order_words, same ? "bit-identical" : "DIFFER");
+        fail += !same || !(d_cam[7] > 0.f) || d_cam[12] != 0.f || written != order_words;
+        fail += compare("rgb planes", r_b, o_black, (size_t)C * H * W, 1e-4f, 0.f, 2);
+        fail += compare("depth plane", r_b + 3 * H * W, o_bdepth, (size_t)H * W, 1e-4f, 1e-4f, 2);
+    }
     ref_destroy(ref);
     if (fail) { printf("capi_smoke FAILED (%d checks)\n", fail); return 10; }
     printf("capi_smoke ok\n");

@@ -36,6 +36,8 @@ def _fresh_rasterizer_policy(request):
     from splatam_amd import rasterizer as rz
     rz.set_sync_mode("auto")
     rz.reset_scene_stats()
+    rz.USE_TILE_RECS = None
     yield
     rz.set_sync_mode("auto")
     rz.reset_scene_stats()
+    rz.USE_TILE_RECS = None

@@ -8,26 +8,17 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXE = os.path.join(ROOT, "tests", "_build", "capi_smoke")
 
 
 def build_capi_smoke(force=False):
-    src = os.path.join(ROOT, "tests", "capi_smoke.c")
-    deps = [src, os.path.join(ROOT, "include", "splat_hip.h"), os.path.join(ROOT, "splatam_amd", "lib", "libsplat_hip.so"),
-            os.path.join(ROOT, "oracle", "_build", "libraster_ref.so")]
+    """(the recipe lives with the library's build: splatam_amd/build.py -- __graft_entry__.build() runs it without importing tests)"""
     from oracle import c_ref
+    from splatam_amd.build import build_capi_smoke as build
     c_ref.build()
-    if not force and os.path.exists(EXE) and all(os.path.getmtime(EXE) >= os.path.getmtime(d) for d in deps):
-        return EXE
-    os.makedirs(os.path.dirname(EXE), exist_ok=True)
-    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
-    cmd = ["gcc", "-std=c99", "-O1", "-Wall", "-Werror=implicit-function-declaration", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
-           "-I", os.path.join(rocm, "include"), src, "-o", EXE, "-L", os.path.join(ROOT, "splatam_amd", "lib"), "-lsplat_hip",
-           "-L", os.path.join(ROOT, "oracle", "_build"), "-lraster_ref", "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-lm",
-           "-Wl,-rpath,$ORIGIN/../../splatam_amd/lib", "-Wl,-rpath,$ORIGIN/../../oracle/_build", "-Wl,-rpath," + os.path.join(rocm, "lib")]
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    assert res.returncode == 0, res.stderr[-4000:]
-    return EXE
+    exe = build(force)
+    if exe is None:
+        pytest.skip("no C toolchain for tests/capi_smoke.c on this machine")
+    return exe
 
 
 def test_plain_c_binding_compiles_against_the_header():

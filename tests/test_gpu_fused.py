@@ -484,6 +484,42 @@ def test_order_hint_changes_nothing_but_speed(order):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["one batch", "several batches", "exact lists"])
+def test_staged_records_handed_to_the_backward_composite_change_nothing_but_speed(case):
+    """SplatState.tile_recs: the forward composite leaves the staged 48-byte record of every list entry (pre-scaled conic, opacity,
+    colours, centre, id, quadrant mask) and the backward composite re-stages its batches from them instead of gathering through the id
+    and culling again.  Same records, same visit order: the planes are untouched and the gradients equal to float-atomic summation
+    order, for lists of one 255-entry batch, of several, and on the exact (unbucketed) lists of an engine's first iteration."""
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    n = 15000 if case != "several batches" else 150000
+    params, variables, frame, cam = _scene(n, 320, 240, seed=41)
+    cfg = slam.REPLICA_MAPPING
+    outs = []
+    for recs in (0, 1):
+        eng = FusedEngine({k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}, cam)
+        eng.use_recs = recs
+        if case != "exact lists":
+            for _ in range(4):
+                eng.loss_backward(frame, 1, cfg, tracking=False)
+                if not eng.check_overflow():
+                    break
+            assert eng.tile_stride > 0
+            assert (eng.max_list_hint > 255) == (case == "several batches"), eng.max_list_hint
+        eng.loss_backward(frame, 1, cfg, tracking=False)
+        torch.cuda.synchronize()
+        ws = eng._workspace(False, with_ssim=False)
+        assert bool(ws.st.tile_recs) == bool(recs)
+        outs.append((eng.buf['out6'].clone(), {k: v.clone() for k, v in eng.grads.items()}, eng.loss()))
+        # ... and the colour pass' own means2D gradient (one more backward composite over the same lists: it gathers) is the same too
+        outs[-1][1]['means2D'] = eng.means2d_gradient().clone()
+    assert torch.equal(outs[0][0], outs[1][0]) and abs(outs[0][2] - outs[1][2]) <= 1e-6 * abs(outs[0][2])
+    for k in outs[0][1]:
+        a, b = outs[0][1][k], outs[1][1][k]
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-12, k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["random", "large", "odd_grid", "tracking"])
 def test_group_binning_changes_nothing_but_speed(case):
     """SplatState.group_count (one record per (Gaussian, 2 x 2-tile group), slots through an LDS histogram; the forward composite

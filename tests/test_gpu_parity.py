@@ -104,13 +104,17 @@ def _check_grads(gg, og, og64=None, flips=None):
     (50, 64, 48, False, False, (0.1, 0.2, 0.3)),           # sparse: most tiles empty
     (20000, 96, 64, False, False, (0, 0, 0)),              # dense: > 1000 Gaussians per tile, early termination
 ])
-@pytest.mark.parametrize("path", ["exact", "fast"])
+@pytest.mark.parametrize("path", ["exact", "fast", "exact + staged records", "fast + staged records"])
 def test_forward_backward_parity(n, W, H, aniso, view, bg, path):
     """Both paths of the default capacity policy: a scene's first call (exact lists: scan, scatter, per-tile sort) and its later ones
     (group binning, lists sorted inside the forward composite, nothing read back) -- the dense scene's lists are beyond what the
     composite sorts, so it must stay on the exact path."""
     cam, rv = scene(n, W, H, 0.9 * W, seed=n, anisotropic=aniso, w2c=tilted_w2c() if view else None, bg=bg)
     gout = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1))
+    if path.endswith("staged records"):         # SplatState.tile_recs forced on (default: by the scene's longest list)
+        from splatam_amd import rasterizer as rz
+        rz.USE_TILE_RECS = True
+        path = path.split(" ")[0]
     if path == "fast" and n == 20000:
         path = "exact"
         with torch.no_grad():           # (the scene's first call; the call under test is its second)

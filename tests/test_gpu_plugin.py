@@ -229,6 +229,25 @@ def test_a_flagged_iteration_moves_nothing_and_is_repeated_or_reported(map_edits
         opt.step()
         torch.cuda.synchronize()
         assert not torch.equal(mp['means3D'].detach(), snap['means3D'])      # ... and the loop goes on
+        # several iterations launched back to back behind a flagged one (their reports are in flight when the first is digested): every
+        # one the device gated is taken back from the host-side step counts -- the count equals the steps that MOVED the map
+        plugin._session.drain()
+        torch.cuda.synchronize()
+        steps_before = eng.map_step if map_edits else int(opt.state[opt.param_groups[0]['params'][0]]['step'])
+        eng.tile_stride, eng.max_list_hint = 64, 40
+        snaps = [mp['means3D'].detach().clone()]
+        for _ in range(4):
+            loss, mv, _ = slam.get_loss(mp, frame, mv, 1, mcfg['loss_weights'], mcfg['use_sil_for_loss'], mcfg['sil_thres'], mcfg['use_l1'],
+                                        mcfg['ignore_outlier_depth_loss'], mapping=True)
+            loss.backward()
+            opt.step()
+            snaps.append(mp['means3D'].detach().clone())
+        plugin._session.drain()
+        torch.cuda.synchronize()
+        moved = sum(0 if torch.equal(a, b) else 1 for a, b in zip(snaps[:-1], snaps[1:]))
+        assert moved < 4                                            # (at least the first of them was gated)
+        steps_after = eng.map_step if map_edits else int(opt.state[opt.param_groups[0]['params'][0]]['step'])
+        assert steps_after - steps_before == moved, (steps_before, steps_after, moved, plugin.session_stats())
 
 
 def test_plugin_speed_against_the_dropin_statements():

@@ -51,3 +51,28 @@ def test_matrix_to_quaternion():
     R = slam.build_rotation(q)[0]
     got = pipeline._matrix_to_quaternion(R)
     assert torch.allclose(got, q, atol=1e-6) or torch.allclose(got, -q, atol=1e-6)
+
+
+def test_save_ply_layout(tmp_path):
+    """splat.ply as /root/reference/scripts/export_ply.py:20-42 lays it out (17 float32 vertex properties; written without plyfile)."""
+    from splatam_amd import export
+    n = 37
+    g = np.random.default_rng(0)
+    means, rots, rgb = g.normal(size=(n, 3)), g.normal(size=(n, 4)), g.uniform(size=(n, 3))
+    logit, log_s = g.normal(size=(n, 1)), g.normal(size=(n, 1))
+    path = export.save_ply(str(tmp_path / "splat.ply"), means, log_s, rots, rgb, logit)
+    raw = open(path, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    lines = head.decode().splitlines()
+    assert lines[:3] == ["ply", "format binary_little_endian 1.0", f"element vertex {n}"]
+    assert [ln.split()[-1] for ln in lines[3:]] == list(export.PLY_ATTRS) and all(ln.startswith("property float ") for ln in lines[3:])
+    t = np.frombuffer(body, dtype="<f4").reshape(n, 17)
+    np.testing.assert_allclose(t[:, 0:3], means.astype(np.float32))
+    assert not t[:, 3:6].any()
+    np.testing.assert_allclose(t[:, 6:9] * 0.28209479177387814 + 0.5, rgb, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(t[:, 9], logit[:, 0].astype(np.float32))
+    np.testing.assert_allclose(t[:, 10:13], np.tile(log_s, (1, 3)).astype(np.float32))
+    np.testing.assert_allclose(t[:, 13:17], rots.astype(np.float32))
+    params = {'means3D': torch.tensor(means), 'log_scales': torch.tensor(log_s), 'unnorm_rotations': torch.tensor(rots),
+              'rgb_colors': torch.tensor(rgb), 'logit_opacities': torch.tensor(logit)}
+    assert open(export.export_params_ply(params, str(tmp_path / "b.ply")), "rb").read() == raw
