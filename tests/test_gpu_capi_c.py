@@ -11,9 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def build_capi_smoke(force=False):
-    """(the recipe lives with the library's build: splatam_amd/build.py -- __graft_entry__.build() runs it without importing tests)"""
+    """(the recipe: scripts/build_capi_smoke.py -- __graft_entry__.build() runs it without importing tests)"""
     from oracle import c_ref
-    from splatam_amd.build import build_capi_smoke as build
+    from scripts.build_capi_smoke import build_capi_smoke as build
     c_ref.build()
     exe = build(force)
     if exe is None:
