@@ -604,6 +604,7 @@ def b_loop_headline(dev, steps=40):
     params, variables, frames, shape = build_scene("B-loop", dev, 2)
     N, W, H = shape
     eng = FusedEngine({k: v.detach().clone() for k, v in params.items()}, frames[1]['cam'], track_max_radius=variables['max_2D_radius'])
+    eng.keep_map_grads = False
     eng.begin_tracking(1)
     for _ in range(3):
         eng.loss_backward(frames[1], 1, slam.REPLICA_TRACKING, tracking=True)
@@ -822,6 +823,7 @@ def main():
     if fused:
         eparams = {k: v.detach().clone() for k, v in params.items()}
         eng = FusedEngine(eparams, frames[1]['cam'], track_max_radius=variables['max_2D_radius'])
+        eng.keep_map_grads = False      # (the loop discards a mapping iteration's gradients after the step, as the reference's zero_grad does)
         eng.begin_tracking(1)
 
         def steps(n, start):
@@ -1052,7 +1054,9 @@ def main():
         wl = (f"C: {N} Gaussians, {W}x{H}, mapping-only, a batch of 8 keyframe views per step sharded over the ranks, one gradient all-reduce"
               if mode_c else f"{args.workload}: {N} Gaussians, {W}x{H}, SplaTAM tracking+mapping loop (2:3 mix), isotropic map"
                    + ("; fused tracking iterations do not form dL/d(rgb, opacity, scale): the reference computes them, steps them with learning "
-                      "rate 0 and discards the optimizer after the frame (parameters after any number of iterations are identical)" if fused else ""))
+                      "rate 0 and discards the optimizer after the frame (parameters after any number of iterations are identical); mapping iterations "
+                      "take their Adam step on gradients held in registers and do not store them (the reference discards them after the step: "
+                      "zero_grad(set_to_none=True))" if fused else ""))
         result = {
             "metric": ("mapping view-iterations/sec @300k Gaussians, 8 keyframe views per step" if mode_c
                        else "track+map iters/sec @300k Gaussians (render+backward Mpix/s alongside)"),

@@ -497,8 +497,9 @@ int splat_iter_fold_sums(double *sums, void *stream);
 
 /* One whole single-view mapping iteration (/root/reference/scripts/splatam.py:846-863: get_loss, backward, optimizer.step) in
  * one call: splat_iter_loss_backward with cfg->tracking clear, with splat_iter_adam_map folded into its last kernel (every
- * Gaussian's parameters, gradients and moments are touched once).  adam->grad[k] must be the ws->d_* buffer of group k (the
- * gradients are still written there) or NULL (group not stepped).  Not for the view-sharded batch: there the gradients are
+ * Gaussian's parameters, gradients and moments are touched once).  adam->grad[k] != NULL: group k is stepped; it must then be the
+ * ws->d_* buffer of group k (the gradients are still written there) -- or ws->d_* of the group is NULL and the gradient is formed,
+ * stepped on and NOT stored (a loop that discards its gradients after the step).  Not for the view-sharded batch: there the gradients are
  * exchanged between splat_iter_loss_backward and splat_iter_adam_map. */
 int splat_iter_mapping_step(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame,
                             const SplatLossConfig *cfg, SplatIterWorkspace *ws, const SplatAdamMap *adam, void *stream);

@@ -214,10 +214,12 @@ int splat_iter_fold_sums(double *sums, void *stream) {
 int splat_iter_mapping_step(const SplatCamera *cam, const SplatMap *map, const SplatFrameData *frame,
                             const SplatLossConfig *cfg, SplatIterWorkspace *ws, const SplatAdamMap *adam, void *stream) {
     if (!cfg || cfg->tracking || !cfg->gaussians_grad || !adam || !ws) return SPLAT_E_INVALID;
-    // a stepped group takes the gradient this iteration forms: adam->grad[k] names the buffer it is ALSO written to
+    // a stepped group (adam->grad[k] != NULL) takes the gradient this iteration forms in registers; adam->grad[k] names the buffer it is
+    // ALSO written to -- or, when the workspace carries no buffer for the group (ws->d_* NULL), it is not stored at all (a loop that
+    // discards its gradients after the step, as the reference's zero_grad(set_to_none=True) does: 48 bytes per Gaussian not written)
     const float *const grads[5] = {ws->d_means3D, ws->d_rgb_colors, ws->d_unnorm_rotations, ws->d_logit_opacities, ws->d_log_scales};
     for (int k = 0; k < 5; ++k)
-        if (adam->grad[k] && (adam->grad[k] != grads[k] || !adam->exp_avg[k] || !adam->exp_avg_sq[k])) return SPLAT_E_INVALID;
+        if (adam->grad[k] && ((grads[k] && adam->grad[k] != grads[k]) || !adam->exp_avg[k] || !adam->exp_avg_sq[k])) return SPLAT_E_INVALID;
     return iter_loss_backward_impl(cam, map, frame, cfg, ws, nullptr, stream, adam);
 }
 

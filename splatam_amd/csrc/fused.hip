@@ -895,10 +895,15 @@ __global__ __launch_bounds__(kBlock, ISO ? 5 : 4) void fused_backward_kernel(Fus
         Pose P;
         load_pose(a.map, a.frame.time_idx, P);
         const float w2c_row2[4] = {a.frame.w2c[8], a.frame.w2c[9], a.frame.w2c[10], a.frame.w2c[11]};
+        // (MAPGRADS = false, camera tracking: the backward composite's tracking form publishes S1..S5 and the depth channel's colour sum
+        //  in slots 0..5 -- render.hip kTrackSlots --: half the accumulator line is read and cleared)
+        constexpr int kRow4 = MAPGRADS ? SPLAT_GRAD_STRIDE / 4 : 2;
         float acc[SPLAT_GRAD_STRIDE];
+#pragma unroll
+        for (int k = 0; k < SPLAT_GRAD_STRIDE; ++k) acc[k] = 0.f;
         float4 *a4 = reinterpret_cast<float4 *>(ws.accum + (size_t)i * SPLAT_GRAD_STRIDE);
 #pragma unroll
-        for (int k = 0; k < SPLAT_GRAD_STRIDE / 4; ++k) {
+        for (int k = 0; k < kRow4; ++k) {
             const float4 v = a4[k];
             acc[4 * k] = v.x; acc[4 * k + 1] = v.y; acc[4 * k + 2] = v.z; acc[4 * k + 3] = v.w;
         }
@@ -913,7 +918,7 @@ __global__ __launch_bounds__(kBlock, ISO ? 5 : 4) void fused_backward_kernel(Fus
         // are zero already -- and AFTER every load above: a store the compiler can neither sink nor prove disjoint pins them up here,
         // ahead of the visibility test.)
 #pragma unroll
-        for (int k = 0; k < SPLAT_GRAD_STRIDE / 4; ++k) a4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < kRow4; ++k) a4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         const bool vis = ws.st.radii[i] > 0;
         float dp[3] = {0.f, 0.f, 0.f}, du[4] = {0.f, 0.f, 0.f, 0.f}, dlogit = 0.f, dls[3] = {0.f, 0.f, 0.f};
         float drgb[3] = {0.f, 0.f, 0.f};
@@ -929,8 +934,8 @@ __global__ __launch_bounds__(kBlock, ISO ? 5 : 4) void fused_backward_kernel(Fus
             if constexpr (MAPGRADS || !ISO) cov3d_backward(G.s, c.scale_modifier, G.rq, dS6, ds, drq);
             // colour channels: 6..8 rgb, 9 z, 10 silhouette (constant), 11 z^2
             drgb[0] = acc[6]; drgb[1] = acc[7]; drgb[2] = acc[8];
-            const float dz = acc[9] + 2.f * G.z * acc[11];
-            glue_backward(P, w2c_row2, p, iso, G, dXc, dz, acc[5], ds, drq, dp, du, &dlogit, dls, pose);
+            const float dz = MAPGRADS ? acc[9] + 2.f * G.z * acc[11] : acc[5];     // (tracking form: the depth channel's sum sits in slot 5)
+            glue_backward(P, w2c_row2, p, iso, G, dXc, dz, MAPGRADS ? acc[5] : 0.f, ds, drq, dp, du, &dlogit, dls, pose);
         }
         constexpr int kWidth[5] = {3, 3, 4, 1, ISO ? 1 : 3};
         // (the moments: one more round trip, all 27 loads at once, issued ahead of the gradient stores; holding them across the adjoint
@@ -1181,8 +1186,10 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
                 hipLaunchKernelGGL(map_loss_backward_kernel<false>, grid, dim3(kBlock), 0, s, a, W, H);
             }
         }
-        e = launch_render_backward_feat8(cam, ws.feat8, ws.st, ws.dL_dout6, ws.accum, P, false, ws.d_rgb_colors != nullptr, s,
-                                         ws.d_logit_opacities != nullptr);
+        // (which sums the backward composite forms: what a stored gradient or a stepped group needs)
+        e = launch_render_backward_feat8(cam, ws.feat8, ws.st, ws.dL_dout6, ws.accum, P, false,
+                                         ws.d_rgb_colors != nullptr || (map_adam && map_adam->grad[1]), s,
+                                         ws.d_logit_opacities != nullptr || (map_adam && map_adam->grad[3]));
         if (e != hipSuccess) return e;
     }
     PoseAdam pa{};

@@ -902,8 +902,12 @@ __device__ __forceinline__ void backward_core(const float *colors, const SplatSt
     const unsigned lo = st.tile_stride > 0 ? (unsigned)tile * (unsigned)st.tile_stride : st.tile_base[tile];
     const int nb = (int)((tmax + kBatchEntries - 1) / kBatchEntries);
 
-    // accumulator slot of published value k: S1..S5 (S6) -> 0..5, colour sums -> 6 + channel
-    auto slot_of = [](int k) { return k < NB ? k : 6 + nth_set_bit(SMASK, k - NB); };
+    // accumulator slot of published value k: S1..S5 (S6) -> 0..5, colour sums -> 6 + channel.  The camera-tracking form (no opacity sum,
+    // the depth channel's colour sum only) puts that one sum in the free slot 5: everything tracking publishes then lies in the first
+    // half of the accumulator line, and the per-Gaussian kernel behind it reads and clears 32 bytes per Gaussian instead of 64
+    // (fused.hip: fused_backward_kernel<.., MAPGRADS = false>)
+    constexpr bool kTrackSlots = !OPAC && SMASK == 0x8u;
+    auto slot_of = [](int k) { return k < NB ? k : (kTrackSlots ? 5 : 6 + nth_set_bit(SMASK, k - NB)); };
     int doff_own = 0, doff_x = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k)

@@ -115,6 +115,7 @@ class FusedEngine:
         # rows in creation (pixel-scan) order: true for a map this engine grew itself (add_valid_depth_points / add_new_gaussians
         # append per pixel in scan order); callers that hand over such a map may set it.  Only a speed hint (SplatState.order_hint)
         self.creation_order = bool(self.managed and P == 0)
+        self.keep_map_grads = True      # mapping_iteration: store the gradients beside the fused Adam step (False: as the reference's loop, which discards them)
         self.use_recs = {"0": 0, "1": 1}.get(os.environ.get("SPLAT_TILE_RECS", "auto"), 2)      # SplatState.tile_recs: 0 never, 1 always, 2 by list length
         self._alloc_lists(self.capacity)
         self._cam = self._make_cam(cam)
@@ -641,7 +642,7 @@ class FusedEngine:
         # staged records handed from the forward to the backward composite: pays where a tile's list is several batches long (every batch
         # but the last is re-staged: B-loop, mapping +1.4 %) and costs where it is one (B: the forward composite's 34 MB of extra stores,
         # mapping -1.4 %): profiles/r06_experiments.md 2.  SPLAT_TILE_RECS=1 / 0 forces it on / off
-        recs_on = self.use_recs == 1 or (self.use_recs == 2 and self.max_list_hint > 255)
+        recs_on = self.use_recs == 1 or (self.use_recs == 2 and self.max_list_hint > 400)
         st.tile_recs = b['tile_recs'].data_ptr() if (recs_on and b.get('tile_recs') is not None) else None
         st.long_items = b['long_items'].data_ptr()
         st.max_list_hint = self.max_list_hint
@@ -665,7 +666,7 @@ class FusedEngine:
         ws.ssim_maps = b['ssim_maps'].data_ptr() if with_ssim else None
         ws.sums = b['sums'].data_ptr()
         ws.max_2D_radius = self.max_2D_radius.data_ptr() if self.max_2D_radius is not None else None
-        if with_map_grads:
+        if with_map_grads and with_map_grads != "step only":      # ("step only": the fused Adam step takes them from registers, nothing is stored)
             g = self.grads
             ws.d_means3D, ws.d_rgb_colors = g['means3D'].data_ptr(), g['rgb_colors'].data_ptr()
             ws.d_unnorm_rotations, ws.d_logit_opacities = g['unnorm_rotations'].data_ptr(), g['logit_opacities'].data_ptr()
@@ -858,11 +859,16 @@ class FusedEngine:
             allreduce_sums(self.buf['sums'])
         self.finish_iteration(pa)
 
-    def mapping_iteration(self, iter_data, iter_time_idx, cfg, bucket_allreduce=None):
+    def mapping_iteration(self, iter_data, iter_time_idx, cfg, bucket_allreduce=None, keep_grads=None):
         """Loop body of /root/reference/scripts/splatam.py:828-869 (without pruning / densification).  Without a gradient
-        exchange the whole iteration is one C call (the Adam step rides in the last kernel: splat_iter_mapping_step)."""
+        exchange the whole iteration is one C call (the Adam step rides in the last kernel: splat_iter_mapping_step).
+        ``keep_grads`` (default ``self.keep_map_grads``): also STORE the gradients the step was taken on (``self.grads``); the
+        reference's loop discards them right after the step (optimizer.zero_grad(set_to_none=True), :860-861), and a loop that does
+        the same saves 32 - 48 bytes of stores per Gaussian and iteration."""
         if bucket_allreduce is None and self.P <= self.fused_adam_max_rows:
-            self.loss_backward(iter_data, iter_time_idx, cfg, tracking=False, map_adam=self._adam_map_args(cfg['lrs']))
+            keep = self.keep_map_grads if keep_grads is None else keep_grads
+            self.loss_backward(iter_data, iter_time_idx, cfg, tracking=False, map_adam=self._adam_map_args(cfg['lrs']),
+                               map_grads=True if keep else "step only")
             return
         self.loss_backward(iter_data, iter_time_idx, cfg, tracking=False)
         if bucket_allreduce is not None:

@@ -332,6 +332,7 @@ def rgbd_slam(dataset, config, engine="fused", num_frames=None, gaussian_capacit
         variables['scene_radius'] = torch.max(depth0) / config['scene_radius_depth_ratio']
         cap = gaussian_capacity or int(H * W * 2.5) + 65536
         eng = FusedEngine(params, cam, gaussian_capacity=cap, variables=variables)
+        eng.keep_map_grads = False      # (a mapping iteration's gradients are discarded after its step: /root/reference/scripts/splatam.py:860-861)
         if config['mean_sq_dist_method'] != "projective":
             raise ValueError(f"Unknown mean_sq_dist_method {config['mean_sq_dist_method']}")
         eng.add_valid_depth_points(color0, depth0, intrinsics, first_frame_w2c)

@@ -293,7 +293,7 @@ USE_TILE_RECS = None
 def _want_recs(will_backward: bool, longest) -> bool:
     if not will_backward or USE_TILE_RECS is False:
         return False
-    return bool(USE_TILE_RECS) or (longest is not None and longest > 255)
+    return bool(USE_TILE_RECS) or (longest is not None and longest > 400)
 
 
 def _alloc_lists(pk: _Pack, dev, capacity: int, longest=None, recs=False):

@@ -484,6 +484,40 @@ def test_order_hint_changes_nothing_but_speed(order):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("aniso", [False, True])
+def test_mapping_step_without_gradient_stores_moves_the_map_the_same(aniso):
+    """mapping_iteration(keep_grads=False): the fused Adam step takes the gradients from registers and nothing is written to
+    ``eng.grads`` (the reference's loop discards them after the step, /root/reference/scripts/splatam.py:860-861).  Parameters and
+    moments after three iterations equal those of the storing form to float-atomic summation order; the gradient buffers stay untouched."""
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    params, variables, frame, cam = _scene(20000, 320, 240, aniso=aniso, seed=43)
+    cfg = slam.REPLICA_MAPPING
+    engs = []
+    for keep in (True, False):
+        eng = FusedEngine({k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}, cam)
+        for _ in range(3):
+            eng.loss_backward(frame, 1, cfg, tracking=False)
+            if not eng.check_overflow():
+                break
+        for g in eng.grads.values():
+            g.fill_(123.0)
+        for _ in range(3):
+            eng.mapping_iteration(frame, 1, cfg, keep_grads=keep)
+        torch.cuda.synchronize()
+        assert not eng.check_overflow(grow=False)
+        engs.append(eng)
+    a, b = engs
+    assert all(float((g - 123.0).abs().max()) == 0.0 for g in b.grads.values())             # nothing was stored
+    assert any(float((g - 123.0).abs().max()) > 0.0 for g in a.grads.values())
+    for k in ('means3D', 'rgb_colors', 'logit_opacities', 'log_scales') + (('unnorm_rotations',) if aniso else ()):
+        moved = float((a.params[k].detach() - params[k]).abs().max())
+        assert moved > 0.0, k
+        assert float((a.params[k].detach() - b.params[k].detach()).abs().max()) <= 2e-3 * moved + 1e-9, k
+        assert float((a.exp_avg[k] - b.exp_avg[k]).abs().max()) <= 1e-4 * float(a.exp_avg[k].abs().max()) + 1e-12, k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["one batch", "several batches", "exact lists"])
 def test_staged_records_handed_to_the_backward_composite_change_nothing_but_speed(case):
     """SplatState.tile_recs: the forward composite leaves the staged 48-byte record of every list entry (pre-scaled conic, opacity,
@@ -505,7 +539,7 @@ def test_staged_records_handed_to_the_backward_composite_change_nothing_but_spee
                 if not eng.check_overflow():
                     break
             assert eng.tile_stride > 0
-            assert (eng.max_list_hint > 255) == (case == "several batches"), eng.max_list_hint
+            assert (eng.max_list_hint > 400) == (case == "several batches"), eng.max_list_hint
         eng.loss_backward(frame, 1, cfg, tracking=False)
         torch.cuda.synchronize()
         ws = eng._workspace(False, with_ssim=False)
