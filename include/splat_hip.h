@@ -342,8 +342,9 @@ typedef struct SplatLossConfig {
     float w_depth;               /* loss_weights['depth'] */
     int32_t defer_finish;        /* 1: stop before the last kernel (pose gradient, loss value, pose Adam step): the caller completes the
                                     partial sums (all-reduce over the ranks that composited other tile rows) and calls splat_iter_finish */
-    int32_t fused_composite;     /* tracking with a pixel-local loss (no outlier rejection), lists the composite sorts itself, no map
-                                    gradients wanted: 1 = forward composite, loss and backward composite as ONE kernel (the backward pass
+    int32_t fused_composite;     /* tracking with a pixel-local loss (no outlier rejection), lists the composite sorts itself (with map
+                                    gradients wanted -- ws->d_rgb_colors / d_logit_opacities -- the kernel carries the backward composite's
+                                    mapping form): 1 = forward composite, loss and backward composite as ONE kernel (the backward pass
                                     walks the batch the forward pass left in LDS; ws->out6, dL_dout6, st.final_T, st.n_contrib are NOT
                                     written), 2 = the same kernel, planes written as well, 0 = two kernels.  Ignored where it does not apply */
 } SplatLossConfig;

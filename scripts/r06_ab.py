@@ -52,7 +52,16 @@ def measure(eng, frames, shape, dev, n=150):
         eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING)
     out["tracking"] = bench.phase_rate(lambda: eng.tracking_iteration(frames[1], slam.REPLICA_TRACKING), n, dev)
     restore()
+
+    def track_full():
+        eng.loss_backward(frames[1], eng.track_time_idx, slam.REPLICA_TRACKING, tracking=True, map_grads=True,
+                          pose_adam=eng._pose_adam_args(slam.REPLICA_TRACKING))
+    for _ in range(30):
+        track_full()
+    out["tracking_full"] = bench.phase_rate(track_full, n, dev)
+    restore()
     out["mix"] = 5.0 / (2.0 / out["tracking"] + 3.0 / out["mapping"])
+    out["mix_full"] = 5.0 / (2.0 / out["tracking_full"] + 3.0 / out["mapping"])
     eng.loss_backward(frames[2], 2, slam.REPLICA_MAPPING, tracking=False)
     torch.cuda.synchronize(dev)
     ws = eng._workspace(False, False)

@@ -1152,9 +1152,12 @@ hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map
     // a band of tile rows (SplatState.tile_row_begin): only the loss that is formed per tile in the composite's epilogue is defined
     if (ws.st.tile_row_end > ws.st.tile_row_begin && !fuse_loss) return hipErrorInvalidValue;
     // ... and with short lists and nothing but the pose gradient wanted, the backward composite rides in the same kernel
-    const bool one_kernel = fuse_loss && sort_in_k6 && cfg.fused_composite != 0 && !ws.d_rgb_colors && !ws.d_logit_opacities;
+    // (map gradients wanted as well -- the reference's backward() forms dL/d(rgb, opacity, scale) in tracking too --: the same kernel
+    //  with the backward composite's mapping form inside)
+    const bool one_kernel = fuse_loss && sort_in_k6 && cfg.fused_composite != 0;
+    const bool full_sums = ws.d_rgb_colors != nullptr || ws.d_logit_opacities != nullptr;
     if (one_kernel) {
-        e = launch_render_track_fused(cam, ws.feat8, ws.st, ws.out6, ws.accum, ep, cfg.fused_composite == 2, s);
+        e = launch_render_track_fused(cam, ws.feat8, ws.st, ws.out6, ws.accum, ep, cfg.fused_composite == 2, s, full_sums);
         if (e != hipSuccess) return e;
     } else {
         e = launch_render_forward_feat8(cam, ws.feat8, ws.st, ws.out6, sort_in_k6, s, fuse_loss ? &ep : nullptr, fuse_loss ? &loss_done : nullptr);

@@ -1262,8 +1262,12 @@ struct TrackFusedArgs {
     int T, per_xcd;
     TrackLossEpilogue ep;
 };
-template <bool KEEP, int DBG = 0>
-__global__ __launch_bounds__(256, 5) void render_track_fused_kernel(TrackFusedArgs args) {
+// FULL: every sum the reference's backward() forms for a tracking iteration -- the colour sums of r, g, b and the opacity sum too
+// (dL/d rgb, opacity, scale: the reference computes them and steps them with learning rate 0, /root/reference/utils/slam_helpers.py:133-136,
+// configs/replica/splatam.py:71-79) -- i.e. the backward composite's MAPPING form behind the forward pass (120 registers, the gradient
+// rows of phase 2 in LDS: four workgroups per CU instead of five)
+template <bool KEEP, int DBG, bool FULL>
+__device__ __forceinline__ void track_fused_body(const TrackFusedArgs &args) {
     constexpr int C = 6, CS = 8, FP = forward_fp<C, CS, false>();
     using BatchT = Batch<FP, 16, true>;
     // LDS, 31.4 KB (five workgroups per CU): [records | quadrant masks + lists | counts] live through both passes; behind them ONE region
@@ -1360,10 +1364,15 @@ __global__ __launch_bounds__(256, 5) void render_track_fused_kernel(TrackFusedAr
         if (Tfin == 1.2345e-33f && last == 0xFFFFFFFFu) accum[0] = dpix[0] + dpix[3];
         return;
     }
-    backward_core<C, CS, 0xFu, 0x8u, false, (DBG & 14)>(feat8, st, accum, B, PB, s_wmax, tile, tx, ty, tid, inside, Tfin, last, dpix, 0.f, staged);
+    if constexpr (FULL) backward_core<C, CS, 0xFu, 0xFu, true, (DBG & 14)>(feat8, st, accum, B, PB, s_wmax, tile, tx, ty, tid, inside, Tfin, last, dpix, 0.f, staged);
+    else backward_core<C, CS, 0xFu, 0x8u, false, (DBG & 14)>(feat8, st, accum, B, PB, s_wmax, tile, tx, ty, tid, inside, Tfin, last, dpix, 0.f, staged);
     // what the next launch's order is built from (SplatState.tile_work): the quadrants' deepest contributors, as the core left them
     if (st.tile_work && tid == 0) st.tile_work[tile] = s_wmax[0] + s_wmax[1] + s_wmax[2] + s_wmax[3];
 }
+template <bool KEEP, int DBG = 0>
+__global__ __launch_bounds__(256, 5) void render_track_fused_kernel(TrackFusedArgs args) { track_fused_body<KEEP, DBG, false>(args); }
+template <bool KEEP>
+__global__ __launch_bounds__(256, 4) void render_track_fused_full_kernel(TrackFusedArgs args) { track_fused_body<KEEP, 0, true>(args); }
 
 // measurement builds (splat_debug_option(4, bits)): the fused iteration's two forms only
 template <int C, int CS, unsigned DMASK, unsigned SMASK, bool OPAC, bool BG, int DBG>
@@ -1519,7 +1528,7 @@ hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat
 // The tracking iteration's composites as ONE launch (render_track_fused_kernel): lists short enough for the composite's own sort, a
 // pixel-local loss (no outlier rejection).  keep_planes: also write out6 / final_T / n_contrib / dL_dout6.
 hipError_t launch_render_track_fused(const SplatCamera &cam, const float *feat8, SplatState &st_in, float *out6, float *accum,
-                                     const TrackLossEpilogue &ep, bool keep_planes, hipStream_t s) {
+                                     const TrackLossEpilogue &ep, bool keep_planes, hipStream_t s, bool full_sums) {
     const int T = launch_tiles(cam, st_in);
     if (T == 0) return hipSuccess;
     const int per = (T + 7) / 8;
@@ -1533,6 +1542,11 @@ hipError_t launch_render_track_fused(const SplatCamera &cam, const float *feat8,
             case 16: hipLaunchKernelGGL((render_track_fused_kernel<false, 16>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, st, out6, accum, T, per, ep}); break;
             default: hipLaunchKernelGGL((render_track_fused_kernel<false>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, st, out6, accum, T, per, ep}); break;
         }
+        return hipGetLastError();
+    }
+    if (full_sums) {
+        if (keep_planes) hipLaunchKernelGGL((render_track_fused_full_kernel<true>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, st, out6, accum, T, per, ep});
+        else hipLaunchKernelGGL((render_track_fused_full_kernel<false>), dim3(8 * per), dim3(256), 0, s, TrackFusedArgs{cam, feat8, st, out6, accum, T, per, ep});
         return hipGetLastError();
     }
     if (keep_planes) {

@@ -63,7 +63,7 @@ struct TrackLossEpilogue {
 hipError_t launch_render_forward_feat8(const SplatCamera &cam, const float *feat8, SplatState &st, float *out6, bool sort_in_kernel,
                                        hipStream_t s, const TrackLossEpilogue *ep = nullptr, bool *ep_done = nullptr);
 hipError_t launch_render_track_fused(const SplatCamera &cam, const float *feat8, SplatState &st, float *out6, float *accum,
-                                     const TrackLossEpilogue &ep, bool keep_planes, hipStream_t s);
+                                     const TrackLossEpilogue &ep, bool keep_planes, hipStream_t s, bool full_sums = false);
 hipError_t launch_render_backward_feat8(const SplatCamera &cam, const float *feat8, const SplatState &st, const float *dL_dout6,
                                         float *accum, int P, bool zero_accum, bool rgb_sums, hipStream_t s, bool opacity_sum = true);
 hipError_t launch_iter_loss_backward(const SplatCamera &cam, const SplatMap &map, const SplatFrameData &frame,

@@ -122,6 +122,7 @@ class FusedEngine:
         self._cam_ok = {}
         self._frame_keep = None
         self.track_fused = os.environ.get("SPLAT_TRACK_FUSED", "1") != "0"    # tracking: forward + loss + backward composite in one kernel
+        self.track_fused_full = os.environ.get("SPLAT_TRACK_FUSED_FULL", "1") != "0"   # ... also when the map's gradients are wanted (the mapping form inside)
         self.fold_sums = os.environ.get("SPLAT_FOLD_SUMS", "1") != "0"     # tile-row-sharded tracking: exchange 256 B instead of 16 KB
         self.skipped_iterations = 0     # of the last check_overflow() / digest_report(): iterations whose Adam step the device skipped
         self._learnt_P = None           # rows of the map the list statistics were learnt on (rebind keeps them for a similar map)
@@ -725,7 +726,10 @@ class FusedEngine:
         self._frame_keep = (im, depth, w2c)
         if keep_planes is None:
             keep_planes = pose_adam is None
-        one_kernel = (2 if keep_planes else 1) if (tracking and self.track_fused and not map_grads) else 0
+        # (with the map's gradients the one-kernel form carries the backward composite's mapping form at four workgroups per CU: ahead
+        #  where a tile's list is one or two batches -- B: +6.4 % --, behind where it is three -- B-loop: -1.2 %; profiles/r06_experiments.md 4)
+        full_ok = self.track_fused_full and 0 < self.max_list_hint <= 400
+        one_kernel = (2 if keep_planes else 1) if (tracking and self.track_fused and (not map_grads or full_ok)) else 0
         lc = self.loss_config(cfg, tracking, do_ba, defer_finish=tile_rows is not None, fused_composite=one_kernel)
         self._tile_rows = tile_rows         # a band: the iteration stops before its last kernel (finish_iteration completes it)
         self._stats_partial = tile_rows is not None

@@ -953,6 +953,45 @@ def test_tracking_composites_in_one_kernel_equal_the_two_kernels(n, W, H, label)
     assert abs(a['loss'] - b['loss']) <= 1e-3 * abs(b['loss'])
 
 
+@pytest.mark.parametrize("n,label", [(20000, "one batch per tile"), (64000, "two to three batches per tile")])
+def test_full_gradient_tracking_in_one_kernel_equals_the_two_kernels(n, label):
+    """The tracking iteration with EVERY gradient the reference's backward() forms (dL/d rgb, opacity, scale too: learning rate 0 in
+    /root/reference/configs/replica/splatam.py:71-79): forward composite, loss and the backward composite's MAPPING form as one
+    kernel (render_track_fused_full_kernel) against K6 + K7: planes bit for bit, loss, pose gradient and the map's gradients to
+    float-atomic summation order."""
+    from splatam_amd import slam
+    from splatam_amd.fused import FusedEngine
+    params, variables, frame, cam = _scene(n, 328, 248, seed=92)
+    cfg = slam.REPLICA_TRACKING
+    out = {}
+    for full in (True, False):
+        eng = FusedEngine({k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}, cam)
+        eng.track_fused_full = full
+        eng.loss_backward(frame, 1, slam.REPLICA_MAPPING, tracking=False)
+        assert not eng.check_overflow() and eng.tile_stride > 0
+        eng.begin_tracking(1)
+        eng.loss_backward(frame, 1, cfg, tracking=True, map_grads=True)
+        torch.cuda.synchronize()
+        assert not eng.check_overflow(grow=False)
+        out[full] = dict(out6=eng.buf['out6'].clone(), dplanes=eng.buf['dL_dout6'].clone(), d=eng.buf['d_cam'].clone(),
+                         grads={k: v.clone() for k, v in eng.grads.items()})
+        # ... and with the pose's Adam step riding along, no planes (bench.py's tracking_full_gradients figure)
+        for _ in range(3):
+            eng.loss_backward(frame, 1, cfg, tracking=True, map_grads=True, pose_adam=eng._pose_adam_args(cfg))
+        torch.cuda.synchronize()
+        assert not eng.check_overflow(grow=False)
+        out[full].update(trans=eng.params['cam_trans'].detach().clone(), g2={k: v.clone() for k, v in eng.grads.items()})
+    a, b = out[True], out[False]
+    assert torch.equal(a['out6'], b['out6']) and torch.equal(a['dplanes'], b['dplanes']), label
+    assert abs(float(a['d'][7]) - float(b['d'][7])) <= 1e-6 * abs(float(b['d'][7]))
+    assert float((a['d'][:7] - b['d'][:7]).abs().max()) <= 2e-5 * float(b['d'][:7].abs().max())
+    for key in ('grads', 'g2'):
+        for k in ('rgb_colors', 'logit_opacities', 'log_scales'):
+            sc = float(b[key][k].abs().max())
+            assert sc > 0 and float((a[key][k] - b[key][k]).abs().max()) <= 5e-5 * sc, (label, key, k)
+    assert float((a['trans'] - b['trans']).abs().max()) <= 2e-5
+
+
 def _offset_view(t):
     """The same values in a contiguous tensor whose first element is 4 bytes past a 16-byte boundary."""
     buf = torch.empty(t.numel() + 1, device=t.device, dtype=t.dtype)
