@@ -818,7 +818,7 @@ def main():
             del probe
         else:
             roof, _ = kernel_roofline(params_d, frames, shape, dev)
-        mpix, ms_call = render_mpix(params_d, frames, shape, dev)
+        mpix, ms_call = render_mpix(params_d, frames, shape, dev, reps=60)
 
     if fused:
         eparams = {k: v.detach().clone() for k, v in params.items()}
@@ -1050,7 +1050,7 @@ def main():
     result = None
     if rank == 0:
         if mpix is None:
-            mpix, ms_call = render_mpix(params_d, frames, shape, dev)
+            mpix, ms_call = render_mpix(params_d, frames, shape, dev, reps=60)
         wl = (f"C: {N} Gaussians, {W}x{H}, mapping-only, a batch of 8 keyframe views per step sharded over the ranks, one gradient all-reduce"
               if mode_c else f"{args.workload}: {N} Gaussians, {W}x{H}, SplaTAM tracking+mapping loop (2:3 mix), isotropic map"
                    + ("; fused tracking iterations do not form dL/d(rgb, opacity, scale): the reference computes them, steps them with learning "
