@@ -121,14 +121,16 @@ class _FlagRing:
         return i, self.base + 4 * i, ev
 
 
-_flag_ring = None
+_flag_rings: dict = {}          # one ring per device (an event belongs to the device it was first recorded on)
 
 
-def _ring() -> _FlagRing:
-    global _flag_ring
-    if _flag_ring is None:
-        _flag_ring = _FlagRing()
-    return _flag_ring
+def _ring(dev_index=None) -> _FlagRing:
+    if dev_index is None:
+        dev_index = torch.cuda.current_device()
+    r = _flag_rings.get(dev_index)
+    if r is None:
+        r = _flag_rings[dev_index] = _FlagRing()
+    return r
 
 
 _zero_bg: dict = {}
@@ -540,7 +542,7 @@ def _rasterize_forward_fast(settings, means3D, colors, opacities, scales, rotati
                                  backward=will_backward)
     out_color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
     out_depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
-    ring = _ring()
+    ring = _ring(dev.index)
     idx, word, ev = ring.take(dev)
     pk.st.status_host = word
     stream = _stream(dev)
@@ -548,7 +550,7 @@ def _rasterize_forward_fast(settings, means3D, colors, opacities, scales, rotati
         # (splat_forward = preprocess + bin (a no-op with group binning) + render: one crossing of the ABI)
         _capi.check(L.splat_forward(C.byref(pk.cam), C.byref(pk.g), C.byref(pk.st), out_color.data_ptr(), out_depth.data_ptr(), stream), "splat_forward")
         ev.record()
-    pk.fast = (idx, ev, key)
+    pk.fast = (idx, ev, key)        # (key[0] is the device index: the flag word lives in that device's ring)
     pk.settings = settings
     pk.num_rendered = None
     _scene_stats[key]['since_exact'] += 1
@@ -569,7 +571,7 @@ def _poll_unchecked(wait: bool = False) -> None:
                 return
             ev.synchronize()
         _unchecked.pop(0)
-        if int(_ring().host[idx]) != 0:
+        if int(_ring(key[0]).host[idx]) != 0:
             fast_path_stats["flagged"] += 1
             _scene_stats.pop(key, None)
             raise RuntimeError("splatam_amd rasterizer (sync mode 'auto'): a per-tile Gaussian list outgrew the bucket learnt for its scene in an "
@@ -589,7 +591,7 @@ def fast_call_flagged(pk) -> bool:
     idx, ev, key = pk.fast
     if not ev.query():
         ev.synchronize()
-    flagged = int(_ring().host[idx]) != 0
+    flagged = int(_ring(key[0]).host[idx]) != 0
     if flagged:
         fast_path_stats["flagged"] += 1
         _scene_stats.pop(key, None)         # the scene goes back to the exact path (and learns its lists again)
