@@ -450,7 +450,8 @@ void state_arrays(LayoutWriter &w, bool iter, int32_t P, int32_t width, int32_t 
         // group binning behind the reference API: the counters sit right in front of the status words (the library zeroes both with
         // one memset per call: launch_preprocess_forward)
         if (group_stride > 0) w.add("group_recs", 16 * G * (size_t)group_stride, 0);
-        w.add("group_count", 4 * G * SPLAT_COUNTER_STRIDE, 0);
+        // (padded to the slab alignment: the status words then sit EXACTLY behind it, and the padding is the array's own)
+        w.add("group_count", (4 * G * SPLAT_COUNTER_STRIDE + SPLAT_SLAB_ALIGN - 1) / SPLAT_SLAB_ALIGN * SPLAT_SLAB_ALIGN, 0);
     }
     w.add(NAME("status"), 4 * 4, z);
 #undef NAME

@@ -345,11 +345,14 @@ hipError_t launch_preprocess_forward(const SplatCamera &cam, const SplatGaussian
     if (group_binning(st, cam.image_width, cam.image_height)) {
         // group counters and status words start at zero: ONE memset when the caller laid the state out with splat_state_layout
         // (SPLAT_LAYOUT_GROUPS puts the status words right behind the counters), two otherwise
+        // (SPLAT_LAYOUT_GROUPS pads the counters to SPLAT_SLAB_ALIGN and puts the status words exactly behind them: the padding is the
+        //  counter array's own, nothing foreign lies in the span)
         const size_t cbytes = sizeof(uint32_t) * (size_t)tile_groups(cam.image_width, cam.image_height) * SPLAT_COUNTER_STRIDE;
+        const size_t padded = (cbytes + SPLAT_SLAB_ALIGN - 1) / SPLAT_SLAB_ALIGN * SPLAT_SLAB_ALIGN;
         const char *c0 = reinterpret_cast<const char *>(st.group_count), *s0 = reinterpret_cast<const char *>(st.status);
         hipError_t e;
-        if (s0 >= c0 + cbytes && s0 <= c0 + cbytes + SPLAT_SLAB_ALIGN) {
-            e = hipMemsetAsync(st.group_count, 0, (size_t)(s0 - c0) + 4 * sizeof(int32_t), s);
+        if (s0 == c0 + padded) {
+            e = hipMemsetAsync(st.group_count, 0, padded + 4 * sizeof(int32_t), s);
         } else {
             e = hipMemsetAsync(st.group_count, 0, cbytes, s);
             if (e == hipSuccess) e = hipMemsetAsync(st.status, 0, 4 * sizeof(int32_t), s);

@@ -136,6 +136,17 @@ def test_scratch_layouts_describe_the_structs():
     assert st.capacity == cap and st.sub_bins == 1 and st.group_recs is None
     assert L.splat_state_bind(C.byref(st), None, base + 8, lay.arrays, lay.n, 1, cap) != 0       # a misaligned slab is refused
     assert L.splat_state_layout(-1, W, H, 1, cap, 0, None, 0, None) < 0 and L.splat_state_layout(P, W, H, 3, cap, 0, None, 0, None) < 0
+    # group binning behind the reference API (ABI 10): no key buckets, the group counters padded to the slab alignment with the status
+    # words exactly behind them (the library zeroes both with one memset), records and accumulator on request
+    Wg, Hg = 1232, 720                                           # 77 x 45 tiles -> 39 x 23 = 897 groups: an odd multiple of 128 bytes
+    Tg = L.splat_num_tiles(Wg, Hg)
+    gl = _capi.state_layout(P, Wg, Hg, 1, Tg * 1024, _capi.SPLAT_LAYOUT_GROUPS | _capi.SPLAT_LAYOUT_RECS | _capi.SPLAT_LAYOUT_BACKWARD)
+    Gg = ((Wg + 15) // 16 + 1) // 2 * (((Hg + 15) // 16 + 1) // 2)
+    assert "keys" not in gl.bytes and gl.bytes["point_list"] == 4 * Tg * 1024 and gl.bytes["tile_recs"] == 48 * Tg * 1024
+    assert gl.bytes["group_recs"] == 16 * Gg * 4 * 1024 and gl.bytes["accum"] == 4 * _capi.SPLAT_GRAD_STRIDE * P
+    assert gl.bytes["group_count"] == -(-(4 * Gg * _capi.SPLAT_COUNTER_STRIDE) // 256) * 256 > 4 * Gg * _capi.SPLAT_COUNTER_STRIDE
+    assert gl.offset["status"] == gl.offset["group_count"] + gl.bytes["group_count"]
+    assert L.splat_state_layout(P, Wg, Hg, 1, 0, _capi.SPLAT_LAYOUT_GROUPS, None, 0, None) < 0       # (needs the bucket capacity: tiles x stride)
     # the fused iteration's workspace
     gs = 4 * 448
     fl = _capi.SPLAT_LAYOUT_SSIM | _capi.SPLAT_LAYOUT_OUTLIER | _capi.SPLAT_LAYOUT_TILE_ORDER
