@@ -68,8 +68,16 @@ size_t splat_num_tiles(int32_t width, int32_t height) {
     return (size_t)((width + SPLAT_TILE - 1) / SPLAT_TILE) * (size_t)((height + SPLAT_TILE - 1) / SPLAT_TILE);
 }
 
+// bucketed lists behind the reference API exist in ONE form: group binning with lists the composite sorts itself, three colour channels,
+// buckets inside the capacity (include/splat_hip.h "GROUP BINNING behind the reference API"); anything else with tile_stride > 0 is refused
+static bool valid_list_mode(const SplatCamera *cam, const SplatGaussians *g, const SplatState *st) {
+    if (st->tile_stride == 0) return true;
+    if (!group_binning(*st, cam->image_width, cam->image_height) || g->channels != 3 || g->shs) return false;
+    return (long long)st->tile_stride * (long long)splat_num_tiles(cam->image_width, cam->image_height) <= st->capacity && st->point_list;
+}
+
 int splat_preprocess_forward(const SplatCamera *cam, const SplatGaussians *g, SplatState *st, void *stream) {
-    if (!valid_inputs(cam, g) || !valid_state(g, st, false)) return SPLAT_E_INVALID;
+    if (!valid_inputs(cam, g) || !valid_state(g, st, false) || !valid_list_mode(cam, g, st)) return SPLAT_E_INVALID;
     return check(launch_preprocess_forward(*cam, *g, *st, (hipStream_t)stream));
 }
 
@@ -82,7 +90,7 @@ int splat_bin_forward(const SplatCamera *cam, const SplatGaussians *g, SplatStat
 int splat_render_forward(const SplatCamera *cam, const SplatGaussians *g, SplatState *st, float *out_color,
                          float *out_depth, void *stream) {
     if (!valid_inputs(cam, g) || !valid_state(g, st, true)) return SPLAT_E_INVALID;
-    if (!out_color || !out_depth || !st->final_T || !st->n_contrib) return SPLAT_E_INVALID;
+    if (!out_color || !out_depth || !st->final_T || !st->n_contrib || !valid_list_mode(cam, g, st)) return SPLAT_E_INVALID;
     return check(launch_render_forward(*cam, *g, *st, out_color, out_depth, (hipStream_t)stream));
 }
 

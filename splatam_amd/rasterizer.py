@@ -526,6 +526,8 @@ def _scene_key(dev, P, settings):
 def _fast_eligible(key, channels, use_sh) -> bool:
     if _SYNC_MODE != "auto" or use_sh or channels != 3 or key[1] == 0:
         return False
+    if (((key[3] + 15) // 16 + 1) // 2) * (((key[2] + 15) // 16 + 1) // 2) > 8192:      # (one LDS counter per 2 x 2-tile group in K1: frames beyond ~2900 x 2900)
+        return False
     stt = _scene_stats.get(key)
     return stt is not None and 0 < stt['longest'] * FAST_MARGIN <= FAST_STRIDE and stt['since_exact'] < FAST_REFRESH
 

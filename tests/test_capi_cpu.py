@@ -74,6 +74,20 @@ def test_invalid_arguments_return_codes_not_crashes():
     assert L.splat_mark_visible(-1, None, None, None, None) == 1
     g.channels = 99
     assert L.splat_render_forward(C.byref(cam), C.byref(g), C.byref(st), None, None, None) == 1
+    # bucketed lists behind the reference API exist only as group binning: a state that asks for buckets without the group arrays (or
+    # with a list-length hint beyond what the composite sorts) is refused before anything is launched
+    lay = _capi.state_layout(10, 64, 64, 1, 16 * 1024, _capi.SPLAT_LAYOUT_GROUPS)
+    st2 = _capi.SplatState()
+    assert L.splat_state_bind(C.byref(st2), None, 1 << 20, lay.arrays, lay.n, 1, 16 * 1024) == 0
+    cam.viewmatrix = cam.projmatrix = 1 << 12
+    g.channels = 3
+    g.means3D = g.opacities = g.colors_precomp = g.scales = g.rotations = 1 << 12
+    st2.tile_stride, st2.group_stride, st2.max_list_hint = 1024, 0, 100                     # no group records
+    assert L.splat_preprocess_forward(C.byref(cam), C.byref(g), C.byref(st2), None) == 1
+    st2.group_stride, st2.max_list_hint = 4096, 2000                                        # lists the composite cannot sort
+    assert L.splat_preprocess_forward(C.byref(cam), C.byref(g), C.byref(st2), None) == 1
+    st2.max_list_hint, st2.tile_stride = 100, 4096                                          # buckets beyond the capacity
+    assert L.splat_preprocess_forward(C.byref(cam), C.byref(g), C.byref(st2), None) == 1
 
 
 def test_python_surface_matches_reference_shape():
