@@ -671,6 +671,9 @@ __device__ __forceinline__ int forward_tile(const float *colors, SplatState &st,
 #ifndef SPLAT_K6_WAVES
 #define SPLAT_K6_WAVES 6
 #endif
+#ifndef SPLAT_K6_FP4_SIX
+#define SPLAT_K6_FP4_SIX 1        // the reference API's forms with 48-byte records (<= 3 channels + depth) at six workgroups per CU too: 80 VGPRs, K6 63.8 -> 60.4 us at B (r06_experiments.md 8)
+#endif
 struct FwdArgs {
     SplatCamera cam;
     const float *colors;
@@ -680,7 +683,7 @@ struct FwdArgs {
     TrackLossEpilogue ep;
 };
 template <int C, int CS, bool WITH_DEPTH, bool SORT, bool TRACK = false>
-__global__ __launch_bounds__(256, (forward_compact6<C, CS, WITH_DEPTH>() ? SPLAT_K6_WAVES : 5)) void render_forward_kernel(FwdArgs args) {
+__global__ __launch_bounds__(256, ((forward_compact6<C, CS, WITH_DEPTH>() || (SPLAT_K6_FP4_SIX && forward_fp<C, CS, WITH_DEPTH>() == 4)) ? SPLAT_K6_WAVES : 5)) void render_forward_kernel(FwdArgs args) {
     static_assert(!TRACK || (C == 6 && !WITH_DEPTH), "the tracking-loss epilogue reads the six fused channels");
     constexpr int FP = forward_fp<C, CS, WITH_DEPTH>();
     // ONE 4x4-PIXEL BLOCK PER 16-LANE ROW: row r of wave w composites block r of quadrant w (gather(): NL = 16) from the block's OWN
