@@ -32,6 +32,10 @@
 
 #include "splat_device.h"
 
+#ifndef SPLAT_BLOCK_RADIAL
+#define SPLAT_BLOCK_RADIAL 1       // the forward composite's 4x4-block lists: radial test per block on top of the box test (r06_experiments.md 9)
+#endif
+
 namespace splat {
 
 constexpr int kBatch = 256;         // records per LDS buffer (one per thread)
@@ -126,13 +130,43 @@ __device__ __forceinline__ void gather(Staged<FP> &s, const SplatState &st, cons
                     xh |= ((mu.x - hx <= tile_x0 + 4.f * b + 3.f) && (mu.x + hx >= tile_x0 + 4.f * b)) ? (1u << b) : 0u;
                     yh |= ((mu.y - hy <= tile_y0 + 4.f * b + 3.f) && (mu.y + hy >= tile_y0 + 4.f * b)) ? (1u << b) : 0u;
                 }
+#if SPLAT_BLOCK_RADIAL
+                // the radial test per BLOCK as well (exact for round splats -- every SplaTAM map): the box test alone visits the blocks in
+                // the corners of the splat's bounding box, 6 % of the block visits at workload B, 8 % on the frame loop's map
+                // (scripts/fwd_balance_stats.py).  lambda_min * distance^2 to the block's box of pixel centres, separable in x and y
+                unsigned rad16 = 0;         // bit 4 * by + bx: block column bx, block row by of the tile passes
+                {
+                    float ex[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const float x0 = tile_x0 + 4.f * b;
+                        const float ddx = fmaxf(fmaxf(x0 - mu.x, mu.x - (x0 + 3.f)), 0.f);
+                        ex[b] = lam_min * ddx * ddx;
+                    }
+                    const float thr = tau2 * 1.001f + 1e-3f;
+#pragma unroll
+                    for (int by = 0; by < 4; ++by) {
+                        const float y0 = tile_y0 + 4.f * by;
+                        const float ddy = fmaxf(fmaxf(y0 - mu.y, mu.y - (y0 + 3.f)), 0.f);
+                        const float left = thr - lam_min * ddy * ddy;         // what the block row leaves for the x term
+#pragma unroll
+                        for (int bx = 0; bx < 4; ++bx) rad16 |= (ex[bx] > left) ? 0u : (1u << (4 * by + bx));
+                    }
+                    if (nan_geo) rad16 = 0xFFFFu;
+                }
+#endif
                 // list L = 4 w + r: set when quadrant w passed the tests above and block r of it ((r & 1, r >> 1) within the quadrant)
                 // is hit in x and in y
                 unsigned m16 = 0;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     const unsigned xq = nan_geo ? 3u : (xh >> (2 * (w & 1))) & 3u, yq = nan_geo ? 3u : (yh >> (2 * (w >> 1))) & 3u;
-                    const unsigned sub = ((yq & 1u) ? xq : 0u) | ((yq & 2u) ? (xq << 2) : 0u);
+                    unsigned sub = ((yq & 1u) ? xq : 0u) | ((yq & 2u) ? (xq << 2) : 0u);
+#if SPLAT_BLOCK_RADIAL
+                    // quadrant w's blocks: tile block columns 2 (w & 1) .., rows 2 (w >> 1) ..
+                    const unsigned r0 = (rad16 >> (4 * (2 * (w >> 1)) + 2 * (w & 1))) & 3u, r1 = (rad16 >> (4 * (2 * (w >> 1) + 1) + 2 * (w & 1))) & 3u;
+                    sub &= r0 | (r1 << 2);
+#endif
                     m16 |= (((mask >> w) & 1u) ? sub : 0u) << (4 * w);
                 }
                 mask = m16;
