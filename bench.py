@@ -233,6 +233,18 @@ def kernel_roofline(params, frames, shape, dev):
     return roof, pk
 
 
+def reference_instances(eng):
+    """R of SURVEY.md 8(d)'s algorithmic bytes: the (Gaussian, tile) instances of the REFERENCE's binning rule (tile rectangle of
+    ceil(3 sigma_max), Appendix A step 8), counted from the rectangles the per-Gaussian kernel stores.  The lists the fused iteration
+    composites are shorter since round 6 (group binning files only the tiles that can hold a pixel with alpha >= 1/255: status[0]); the
+    size of the problem is the reference's."""
+    rect = eng.buf['rect'][:eng.P].view(-1, 2)
+    vis = eng.buf['radii'][:eng.P] > 0
+    w = (rect[:, 1] & 0xFFFF) - (rect[:, 0] & 0xFFFF)
+    h = ((rect[:, 1] >> 16) & 0xFFFF) - ((rect[:, 0] >> 16) & 0xFFFF)
+    return int((w * h * vis).sum())
+
+
 def fused_roofline(eng, frames, shape, dev, workload="B"):
     """Live HIP-event timing of the two 6-channel composite kernels of the fused iteration on the stream they are
     launched on (splat_iter_time_kernel), in the learnt list state the loop runs in.
@@ -261,7 +273,7 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
     # the state the mapping loop runs in: learnt lists, the gradient planes of a mapping iteration
     eng.loss_backward(frames[2 % len(frames)], 2 % len(frames), slam.REPLICA_MAPPING, tracking=False)
     torch.cuda.synchronize(dev)
-    R = int(eng.buf['status'][0])
+    R, list_entries = reference_instances(eng), int(eng.buf['status'][0])
     ws = eng._workspace(False, False)
     # one kernel launched 30x in a row between two events on the iteration's stream (splat_iter_time_kernel): 0 the list-reading forward
     # composite (what the iteration launches on long lists), 1 the backward composite (mapping form), 2 the sorting forward composite
@@ -330,7 +342,7 @@ def fused_roofline(eng, frames, shape, dev, workload="B"):
              "render_forward_list_reading_ms": r4(b2b["render_forward_list_reading"]),
              "render_forward_sorting_ms": r4(b2b["render_forward_sorting"]),
              "render_backward_30_in_a_row_ms": r4(b2b["render_backward"]), "forward_backward_pair_ms": r4(b2b["forward_backward_pair"]),
-             "num_rendered": R,
+             "num_rendered": R, "list_entries": list_entries,
              # secondary ceiling: live (pixel, Gaussian) pairs; filled from the oracle's count by the cpu_baseline leg
              "pairs_per_launch": None, "pair_evals_per_s": None,
              # filled with pairs_per_launch (cpu_baseline leg): vector lane-operations (64 x SQ_INSTS_VALU) per live pair, and the pair
@@ -628,7 +640,7 @@ def b_loop_headline(dev, steps=40):
     restore()
     eng.loss_backward(frames[2], 2, slam.REPLICA_MAPPING, tracking=False)
     torch.cuda.synchronize(dev)
-    R = int(eng.buf['status'][0])
+    R, list_entries = reference_instances(eng), int(eng.buf['status'][0])
     ws = eng._workspace(False, False)
     L = _capi.lib()
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -646,7 +658,8 @@ def b_loop_headline(dev, steps=40):
     out = {"workload": f"B-loop: {N} Gaussians in creation order, {W}x{H} (the map the frame loop builds at B's frame size)",
            "iters_per_s": round(5.0 / (2.0 / track_rate + 3.0 / map_rate), 3), "tracking_iters_per_s": round(track_rate, 3),
            "mapping_iters_per_s": round(map_rate, 3), "render_forward_ms": None if k6 is None else round(k6, 4),
-           "render_backward_ms": None if k7 is None else round(k7, 4), "num_rendered": R, "algorithmic_bytes": bytes_bwd,
+           "render_backward_ms": None if k7 is None else round(k7, 4), "num_rendered": R, "list_entries": list_entries,
+           "algorithmic_bytes": bytes_bwd,
            "roofline_frac": None if not k7 else round(bytes_bwd / (k7 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "valid": ok}
     del eng
     return out

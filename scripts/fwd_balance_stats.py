@@ -154,3 +154,38 @@ for ti in sample[:300]:
     live = (power <= 0) & (alpha >= 1.0 / 255.0)
     qe += int(live.reshape(len(k), 2, 8, 2, 8).any((2, 4)).sum()); qk += int(quadrant_cull(k, tx[a] * 16.0, ty[a] * 16.0).sum())
 print(f"quadrant visits over 300 tiles: staging cull {qk}, exact {qe} ({100 * qe / qk:.1f} %)")
+
+# ---- list entries that no quadrant of their tile visits (the tile rectangle comes from ceil(3 sigma), the live region from alpha >= 1/255)
+dead_k = dead_e = tot_e = 0
+for ti in sample[:300]:
+    a, b = starts[ti], ends[ti]
+    k = gi[a:b]
+    X = tx[a] * 16 + px_; Y = ty[a] * 16 + py_
+    dx = xy[k, 0][:, None, None] - X[None]; dy = xy[k, 1][:, None, None] - Y[None]
+    power = -0.5 * (conic[k, 0][:, None, None] * dx * dx + conic[k, 2][:, None, None] * dy * dy) - conic[k, 1][:, None, None] * dx * dy
+    alpha = np.minimum(0.99, op[k][:, None, None] * np.exp(power))
+    live = (power <= 0) & (alpha >= 1.0 / 255.0)
+    tot_e += len(k); dead_e += int((~live.any((1, 2))).sum()); dead_k += int((~quadrant_cull(k, tx[a] * 16.0, ty[a] * 16.0).any((1, 2))).sum())
+print(f"list entries over 300 tiles: {tot_e}; visited by no quadrant: staging cull {dead_k} ({100 * dead_k / tot_e:.1f} %), exact {dead_e} ({100 * dead_e / tot_e:.1f} %)")
+
+# ---- ... and how many of them a TILE-level test at binning time would drop: live box vs the tile's pixel centres, then + the radial test per tile
+def tile_cull(k, tx0, ty0, radial):
+    a, b2, c = conic[k, 0], conic[k, 1], conic[k, 2]
+    tau2 = 2.0 * np.log(255.0 * op[k])
+    det = a * c - b2 * b2
+    hx = np.sqrt(np.maximum(tau2, 0) * c / det) * 1.00001 + 0.01
+    hy = np.sqrt(np.maximum(tau2, 0) * a / det) * 1.00001 + 0.01
+    mid = 0.5 * (a + c)
+    lam = mid - np.sqrt(np.maximum(0, mid * mid - det))
+    mx, my = xy[k, 0], xy[k, 1]
+    keep = (mx - hx <= tx0 + 15) & (mx + hx >= tx0) & (my - hy <= ty0 + 15) & (my + hy >= ty0) & (tau2 >= 0)
+    if radial:
+        ddx = np.maximum(np.maximum(tx0 - mx, mx - (tx0 + 15)), 0); ddy = np.maximum(np.maximum(ty0 - my, my - (ty0 + 15)), 0)
+        keep &= ~(lam * (ddx * ddx + ddy * ddy) > tau2 * 1.001 + 1e-3)
+    return keep
+db = dr = 0
+for ti in sample[:300]:
+    a, b = starts[ti], ends[ti]
+    k = gi[a:b]
+    db += int((~tile_cull(k, tx[a] * 16.0, ty[a] * 16.0, False)).sum()); dr += int((~tile_cull(k, tx[a] * 16.0, ty[a] * 16.0, True)).sum())
+print(f"dropped by a tile-level box test {db} ({100 * db / tot_e:.1f} %), box + radial {dr} ({100 * dr / tot_e:.1f} %)")

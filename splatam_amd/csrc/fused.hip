@@ -102,6 +102,8 @@ __device__ __forceinline__ bool preprocess_finish(const FusedArgs &a, const CamC
         o.y0 = max(o.y0, st.tile_row_begin);
         o.y1 = max(o.y0, min(o.y1, st.tile_row_end));
     }
+    o.lx0 = o.x0; o.ly0 = o.y0; o.lx1 = o.x1; o.ly1 = o.y1;
+    if (vis && st.group_stride > 0) live_tile_rect(o.conic, G.op, o.px, o.py, o.lx0, o.ly0, o.lx1, o.ly1);      // group binning files the live part only
     st.depth[i] = o.depth;
     reinterpret_cast<float2 *>(st.xy)[i] = make_float2(o.px, o.py);
     reinterpret_cast<float4 *>(st.conic_opacity)[i] = make_float4(o.conic[0], o.conic[1], o.conic[2], G.op);
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(BLOCK) void fused_preprocess_kernel(FusedArgs a) {
         return;                                              // (uniform over the launch)
     }
     if constexpr (GROUP) {
-        file_group_records<BLOCK>(st, s_grp, i, vis && o.y1 > o.y0, o.x0, o.y0, o.x1, o.y1, o.depth, ggx, num_groups);
+        file_group_records<BLOCK>(st, s_grp, i, vis && o.ly1 > o.ly0 && o.lx1 > o.lx0, o.lx0, o.ly0, o.lx1, o.ly1, o.depth, ggx, num_groups);
         return;
     }
     // bucketed path: the returning atomic IS the slot

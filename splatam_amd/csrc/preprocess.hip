@@ -85,7 +85,8 @@ __global__ __launch_bounds__(kGroupBlock) void preprocess_forward_group_kernel(S
             for (int k = 0; k < SPLAT_GRAD_STRIDE / 4; ++k) a4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    file_group_records<kGroupBlock>(st, s_grp, i, vis && o.y1 > o.y0 && o.x1 > o.x0, o.x0, o.y0, o.x1, o.y1, o.depth, ggx, num_groups);
+    if (vis) live_tile_rect(o.conic, g.opacities[i], o.px, o.py, o.lx0, o.ly0, o.lx1, o.ly1);      // the lists of this path are the library's own: the live part only
+    file_group_records<kGroupBlock>(st, s_grp, i, vis && o.ly1 > o.ly0 && o.lx1 > o.lx0, o.lx0, o.ly0, o.lx1, o.ly1, o.depth, ggx, num_groups);
 }
 
 // K1 for exact lists known to be very long (dense_exact_lists, splat_device.h): the workgroup's instances are counted per tile in LDS and

@@ -80,6 +80,7 @@ struct Projected {
     float cov2d[3];     // (a, b, c) after dilation
     int radius;         // ceil(3 sigma_max); 0 when culled
     int x0, y0, x1, y1; // tile rect, max exclusive
+    int lx0, ly0, lx1, ly1; // the part of it group binning files (live_tile_rect below; the whole rect until a caller tightens it)
 };
 
 // EWA linearisation shared by forward and backward: the 2x3 matrix T = J W
@@ -128,6 +129,7 @@ SPLAT_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi :
 // Forward of one Gaussian.  Returns false (radius 0) when culled.
 SPLAT_HD bool project_gaussian(const CamConst &c, const float *p, const float *S6, Projected &o) {
     o.radius = 0; o.x0 = o.y0 = o.x1 = o.y1 = 0;
+    o.lx0 = o.ly0 = o.lx1 = o.ly1 = 0;
     o.depth = 0.f; o.px = o.py = 0.f;
     o.conic[0] = o.conic[1] = o.conic[2] = 0.f;
     o.cov2d[0] = o.cov2d[1] = o.cov2d[2] = 0.f;
@@ -161,7 +163,37 @@ SPLAT_HD bool project_gaussian(const CamConst &c, const float *p, const float *S
     o.conic[0] = abc[2] * di; o.conic[1] = -abc[1] * di; o.conic[2] = abc[0] * di;
     o.cov2d[0] = abc[0]; o.cov2d[1] = abc[1]; o.cov2d[2] = abc[2];
     o.radius = (int)radius; o.x0 = x0; o.y0 = y0; o.x1 = x1; o.y1 = y1;
+    o.lx0 = x0; o.ly0 = y0; o.lx1 = x1; o.ly1 = y1;
     return true;
+}
+
+// The part of a Gaussian's tile rectangle [x0, x1) x [y0, y1) whose tiles can hold a pixel with alpha >= 1/255 (the composites' blend
+// threshold, Appendix A "skip if alpha < 1/255"): the live region {(p - mu)^T Q (p - mu) <= 2 ln(255 o)} has the half extents
+// sqrt(2 ln(255 o) Q^-1_ii); a tile of pixel centres 16 t .. 16 t + 15 outside that box blends nothing of this Gaussian.  The reference's
+// rectangle comes from ceil(3 sigma_max) and holds 12-13 % such tiles at the SplaTAM workloads (scripts/fwd_balance_stats.py): list
+// entries that are sorted, staged and culled for nothing.  Used where the lists are this library's own business (GROUP BINNING: the
+// forward composite builds, sorts and publishes the list, the backward composite replays it); the exact path keeps the reference's
+// lists entry for entry.  Conservative by the same margins as the composites' staging cull (render.hip gather()); NaN geometry or
+// opacity leaves the rectangle alone (the NaN must reach the image as it does in the reference).
+SPLAT_HD void live_tile_rect(const float *conic, float opacity, float px, float py, int &x0, int &y0, int &x1, int &y1) {
+    const float tau2 = 2.0f * logf(255.0f * opacity);
+    if (tau2 < 0.f) { x1 = x0; y1 = y0; return; }        // opacity < 1/255: no pixel can pass the alpha test
+    if (!(tau2 >= 0.f)) return;
+    const float det = conic[0] * conic[2] - conic[1] * conic[1];
+    const float hx = sqrtf(tau2 * conic[2] / det) * 1.00001f + 0.01f;
+    const float hy = sqrtf(tau2 * conic[0] / det) * 1.00001f + 0.01f;
+    if (!(hx == hx) || !(hy == hy)) return;
+    const float inv = 1.0f / (float)kTile, big = 1.0e6f;
+    const int tx0 = (int)ceilf(fminf(fmaxf((px - hx - (float)(kTile - 1)) * inv, -1.f), big));
+    const int ty0 = (int)ceilf(fminf(fmaxf((py - hy - (float)(kTile - 1)) * inv, -1.f), big));
+    const int tx1 = (int)floorf(fminf(fmaxf((px + hx) * inv, -2.f), big)) + 1;
+    const int ty1 = (int)floorf(fminf(fmaxf((py + hy) * inv, -2.f), big)) + 1;
+    x0 = x0 > tx0 ? x0 : tx0;
+    y0 = y0 > ty0 ? y0 : ty0;
+    x1 = x1 < tx1 ? x1 : tx1;
+    y1 = y1 < ty1 ? y1 : ty1;
+    if (x1 < x0) x1 = x0;
+    if (y1 < y0) y1 = y0;
 }
 
 // Adjoint of project_gaussian for one visible Gaussian.

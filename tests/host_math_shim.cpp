@@ -8,6 +8,13 @@ using namespace splat;
 
 extern "C" {
 
+// live_tile_rect (group binning files only the tiles that can blend): rect[4] = x0, y0, x1, y1 in, tightened in place
+void hm_live_tile_rect(int P, const float *conic, const float *opacity, const float *xy, int *rect) {
+    for (int i = 0; i < P; ++i)
+        live_tile_rect(conic + 3 * i, opacity[i], xy[2 * i], xy[2 * i + 1], rect[4 * i], rect[4 * i + 1], rect[4 * i + 2], rect[4 * i + 3]);
+}
+
+
 void hm_forward(int P, const float *means, const float *scales, const float *rots, const float *view, const float *proj,
                 int W, int H, float tfx, float tfy, float mod, float *depth, float *xy, float *conic, int *radii, int *rect) {
     CamConst c;

@@ -194,7 +194,7 @@ def test_tracking_loop_matches_reference_loop():
 @pytest.mark.parametrize("tracking", [True, False])
 def test_bucketed_lists_match_exact_lists(tracking):
     """check_overflow() teaches the engine the list statistics; from then on the per-tile lists are bucketed (no scan /
-    scatter pass).  Same lists, same results: only the order of float atomics differs."""
+    scatter pass).  Same lists but for the entries that cannot blend, same results: only the order of float atomics differs."""
     from splatam_amd import slam
     from splatam_amd.fused import FusedEngine
     params, variables, frame, cam = _scene(20000, 320, 240, aniso=not tracking, seed=21)
@@ -213,7 +213,10 @@ def test_bucketed_lists_match_exact_lists(tracking):
         eng.loss_backward(frame, 1, cfg, tracking=tracking)
         torch.cuda.synchronize()
         assert float(eng.buf['d_cam'][12]) == 0.0
-        assert int(eng.buf['status'][0]) == n_exact
+        # (group binning: the entries whose tile cannot hold a pixel with alpha >= 1/255 are not filed -- splat_math.h live_tile_rect)
+        n_group = int(eng.buf['status'][0])
+        assert 0.6 * n_exact <= n_group <= n_exact and (ref_lists is None or n_group == ref_lists)
+        ref_lists = n_group
         got = eng.buf['d_cam'][:8]
         assert (got - ref_cam).abs().max() <= 1e-4 * ref_cam.abs().max()
         if not tracking:
@@ -557,8 +560,9 @@ def test_staged_records_handed_to_the_backward_composite_change_nothing_but_spee
 @pytest.mark.parametrize("case", ["random", "large", "odd_grid", "tracking"])
 def test_group_binning_changes_nothing_but_speed(case):
     """SplatState.group_count (one record per (Gaussian, 2 x 2-tile group), slots through an LDS histogram; the forward composite
-    filters its group's records by tile rectangle): the per-tile lists after the composite's sort -- and the counts it
-    publishes -- are exactly those of the per-tile buckets, hence bit-identical renders and list statistics.  "large": splats
+    filters its group's records by tile rectangle): the per-tile lists after the composite's sort are those of the per-tile
+    buckets WITHOUT the entries whose tile cannot hold a pixel with alpha >= 1/255 (splat_math.h live_tile_rect: 12-13 % of the
+    reference's instances at the SplaTAM workloads), hence bit-identical renders and list statistics that can only shrink.  "large": splats
     wide enough to touch more than four groups (a lane's further records take their own atomics); "odd_grid": an odd number of
     tile columns / rows (edge groups of one tile); "tracking": the composite with the loss epilogue, and the render-only call."""
     from splatam_amd import slam
@@ -597,7 +601,9 @@ def test_group_binning_changes_nothing_but_speed(case):
         assert float(eng.buf['tile_count'].abs().max()) == 0.0 and float(gc[:, 0].abs().max()) == 0.0 and float(gc[:, 2:].abs().max()) == 0.0
         outs.append((out6, grads, loss, stat[0], stat[2]))
     assert torch.equal(outs[0][0], outs[1][0])
-    assert outs[0][3] == outs[1][3] and outs[0][4] == outs[1][4], (outs[0][3:], outs[1][3:])     # num_rendered, longest list
+    # list entries, longest list: group binning drops the instances that cannot blend -- some, never most of them
+    assert 0.6 * outs[0][3] <= outs[1][3] <= outs[0][3] and 0.6 * outs[0][4] <= outs[1][4] <= outs[0][4], (outs[0][3:], outs[1][3:])
+    assert outs[1][3] < outs[0][3]
     assert abs(outs[0][2] - outs[1][2]) <= 1e-6 * abs(outs[0][2])
     assert float((outs[0][1] - outs[1][1]).abs().max()) <= 2e-5 * float(outs[0][1].abs().max())
 

@@ -196,3 +196,44 @@ def test_fused_adam_matches_torch(shim):
         shim.hm_adam(1000, _p(pn), _p(_np(grad)), _p(m), _p(v), C.c_float(0.9), C.c_float(0.999), C.c_float(0.0025 / bc1),
                      C.c_float(bc2 ** 0.5), C.c_float(1e-15))
         np.testing.assert_allclose(pn, p.detach().numpy(), rtol=0, atol=3e-7)
+
+
+@pytest.mark.parametrize("aniso", [False, True])
+def test_live_tile_rect_keeps_every_tile_that_blends(shim, aniso):
+    """Group binning files a Gaussian only in the tiles of its rectangle that can hold a pixel with alpha >= 1/255
+    (splat_math.h live_tile_rect).  The rule must be conservative: every pixel the composite would blend (power <= 0,
+    min(0.99, o G) >= 1/255 -- SURVEY Appendix A, forward composite) lies in a kept tile; and it must cut something."""
+    W, H = 200, 136
+    cam, rv = scene(3000, W, H, 170.0, seed=11, anisotropic=aniso)
+    rv['opacities'][:50] = 0.003            # below 1/255: nothing blends, nothing is filed
+    rv['opacities'][50:100] = 0.0045        # just above it
+    rv['scales'][100:150] *= 4.0            # splats that span several tiles
+    geom = R.preprocess(rv['means3D'], None, rv['scales'], rv['rotations'], None, cam)
+    P = rv['means3D'].shape[0]
+    conic, xy, op = _np(geom.conic), _np(geom.xy), _np(rv['opacities']).reshape(-1)
+    rect0 = np.concatenate([geom.rect_min.numpy(), geom.rect_max.numpy()], 1).astype(np.int32)
+    rect = rect0.copy()
+    shim.hm_live_tile_rect(P, _p(conic), _p(op), _p(xy), _p(rect, C.c_int))
+    vis = geom.radii.numpy() > 0
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    kept = dropped = 0
+    for i in np.nonzero(vis)[0]:
+        x0, y0, x1, y1 = rect0[i]
+        sx, sy = slice(16 * x0, min(W, 16 * x1)), slice(16 * y0, min(H, 16 * y1))
+        dx, dy = xy[i, 0] - xs[sy, sx], xy[i, 1] - ys[sy, sx]
+        power = -0.5 * (conic[i, 0] * dx * dx + conic[i, 2] * dy * dy) - conic[i, 1] * dx * dy
+        live = (power <= 0) & (np.minimum(0.99, op[i] * np.exp(power)) >= 1.0 / 255.0)
+        ly, lx = np.nonzero(live)
+        tx, ty = (lx + 16 * x0) // 16, (ly + 16 * y0) // 16
+        a0, b0, a1, b1 = rect[i]
+        assert a0 >= x0 and b0 >= y0 and a1 <= x1 and b1 <= y1
+        assert ((tx >= a0) & (tx < a1) & (ty >= b0) & (ty < b1)).all(), (i, rect0[i], rect[i])
+        kept += (a1 - a0) * (b1 - b0)
+        dropped += (x1 - x0) * (y1 - y0) - (a1 - a0) * (b1 - b0)
+    assert dropped > 0.05 * (kept + dropped), (kept, dropped)
+    assert (rect[:50, 2] == rect[:50, 0]).all() or not vis[:50].any()      # opacity below the blend threshold: empty
+    # NaN geometry leaves the rectangle alone
+    bad = conic[:4].copy(); bad[:, 0] = np.nan
+    r4 = rect0[:4].copy()
+    shim.hm_live_tile_rect(4, _p(bad), _p(op[100:104].copy()), _p(xy[:4].copy()), _p(r4, C.c_int))
+    assert (r4 == rect0[:4]).all()
