@@ -189,3 +189,36 @@ for ti in sample[:300]:
     k = gi[a:b]
     db += int((~tile_cull(k, tx[a] * 16.0, ty[a] * 16.0, False)).sum()); dr += int((~tile_cull(k, tx[a] * 16.0, ty[a] * 16.0, True)).sum())
 print(f"dropped by a tile-level box test {db} ({100 * db / tot_e:.1f} %), box + radial {dr} ({100 * dr / tot_e:.1f} %)")
+
+# ---- the forward composite stages the list 255 entries at a time: the longest-of-four rule applies per BATCH
+def batch_trips(which_cull):
+    per_batch = whole = 0
+    for ti in sample[:300]:
+        a, b = starts[ti], ends[ti]
+        k = gi[a:b]
+        keep = tile_cull(k, tx[a] * 16.0, ty[a] * 16.0, False)          # what group binning files
+        k = k[keep]
+        m = kernel_cull(k, tx[a] * 16.0, ty[a] * 16.0, which_cull)      # [e, by, bx]
+        for s in range(0, len(k), 255):
+            lens = m[s:s + 255].sum(0)
+            per_batch += sum(int(np.ceil(lens[2 * qy:2 * qy + 2, 2 * qx:2 * qx + 2].max() / 4.0)) for qy in range(2) for qx in range(2))
+        lens = m.sum(0)
+        whole += sum(int(np.ceil(lens[2 * qy:2 * qy + 2, 2 * qx:2 * qx + 2].max() / 4.0)) for qy in range(2) for qx in range(2))
+    return per_batch, whole
+pb, wh = batch_trips(True)
+print(f"forward trips of four entries over 300 tiles, per 255-entry batch {pb}, if the whole list were one batch {wh} ({100 * wh / pb:.1f} %)")
+
+# ---- ... and what dealing the sixteen blocks to the sixteen (wave, row) slots BY LENGTH, batch by batch, would leave
+def batch_trips_dealt():
+    dealt = 0
+    for ti in sample[:300]:
+        a, b = starts[ti], ends[ti]
+        k = gi[a:b]
+        k = k[tile_cull(k, tx[a] * 16.0, ty[a] * 16.0, False)]
+        m = kernel_cull(k, tx[a] * 16.0, ty[a] * 16.0, True)
+        for s in range(0, len(k), 255):
+            l = np.sort(m[s:s + 255].sum(0).reshape(-1))[::-1]
+            dealt += sum(int(np.ceil(l[4 * w] / 4.0)) for w in range(4))
+    return dealt
+dl = batch_trips_dealt()
+print(f"blocks dealt by length per batch: {dl} trips ({100 * dl / pb:.1f} % of today's)")
