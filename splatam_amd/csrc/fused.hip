@@ -899,7 +899,11 @@ __global__ __launch_bounds__(kBlock, ISO ? 5 : 4) void fused_backward_kernel(Fus
         const float w2c_row2[4] = {a.frame.w2c[8], a.frame.w2c[9], a.frame.w2c[10], a.frame.w2c[11]};
         // (MAPGRADS = false, camera tracking: the backward composite's tracking form publishes S1..S5 and the depth channel's colour sum
         //  in slots 0..5 -- render.hip kTrackSlots --: half the accumulator line is read and cleared)
-        constexpr int kRow4 = MAPGRADS ? SPLAT_GRAD_STRIDE / 4 : 2;
+        //  (MAPGRADS = true: the fused iteration's backward composites carry gradient in r, g, b, z only -- launch_render_backward_feat8,
+        //  the full-gradient tracking composite -- i.e. S1..S6 and four colour sums in slots 0..9: three quarters of the line; slots 10..15
+        //  are never written on this path and stay at the zero they were allocated with)
+        constexpr int kRow4 = MAPGRADS ? 3 : 2;
+        static_assert(SPLAT_GRAD_STRIDE >= 12, "slots 0..9 live in the first three float4 of the accumulator row");
         float acc[SPLAT_GRAD_STRIDE];
 #pragma unroll
         for (int k = 0; k < SPLAT_GRAD_STRIDE; ++k) acc[k] = 0.f;
