@@ -222,3 +222,20 @@ def batch_trips_dealt():
     return dealt
 dl = batch_trips_dealt()
 print(f"blocks dealt by length per batch: {dl} trips ({100 * dl / pb:.1f} % of today's)")
+
+# ---- ... with ONE dealing per tile, made from the first batch's lengths and kept for the tile's later batches (no pixel state moves)
+def batch_trips_dealt_once(by_total=False):
+    dealt = 0
+    for ti in sample[:300]:
+        a, b = starts[ti], ends[ti]
+        k = gi[a:b]
+        k = k[tile_cull(k, tx[a] * 16.0, ty[a] * 16.0, False)]
+        m = kernel_cull(k, tx[a] * 16.0, ty[a] * 16.0, True).reshape(len(k), 16)
+        first = m[:255].sum(0) if not by_total else m.sum(0)
+        order = np.argsort(-first, kind="stable")
+        for s in range(0, len(k), 255):
+            l = m[s:s + 255].sum(0)[order]
+            dealt += sum(int(np.ceil(l[4 * w:4 * w + 4].max() / 4.0)) for w in range(4))
+    return dealt
+d1 = batch_trips_dealt_once()
+print(f"blocks dealt ONCE per tile by the first batch's lengths: {d1} trips ({100 * d1 / pb:.1f} % of today's)")
