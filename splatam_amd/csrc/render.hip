@@ -99,8 +99,10 @@ __device__ __forceinline__ void gather(Staged<FP> &s, const SplatState &st, cons
         if constexpr (WITH_DEPTH) s.feat[C] = st.depth[id];
         // live region {alpha >= 1/255}: (p-mu)^T Q (p-mu) <= 2 tau, tau = ln(255 o); half extents sqrt(2 tau Q^-1_ii)
         unsigned mask = 0;
-        const float tau2 = 2.0f * __logf(255.0f * co.w);
-        if (tau2 >= 0.f) {
+        // (the threshold itself is decided on the opacity, as the visit decides it -- alpha <= opacity --: 255 o may round below 1 for
+        //  o == 1/255, and __logf is approximate)
+        const float tau2 = fmaxf(2.0f * __logf(255.0f * co.w), 0.f);
+        if (co.w >= kAlphaMin) {
             const float det = co.x * co.z - co.y * co.y;
             const float hx = sqrtf(tau2 * co.z / det) * 1.00001f + 0.01f;
             const float hy = sqrtf(tau2 * co.x / det) * 1.00001f + 0.01f;

@@ -176,9 +176,10 @@ SPLAT_HD bool project_gaussian(const CamConst &c, const float *p, const float *S
 // lists entry for entry.  Conservative by the same margins as the composites' staging cull (render.hip gather()); NaN geometry or
 // opacity leaves the rectangle alone (the NaN must reach the image as it does in the reference).
 SPLAT_HD void live_tile_rect(const float *conic, float opacity, float px, float py, int &x0, int &y0, int &x1, int &y1) {
-    const float tau2 = 2.0f * logf(255.0f * opacity);
-    if (tau2 < 0.f) { x1 = x0; y1 = y0; return; }        // opacity < 1/255: no pixel can pass the alpha test
-    if (!(tau2 >= 0.f)) return;
+    if (opacity < kAlphaMin) { x1 = x0; y1 = y0; return; }       // alpha <= opacity < 1/255 at every pixel: nothing passes the alpha test
+    if (!(opacity >= kAlphaMin)) return;                         // NaN
+    // (the threshold itself is decided on the opacity, as the composite decides it; 255 o may round below 1 for o == 1/255)
+    const float tau2 = fmaxf(2.0f * logf(255.0f * opacity), 0.f);
     const float det = conic[0] * conic[2] - conic[1] * conic[1];
     const float hx = sqrtf(tau2 * conic[2] / det) * 1.00001f + 0.01f;
     const float hy = sqrtf(tau2 * conic[0] / det) * 1.00001f + 0.01f;

@@ -314,3 +314,23 @@ def test_composite_kernels_multi_batch_and_config_a():
         oc, orad, od, og, _ = _c_oracle(cam, rv, gout)
         flips = _check_forward(gc, gr, gd, oc, orad, od, W * H, cam, rv)
         _check_grads(gg, og, flips=flips)
+
+
+@pytest.mark.parametrize("path", ["exact", "fast"])
+def test_gaussian_exactly_at_the_blend_threshold_is_blended(path):
+    """opacity == float32(1 / 255), centre exactly on a pixel centre: alpha == 1/255 there and the composite blends it
+    (Appendix A: skip if alpha < 1/255).  The staging cull and the live tile rectangle of group binning decide that case on the
+    opacity itself (log(255 o) may round below zero); one step below the threshold nothing is blended."""
+    W, H = 33, 17                                    # odd sizes: the optical axis hits the centre of pixel (16, 8)
+    cam = R.make_camera(W, H, 40.0, 40.0, W / 2.0, H / 2.0)          # pixel centres at fx X / Z + cx - 0.5
+    thr = np.float32(1.0) / np.float32(255.0)
+    rv = dict(means3D=torch.tensor([[0.0, 0.0, 2.0], [0.0, 0.0, 3.0]]), means2D=torch.zeros(2, 3),
+              opacities=torch.tensor([[float(thr)], [float(np.nextafter(thr, np.float32(0)))]]),
+              colors_precomp=torch.tensor([[1.0, 0.5, 0.25], [0.0, 1.0, 0.0]]), scales=torch.full((2, 3), 0.05),
+              rotations=torch.tensor([[1.0, 0, 0, 0]] * 2))
+    gc, gr, gd, _ = _gpu_render(cam, rv, path=path)
+    oc, orad, od, _, _ = _c_oracle(cam, rv)
+    assert oc[0, 8, 16] == thr * np.float32(1.0) and oc[1, 8, 16] == np.float32(thr * np.float32(0.5))      # the oracle blends the first, not the second
+    assert np.array_equal(gr, orad)
+    assert np.array_equal(gc[:, 8, 16], oc[:, 8, 16]), (gc[:, 8, 16], oc[:, 8, 16])
+    assert np.abs(gc - oc).max() <= 1e-6 and np.abs(gd - od).max() <= 1e-6

@@ -237,3 +237,16 @@ def test_live_tile_rect_keeps_every_tile_that_blends(shim, aniso):
     r4 = rect0[:4].copy()
     shim.hm_live_tile_rect(4, _p(bad), _p(op[100:104].copy()), _p(xy[:4].copy()), _p(r4, C.c_int))
     assert (r4 == rect0[:4]).all()
+
+
+def test_live_tile_rect_at_the_blend_threshold(shim):
+    """opacity == float32(1 / 255) with the centre ON a pixel centre: alpha == 1/255 there, the composite blends it (alpha >= 1/255), so the
+    tile must stay -- decided on the opacity itself, not on log(255 o), which may round below zero; just below the threshold nothing stays."""
+    thr = np.float32(1.0) / np.float32(255.0)
+    conic = np.array([[1.0, 0.0, 1.0]] * 2, np.float32)
+    xy = np.array([[24.0, 40.0]] * 2, np.float32)
+    op = np.array([thr, np.nextafter(thr, np.float32(0))], np.float32)
+    rect = np.array([[0, 1, 3, 4]] * 2, np.int32)
+    shim.hm_live_tile_rect(2, _p(conic), _p(op), _p(xy), _p(rect, C.c_int))
+    assert rect[0, 0] <= 1 < rect[0, 2] and rect[0, 1] <= 2 < rect[0, 3], rect[0]
+    assert rect[1, 2] == rect[1, 0] and rect[1, 3] == rect[1, 1], rect[1]
