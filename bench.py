@@ -483,7 +483,12 @@ def render_mpix(params, frames, shape, dev, reps=10):
         im.backward(gout)
         for v in inp.values():
             v.grad = None
-    once()
+    # warm-up: the scene's first call is the exact (list-learning) one, the next ones pay the first uses of the fast path (layouts, pinned
+    # flag ring, allocator) and the clock ramp of an idle GPU (profiles/r05_experiments.md 10) -- 60 calls are 12 ms, all of it inside
+    # that ramp: the same call read 0.248 ms here and 0.198 - 0.209 ms in scripts/r06_dropin.py on the same box (r06_v5).  The timed calls
+    # include the policy's own exact call (every 64th)
+    for _ in range(48):
+        once()
     rate = phase_rate(once, reps, dev)
     return W * H * rate / 1e6, 1e3 / rate
 
@@ -827,7 +832,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         # (BASELINE metric (i) first: the roofline leg below runs torch.profiler, and a process that has profiled once pays for it in every
         #  later autograd call -- the drop-in call is host-bound, it read 0.23 ms behind the profiler against 0.21 ms in a fresh process)
-        mpix, ms_call = render_mpix(params_d, frames, shape, dev, reps=60)
+        mpix, ms_call = render_mpix(params_d, frames, shape, dev, reps=128)
         if fused:
             probe = FusedEngine({k: v.detach().clone() for k, v in params.items()}, frames[1]['cam'])
             roof = fused_roofline(probe, frames, shape, dev, args.workload)
@@ -1065,7 +1070,7 @@ def main():
     result = None
     if rank == 0:
         if mpix is None:
-            mpix, ms_call = render_mpix(params_d, frames, shape, dev, reps=60)
+            mpix, ms_call = render_mpix(params_d, frames, shape, dev, reps=128)
         wl = (f"C: {N} Gaussians, {W}x{H}, mapping-only, a batch of 8 keyframe views per step sharded over the ranks, one gradient all-reduce"
               if mode_c else f"{args.workload}: {N} Gaussians, {W}x{H}, SplaTAM tracking+mapping loop (2:3 mix), isotropic map"
                    + ("; fused tracking iterations do not form dL/d(rgb, opacity, scale): the reference computes them, steps them with learning "
