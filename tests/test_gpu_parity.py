@@ -334,3 +334,29 @@ def test_gaussian_exactly_at_the_blend_threshold_is_blended(path):
     assert np.array_equal(gr, orad)
     assert np.array_equal(gc[:, 8, 16], oc[:, 8, 16]), (gc[:, 8, 16], oc[:, 8, 16])
     assert np.abs(gc - oc).max() <= 1e-6 and np.abs(gd - od).max() <= 1e-6
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_culls_drop_nothing_on_extreme_splats(seed):
+    """The fast path of the auto policy files a Gaussian only in the tiles of its live box (splat_math.h live_tile_rect) and both
+    paths visit only the 4x4 blocks inside its live disc (render.hip gather()): an entry or a visit they drop must fail the alpha
+    test at every pixel, so the image of the fast path equals the exact path's BIT FOR BIT and the gradients to float-atomic
+    order -- on splats the SplaTAM maps never hold: needles (anisotropy up to 100), opacities from below the blend threshold to
+    1, footprints from a third of a pixel to a quarter of the frame, a tilted camera."""
+    W, H = 208, 144
+    cam, rv = scene(2500, W, H, 160.0, seed=seed, anisotropic=True, w2c=tilted_w2c())
+    g = torch.Generator().manual_seed(seed)
+    n = rv['means3D'].shape[0]
+    rv['scales'] = rv['scales'][:, :1] * torch.exp(torch.empty(n, 3).uniform_(-1.5, 3.0, generator=g))
+    rv['rotations'] = torch.nn.functional.normalize(torch.randn(n, 4, generator=g), dim=1)
+    rv['opacities'] = torch.exp(torch.empty(n, 1).uniform_(np.log(0.002), 0.0, generator=g))
+    gout = torch.randn(3, H, W, generator=g)
+    ec, er, ed, eg = _gpu_render(cam, rv, gout)                      # a scene's first call: the exact path
+    fc, fr, fd, fg = _gpu_render(cam, rv, gout, path="fast")
+    assert np.array_equal(er, fr)
+    assert np.array_equal(ec, fc) and np.array_equal(ed, fd), (np.abs(ec - fc).max(), np.abs(ed - fd).max())
+    for k in eg:
+        assert np.abs(eg[k] - fg[k]).max() <= 2e-4 * grad_scale(eg[k]) + 1e-12, k      # (sums over up to a quarter of the frame, in another order)
+    oc, orad, od, _, _ = _c_oracle(cam, rv)
+    assert np.array_equal(er, orad)
+    assert_close_outliers(ec, oc, 1e-4, max_outlier_frac=2e-3, outlier_atol=0.2, what="extreme splats: colour vs oracle")
